@@ -1,0 +1,109 @@
+"""Pin the oracle (oracle/render_ref.py) against outputs of the upstream reference.
+
+The fixtures under tests/golden/ were produced by tests/golden/make_golden.py, which
+imports the reference read-only in the build container.  Tolerances are the float32
+re-association noise between upstream's einsum/bmm calls and the oracle's explicit
+left-to-right sums (measured: <=1e-6 on sample coordinates, <=5e-6 on rgb).
+"""
+import numpy as np
+import pytest
+import torch
+
+from coponerf_amd import synthetic as syn
+from oracle import render_ref as orc
+from tests.helpers import load_case, case_inputs, tap_indices
+
+CASES = ["c1_val", "train_b2", "wide_val", "hd_val"]
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return syn.make_render_weights()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference(name, weights):
+    cfg, gold = load_case(name)
+    inp, z, rel, flow = case_inputs(cfg)
+    with torch.no_grad():
+        out = orc.forward(inp, z, rel, flow, cfg["val"], weights, npoints=cfg["S"])
+    g = {k: torch.from_numpy(v) for k, v in gold.items()}
+
+    assert out["pixel_val"].shape == g["pixel_val"].shape
+    assert (out["pixel_val"] - g["pixel_val"]).abs().max() <= 2e-6
+    # bilinear tap indices of every level: identical but for coordinates within rounding of a texel edge
+    for a, b in zip(tap_indices(out["pixel_val"], cfg["H"]), tap_indices(g["pixel_val"], cfg["H"])):
+        assert (a != b).float().mean() <= 1e-4
+    assert (out["rgb"] - g["rgb"]).abs().max() <= 2e-5
+    assert (out["at_wt"] - g["at_wt"]).abs().max() <= 1e-6
+    assert torch.equal(out["valid_mask"], g["valid_mask"])
+    assert (out["coords"] - g["coords"]).abs().max() <= 1e-6
+    assert (out["depth_ray"] - g["depth_ray"]).abs().max() <= 2e-3   # sum of at_wt * pt with |pt| up to 100
+    for k in ("T_to_C1_pts", "T_to_C2_pts"):   # division by (depth + 1e-6): relative tolerance
+        assert ((out[k] - g[k]).abs() / (g[k].abs() + 1)).max() <= 5e-3
+    assert (out["at_wt_max"] != g["at_wt_max"]).float().mean() <= 2e-3
+    for k in ("mask_c2", "matchability_cycle_mask"):
+        assert (out[k] != g[k]).float().mean() <= 5e-3
+    assert ((out["C2_pts_to_C1"] - g["C2_pts_to_C1"]).abs() > 1e-4).float().mean() <= 5e-3
+    for k in ("rel_pose_flip", "gt_rel_pose", "gt_rel_pose_flip"):
+        assert (out[k] - g[k]).abs().max() <= 1e-6
+
+
+def test_intermediates_match_reference(weights):
+    cfg, gold = load_case("inter")
+    inp, z, rel, flow = case_inputs(cfg)
+    with torch.no_grad():
+        out = orc.forward(inp, z, rel, flow, cfg["val"], weights, npoints=cfg["S"], keep=True)
+    g = {k: torch.from_numpy(v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in gold.items()}
+    assert (out["pt"] - g["pt"]).abs().max() <= 1e-5 * max(1.0, float(g["pt"].abs().max()))
+    assert (out["prim"] - g["prim"]).abs().max() <= 4e-3           # fixture stored as fp16
+    assert (out["sec"] - g["sec"]).abs().max() <= 4e-3
+    enc = out["X"].view(1, 2, cfg["R"], cfg["S"], 2, 416)[0]        # (V,R,S,2,416)
+    enc4 = torch.stack([enc[0, :, :, 0], enc[0, :, :, 1], enc[1, :, :, 0], enc[1, :, :, 1]], 0)
+    assert (enc4 - g["enc"]).abs().max() <= 2e-4
+    N = 2
+    assert (out["value"].reshape(N, cfg["R"], cfg["S"], 416) - g["value"]).abs().max() <= 2e-4
+    assert (out["key"].reshape(N, cfg["R"], cfg["S"], 128) - g["key"]).abs().max() <= 2e-4
+    assert (out["ce"].reshape(N, cfg["R"], cfg["S"], 128) - g["ce"]).abs().max() <= 2e-5
+    assert (out["rgb_raw"] - g["rgb_raw"]).abs().max() <= 2e-5
+    assert (out["rgb"] - g["rgb"]).abs().max() <= 2e-5
+
+
+def test_segment_clipper_edge_cases():
+    """Degenerate rays through epipolar.project_rays (camera at origin, origin behind the plane,
+    parallel ray, miss, both ends inside, ...)."""
+    _, g = load_case_raw("edges")
+    o, d, K = (torch.from_numpy(g[k]) for k in ("o", "d", "K"))
+    # the oracle takes one origin per camera: run each ray as its own camera
+    xy0, xy1, ok, t0, t1 = orc.project_rays(o, d[:, None, :], K[None].expand(len(o), -1, -1).contiguous())
+    same = lambda a, b: bool(((a == b) | (torch.isnan(a) & torch.isnan(b)) | ((a - b).abs() <= 1e-6)).all())
+    assert torch.equal(ok[:, 0], torch.from_numpy(g["overlaps_image"]))
+    assert same(xy0[:, 0], torch.from_numpy(g["xy_min"]))
+    assert same(xy1[:, 0], torch.from_numpy(g["xy_max"]))
+    assert same(t0[:, 0], torch.from_numpy(g["t_min"]))
+    assert same(t1[:, 0], torch.from_numpy(g["t_max"]))
+
+
+def load_case_raw(name):
+    import os
+    from tests.helpers import GOLDEN
+    return None, dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
+
+
+def test_bilinear_taps_reproduce_grid_sample():
+    """The explicit tap/weight restatement equals ATen's grid_sampler for both padding modes."""
+    torch.manual_seed(0)
+    fmap = torch.randn(1, 5, 16, 16)
+    g = torch.rand(1, 64, 32, 2) * 3 - 1.5
+    g[0, 0, 0] = torch.tensor([1e8, -1e8])
+    for border in (True, False):
+        ref = torch.nn.functional.grid_sample(fmap, g, mode="bilinear", padding_mode="border" if border else "zeros",
+                                              align_corners=False)
+        ix, iy, fx, fy = orc.bilinear_taps(g, 16, 16, border)
+        acc = torch.zeros_like(ref)
+        for dx, dy, wgt in ((0, 0, (1 - fx) * (1 - fy)), (1, 0, fx * (1 - fy)), (0, 1, (1 - fx) * fy), (1, 1, fx * fy)):
+            x, y = ix + dx, iy + dy
+            inside = (x >= 0) & (x <= 15) & (y >= 0) & (y <= 15)
+            v = fmap[0][:, y.clamp(0, 15), x.clamp(0, 15)]          # (5,1,64,32)
+            acc += (v[:, 0] * (wgt * inside)[0])[None]
+        assert (acc - ref).abs().max() <= 1e-5
