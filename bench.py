@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Headline benchmark: rendered rays/sec of the CoPoNeRF render path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one RealEstate10K-shaped 256x256 stereo pair per GPU, full-image render
+(65 536 query rays), 64 samples per epipolar line, synthetic latents/cameras/weights of the reference's shapes
+(no dataset or checkpoint offline).  A "step" is one full-image render pass (forward with z/rel_pose/flow given,
+val=True, no_grad — the test.py path) with the feature maps already resident in HBM.  Weak scaling: every rank
+renders its own pair; no data-path collective (stereo pairs are independent).
+
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (dominant kernel: the first per-sample
+GEMM, timed with HIP events on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle on a
+bounded sample of the same workload, all host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def f_ray(S: int) -> float:
+    """Algorithmic FLOPs per rendered ray, V = 2."""
+    return S * 10419968.0 + 1053952.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--pairs", type=int, default=1, help="stereo pairs per GPU")
+    ap.add_argument("--chunk-rays", type=int, default=2048)
+    ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the render path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from coponerf_amd import CoPoNeRF, synthetic as syn
+    H, S, B = args.height, args.samples, args.pairs
+    torch.manual_seed(0)
+    model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+    model.load_state_dict(syn.make_render_weights(), strict=False)
+    model = model.to(dev).eval()
+    model._engine.chunk_rays = args.chunk_rays
+
+    def to(o):
+        if torch.is_tensor(o):
+            return o.to(dev)
+        if isinstance(o, dict):
+            return {k: to(v) for k, v in o.items()}
+        return type(o)(to(v) for v in o)
+
+    inp_cpu = syn.make_inputs(B, H, H, 0, seed=100 + rank, full_image=True)
+    z_cpu, rel_cpu, flow_cpu = syn.make_latents(B, H, H, seed=200 + rank)
+    inp, z, rel, flow = to(inp_cpu), to(z_cpu), rel_cpu.to(dev), to(flow_cpu)
+    R = inp["query"]["uv"].shape[2]
+    rays_per_step = B * R
+
+    def step():
+        with torch.no_grad():
+            return model(inp, z=z, rel_pose=rel, val=True, flow=flow)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    model._engine.profile = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, model._engine.profile = model._engine.profile, None
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    value = rays_per_step * world * args.steps / elapsed
+    line = {
+        "metric": "rendered rays/sec (RealEstate10K-shaped 256x256 stereo pair, full-image render, 64 samples/ray)",
+        "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16 (fp16-input/fp32-accumulate MFMA for the per-sample MLPs; f32 decoder; f64 geometry island)",
+        "data": "synthetic",
+        "config": {"workload": f"configs[1]: {H}x{H} stereo pair, full-image render {R} rays x {S} samples, "
+                               f"{B} pair(s) per GPU, render path only (z/rel_pose/flow given, val=True)",
+                   "chunk_rays": args.chunk_rays, "pairs_per_gpu": B},
+        "path_tflops": value * f_ray(S) / 1e12,
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: first encoder GEMM (835 -> 832 + ReLU), 53 % of the path's FLOPs
+        name = "gemm_f16:query_encode_latent"
+        evs = prof.get(name, [])
+        if evs:
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            flops = evs[0][2]
+            avg_ms = sum(ms) / len(ms)
+            achieved = flops / (avg_ms * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel<13> (query_encode_latent 835->832)",
+                                "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": None,
+                                "avg_launch_ms": avg_ms, "launches": len(ms), "flops_per_launch": flops}
+            kern = {}
+            for k, v in prof.items():
+                tot = sum(a.elapsed_time(b) for a, b, _ in v)
+                kern[k] = {"ms_per_step": tot / args.steps, "tflops": sum(f for _, _, f in v) / (tot * 1e-3) / 1e12}
+            line["gemm_breakdown"] = kern
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload, all host cores
+        if args.cpu_rays > 0:
+            from oracle import render_ref as orc
+            cores = os.cpu_count() or 1
+            torch.set_num_threads(cores)
+            n = args.cpu_rays
+            sub = {"context": inp_cpu["context"],
+                   "query": {k: (v[:, :, :n].contiguous() if k in ("uv", "rgb") else v)
+                             for k, v in inp_cpu["query"].items()}}
+            w = syn.make_render_weights()
+            with torch.no_grad():
+                orc.forward({"context": sub["context"], "query": {k: (v[:, :, :64].contiguous() if k in ("uv", "rgb") else v)
+                                                                   for k, v in sub["query"].items()}},
+                            z_cpu, rel_cpu, flow_cpu, True, w, npoints=S)           # warm-up
+                c0 = time.perf_counter()
+                ref = orc.forward(sub, z_cpu, rel_cpu, flow_cpu, True, w, npoints=S)
+                cpu_s = time.perf_counter() - c0
+            line["cpu_baseline"] = {"value": B * n / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port",
+                                    "sample": f"first {n} rays of each pair of the same {H}x{H}x{S} workload, "
+                                              f"oracle/render_ref.py (PyTorch CPU ops), {cpu_s:.1f} s"}
+            err = (out["rgb"][:, :, :n].cpu() - ref["rgb"]).abs()
+            mse = float((err ** 2).mean())
+            line["parity"] = {"rgb_max_abs_vs_oracle": float(err.max()),
+                              "psnr_vs_oracle_db": float(10 * torch.log10(torch.tensor(4.0 / max(mse, 1e-20)))),
+                              "pixel_val_bit_identical": bool(torch.equal(out["pixel_val"][:, :n], ref["pixel_val"]))}
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""ctypes binding of libcoponerf_hip.so (C ABI: include/coponerf_hip.h).
+
+The library is the product's only compute path: if it is missing or a symbol
+is absent this module raises — there is no PyTorch/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcoponerf_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "coponerf_hip.h")
+
+_P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes (every function returns int status except the two noted below)
+SIGNATURES: Dict[str, List] = {
+    "cpn_project_rays": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_sample_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "cpn_nchw_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "cpn_pack_weight_f16": [_P, _I, _I, _P, _I, _P],
+    "cpn_gather_rows": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_gemm_f16": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "cpn_attend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_linear_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
+}
+
+CAM_STRIDE = 96
+CAM_TQ, CAM_M, CAM_AOWN, CAM_AOTH, CAM_KQ, CAM_KC, CAM_KO, CAM_KN = 0, 16, 32, 48, 64, 68, 72, 76
+XIN_K, XIN_STRIDE = 864, 896
+ABI_VERSION = 1
+
+
+def declared_symbols() -> List[str]:
+    """Every function name include/coponerf_hip.h declares."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(cpn_[a-z0-9_]+)\s*\(", text)))
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and type the shared library; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python coponerf_amd/csrc/build.py` "
+            "(or __graft_entry__.build()).  coponerf_amd has no non-HIP compute path.")
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    handle.cpn_abi_version.argtypes = []
+    handle.cpn_abi_version.restype = ctypes.c_int
+    handle.cpn_last_error.argtypes = []
+    handle.cpn_last_error.restype = ctypes.c_char_p
+    got = handle.cpn_abi_version()
+    if got != ABI_VERSION:
+        raise HipLibraryError(f"{LIB_PATH} has ABI version {got}, binding expects {ABI_VERSION}; rebuild it")
+    _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().cpn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")
+
+
+def call(name: str, *args) -> None:
+    """Invoke an entry point; tensors are passed as .data_ptr() integers by the caller."""
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,119 @@
+// K4 — joint softmax over the V*S epipolar samples of one query ray + attention-weighted value sum.
+//
+// Replaces einsum('bijk,bijk->bjk') / 11.31, F.softmax over (n_context * npoints), the broadcast
+// multiply-sum and the sum over views (/root/reference models/CoPoNeRF.py:450-461 and 475-485).
+// The reference has NO alpha compositing: the along-ray reduction is (max, sum-exp, weighted sum), which
+// maps onto wave reductions — with S = 64 each view's sample axis is exactly one 64-lane wavefront.
+//
+// One 256-thread workgroup per query ray: T = V*S rows.
+//   phase 1  logits: 2 lanes per row, 64 fp16 products each (8 x 16-B loads per operand), fp32 accumulate
+//   phase 2  block max / sum-exp through LDS (fp32), weights to LDS
+//   phase 3  z[c] = sum_rows w[row] * value[row][c], c = tid and tid+256 (416 channels), coalesced row reads
+// HBM/L2-bound: per ray 2 x T x 256 B (q operands) + T x 1664 B (values) = 278 KiB at T = 128.
+#include "common.h"
+
+namespace {
+
+constexpr int CH = 416;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attend_kernel(const __half* __restrict__ qa, const __half* __restrict__ qb,
+                                                     const float* __restrict__ value,
+                                                     const float* __restrict__ zprev, int V,
+                                                     int R, int S, int ray0, float* __restrict__ zout,
+                                                     float* __restrict__ at_wt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wts = reinterpret_cast<float*>(smem_raw);          // T weights
+    float* red = wts + V * S;                                 // 8 floats of reduction scratch
+    const int T = V * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long lray = blockIdx.x;                        // ray inside the chunk
+    const size_t row0 = (size_t)lray * T;
+
+    // ---- phase 1: logits (CoPoNeRF.py:450 / :475) — the division by 11.31 is kept a division
+    float lmax = -INFINITY;
+    for (int base = 0; base < T; base += 128) {
+        const int row = base + (tid >> 1);
+        if (row < T) {
+            const int hsel = tid & 1;
+            const half8* pa = reinterpret_cast<const half8*>(qa + (row0 + row) * 128 + hsel * 64);
+            const half8* pb = reinterpret_cast<const half8*>(qb + (row0 + row) * 128 + hsel * 64);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const half8 a = pa[k], b = pb[k];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)b[e];
+            }
+            acc += __shfl_xor(acc, 1);
+            const float logit = acc / 11.31f;
+            if (hsel == 0) wts[row] = logit;
+            lmax = fmaxf(lmax, logit);
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // ---- phase 2: exp / sum
+    float lsum = 0.f;
+    for (int row = tid; row < T; row += 256) {
+        const float e = __expf(wts[row] - gmax);
+        wts[row] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    for (int row = tid; row < T; row += 256) {
+        const float w = wts[row] * inv;
+        wts[row] = w;
+        if (at_wt) {                                           // (N,R,S) layout, n = b*V + v
+            const long long ray = ray0 + lray;
+            const int b = (int)(ray / R), r = (int)(ray % R);
+            const int v = row / S, s = row - v * S;
+            at_wt[(((size_t)(b * V + v)) * R + r) * S + s] = w;
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: weighted value sum, per-view partial sums added view by view (CoPoNeRF.py:456-461)
+    for (int c = tid; c < CH; c += 256) {
+        float total = 0.f;
+        for (int v = 0; v < V; ++v) {
+            float acc = 0.f;
+            const float* vp = value + (row0 + (size_t)v * S) * CH + c;
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) acc += wts[v * S + s] * vp[(size_t)s * CH];
+            if (zprev) acc += zprev[(size_t)lray * CH + c];   // round 2: the round-1 vector sits in every view slot (:481-485)
+            total += acc;
+        }
+        zout[(size_t)lray * CH + c] = total;
+    }
+}
+
+}  // namespace
+
+extern "C" int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const float* zprev,
+                          int B, int V, int R, int S, int ray0, int nrays, float* zout,
+                          float* at_wt, void* stream) {
+    CPN_REQUIRE(qa && qb && value && zout, CPN_E_ARG, "cpn_attend: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && V * S <= 4096, CPN_E_SHAPE, "cpn_attend: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_attend: ray range outside B*R");
+    const size_t lds = (size_t)(V * S + 8) * sizeof(float);
+    hipLaunchKernelGGL(attend_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
+                       (const __half*)qb, value, zprev, V, R, S, ray0, zout, at_wt);
+    CPN_LAUNCH_CHECK("cpn_attend");
+    return 0;
+}

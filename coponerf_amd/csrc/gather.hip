@@ -1,0 +1,225 @@
+// K2 — bilinear multi-scale feature gather into fp16 encoder-input rows, plus the layout /
+// packing helpers and the tiny fp32 first layers of the attention MLPs.
+//
+// Replaces F.grid_sample(..., 'bilinear', 'border' | 'zeros', align_corners=False) x 8 and the
+// torch.cat's around them (/root/reference models/CoPoNeRF.py:312, 370, 384-394).
+//
+// Layout: feature maps are NHWC fp16 so that one bilinear tap of one level is ONE contiguous
+// 512-B (256 ch) or 128-B (64 ch) segment; a thread owns 8 channels (16 B) of one output row, so a
+// wave reads 4 x 1 KiB fully-coalesced segments and writes 1 KiB of the row.  HBM/L2-bound:
+// per output row 4 taps x 832 ch x 2 B = 6.5 KiB read (mostly L2 hits: 44.6 MB fp32 -> 22.3 MB fp16
+// per pair at 256^2, neighbouring samples share texels) and 1.75 KiB written.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// (N,C,h,w) fp32 -> (N,h,w,C) fp16, 32x32 LDS tile transpose over (C, h*w)
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_f16_kernel(const float* __restrict__ src, __half* __restrict__ dst, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;                 // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? src[((size_t)n * C + c) * HW + p] : 0.0f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        if (p < HW && c < C) dst[((size_t)n * HW + p) * C + c] = __float2half(tile[tx][j]);
+    }
+}
+
+__global__ void pack_weight_f16_kernel(const float* __restrict__ src, int n_out, int k_in,
+                                       __half* __restrict__ dst, int ld) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n_out * ld) return;
+    const int k = (int)(idx % ld), n = (int)(idx / ld);
+    dst[idx] = __float2half(k < k_in ? src[(size_t)n * k_in + k] : 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear tap set of one level, exactly ATen's grid_sampler_2d (align_corners=False)
+// ---------------------------------------------------------------------------------------------
+struct Taps {
+    int off[4];      // texel offsets (in texels) of nw, ne, sw, se; clamped into the map
+    float w[4];      // weights; 0 for out-of-map taps (zeros padding)
+};
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int Wl, int Hl, bool border) {
+    float x = ((gx + 1.0f) * (float)Wl - 1.0f) / 2.0f;
+    float y = ((gy + 1.0f) * (float)Hl - 1.0f) / 2.0f;
+    if (border) {
+        x = fminf(fmaxf(x, 0.0f), (float)(Wl - 1));
+        y = fminf(fmaxf(y, 0.0f), (float)(Hl - 1));
+    } else {
+        // |coordinate| can reach 1e10 (geometry.py:390-391): keep the int conversion defined; anything
+        // beyond one texel outside the map has all four taps out of range anyway.
+        x = fminf(fmaxf(x, -2.0f), (float)Wl + 1.0f);
+        y = fminf(fmaxf(y, -2.0f), (float)Hl + 1.0f);
+    }
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float fx = x - xf, fy = y - yf;
+    Taps t;
+    const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int xi = x0 + i, yi = y0 + j;
+            const bool inside = (xi >= 0) && (xi <= Wl - 1) && (yi >= 0) && (yi <= Hl - 1);
+            const int xc = min(max(xi, 0), Wl - 1), yc = min(max(yi, 0), Hl - 1);
+            t.off[j * 2 + i] = yc * Wl + xc;
+            t.w[j * 2 + i] = inside ? wx[i] * wy[j] : 0.0f;
+        }
+    return t;
+}
+
+// 108 16-byte chunks per row: 32 | 32 | 32 (levels 0-2, 256 ch) | 8 (level 3, 64 ch) | 1 (pe) | 3 (zero)
+constexpr int CHUNKS_PER_ROW = CPN_XIN_K / 8;
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(
+    const __half* __restrict__ map0, const __half* __restrict__ map1, const __half* __restrict__ map2,
+    const __half* __restrict__ map3, int H, int W, const float* __restrict__ pixel_val,
+    const float* __restrict__ sec_grid, const float* __restrict__ pe6, int V, int R, int S, int ray0,
+    long long nrows, __half* __restrict__ xin) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = gid / CHUNKS_PER_ROW;
+    const int chunk = (int)(gid - row * CHUNKS_PER_ROW);
+    if (row >= nrows) return;
+    // row = ((ray*V + v)*S + s)*2 + j  within the chunk of rays starting at ray0
+    const int j = (int)(row & 1);
+    long long t = row >> 1;
+    const int s = (int)(t % S); t /= S;
+    const int v = (int)(t % V); t /= V;
+    const long long ray = ray0 + t;
+    const int b = (int)(ray / R), r = (int)(ray % R);
+    const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + s;      // sample index in (N,R,S) arrays
+
+    half8 out;
+    if (chunk < 104) {
+        int lvl, c8;
+        if (chunk < 96) { lvl = chunk >> 5; c8 = chunk & 31; } else { lvl = 3; c8 = chunk - 96; }
+        const int shift = 4 - lvl - (lvl == 3);                       // H/16, H/8, H/4, H
+        const int Hl = H >> shift, Wl = W >> shift;
+        const int C = (lvl == 3) ? 64 : 256;
+        const __half* base = (lvl == 0) ? map0 : (lvl == 1) ? map1 : (lvl == 2) ? map2 : map3;
+        // j = 0: own image at the epipolar sample (border); j = 1: other image at the reprojected point (zeros)
+        const float* g = (j == 0 ? pixel_val : sec_grid) + sidx * 2;
+        const int img = b * V + (j == 0 ? v : (V - 1 - v));
+        const Taps tp = make_taps(g[0], g[1], Wl, Hl, j == 0);
+        const __half* m = base + (size_t)img * Hl * Wl * C + c8 * 8;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const half8 tv = *reinterpret_cast<const half8*>(m + (size_t)tp.off[k] * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)tv[e] * tp.w[k];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = (_Float16)acc[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = (_Float16)0.0f;
+        if (chunk == 104) {
+            const float* pe = pe6 + sidx * 6 + j * 3;
+            out[0] = (_Float16)pe[0]; out[1] = (_Float16)pe[1]; out[2] = (_Float16)pe[2];
+        }
+    }
+    *reinterpret_cast<half8*>(xin + (size_t)row * CPN_XIN_STRIDE + chunk * 8) = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// first (16 -> 128) layer of query_embed / query_repeat_embed in exact fp32, output fp16 rows.
+// thread = (row, group of 8 outputs): 16 threads per row, 16-B coalesced stores.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void local_hidden_kernel(
+    const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w, int ldw,
+    const float* __restrict__ bias, const float* __restrict__ add, int V, int R, int S, int ray0,
+    long long nrows, __half* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = gid >> 4;
+    const int og = (int)(gid & 15);
+    if (row >= nrows) return;
+    long long t = row;
+    const int s = (int)(t % S); t /= S;
+    const int v = (int)(t % V); t /= V;
+    const long long ray = ray0 + t;
+    const int b = (int)(ray / R), r = (int)(ray % R);
+    const size_t nr = ((size_t)(b * V + v)) * R + r;
+    const float* lc = loc8 + (nr * S + s) * 8;
+    const float* c9 = coords9 + nr * 9;
+    // local_coords channel order (CoPoNeRF.py:445): ctx dir 0-2, zeros 3-5, query dir 6-8, depth 9-12, origin 13-15
+    const float L[16] = {lc[0], lc[1], lc[2], 0.f, 0.f, 0.f, c9[0], c9[1], c9[2],
+                         lc[3], lc[4], lc[5], lc[6], c9[6], c9[7], c9[8]};
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int n = og * 8 + e;
+        const float* wr = w + (size_t)n * ldw;
+        float acc = bias[n];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += wr[k] * L[k];
+        if (add) acc += add[(size_t)t * 128 + n];
+        o[e] = (_Float16)fmaxf(acc, 0.0f);
+    }
+    *reinterpret_cast<half8*>(out + (size_t)row * 128 + og * 8) = o;
+}
+
+}  // namespace
+
+extern "C" int cpn_nchw_to_nhwc_f16(const float* src, uint16_t* dst, int N, int C, int h, int w, void* stream) {
+    CPN_REQUIRE(src && dst, CPN_E_ARG, "cpn_nchw_to_nhwc_f16: null pointer");
+    CPN_REQUIRE(N > 0 && C > 0 && h > 0 && w > 0 && N < 65536, CPN_E_SHAPE, "cpn_nchw_to_nhwc_f16: bad shape");
+    const int HW = h * w;
+    dim3 grid(cpn_cdiv(HW, 32), cpn_cdiv(C, 32), N);
+    hipLaunchKernelGGL(nchw_to_nhwc_f16_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, src, (__half*)dst, C, HW);
+    CPN_LAUNCH_CHECK("cpn_nchw_to_nhwc_f16");
+    return 0;
+}
+
+extern "C" int cpn_pack_weight_f16(const float* src, int n_out, int k_in, uint16_t* dst, int ld, void* stream) {
+    CPN_REQUIRE(src && dst, CPN_E_ARG, "cpn_pack_weight_f16: null pointer");
+    CPN_REQUIRE(n_out > 0 && k_in > 0 && ld >= k_in, CPN_E_SHAPE, "cpn_pack_weight_f16: bad shape");
+    const long long total = (long long)n_out * ld;
+    hipLaunchKernelGGL(pack_weight_f16_kernel, dim3(cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, n_out, k_in, (__half*)dst, ld);
+    CPN_LAUNCH_CHECK("cpn_pack_weight_f16");
+    return 0;
+}
+
+extern "C" int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const uint16_t* map2,
+                               const uint16_t* map3, int H, int W, const float* pixel_val, const float* sec_grid,
+                               const float* pe6, int B, int V, int R, int S, int ray0, int nrays, uint16_t* xin,
+                               void* stream) {
+    CPN_REQUIRE(map0 && map1 && map2 && map3 && pixel_val && sec_grid && pe6 && xin, CPN_E_ARG,
+                "cpn_gather_rows: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && W >= 16 && (H % 16) == 0 && (W % 16) == 0,
+                CPN_E_SHAPE, "cpn_gather_rows: need V==2 and H,W multiples of 16 (got H=%d W=%d V=%d)", H, W, V);
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_gather_rows: ray range [%d,%d) outside B*R=%lld", ray0, ray0 + nrays, (long long)B * R);
+    const long long nrows = (long long)nrays * V * S * 2;
+    const long long total = nrows * CHUNKS_PER_ROW;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __half*)map0, (const __half*)map1, (const __half*)map2, (const __half*)map3, H, W,
+                       pixel_val, sec_grid, pe6, V, R, S, ray0, nrows, (__half*)xin);
+    CPN_LAUNCH_CHECK("cpn_gather_rows");
+    return 0;
+}
+
+extern "C" int cpn_local_hidden(const float* loc8, const float* coords9, const float* w, int ldw, const float* bias,
+                                const float* add, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out,
+                                void* stream) {
+    CPN_REQUIRE(loc8 && coords9 && w && bias && out, CPN_E_ARG, "cpn_local_hidden: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && ldw >= 16, CPN_E_SHAPE, "cpn_local_hidden: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_local_hidden: ray range outside B*R");
+    const long long nrows = (long long)nrays * V * S;
+    hipLaunchKernelGGL(local_hidden_kernel, dim3(cpn_cdiv(nrows * 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                       loc8, coords9, w, ldw, bias, add, V, R, S, ray0, nrows, (__half*)out);
+    CPN_LAUNCH_CHECK("cpn_local_hidden");
+    return 0;
+}

@@ -1,0 +1,91 @@
+// K5 — exact-fp32 per-ray linear layers on the f32 MFMA (v_mfma_f32_16x16x4_f32, an fmaf chain bit for bit).
+//
+// Replaces nn.Conv1d encode_latent (/root/reference models/CoPoNeRF.py:468) and the light-field decoder
+// lightfield.ResnetFC / ResnetBlockFC (/root/reference models/lightfield.py:52-61, 131-167): per QUERY RAY
+// (not per sample) 850 -> 128 -> ... -> 3, 0.13 % of the path's FLOPs — kept in fp32 because its output is the
+// rendered colour itself.
+//
+//   Y = act_out( act_in(X) . W^T + bias + res )      X (M,K)  W (N,K)  N <= 128, K % 16 == 0
+//
+// One wave = 16 rows x (16*NT) columns; operands swapped (A = W rows, B = X rows) so a lane holds 4 consecutive
+// output columns of one row -> float4 stores.  Operands are read straight from L2 in the fragment layout as
+// float4 (lane: row l&15, k = kb + 4*(l>>4) + e); the e-th element of every lane forms one k4 MFMA step, which
+// is a fixed permutation of k shared by both operands.  No LDS: the weights (<= 213 KB) are L2-resident and the
+// activations are read once.  Bound: L2 bandwidth on the W re-reads, irrelevant at 0.84 MFLOP per ray.
+#include "common.h"
+
+namespace {
+
+template <int NT>
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ X, int ldx,
+                                                         const float* __restrict__ W, int ldw,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ res, int ldr,
+                                                         float* __restrict__ Y, int ldy, int M, int N, int K,
+                                                         int relu_in, int relu_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (blockIdx.x * 4 + wave) * 16;
+    if (m0 >= M) return;
+    const int fi = lane & 15, fg = lane >> 4;
+    int xr = m0 + fi;
+    xr = xr < M ? xr : M - 1;
+    const float* xp = X + (size_t)xr * ldx + fg * 4;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < K; kb += 16) {
+        f32x4 xv = *reinterpret_cast<const f32x4*>(xp + kb);
+        if (relu_in) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = fmaxf(xv[e], 0.0f);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = t * 16 + fi;
+            f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < N) wv = *reinterpret_cast<const f32x4*>(W + (size_t)n * ldw + kb + fg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], xv[e], acc[t], 0, 0, 0);
+        }
+    }
+    const int m = m0 + fi;
+    if (m >= M) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = t * 16 + fg * 4 + i;
+            if (n >= N) continue;
+            float v = acc[t][i];
+            if (bias) v += bias[n];
+            if (res) v += res[(size_t)m * ldr + n];
+            if (relu_out) v = fmaxf(v, 0.0f);
+            Y[(size_t)m * ldy + n] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cpn_linear_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* res,
+                              int ldr, float* Y, int ldy, int M, int N, int K, int relu_in, int relu_out,
+                              void* stream) {
+    CPN_REQUIRE(X && W && Y, CPN_E_ARG, "cpn_linear_f32: null pointer");
+    CPN_REQUIRE(M > 0 && N > 0 && N <= 128 && K > 0 && (K % 16) == 0, CPN_E_SHAPE,
+                "cpn_linear_f32: need N<=128 and K%%16==0 (got N=%d K=%d)", N, K);
+    CPN_REQUIRE(ldx >= K && ldw >= K && (ldx % 4) == 0 && (ldw % 4) == 0 && ldy >= N && (!res || ldr >= N),
+                CPN_E_SHAPE, "cpn_linear_f32: bad leading dimensions");
+    CPN_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0, CPN_E_ARG, "cpn_linear_f32: X/W must be 16-B aligned");
+    const hipStream_t s = (hipStream_t)stream;
+    dim3 grid(cpn_cdiv(M, 64)), block(256);
+    if (N <= 16)
+        hipLaunchKernelGGL(linear_f32_kernel<1>, grid, block, 0, s, X, ldx, W, ldw, bias, res, ldr, Y, ldy, M, N, K,
+                           relu_in, relu_out);
+    else
+        hipLaunchKernelGGL(linear_f32_kernel<8>, grid, block, 0, s, X, ldx, W, ldw, bias, res, ldr, Y, ldy, M, N, K,
+                           relu_in, relu_out);
+    CPN_LAUNCH_CHECK("cpn_linear_f32");
+    return 0;
+}

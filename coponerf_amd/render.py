@@ -1,0 +1,295 @@
+"""Host side of the MI355X render path: drives libcoponerf_hip.so kernel by kernel.
+
+Mirrors the body of the reference's CoPoNeRF.forward (/root/reference models/CoPoNeRF.py:208-576):
+pose algebra (4x4, on the host) -> K1 ray projection -> K1b per-sample geometry -> K2 gathers ->
+K3 per-sample GEMMs -> K4 two rounds of joint-softmax attention -> K5 light-field decoder -> masking.
+PyTorch is used for device memory, the current HIP stream and a handful of O(B) 4x4 operations only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _hip
+from ._hip import call
+
+V = 2  # context views; the kernels are specialised for stereo pairs like the reference's released model
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ----------------------------------------------------------------------------------------------
+# (a1) pose algebra on the host — O(B) 4x4 matrices, float32, LAPACK: deterministic and identical to
+# what the CPU oracle computes, so everything downstream can be compared bit for bit.
+# ----------------------------------------------------------------------------------------------
+def _rigid_inverse(m: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros_like(m)
+    rt = m[..., :3, :3].transpose(-1, -2)
+    out[..., :3, :3] = rt
+    out[..., :3, 3] = (-(rt @ m[..., :3, 3:]))[..., 0]
+    out[..., 3, 3] = 1
+    return out
+
+
+def build_camera_block(ctx_c2w: torch.Tensor, ctx_K: torch.Tensor, qry_c2w: torch.Tensor, qry_K: torch.Tensor,
+                       rel_pose: Optional[torch.Tensor], val: bool, H: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CPU tensors in, (cam (B*V, CAM_STRIDE) float32 CPU, Tq (B,V,4,4) CPU) out.
+
+    CoPoNeRF.py:239-244 (query pose in each context frame), :325-332 (context-to-context poses),
+    :259-261 (normalised intrinsics: rows 0,1 divided by H)."""
+    B = ctx_c2w.shape[0]
+    inv_ctx = torch.inverse(ctx_c2w)
+    M = inv_ctx @ ctx_c2w
+    if val:
+        q0 = inv_ctx[:, 0].unsqueeze(1) @ qry_c2w
+        q1 = _rigid_inverse(rel_pose).unsqueeze(1) @ q0
+        Tq = torch.cat((q0, q1), dim=1)
+        A1 = torch.cat((torch.inverse(ctx_c2w[:, 0:1]) @ ctx_c2w[:, 0].unsqueeze(1), rel_pose.unsqueeze(1)), dim=1)
+        A2 = torch.cat((_rigid_inverse(rel_pose).unsqueeze(1),
+                        torch.inverse(ctx_c2w[:, 1:2]) @ ctx_c2w[:, -1].unsqueeze(1)), dim=1)
+    else:
+        Tq = inv_ctx @ qry_c2w
+        A1 = torch.inverse(ctx_c2w[:, 0:1]) @ ctx_c2w
+        A2 = torch.inverse(ctx_c2w[:, 1:2]) @ ctx_c2w
+    Kn = ctx_K[:, :, :3, :3].clone()
+    Kn[:, :, :2, :] = Kn[:, :, :2, :] / H
+    cam = torch.zeros(B, V, _hip.CAM_STRIDE, dtype=torch.float32)
+    cam[:, :, _hip.CAM_TQ:_hip.CAM_TQ + 16] = Tq.reshape(B, V, 16)
+    cam[:, :, _hip.CAM_M:_hip.CAM_M + 16] = M.reshape(B, V, 16)
+    # own-frame / other-frame transforms of each view's points: view 0 -> (A1[0], A2[0]), view 1 -> (A2[1], A1[1])
+    cam[:, 0, _hip.CAM_AOWN:_hip.CAM_AOWN + 16] = A1[:, 0].reshape(B, 16)
+    cam[:, 0, _hip.CAM_AOTH:_hip.CAM_AOTH + 16] = A2[:, 0].reshape(B, 16)
+    cam[:, 1, _hip.CAM_AOWN:_hip.CAM_AOWN + 16] = A2[:, 1].reshape(B, 16)
+    cam[:, 1, _hip.CAM_AOTH:_hip.CAM_AOTH + 16] = A1[:, 1].reshape(B, 16)
+
+    def k4(K):  # fx fy cx cy
+        return torch.stack((K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2]), -1)
+
+    cam[:, :, _hip.CAM_KQ:_hip.CAM_KQ + 4] = k4(qry_K[:, 0])[:, None, :]
+    kc = k4(ctx_K)
+    cam[:, :, _hip.CAM_KC:_hip.CAM_KC + 4] = kc
+    cam[:, 0, _hip.CAM_KO:_hip.CAM_KO + 4] = kc[:, 1]
+    cam[:, 1, _hip.CAM_KO:_hip.CAM_KO + 4] = kc[:, 0]
+    cam[:, :, _hip.CAM_KN:_hip.CAM_KN + 9] = Kn.reshape(B, V, 9)
+    return cam.reshape(B * V, _hip.CAM_STRIDE), Tq
+
+
+# ----------------------------------------------------------------------------------------------
+class RenderEngine:
+    """Owns the device-side caches (packed fp16 weights, NHWC fp16 feature maps, workspace) of one model."""
+
+    # per-sample 1x1 convs that run on the fp16 MFMA GEMM: name -> (N_out, K_in, packed leading dimension)
+    GEMM_WEIGHTS = {
+        "query_encode_latent": (832, 835, _hip.XIN_STRIDE),
+        "query_encode_latent_2": (416, 832, 832),
+        "latent_value": (416, 832, 832),
+        "key_map": (128, 832, 832),
+        "key_map_2": (128, 128, 128),
+        "query_embed_2": (128, 128, 128),
+        "query_repeat_embed_2": (128, 128, 128),
+    }
+
+    def __init__(self, chunk_rays: int = 2048):
+        self.chunk_rays = int(chunk_rays)
+        self._wkey = None
+        self._w: Dict[str, torch.Tensor] = {}
+        self._mkey = None
+        self._maps: List[torch.Tensor] = []
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._interval: Dict[Tuple[int, str], torch.Tensor] = {}
+        # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops)
+        self.profile: Optional[Dict[str, list]] = None
+
+    # ---- caches --------------------------------------------------------------------------------
+    def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
+        n = int(math.prod(shape))
+        t = self._ws.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype or t.device != device:
+            t = torch.empty(n, dtype=dtype, device=device)
+            self._ws[name] = t
+        return t[:n].view(*shape)
+
+    def _weights(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        key = tuple((k, p.data_ptr(), p._version) for k, p in sorted(params.items()))
+        if key == self._wkey:
+            return self._w
+        dev = params["query_encode_latent.weight"].device
+        w: Dict[str, torch.Tensor] = {}
+        s = _stream()
+        for name, (n_out, k_in, ld) in self.GEMM_WEIGHTS.items():
+            src = params[name + ".weight"].detach().reshape(n_out, k_in).contiguous().float()
+            dst = torch.empty(n_out, ld, dtype=torch.float16, device=dev)
+            call("cpn_pack_weight_f16", src.data_ptr(), n_out, k_in, dst.data_ptr(), ld, s)
+            w[name + ".w16"] = dst
+            w[name + ".b"] = params[name + ".bias"].detach().float().contiguous()
+        f32 = lambda n: params[n].detach().float().contiguous()
+        w["query_embed.w"] = f32("query_embed.weight").reshape(128, 16)
+        w["query_embed.b"] = f32("query_embed.bias")
+        wr = f32("query_repeat_embed.weight").reshape(128, 144)
+        w["query_repeat_embed.w_z"] = wr[:, :128].contiguous()           # acts on encode_latent(z_local)
+        w["query_repeat_embed.w_l"] = wr[:, 128:].contiguous()           # acts on local_coords (16)
+        w["query_repeat_embed.b"] = f32("query_repeat_embed.bias")
+        w["encode_latent.w"] = f32("encode_latent.weight").reshape(128, 416)
+        w["encode_latent.b"] = f32("encode_latent.bias")
+        lin_in = torch.zeros(128, 32, dtype=torch.float32, device=dev)   # K padded 18 -> 32
+        lin_in[:, :18] = f32("phi.lin_in.weight")
+        w["phi.lin_in.w"], w["phi.lin_in.b"] = lin_in, f32("phi.lin_in.bias")
+        for k in range(3):
+            wz = f32(f"phi.lin_z.{k}.weight")
+            # phi sees [z_local ; z_local] (CoPoNeRF.py:547-554): fold the two 416-column halves
+            w[f"phi.lin_z.{k}.w"] = (wz[:, :416] + wz[:, 416:]).contiguous()
+            w[f"phi.lin_z.{k}.b"] = f32(f"phi.lin_z.{k}.bias")
+            for fc in ("fc_0", "fc_1"):
+                w[f"phi.blocks.{k}.{fc}.w"] = f32(f"phi.blocks.{k}.{fc}.weight")
+                w[f"phi.blocks.{k}.{fc}.b"] = f32(f"phi.blocks.{k}.{fc}.bias")
+        w["phi.lin_out.w"], w["phi.lin_out.b"] = f32("phi.lin_out.weight"), f32("phi.lin_out.bias")
+        self._w, self._wkey = w, key
+        return w
+
+    def _feature_maps(self, z: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in z)
+        if key == self._mkey:
+            return self._maps
+        maps, s = [], _stream()
+        for t in z:
+            src = t.detach().float().contiguous()
+            n, c, h, w_ = src.shape
+            dst = torch.empty(n, h, w_, c, dtype=torch.float16, device=src.device)
+            call("cpn_nchw_to_nhwc_f16", src.data_ptr(), dst.data_ptr(), n, c, h, w_, s)
+            maps.append(dst)
+        self._maps, self._mkey = maps, key
+        return maps
+
+    # ---- the render pass -------------------------------------------------------------------------
+    @torch.no_grad()
+    def render(self, params: Dict[str, torch.Tensor], ctx_c2w, ctx_K, qry_c2w, qry_K, uv, z: Sequence[torch.Tensor],
+               rel_pose, val: bool, S: int, H: int, W: int) -> Dict[str, torch.Tensor]:
+        """uv (B,1,R,2) on the device; 4x4 inputs on any device.  Returns device tensors:
+        rgb (B,1,R,3), valid_mask (B,R,1), pixel_val (N,R,S,2), pt (N,R,S,3), at_wt (N,R,S),
+        coords (N,R,9), z_local (B*R,416), Tq (B,V,4,4) (device copy of the host pose algebra)."""
+        dev = uv.device
+        if dev.type != "cuda":
+            raise RuntimeError("coponerf_amd renders on a HIP device only (got uv on %s)" % dev)
+        B, _, R, _ = uv.shape
+        if z[0].shape[0] != B * V or len(z) != 4:
+            raise ValueError("expected 4 latent maps with a leading dimension of B*2")
+        N = B * V
+        s = _stream()
+        w = self._weights(params)
+        maps = self._feature_maps(z)
+
+        cam_cpu, Tq_cpu = build_camera_block(ctx_c2w.detach().float().cpu(), ctx_K.detach().float().cpu(),
+                                             qry_c2w.detach().float().cpu(), qry_K.detach().float().cpu(),
+                                             None if rel_pose is None else rel_pose.detach().float().cpu(), val, H)
+        cam = cam_cpu.to(dev)
+        ikey = (S, str(dev))
+        if ikey not in self._interval:
+            self._interval[ikey] = torch.linspace(0, 1, S).to(dev)       # CPU linspace, as the oracle's
+        interval = self._interval[ikey]
+        uvc = uv.detach().float().reshape(B, R, 2).contiguous()
+
+        f32, f16 = torch.float32, torch.float16
+        coords9 = torch.empty(N, R, 9, dtype=f32, device=dev)
+        seg = self._buf("seg", (N, R, 4), f32, dev)
+        overlaps = self._buf("overlaps", (N, R), torch.uint8, dev)
+        pixel_val = torch.empty(N, R, S, 2, dtype=f32, device=dev)
+        pt = torch.empty(N, R, S, 3, dtype=f32, device=dev)
+        at_wt = torch.empty(N, R, S, dtype=f32, device=dev)
+        sec_grid = self._buf("sec_grid", (N, R, S, 2), f32, dev)
+        pe6 = self._buf("pe6", (N, R, S, 6), f32, dev)
+        loc8 = self._buf("loc8", (N, R, S, 8), f32, dev)
+        call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), B, V, R, coords9.data_ptr(), seg.data_ptr(),
+             overlaps.data_ptr(), s)
+        call("cpn_sample_geometry", cam.data_ptr(), coords9.data_ptr(), seg.data_ptr(), interval.data_ptr(),
+             B, V, R, S, H, W, pixel_val.data_ptr(), pt.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(),
+             loc8.data_ptr(), s)
+
+        nray_total = B * R
+        zl = torch.empty(nray_total, 416, dtype=f32, device=dev)
+        C = min(self.chunk_rays, nray_total)
+        T = V * S                       # rows per ray for the attention stage
+        xin = self._buf("xin", (C * T * 2, _hip.XIN_STRIDE), f16, dev)
+        hid = self._buf("hid", (C * T * 2, 832), f16, dev)
+        enc = self._buf("enc", (C * T, 832), f16, dev)
+        value = self._buf("value", (C * T, 416), f32, dev)
+        kh = self._buf("kh", (C * T, 128), f16, dev)
+        key2 = self._buf("key2", (C * T, 128), f16, dev)
+        hq = self._buf("hq", (C * T, 128), f16, dev)
+        ce = self._buf("ce", (C * T, 128), f16, dev)
+        q2 = self._buf("q2", (C * T, 128), f16, dev)
+        z1 = self._buf("z1", (C, 416), f32, dev)
+        ze = self._buf("ze", (C, 128), f32, dev)
+        addq = self._buf("addq", (C, 128), f32, dev)
+
+        def gemm(a, lda, wname, out, ldc, m, n, k, relu, out_f32):
+            prof = self.profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            call("cpn_gemm_f16", a.data_ptr(), lda, w[wname + ".w16"].data_ptr(), w[wname + ".w16"].shape[1],
+                 w[wname + ".b"].data_ptr(), out.data_ptr(), ldc, m, n, k, int(relu), int(out_f32), s)
+            if prof is not None:
+                e1.record()
+                k_alg = self.GEMM_WEIGHTS[wname][1]                    # unpadded K: algorithmic FLOPs
+                prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * k_alg))
+
+        for ray0 in range(0, nray_total, C):
+            n = min(C, nray_total - ray0)
+            rows, rows2 = n * T, n * T * 2
+            call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
+                 H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, ray0, n,
+                 xin.data_ptr(), s)
+            gemm(xin, _hip.XIN_STRIDE, "query_encode_latent", hid, 832, rows2, 832, _hip.XIN_K, True, False)
+            gemm(hid, 832, "query_encode_latent_2", enc, 416, rows2, 416, 832, False, False)   # (rows2,416)=(rows,832)
+            gemm(enc, 832, "latent_value", value, 416, rows, 416, 832, False, True)
+            gemm(enc, 832, "key_map", kh, 128, rows, 128, 832, True, False)
+            gemm(kh, 128, "key_map_2", key2, 128, rows, 128, 128, False, False)
+            call("cpn_local_hidden", loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
+                 w["query_embed.b"].data_ptr(), 0, B, V, R, S, ray0, n, hq.data_ptr(), s)
+            gemm(hq, 128, "query_embed_2", ce, 128, rows, 128, 128, False, False)
+            # round 1 (CoPoNeRF.py:450-461)
+            call("cpn_attend", key2.data_ptr(), ce.data_ptr(), value.data_ptr(), 0, B, V, R, S, ray0, n,
+                 z1.data_ptr(), at_wt.data_ptr(), s)
+            # round 2 (CoPoNeRF.py:467-485)
+            call("cpn_linear_f32", z1.data_ptr(), 416, w["encode_latent.w"].data_ptr(), 416,
+                 w["encode_latent.b"].data_ptr(), 0, 0, ze.data_ptr(), 128, n, 128, 416, 0, 0, s)
+            call("cpn_linear_f32", ze.data_ptr(), 128, w["query_repeat_embed.w_z"].data_ptr(), 128, 0, 0, 0,
+                 addq.data_ptr(), 128, n, 128, 128, 0, 0, s)
+            call("cpn_local_hidden", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
+                 w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), B, V, R, S, ray0, n, hq.data_ptr(), s)
+            gemm(hq, 128, "query_repeat_embed_2", q2, 128, rows, 128, 128, False, False)
+            call("cpn_attend", q2.data_ptr(), ce.data_ptr(), value.data_ptr(), z1.data_ptr(), B, V, R, S, ray0, n,
+                 zl[ray0:ray0 + n].data_ptr(), 0, s)
+
+        # ---- light-field decoder phi over all rays (lightfield.py:131-167), exact fp32
+        c18 = torch.zeros(nray_total, 32, dtype=f32, device=dev)
+        c18[:, :18] = coords9.view(B, V, R, 9).permute(0, 2, 1, 3).reshape(nray_total, 18)
+        x = self._buf("phi_x", (nray_total, 128), f32, dev)
+        net = self._buf("phi_net", (nray_total, 128), f32, dev)
+        rgb_raw = self._buf("rgb_raw", (nray_total, 4), f32, dev)
+
+        def lin(X, ldx, wn, Y, ldy, n_out, k, res=None, relu_in=0):
+            call("cpn_linear_f32", X.data_ptr(), ldx, w[wn + ".w"].data_ptr(), w[wn + ".w"].shape[1],
+                 w[wn + ".b"].data_ptr(), _ptr(res), ldy if res is not None else 0, Y.data_ptr(), ldy,
+                 nray_total, n_out, k, relu_in, 0, s)
+
+        lin(c18, 32, "phi.lin_in", x, 128, 128, 32)
+        for k in range(3):
+            lin(zl, 416, f"phi.lin_z.{k}", x, 128, 128, 416, res=x)
+            lin(x, 128, f"phi.blocks.{k}.fc_0", net, 128, 128, 128, relu_in=1)
+            lin(net, 128, f"phi.blocks.{k}.fc_1", x, 128, 128, 128, res=x, relu_in=1)
+        lin(x, 128, "phi.lin_out", rgb_raw, 4, 3, 128, relu_in=1)
+        rgb = torch.empty(B, 1, R, 3, dtype=f32, device=dev)
+        valid = torch.empty(B, R, 1, dtype=f32, device=dev)
+        call("cpn_mask_rgb", rgb_raw.data_ptr(), 4, overlaps.data_ptr(), B, V, R, rgb.data_ptr(), valid.data_ptr(), s)
+        return {"rgb": rgb, "valid_mask": valid, "pixel_val": pixel_val, "pt": pt, "at_wt": at_wt,
+                "coords": coords9, "z_local": zl, "Tq": Tq_cpu.to(dev), "sec_grid": sec_grid.clone(),
+                "rgb_raw": rgb_raw[:, :3].clone()}

@@ -1,0 +1,128 @@
+/* coponerf_hip.h — C ABI of libcoponerf_hip.so (gfx950 / MI355X).
+ *
+ * The upstream reference (cvlab-kaist/CoPoNeRF) has no FFI: its hot path is a
+ * chain of ATen calls inside models/CoPoNeRF.py:208-576.  Each entry point
+ * below replaces one group of those calls; the Python class
+ * coponerf_amd.CoPoNeRF.CoPoNeRF (same constructor / get_z / forward contract
+ * as models/CoPoNeRF.py:19-576) binds them through ctypes (coponerf_amd/_hip.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; nothing is
+ *     allocated or freed by the library; outputs are caller-allocated.
+ *   - return value: 0 = ok, otherwise a negative argument error (CPN_E_*) or a
+ *     positive hipError_t; cpn_last_error() gives a message.  Never throws.
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream).
+ *   - fp16 buffers are IEEE binary16 ("half"), declared as uint16_t here.
+ *   - N = B*V camera slots, ordered n = b*V + v  (V == 2).
+ *   - "sample arrays" are (N,R,S,·) ; "row arrays" feed the GEMMs and are ordered
+ *       row = (((b*R + r)*V + v)*S + s)*J + j        J = 2 encoder inputs per sample
+ *     so that all V*S*J rows of one query ray are contiguous.
+ */
+#ifndef COPONERF_HIP_H
+#define COPONERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPN_ABI_VERSION 1
+
+#define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
+#define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
+
+/* camera block: CPN_CAM_STRIDE floats per (b,v), built on the host from 4x4 matrices */
+#define CPN_CAM_STRIDE 96
+#define CPN_CAM_TQ    0    /* 16: query camera -> frame of context view v   (CoPoNeRF.py:241-244) */
+#define CPN_CAM_M     16   /* 16: inv(c2w_v) @ c2w_v, ~identity             (CoPoNeRF.py:239)     */
+#define CPN_CAM_AOWN  32   /* 16: view-v frame -> view-v frame              (CoPoNeRF.py:326-332) */
+#define CPN_CAM_AOTH  48   /* 16: view-v frame -> frame of the other view                          */
+#define CPN_CAM_KQ    64   /* fx fy cx cy of the query camera, pixel units                         */
+#define CPN_CAM_KC    68   /* fx fy cx cy of context view v                                        */
+#define CPN_CAM_KO    72   /* fx fy cx cy of the other context view                                */
+#define CPN_CAM_KN    76   /* 9: K_v[:3,:3] with rows 0,1 divided by H      (CoPoNeRF.py:259-261) */
+
+/* padded K of the first encoder layer: 835 inputs -> 864 consumed (27 x 32), row stride 896 halves */
+#define CPN_XIN_K      864
+#define CPN_XIN_STRIDE 896
+
+int         cpn_abi_version(void);
+const char* cpn_last_error(void);
+
+/* ---- K1: query rays -> Pluecker coords + clipped epipolar segment ------------------------------
+ * replaces geometry.plucker_embedding (utils_training/geometry.py:236-245, :426-433, :409-419, :353-371),
+ * epipolar.project_rays (models/epipolar.py:175-253) and the start/end scrub (models/CoPoNeRF.py:279-291).
+ *   cam     (N, CPN_CAM_STRIDE)        uv (B,R,2) pixels (x = column, y = row)
+ *   coords9 (N,R,9)  = dir3 | moment3 | origin3
+ *   seg     (N,R,4)  = start.xy | end.xy in [-1,1], NaN/Inf -> 0
+ *   overlaps(N,R)    uint8 0/1                                                                   */
+int cpn_project_rays(const float* cam, const float* uv, int B, int V, int R,
+                     float* coords9, float* seg, uint8_t* overlaps, void* stream);
+
+/* ---- K1b: per-sample geometry -------------------------------------------------------------------
+ * replaces sample generation (CoPoNeRF.py:294-309), geometry.get_3d_point_epipolar / get_intersection
+ * (geometry.py:98-162, float64 inside), utils.encode_relative_point (utils.py:99-108), geometry.project +
+ * utils.normalize_for_grid_sample (geometry.py:374-393, utils.py:242-245), geometry.get_ray_directions_cam
+ * (geometry.py:313-324) and the depth encoding (CoPoNeRF.py:428-445).
+ *   interval (S) = linspace(0,1,S) as the host computes it
+ *   pixel_val (N,R,S,2)   pt (N,R,S,3)   sec_grid (N,R,S,2): coords of this sample's 3-D point in the OTHER image
+ *   pe6 (N,R,S,6) = tanh(nan_to_num(pt_own)/5) | tanh(nan_to_num(pt_other)/5)
+ *   loc8 (N,R,S,8) = context-pixel ray dir 3 | tanh(depth*{1,.1,.01,.001}) 4 | 0                                */
+int cpn_sample_geometry(const float* cam, const float* coords9, const float* seg, const float* interval,
+                        int B, int V, int R, int S, int H, int W,
+                        float* pixel_val, float* pt, float* sec_grid, float* pe6, float* loc8, void* stream);
+
+/* ---- layout: (N,C,h,w) fp32 -> (N,h,w,C) fp16 feature map (once per get_z) --------------------- */
+int cpn_nchw_to_nhwc_f16(const float* src, uint16_t* dst, int N, int C, int h, int w, void* stream);
+
+/* ---- pack a (N_out, K_in) fp32 weight into fp16 [N_out][ld] with zero padding (once per weight version) */
+int cpn_pack_weight_f16(const float* src, int n_out, int k_in, uint16_t* dst, int ld, void* stream);
+
+/* ---- K2: bilinear gathers -> encoder input rows ---------------------------------------------------
+ * replaces F.grid_sample x4 'border' (CoPoNeRF.py:312), x4 'zeros' (CoPoNeRF.py:370) and the concatenations
+ * (CoPoNeRF.py:384-394).  maps[l] are NHWC fp16, l = 0..3 with sizes (H/16, H/8, H/4, H) and 256,256,256,64 ch.
+ * The rows of query rays [ray0, ray0+nrays) (ray = b*R + r) are written to xin (nrays*V*S*2, CPN_XIN_STRIDE) fp16:
+ *   cols 0..831 features, 832..834 tanh(pt/5), 835..863 zero.                                                   */
+int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const uint16_t* map2, const uint16_t* map3,
+                    int H, int W, const float* pixel_val, const float* sec_grid, const float* pe6,
+                    int B, int V, int R, int S, int ray0, int nrays, uint16_t* xin, void* stream);
+
+/* ---- small fp32 first layers feeding the attention MLPs --------------------------------------------
+ * out[row, 0:128] = fp16( relu( W[:, 0:16] . L(row) + bias + add[ray, 0:128] ) ),  rows = (b,r,v,s), ray = (b,r)
+ * with L = [loc8 dir 3 | 0 0 0 | query dir 3 | loc8 depth 4 | query origin 3]      (CoPoNeRF.py:445)
+ * query_embed (CoPoNeRF.py:446): w = query_embed.weight (128,16), add = NULL
+ * query_repeat_embed (CoPoNeRF.py:472-473): w = weight[:, 128:144] (ld 144), add = weight[:, :128] . z_embed + 0 */
+int cpn_local_hidden(const float* loc8, const float* coords9, const float* w, int ldw, const float* bias,
+                     const float* add, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out, void* stream);
+
+/* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
+ * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).
+ *   A (M, lda) fp16, W (N, ldw) fp16 (both K-contiguous), bias (N) fp32, K multiple of 32, N multiple of 16*tile
+ *   out_f32 = 0: C fp16 (M, ldc) ; 1: C fp32 (M, ldc)                                                           */
+int cpn_gemm_f16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                 void* C, int ldc, int M, int N, int K, int relu, int out_f32, void* stream);
+
+/* ---- K4: joint softmax over (V*S) + weighted value sum, one query ray per workgroup ---------------
+ * replaces einsum / softmax / broadcast-mul-sum (CoPoNeRF.py:450-461, 475-485).
+ *   qa, qb (rays*V*S, 128) fp16: logit = <qa,qb> / 11.31 ; value (rays*V*S, 416) fp32
+ *   zprev (rays,416) or NULL: added once PER VIEW before the views are summed, i.e. zout = sum_w value + V*zprev
+ *     (the reference leaves the round-1 vector in both view slots, CoPoNeRF.py:481-485)
+ *   at_wt (N,R,S) or NULL: softmax weights scattered to the (b,v,r,s) layout                                     */
+int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const float* zprev,
+               int B, int V, int R, int S, int ray0, int nrays, float* zout, float* at_wt, void* stream);
+
+/* ---- K5: exact-fp32 per-ray linear layer (MFMA 16x16x4 f32)  Y = act_out( act_in(X) . W^T + bias + res ) --
+ * replaces nn.Conv1d encode_latent (CoPoNeRF.py:468) and lightfield.ResnetFC (models/lightfield.py:131-167).
+ *   X (M, ldx), W (N, ldw), bias (N) or NULL, res (M, ldr) or NULL, Y (M, ldy); N <= 128; K multiple of 4      */
+int cpn_linear_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* res, int ldr,
+                   float* Y, int ldy, int M, int N, int K, int relu_in, int relu_out, void* stream);
+
+/* ---- output masking: rgb = rgb*valid + (1-valid), valid = any_v overlaps (CoPoNeRF.py:562-566) ------ */
+int cpn_mask_rgb(const float* rgb_raw, int ld, const uint8_t* overlaps, int B, int V, int R,
+                 float* rgb, float* valid, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COPONERF_HIP_H */

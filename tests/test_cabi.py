@@ -1,0 +1,46 @@
+"""The C-ABI library loads and exports every symbol include/coponerf_hip.h declares (no compute: no GPU here)."""
+import os
+
+import pytest
+
+from coponerf_amd import _hip
+
+
+def test_library_is_built_and_exports_header_symbols():
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _hip.lib()
+    declared = _hip.declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/coponerf_hip.h but not exported"
+    assert set(_hip.SIGNATURES) | {"cpn_abi_version", "cpn_last_error"} == set(declared)
+    assert lib.cpn_abi_version() == _hip.ABI_VERSION
+
+
+def test_argument_errors_are_status_codes_not_crashes():
+    lib = _hip.lib()
+    # null pointers are rejected before any launch (works without a GPU)
+    assert lib.cpn_project_rays(None, None, 1, 2, 4, None, None, None, None) == -1
+    assert b"null" in lib.cpn_last_error()
+    with pytest.raises(RuntimeError, match="cpn_gemm_f16"):
+        _hip.call("cpn_gemm_f16", 16, 8, 16, 8, 16, 16, 8, 4, 100, 30, 0, 0, None)   # K not a multiple of 32
+
+
+def test_missing_library_raises(monkeypatch):
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libcoponerf_hip.so")
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.lib()
+
+
+def test_model_has_reference_parameter_names():
+    """state_dict keys/shapes of the render path = SURVEY.md Appendix C.1 (checkpoint contract)."""
+    from coponerf_amd import CoPoNeRF, synthetic as syn
+    m = CoPoNeRF.CoPoNeRF(n_view=2)
+    sd = m.state_dict()
+    for name, shape in syn.RENDER_PARAM_SHAPES.items():
+        assert name in sd and tuple(sd[name].shape) == shape, name
+    assert tuple(sd["conv_map.weight"].shape) == (64, 3, 7, 7)
+    assert m.npoints == 64 and CoPoNeRF.CoPoNeRF(n_view=2, npoints=0).npoints == 64
