@@ -24,8 +24,8 @@ What it restates (file:line relative to /root/reference):
 Numerical contract: every geometric quantity that decides a *sample index*
 (pixel_val, secondary sample coordinates, bilinear tap indices) is written as
 an explicit sequence of IEEE-754 add/sub/mul/div/sqrt on scalars-per-element —
-no BLAS, no einsum — so that the HIP kernels, compiled with -ffp-contract=off,
-reproduce it bit for bit.  Where upstream calls einsum/bmm for 3- or 4-term dot
+no BLAS, no einsum, and float32 sqrt pinned to the correctly rounded value (_sqrt_cr) — so that the HIP
+kernels, compiled with -ffp-contract=off, reproduce it bit for bit on any host CPU.  Where upstream calls einsum/bmm for 3- or 4-term dot
 products the summation here is left-to-right; tests/golden pins how close that
 is to upstream (bit-identical on the fixtures, see tests/test_oracle_golden.py).
 """
@@ -86,8 +86,15 @@ def _cross(a, b):
     return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
 
 
+def _sqrt_cr(x):
+    """Correctly rounded sqrt.  torch.sqrt on float32 CPU tensors is a vectorised approximation whose last bit
+    depends on the CPU (0.7 % of results off by 1 ulp on a Xeon, 19.6 % on an EPYC 9575F — measured); the
+    float64 route is exact after rounding and identical everywhere, and equals gfx950's IEEE sqrtf."""
+    return torch.sqrt(x.double()).to(x.dtype) if x.dtype == torch.float32 else torch.sqrt(x)
+
+
 def _norm3(v):
-    return torch.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+    return _sqrt_cr((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
 
 
 def _normalize3(v, eps=1e-12):
@@ -311,7 +318,7 @@ def local_coords(pixel_val, Kc, H, W, dir_q, origin_q, pt):
     cam = _normalize3(((px - cx) / fx * one, (py - cy) / fy * one, one))
     oq = origin_q[:, None, None, :]
     dlt = pt - oq
-    depth = _scrub(torch.sqrt((dlt[..., 0] * dlt[..., 0] + dlt[..., 1] * dlt[..., 1]) + dlt[..., 2] * dlt[..., 2]), 1e6)
+    depth = _scrub(_sqrt_cr((dlt[..., 0] * dlt[..., 0] + dlt[..., 1] * dlt[..., 1]) + dlt[..., 2] * dlt[..., 2]), 1e6)
     enc = [torch.tanh(depth), torch.tanh(depth / 10.), torch.tanh(depth / 100.), torch.tanh(depth / 1000.)]
     zero = torch.zeros_like(px)
     dq = dir_q[:, :, None, :].expand(-1, -1, px.shape[2], -1)
