@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--pairs", type=int, default=1, help="stereo pairs per GPU")
     ap.add_argument("--chunk-rays", type=int, default=2048)
-    ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,26 +137,37 @@ def main():
                 tot = sum(a.elapsed_time(b) for a, b, _ in v)
                 kern[k] = {"ms_per_step": tot / args.steps, "tflops": sum(f for _, _, f in v) / (tot * 1e-3) / 1e12}
             line["gemm_breakdown"] = kern
-        # ---- CPU baseline: the oracle on a bounded sample of the same workload, all host cores
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload on the host cores.  PyTorch CPU ops
+        #      stop scaling (and regress) far below a 256-thread host, so the thread count is probed first and the
+        #      best one is used and reported; the sample is sized for ~20 s of CPU work.
         if args.cpu_rays > 0:
             from oracle import render_ref as orc
-            cores = os.cpu_count() or 1
-            torch.set_num_threads(cores)
-            n = args.cpu_rays
-            sub = {"context": inp_cpu["context"],
-                   "query": {k: (v[:, :, :n].contiguous() if k in ("uv", "rgb") else v)
-                             for k, v in inp_cpu["query"].items()}}
             w = syn.make_render_weights()
-            with torch.no_grad():
-                orc.forward({"context": sub["context"], "query": {k: (v[:, :, :64].contiguous() if k in ("uv", "rgb") else v)
-                                                                   for k, v in sub["query"].items()}},
-                            z_cpu, rel_cpu, flow_cpu, True, w, npoints=S)           # warm-up
-                c0 = time.perf_counter()
-                ref = orc.forward(sub, z_cpu, rel_cpu, flow_cpu, True, w, npoints=S)
-                cpu_s = time.perf_counter() - c0
-            line["cpu_baseline"] = {"value": B * n / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port",
+
+            def cpu_run(n):
+                sub = {"context": inp_cpu["context"],
+                       "query": {k: (v[:, :, :n].contiguous() if k in ("uv", "rgb") else v)
+                                 for k, v in inp_cpu["query"].items()}}
+                with torch.no_grad():
+                    c0 = time.perf_counter()
+                    r = orc.forward(sub, z_cpu, rel_cpu, flow_cpu, True, w, npoints=S)
+                    return r, time.perf_counter() - c0
+
+            ncpu = os.cpu_count() or 1
+            best_t, best_rate = 1, 0.0
+            for t in sorted({min(ncpu, c) for c in (8, 32, 96)}):
+                torch.set_num_threads(t)
+                cpu_run(32)                                              # warm-up at this thread count
+                _, dt = cpu_run(128)
+                if 128 / dt > best_rate:
+                    best_t, best_rate = t, 128 / dt
+            torch.set_num_threads(best_t)
+            n = int(max(256, min(args.cpu_rays, best_rate * 20.0)))
+            ref, cpu_s = cpu_run(n)
+            line["cpu_baseline"] = {"value": B * n / cpu_s, "unit": "rays/s", "cores": best_t, "kind": "port",
                                     "sample": f"first {n} rays of each pair of the same {H}x{H}x{S} workload, "
-                                              f"oracle/render_ref.py (PyTorch CPU ops), {cpu_s:.1f} s"}
+                                              f"oracle/render_ref.py (PyTorch CPU ops), {best_t} of {ncpu} host "
+                                              f"threads (best of a 3-point probe), {cpu_s:.1f} s"}
             err = (out["rgb"][:, :, :n].cpu() - ref["rgb"]).abs()
             mse = float((err ** 2).mean())
             line["parity"] = {"rgb_max_abs_vs_oracle": float(err.max()),

@@ -140,33 +140,41 @@ __global__ __launch_bounds__(256) void local_hidden_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w, int ldw,
     const float* __restrict__ bias, const float* __restrict__ add, int V, int R, int S, int ray0,
     long long nrows, __half* __restrict__ out) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long row = gid >> 4;
-    const int og = (int)(gid & 15);
-    if (row >= nrows) return;
-    long long t = row;
-    const int s = (int)(t % S); t /= S;
-    const int v = (int)(t % V); t /= V;
-    const long long ray = ray0 + t;
-    const int b = (int)(ray / R), r = (int)(ray % R);
-    const size_t nr = ((size_t)(b * V + v)) * R + r;
-    const float* lc = loc8 + (nr * S + s) * 8;
-    const float* c9 = coords9 + nr * 9;
-    // local_coords channel order (CoPoNeRF.py:445): ctx dir 0-2, zeros 3-5, query dir 6-8, depth 9-12, origin 13-15
-    const float L[16] = {lc[0], lc[1], lc[2], 0.f, 0.f, 0.f, c9[0], c9[1], c9[2],
-                         lc[3], lc[4], lc[5], lc[6], c9[6], c9[7], c9[8]};
-    half8 o;
+    // thread = (row lane, group of 8 outputs); the 8 x 16 weights of the group live in registers and the
+    // block strides over rows, so the kernel is FMA-bound (128 FMA per 16-byte store) instead of load-bound.
+    const int og = threadIdx.x & 15;
+    float wr[8][16], br[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int n = og * 8 + e;
-        const float* wr = w + (size_t)n * ldw;
-        float acc = bias[n];
+        br[e] = bias[og * 8 + e];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc += wr[k] * L[k];
-        if (add) acc += add[(size_t)t * 128 + n];
-        o[e] = (_Float16)fmaxf(acc, 0.0f);
+        for (int k = 0; k < 16; ++k) wr[e][k] = w[(size_t)(og * 8 + e) * ldw + k];
     }
-    *reinterpret_cast<half8*>(out + (size_t)row * 128 + og * 8) = o;
+    for (long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); row < nrows;
+         row += (long long)gridDim.x * 16) {
+        long long t = row;
+        const int s = (int)(t % S); t /= S;
+        const int v = (int)(t % V); t /= V;
+        const long long ray = ray0 + t;
+        const int b = (int)(ray / R), r = (int)(ray % R);
+        const size_t nr = ((size_t)(b * V + v)) * R + r;
+        const f32x4 l0 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8);
+        const f32x4 l1 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8 + 4);
+        const float* c9 = coords9 + nr * 9;
+        // local_coords channel order (CoPoNeRF.py:445): ctx dir 0-2, zeros 3-5, query dir 6-8, depth 9-12, origin 13-15
+        const float L[16] = {l0[0], l0[1], l0[2], 0.f, 0.f, 0.f, c9[0], c9[1], c9[2],
+                             l0[3], l1[0], l1[1], l1[2], c9[6], c9[7], c9[8]};
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float acc = br[e];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += wr[e][k] * L[k];
+            if (add) acc += add[(size_t)t * 128 + og * 8 + e];
+            o[e] = (_Float16)fmaxf(acc, 0.0f);
+        }
+        *reinterpret_cast<half8*>(out + (size_t)row * 128 + og * 8) = o;
+    }
 }
 
 }  // namespace
@@ -218,7 +226,8 @@ extern "C" int cpn_local_hidden(const float* loc8, const float* coords9, const f
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_local_hidden: ray range outside B*R");
     const long long nrows = (long long)nrays * V * S;
-    hipLaunchKernelGGL(local_hidden_kernel, dim3(cpn_cdiv(nrows * 16, 256)), dim3(256), 0, (hipStream_t)stream,
+    const unsigned blocks = (unsigned)(cpn_cdiv(nrows, 16) < 8192u ? cpn_cdiv(nrows, 16) : 8192u);
+    hipLaunchKernelGGL(local_hidden_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        loc8, coords9, w, ldw, bias, add, V, R, S, ray0, nrows, (__half*)out);
     CPN_LAUNCH_CHECK("cpn_local_hidden");
     return 0;

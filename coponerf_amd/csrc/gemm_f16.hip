@@ -20,6 +20,7 @@
 // Roofline: compute-bound (arithmetic intensity of the 256 x 208 tile = 115 FLOP/B of L2 traffic);
 // algorithmic FLOPs per launch = 2*M*N*K.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -39,18 +40,32 @@ struct Cfg {
     static constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
 };
 
+// blockIdx.x -> (m tile, n tile).  Blocks are dispatched round-robin over the 8 XCDs (private L2 each), so the
+// linear id is first remapped to give every XCD a contiguous range of logical tiles (bijective for any grid size),
+// then the N tile index runs fastest: the n_tiles workgroups that share one 256-row activation tile execute
+// back to back on the same XCD and hit its L2 instead of re-streaming the tile from HBM.
+__device__ __forceinline__ void tile_of_block(int n_tiles, int& m_tile, int& n_tile) {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    n_tile = logical % n_tiles;
+    m_tile = logical / n_tiles;
+}
+
 template <int NT, bool OUT_F32, bool RELU>
 __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict__ A, int lda,
                                                        const __half* __restrict__ W, int ldw,
                                                        const float* __restrict__ bias, void* __restrict__ Cv,
-                                                       int ldc, int M, int K32) {
+                                                       int ldc, int M, int K32, int n_tiles) {
     using C_ = Cfg<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * C_::BN;
+    int m_tile, n_tile;
+    tile_of_block(n_tiles, m_tile, n_tile);
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * C_::BN;
     const int nk = (K32 + 1) >> 1;                     // 64-deep steps; the last may hold a single k32
 
     // ---- per-lane DMA sources: unit u covers image rows [8u, 8u+8); lane -> (row, physical chunk).
@@ -156,23 +171,174 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4-wave variant: one wave per SIMD, wave tile 64 x (16*NT), up to 512 registers per lane.
+// Each weight fragment read from LDS now feeds 4 MFMAs instead of 2 (LDS read traffic per MFMA drops from
+// 0.58 to 0.33 KiB), and both k32 fragment sets of a 64-deep stage are in flight before the first MFMA.
+// ---------------------------------------------------------------------------------------------
+template <int NT, bool OUT_F32, bool RELU>
+__global__ __launch_bounds__(256, 1) void gemm_f16_w4_kernel(const __half* __restrict__ A, int lda,
+                                                             const __half* __restrict__ W, int ldw,
+                                                             const float* __restrict__ bias,
+                                                             void* __restrict__ Cv, int ldc, int M, int K32, int n_tiles) {
+    using C_ = Cfg<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int m_tile, n_tile;
+    tile_of_block(n_tiles, m_tile, n_tile);
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * C_::BN;
+    const int nk = (K32 + 1) >> 1;
+
+    // DMA (buffer_load ... lds): wave w moves units w, w+4, ...; unit u = image rows [8u, 8u+8).  Rows advance by
+    // 32 per round, so the source swizzle ((row>>1)&7) and hence the per-lane byte offset are round-invariant:
+    // ONE voffset VGPR per operand, everything else in the scalar offset.  The A descriptor ends at row
+    // min(BM, M-m0): rows past M read as zero (hardware bounds check) instead of being clamped.
+    constexpr int MAXU = (C_::UNITS + 3) / 4;
+    constexpr int UA4 = C_::UNITS_A / 4;
+    const int r0 = wave * 8 + (lane >> 3);
+    const int lchunk = (lane & 7) ^ ((r0 >> 1) & 7);
+    const int rows_valid = (M - m0) < BM ? (M - m0) : BM;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(A + (size_t)m0 * lda), 0, rows_valid * lda * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(W + (size_t)n0 * ldw), 0, C_::BN * ldw * 2, 0x00020000);
+    const int voff_a = (r0 * lda + lchunk * 8) * 2;
+    const int voff_w = (r0 * ldw + lchunk * 8) * 2;
+    auto stage = [&](int kt, int buf) {
+        char* sbase = smem + buf * C_::STAGE_BYTES + wave * 1024;
+        const int kbytes = kt * BK * 2;
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            if (wave + 4 * i >= C_::UNITS) break;
+            if (i < UA4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(sbase + i * 4096), 16, voff_a,
+                                                         kbytes + i * 64 * lda, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(sbase + i * 4096), 16, voff_w,
+                                                         kbytes + (i - UA4) * 64 * ldw, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fk = lane >> 4;
+    const int swz = (frow >> 1) & 7;
+    const int xoff = (wave * 64 + frow) * ROW_BYTES;
+    const int woff = (BM + frow) * ROW_BYTES;
+    const int coff0 = ((fk ^ swz) << 4), coff1 = (((4 + fk) ^ swz) << 4);
+
+    auto load_frags = [&](const char* sbase, int coff, half8 (&xa)[4], half8 (&wb)[NT]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            xa[mt] = *reinterpret_cast<const half8*>(sbase + xoff + mt * 16 * ROW_BYTES + coff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            wb[nt] = *reinterpret_cast<const half8*>(sbase + woff + nt * 16 * ROW_BYTES + coff);
+    };
+    auto mma = [&](const half8 (&xa)[4], const half8 (&wb)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[nt], xa[mt], acc[mt][nt], 0, 0, 0);
+    };
+
+    // Software pipeline (one wave per SIMD has no partner wave to hide LDS latency behind):
+    //   phase A  MFMAs on fragment set 0 (stage kt, first k32)  ||  ds_reads of set 1 (stage kt, second k32)
+    //   barrier  -> stage kt+1 has landed for every wave, every wave is done reading stage kt
+    //   phase B  DMA of stage kt+2 into the buffer just freed;
+    //            MFMAs on set 1  ||  ds_reads of set 0 for stage kt+1
+    // so the barrier sits between two MFMA blocks whose operands are already in registers.
+    // sched_group_barrier pins the interleave to 1 ds_read per 3 MFMAs (17 reads under 52 MFMAs).
+#define CPN_INTERLEAVE_READS_MFMA()                                             \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4 + NT; ++q_) {                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* 1 DS read */      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); /* 3 MFMA    */      \
+    }                                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 3 * (4 + NT), 0);
+
+    const int nfull = K32 >> 1;
+    half8 xa0[4], wb0[NT], xa1[4], wb1[NT];
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    load_frags(smem, coff0, xa0, wb0);
+    for (int kt = 0; kt < nfull; ++kt) {
+        const char* scur = smem + (kt & 1) * C_::STAGE_BYTES;
+        const char* snxt = smem + ((kt + 1) & 1) * C_::STAGE_BYTES;
+        load_frags(scur, coff1, xa1, wb1);
+        mma(xa0, wb0);
+        CPN_INTERLEAVE_READS_MFMA();
+        // the compiler does not count buffer_load...lds against the barrier: drain this wave's DMA explicitly
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 < nk) stage(kt + 2, kt & 1);
+        load_frags(snxt, coff0, xa0, wb0);             // harmless garbage after the last stage
+        mma(xa1, wb1);
+        CPN_INTERLEAVE_READS_MFMA();
+    }
+    if (K32 & 1) mma(xa0, wb0);                        // odd trailing k32 step (already in set 0)
+#undef CPN_INTERLEAVE_READS_MFMA
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 16 + (lane >> 4) * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wave * 64 + mt * 16 + (lane & 15);
+            if (m >= M) continue;
+            f32x4 v = acc[mt][nt] + bv;
+            if (RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+            }
+            if (OUT_F32) {
+                *reinterpret_cast<f32x4*>((float*)Cv + (size_t)m * ldc + n) = v;
+            } else {
+                half4 h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[i];
+                *reinterpret_cast<half4*>((__half*)Cv + (size_t)m * ldc + n) = h;
+            }
+        }
+    }
+}
+
 template <int NT, bool OUT_F32, bool RELU>
 int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
            int K32, hipStream_t stream) {
     using C_ = Cfg<NT>;
     const size_t lds = 2 * C_::STAGE_BYTES;
-    auto kern = gemm_f16_kernel<NT, OUT_F32, RELU>;
+    static const int variant = getenv("CPN_GEMM_VARIANT") ? atoi(getenv("CPN_GEMM_VARIANT")) : 0;
+    auto kern8 = gemm_f16_kernel<NT, OUT_F32, RELU>;
+    auto kern4 = gemm_f16_w4_kernel<NT, OUT_F32, RELU>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)kern4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             cpn_set_error("cpn_gemm_f16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
             return (int)e;
         }
         attr_set = true;
     }
-    dim3 grid(cpn_cdiv(M, BM), N / C_::BN);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32);
+    const int n_tiles = N / C_::BN;
+    dim3 grid(cpn_cdiv(M, BM) * n_tiles);
+    if (variant == 0)
+        hipLaunchKernelGGL(kern8, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles);
+    else
+        hipLaunchKernelGGL(kern4, grid, dim3(256), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles);
     CPN_LAUNCH_CHECK("cpn_gemm_f16");
     return 0;
 }

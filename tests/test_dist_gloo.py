@@ -1,0 +1,66 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel helpers in coponerf_amd/dist.py."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coponerf_amd import dist as cd
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.Linear(16, 4),
+                                torch.nn.Linear(4, 4))
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    nb = cd.broadcast_parameters(model, bucket_bytes=256)
+    x = torch.full((4, 8), float(rank + 1)) + torch.arange(4.0)[:, None]
+    model[:3](x).sum().backward()                      # the last Linear gets no gradient (skip-None path)
+    expected = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    ncoll = cd.average_gradients(model.parameters(), bucket_bytes=512)
+    ok = True                                          # reference semantics: per-parameter all_reduce(SUM) / world
+    for p, e in zip(model.parameters(), expected):
+        if e is None:
+            ok &= p.grad is None
+            continue
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        ok &= bool(torch.allclose(p.grad, e / world, atol=1e-6))
+    finite_all = cd.grads_finite(model.parameters())
+    if rank == 1:
+        next(model.parameters()).grad[0, 0] = float("nan")
+    finite_after_nan = cd.grads_finite(model.parameters())   # False on BOTH ranks: same branch, no deadlock
+    w0 = model[0].weight.detach().clone()
+    gathered = [torch.zeros_like(w0) for _ in range(world)]
+    dist.all_gather(gathered, w0)
+    q.put((rank, ok, ncoll, nb, finite_all, finite_after_nan, bool(torch.equal(gathered[0], gathered[1])),
+           list(cd.shard_pairs(5, rank, world))))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_and_finite_flag_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, ncoll, nb, finite_all, finite_after_nan, synced, shard in res:
+        assert ok and synced
+        assert 1 <= ncoll < 6 and nb >= 1            # fewer collectives than the 6 gradient tensors
+        assert finite_all is True and finite_after_nan is False
+    assert res[0][-1] == [0, 2, 4] and res[1][-1] == [1, 3]
