@@ -115,7 +115,7 @@ class CoPoNeRF(nn.Module):
         core = self._engine.render(self._render_params(), ctx["cam2world"], ctx["intrinsics"], qry["cam2world"],
                                    qry["intrinsics"], qry["uv"], z, rel_pose, val, self.npoints, self.H, self.W)
         out = {"flow": flow, "uv": qry["uv"], "coords": core["coords"]}
-        out["pixel_val"] = core["pixel_val"].cpu()               # models/CoPoNeRF.py:490 (callers expect a CPU tensor)
+        out["pixel_val"] = core["pixel_val_cpu"]                  # models/CoPoNeRF.py:490 (callers expect a CPU tensor)
         out["at_wts"] = [core["at_wt"]]
         out.update(aux_outputs(input, flow, core["at_wt"], core["pt"], core["Tq"]))
         out["at_wt"] = core["at_wt"]

@@ -107,6 +107,7 @@ class RenderEngine:
         self._interval: Dict[Tuple[int, str], torch.Tensor] = {}
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops)
         self.profile: Optional[Dict[str, list]] = None
+        self._copy_stream: Optional[torch.cuda.Stream] = None
 
     # ---- caches --------------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
@@ -212,6 +213,19 @@ class RenderEngine:
              B, V, R, S, H, W, pixel_val.data_ptr(), pt.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(),
              loc8.data_ptr(), s)
 
+        # the caller contract wants pixel_val on the CPU (CoPoNeRF.py:490): start the 8*N*R*S-byte device->host copy
+        # now, into pinned memory on a side stream, so it overlaps the GEMMs instead of stalling the step's tail
+        if self._copy_stream is None or self._copy_stream.device != dev:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        pixel_val_cpu = torch.empty(pixel_val.shape, dtype=f32, pin_memory=True)
+        geom_done = torch.cuda.Event()
+        geom_done.record()
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(geom_done)
+            pixel_val_cpu.copy_(pixel_val, non_blocking=True)
+            copy_done = torch.cuda.Event()
+            copy_done.record()
+
         nray_total = B * R
         zl = torch.empty(nray_total, 416, dtype=f32, device=dev)
         C = min(self.chunk_rays, nray_total)
@@ -290,6 +304,8 @@ class RenderEngine:
         rgb = torch.empty(B, 1, R, 3, dtype=f32, device=dev)
         valid = torch.empty(B, R, 1, dtype=f32, device=dev)
         call("cpn_mask_rgb", rgb_raw.data_ptr(), 4, overlaps.data_ptr(), B, V, R, rgb.data_ptr(), valid.data_ptr(), s)
-        return {"rgb": rgb, "valid_mask": valid, "pixel_val": pixel_val, "pt": pt, "at_wt": at_wt,
+        copy_done.synchronize()
+        return {"rgb": rgb, "valid_mask": valid, "pixel_val": pixel_val, "pixel_val_cpu": pixel_val_cpu, "pt": pt,
+                "at_wt": at_wt,
                 "coords": coords9, "z_local": zl, "Tq": Tq_cpu.to(dev), "sec_grid": sec_grid.clone(),
                 "rgb_raw": rgb_raw[:, :3].clone()}
