@@ -17,6 +17,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
+from . import getz as _getz
 from .aux_outputs import aux_outputs
 from .render import RenderEngine, _rigid_inverse
 
@@ -62,6 +63,11 @@ class CoPoNeRF(nn.Module):
         self.repeat_attention = True
         latent = 256 * 3 + 64                                   # 832
         hidden = 128
+        # ---- get_z stack (models/CoPoNeRF.py:33-67): pose head, UFC aggregation, ResNet-34 encoder
+        self.cross_attention = _getz.CrossBlock()
+        self.pose_regressor, self.rotation_regressor, self.translation_regressor = _getz.make_pose_heads()
+        self.feature_cost_aggregation = _getz.UFC()
+        self.encoder = _getz.SpatialEncoder()
         # ---- render-path layers (models/CoPoNeRF.py:69-104); unused upstream layers are kept so that
         #      checkpoints round-trip with identical keys.
         self.conv_map = nn.Conv2d(3, 64, kernel_size=7, stride=1, padding=3)
@@ -93,12 +99,14 @@ class CoPoNeRF(nn.Module):
     def _render_params(self) -> Dict[str, torch.Tensor]:
         return {k: v for k, v in self.named_parameters() if k.split(".")[0] in RENDER_PARAM_PREFIXES}
 
-    def get_z(self, input, val: bool = False):
-        """Features, estimated relative pose and flows (models/CoPoNeRF.py:159-206).  The encoder / UFC /
-        pose-head stack is SURVEY.md §8 rows a22-a29 and is not built yet in this round."""
-        raise NotImplementedError(
-            "coponerf_amd round 1 covers the render path (forward with z/rel_pose/flow given); get_z "
-            "(ResNet-34 encoder + UFC 4-D aggregation + pose head) is the next scope row")
+    def get_z(self, input, val: bool = False, ops=None):
+        """Features, estimated relative pose and flows (models/CoPoNeRF.py:159-206):
+        ([(2B,256,16,16),(2B,256,32,32),(2B,256,64,64),(2B,64,256,256)], (B,4,4), 4 x (B,2,64,64)).
+        The 4-D operators of UFC run on the HIP kernels (coponerf_amd.ufc_ops.HipOps); `ops` is a test hook."""
+        if ops is None:
+            from .ufc_ops import HipOps
+            ops = HipOps()
+        return _getz.get_z(self, input, ops)
 
     def forward(self, input, z=None, rel_pose=None, val: bool = False, flow=None, debug: bool = False):
         if self.n_view != 2:

@@ -21,6 +21,7 @@ UNITS = [
     ("gemm_f16.hip", []),
     ("attend.hip", []),
     ("linear_f32.hip", []),
+    ("ufc.hip", []),
 ]
 
 

@@ -1,0 +1,297 @@
+// K6-K8 — the 4-D operators of UFC (get_z path).
+//
+//   cpn_conv4d_gn_relu   conv4d.Conv4d (+ MaxPool4d for stride > 1) + GroupNorm(1 group) + ReLU
+//                        (/root/reference models/conv4d.py:7-30, 57-163): 63 calls per get_z
+//   cpn_correlation      aggregation.correlation / correlation_token (models/aggregation.py:70-80)
+//   cpn_soft_argmax_pair aggregation.soft_argmax in both directions (models/aggregation.py:119-144, 555-560)
+//
+// The reference spends 44 % of get_z in einops `rearrange` copies of 6-D tensors around stock Conv2d / MaxPool2d
+// calls; here both separable branches, the pooling, both biases and the GroupNorm statistics are one pass over
+// the volume with direct 6-D indexing — no transposed copies.  All of it is HBM/L2-bound streaming work
+// (volumes 16^4 x {8,32} ch = 2-8 MB, raw correlations up to 64^4 = 67 MB): coalescing along the innermost
+// support axis, one scalar-broadcast weight per (out-channel, in-channel, tap).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// conv4d: y[b,o,qy,qx,sy,sx] = bq[o] + bs[o]
+//        + sum_{c,i,j} Wq[o,c,i,j] * Ps(x)[b,c, qy*s+i-p, qx*s+j-p, sy, sx]      (query branch, support dims pooled)
+//        + sum_{c,i,j} Ws[o,c,i,j] * Pq(x)[b,c, qy, qx, sy*s+i-p, sx*s+j-p]      (support branch, query dims pooled)
+// thread = one output position, blockIdx.y = output channel (uniform -> scalar weight loads), blockIdx.z = batch
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv4d_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                     const float* __restrict__ bq, const float* __restrict__ ws,
+                                                     const float* __restrict__ bs, int Cin, int Hq, int Wq, int Hs,
+                                                     int Ws, int k, int s, int p, int Oq, int Pq_, int Os, int Ps_,
+                                                     float* __restrict__ y, double* __restrict__ stats) {
+    // Oq x Pq_ = output query dims, Os x Ps_ = output support dims
+    const int o = blockIdx.y, b = blockIdx.z, Cout = gridDim.y;
+    const long long npos = (long long)Oq * Pq_ * Os * Ps_;
+    const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float val = 0.0f;
+    const bool active = pos < npos;
+    if (active) {
+        int sx = (int)(pos % Ps_);
+        long long t = pos / Ps_;
+        const int sy = (int)(t % Os); t /= Os;
+        const int qx = (int)(t % Pq_);
+        const int qy = (int)(t / Pq_);
+        const size_t cstride = (size_t)Hq * Wq * Hs * Ws;
+        const float* xb = x + (size_t)b * Cin * cstride;
+        float acc = bq[o] + bs[o];
+        for (int c = 0; c < Cin; ++c) {
+            const float* xc = xb + c * cstride;
+            const float* wqc = wq + ((size_t)o * Cin + c) * k * k;
+            const float* wsc = ws + ((size_t)o * Cin + c) * k * k;
+            for (int i = 0; i < k; ++i)
+                for (int j = 0; j < k; ++j) {
+                    // ---- query branch: conv over (Hq, Wq), support dims max-pooled by s (ceil mode)
+                    const int Y = qy * s + i - p, X = qx * s + j - p;
+                    if (Y >= 0 && Y < Hq && X >= 0 && X < Wq) {
+                        const float* base = xc + ((size_t)Y * Wq + X) * Hs * Ws;
+                        float m = -INFINITY;
+                        for (int dy = 0; dy < s; ++dy)
+                            for (int dx = 0; dx < s; ++dx) {
+                                const int yy = sy * s + dy, xx = sx * s + dx;
+                                if (yy < Hs && xx < Ws) m = fmaxf(m, base[(size_t)yy * Ws + xx]);
+                            }
+                        acc += wqc[i * k + j] * m;
+                    }
+                    // ---- support branch: conv over (Hs, Ws), query dims max-pooled by s
+                    const int U = sy * s + i - p, Vv = sx * s + j - p;
+                    if (U >= 0 && U < Hs && Vv >= 0 && Vv < Ws) {
+                        float m = -INFINITY;
+                        for (int dy = 0; dy < s; ++dy)
+                            for (int dx = 0; dx < s; ++dx) {
+                                const int yy = qy * s + dy, xx = qx * s + dx;
+                                if (yy < Hq && xx < Wq) m = fmaxf(m, xc[(((size_t)yy * Wq + xx) * Hs + U) * Ws + Vv]);
+                            }
+                        acc += wsc[i * k + j] * m;
+                    }
+                }
+        }
+        val = acc;
+        y[((size_t)b * Cout + o) * npos + pos] = acc;
+    }
+    // GroupNorm statistics of the whole (C, volume) slab of sample b, accumulated in double
+    double s1 = active ? (double)val : 0.0, s2 = active ? (double)val * val : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(stats + b * 2, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(stats + b * 2 + 1, red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_relu_kernel(float* __restrict__ y, const double* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, int Cout, long long npos) {
+    const int b = blockIdx.z, o = blockIdx.y;
+    const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= npos) return;
+    const double n = (double)Cout * (double)npos;
+    const double mean = stats[b * 2] / n;
+    const double var = stats[b * 2 + 1] / n - mean * mean;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const size_t idx = ((size_t)b * Cout + o) * npos + pos;
+    const float v = (y[idx] - (float)mean) * rstd * gamma[o] + beta[o];
+    y[idx] = fmaxf(v, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// correlation: tokens (B, L, C) -> x / (||x|| + eps), then C[b] = S_n[b] . T_n[b]^T with the exact-f32 MFMA
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long long rows, int C, float eps) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) ss += xr[c] * xr[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float d = sqrtf(ss) + eps;
+    for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = xr[c] / d;
+}
+
+// C (M x N) = A (M x K) . B (N x K)^T per batch; wave = 16 rows x 128 cols, block = 64 rows; K % 16 == 0
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                          float* __restrict__ Cm, int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int m0 = (blockIdx.y * 4 + wave) * 16, n0 = blockIdx.x * 128;
+    if (m0 >= M) return;
+    const float* Ab = A + (size_t)b * M * K;
+    const float* Bb = Bm + (size_t)b * N * K;
+    float* Cb = Cm + (size_t)b * M * N;
+    const int fi = lane & 15, fg = lane >> 4;
+    int ar = m0 + fi;
+    ar = ar < M ? ar : M - 1;
+    const float* ap = Ab + (size_t)ar * K + fg * 4;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < K; kb += 16) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int n = n0 + t * 16 + fi;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < N) bv = *reinterpret_cast<const f32x4*>(Bb + (size_t)n * K + kb + fg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], av[e], acc[t], 0, 0, 0);
+        }
+    }
+    const int m = m0 + fi;
+    if (m >= M) return;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + t * 16 + fg * 4 + i;
+            if (n < N) Cb[(size_t)m * N + n] = acc[t][i];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// soft-argmax with temperature beta over the 4-D correlation c (B, S = h*h, T = h*h)
+//   rows: for every source pixel s, softmax over t   -> expected (x, y) of the target   (t_to_s maps)
+//   cols: for every target pixel t, softmax over s   -> expected (x, y) of the source   (s_to_t maps)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lin11(int i, int n) { return -1.0f + (2.0f / (float)(n - 1)) * (float)i; }
+
+__global__ __launch_bounds__(256) void soft_argmax_rows_kernel(const float* __restrict__ c, int h, float beta,
+                                                               float* __restrict__ out) {
+    const int T = h * h;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const float* row = c + ((size_t)b * T + s) * T;
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int t = threadIdx.x; t < T; t += 256) m = fmaxf(m, row[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float se = 0.f, sx = 0.f, sy = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float e = expf((row[t] - m) / beta);
+        se += e;
+        sx += e * lin11(t % h, h);
+        sy += e * lin11(t / h, h);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        se += __shfl_xor(se, off);
+        sx += __shfl_xor(sx, off);
+        sy += __shfl_xor(sy, off);
+    }
+    if (lane == 0) { red[4 + wave] = se; red[8 + wave] = sx; red[12 + wave] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (red[4] + red[5]) + (red[6] + red[7]);
+        out[((size_t)b * 2 + 0) * T + s] = ((red[8] + red[9]) + (red[10] + red[11])) / tot;
+        out[((size_t)b * 2 + 1) * T + s] = ((red[12] + red[13]) + (red[14] + red[15])) / tot;
+    }
+}
+
+// block = 64 target pixels x 4 source groups; online softmax per thread, 4 partials merged through LDS
+__global__ __launch_bounds__(256) void soft_argmax_cols_kernel(const float* __restrict__ c, int h, float beta,
+                                                               float* __restrict__ out) {
+    const int T = h * h;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    __shared__ float part[4][4][64];
+    float m = -INFINITY, se = 0.f, sx = 0.f, sy = 0.f;
+    if (t < T) {
+        const float* col = c + (size_t)b * T * T + t;
+        for (int s = g; s < T; s += 4) {
+            const float v = col[(size_t)s * T];
+            if (v > m) {
+                const float r = expf((m - v) / beta);
+                se *= r; sx *= r; sy *= r;
+                m = v;
+            }
+            const float e = expf((v - m) / beta);
+            se += e;
+            sx += e * lin11(s % h, h);
+            sy += e * lin11(s / h, h);
+        }
+    }
+    const int l = threadIdx.x & 63;
+    part[g][0][l] = m; part[g][1][l] = se; part[g][2][l] = sx; part[g][3][l] = sy;
+    __syncthreads();
+    if (g == 0 && t < T) {
+        float M = fmaxf(fmaxf(part[0][0][l], part[1][0][l]), fmaxf(part[2][0][l], part[3][0][l]));
+        float E = 0.f, X = 0.f, Y = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const float r = expf((part[q][0][l] - M) / beta);
+            E += part[q][1][l] * r; X += part[q][2][l] * r; Y += part[q][3][l] * r;
+        }
+        out[((size_t)b * 2 + 0) * T + t] = X / E;
+        out[((size_t)b * 2 + 1) * T + t] = Y / E;
+    }
+}
+
+}  // namespace
+
+extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
+                                  const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout, int Hq,
+                                  int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream) {
+    CPN_REQUIRE(x && wq && bq && ws && bs && gn_w && gn_b && y && stats, CPN_E_ARG, "cpn_conv4d_gn_relu: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && Cin > 0 && Cout > 0 && Cout < 65536 && k > 0 && s > 0 && p >= 0, CPN_E_SHAPE,
+                "cpn_conv4d_gn_relu: bad shape");
+    auto co = [&](int n) { return (n + 2 * p - k) / s + 1; };
+    auto po = [&](int n) { return (n + s - 1) / s; };
+    const int Oq = co(Hq), Pq_ = co(Wq), Os = co(Hs), Ps_ = co(Ws);
+    CPN_REQUIRE(Oq == po(Hq) && Pq_ == po(Wq) && Os == po(Hs) && Ps_ == po(Ws), CPN_E_SHAPE,
+                "cpn_conv4d_gn_relu: conv output (%d) and pooled size (%d) of the two branches disagree", Oq, po(Hq));
+    const long long npos = (long long)Oq * Pq_ * Os * Ps_;
+    const hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cpn_cdiv(npos, 256), Cout, B);
+    hipLaunchKernelGGL(conv4d_kernel, grid, dim3(256), 0, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, k, s, p, Oq, Pq_,
+                       Os, Ps_, y, stats);
+    CPN_LAUNCH_CHECK("cpn_conv4d_gn_relu(conv)");
+    hipLaunchKernelGGL(gn_relu_kernel, grid, dim3(256), 0, st, y, stats, gn_w, gn_b, eps, Cout, npos);
+    CPN_LAUNCH_CHECK("cpn_conv4d_gn_relu(norm)");
+    return 0;
+}
+
+extern "C" int cpn_correlation(const float* src, const float* trg, int B, int L, int C, float eps, float* src_n,
+                               float* trg_n, float* out, void* stream) {
+    CPN_REQUIRE(src && trg && src_n && trg_n && out, CPN_E_ARG, "cpn_correlation: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && L > 0 && C > 0 && (C % 16) == 0, CPN_E_SHAPE,
+                "cpn_correlation: C=%d must be a multiple of 16", C);
+    const hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)B * L;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, src, src_n, rows, C, eps);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, trg, trg_n, rows, C, eps);
+    CPN_LAUNCH_CHECK("cpn_correlation(normalise)");
+    dim3 grid(cpn_cdiv(L, 128), cpn_cdiv(L, 64), B);
+    hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(256), 0, st, src_n, trg_n, out, L, L, C);
+    CPN_LAUNCH_CHECK("cpn_correlation(gemm)");
+    return 0;
+}
+
+extern "C" int cpn_soft_argmax_pair(const float* c, int B, int h, float beta, float* t_to_s, float* s_to_t,
+                                    void* stream) {
+    CPN_REQUIRE(c && t_to_s && s_to_t, CPN_E_ARG, "cpn_soft_argmax_pair: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && h > 1 && beta > 0.f, CPN_E_SHAPE, "cpn_soft_argmax_pair: bad shape");
+    const hipStream_t st = (hipStream_t)stream;
+    const int T = h * h;
+    hipLaunchKernelGGL(soft_argmax_rows_kernel, dim3(T, B), dim3(256), 0, st, c, h, beta, t_to_s);
+    hipLaunchKernelGGL(soft_argmax_cols_kernel, dim3(cpn_cdiv(T, 64), B), dim3(256), 0, st, c, h, beta, s_to_t);
+    CPN_LAUNCH_CHECK("cpn_soft_argmax_pair");
+    return 0;
+}

@@ -1,0 +1,396 @@
+"""get_z: image encoder -> UFC joint feature / 4-D cost-volume aggregation -> pose head.
+
+Restates `CoPoNeRF.get_z` (/root/reference models/CoPoNeRF.py:159-206) with the reference's parameter names
+(checkpoint contract):
+
+  encoder.*                   ResNet-34 trunk, no first max-pool (models/backbone.py:10-102)          stock ops
+  conv_map                    7x7 conv on the normalised image (CoPoNeRF.py:69,187)                    stock op
+  feature_cost_aggregation.*  UFC (models/aggregation.py:146-562, models/conv4d.py:57-163)            in scope (§8 a22-a29)
+  cross_attention.*           CrossBlock / "fundamental-matrix" attention (models/backbone.py:280-428) stock ops
+  pose/rotation/translation_regressor                                                               stock ops
+
+The 4-D operators that dominate UFC (Conv4d + GroupNorm + ReLU, cosine correlation, soft-argmax) go through an
+`ops` object: `HipOps` binds the gfx950 kernels of libcoponerf_hip.so, and the test oracle binds its own CPU
+restatement (oracle/ufc_ref.py) to pin this glue code against fixtures of the upstream model.  Everything else is
+plain PyTorch-ROCm module code, exactly the kind of op the reference itself calls.  256x256 inputs only, like the
+reference (UFC feat_size 16/32/64, learned pos_embed, pose head input size).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# ResNet-34 trunk with torchvision-compatible parameter names (encoder.model.*)
+# ----------------------------------------------------------------------------------------------
+class _BasicBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, stride: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        return self.relu(out + idt)
+
+
+class _ResNet34Trunk(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for i, (cout, n, s) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)], start=1):
+            setattr(self, f"layer{i}", nn.Sequential(*[_BasicBlock(cin if j == 0 else cout, cout, s if j == 0 else 1)
+                                                       for j in range(n)]))
+            cin = cout
+        self.avgpool = nn.Sequential()      # the reference replaces both by empty Sequentials (backbone.py:56-57)
+        self.fc = nn.Sequential()
+
+
+class SpatialEncoder(nn.Module):
+    """backbone.py:10-102 with use_first_pool=False, num_layers=5: returns [512@H/16, 256@H/8, 128@H/4, 64@H/2, 64@H/2]."""
+
+    def __init__(self):
+        super().__init__()
+        self.model = _ResNet34Trunk()
+
+    def forward(self, x):
+        m = self.model
+        x = m.relu(m.bn1(m.conv1(x)))
+        lat = [x]
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            x = getattr(m, name)(x)
+            lat.append(x)
+        return lat[::-1]
+
+
+# ----------------------------------------------------------------------------------------------
+# 4-D operators: parameter containers + dispatch to `ops`
+# ----------------------------------------------------------------------------------------------
+class Conv4d(nn.Module):
+    """Parameters of conv4d.Conv4d (conv4d.py:57-135): two 2-D kernels, one over the query pair of dims, one over
+    the support pair; with stride > 1 the other pair is max-pooled (kernel = stride, ceil_mode)."""
+
+    def __init__(self, cin: int, cout: int, k: int, s: int, p: int):
+        super().__init__()
+        self.query_conv = nn.Conv2d(cin, cout, (k, k), stride=(s, s), padding=(p, p))
+        self.supp_conv = nn.Conv2d(cin, cout, (k, k), stride=(s, s), padding=(p, p))
+        self.k, self.s, self.p = k, s, p
+
+
+class Encoder4D(nn.Module):
+    """conv4d.Encoder4D (conv4d.py:138-163): [Conv4d -> GroupNorm(1 group) -> ReLU] x n."""
+
+    def __init__(self, levels: Sequence[int], k: int = 3, s: int = 1, p: int = 1):
+        super().__init__()
+        self.conv4d = nn.ModuleList([
+            nn.Sequential(Conv4d(levels[i], levels[i + 1], k, s, p), nn.GroupNorm(1, levels[i + 1]), nn.ReLU())
+            for i in range(len(levels) - 1)])
+
+    def forward(self, x, ops):
+        for blk in self.conv4d:
+            c4, gn = blk[0], blk[1]
+            x = ops.conv4d_gn_relu(x, c4.query_conv.weight, c4.query_conv.bias, c4.supp_conv.weight,
+                                   c4.supp_conv.bias, c4.k, c4.s, c4.p, gn.weight, gn.bias, gn.eps)
+        return x
+
+
+class _DWConv(nn.Module):
+    def __init__(self, dim: int, size: int):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+        self.size = size
+
+    def forward(self, x):                       # (B, L, C) tokens
+        B, L, C = x.shape
+        y = self.dwconv(x.transpose(1, 2).reshape(B, C, self.size, self.size))
+        return y.flatten(2).transpose(1, 2)
+
+
+def _tokens_to_map(x, h):
+    B, L, C = x.shape
+    return x.transpose(1, 2).reshape(B, C, h, L // h)
+
+
+def _map_to_tokens(x):
+    return x.flatten(2).transpose(1, 2)
+
+
+def _linear_attention(q, k, v, eps=1e-6):
+    """aggregation.LinearAttention (aggregation.py:84-117): phi = ELU + 1."""
+    Q, K = F.elu(q) + 1, F.elu(k) + 1
+    L = v.shape[1]
+    v = v / L
+    KV = torch.einsum("nshd,nshv->nhdv", K, v)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
+    return (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * L).contiguous()
+
+
+def _corr_to_maps(corr):
+    """(B,H,Hs,Ws,Ht,Wt) -> (B, H*Ht*Wt, Hs, Ws)."""
+    B, H, Hs, Ws, Ht, Wt = corr.shape
+    return corr.permute(0, 1, 4, 5, 2, 3).reshape(B, H * Ht * Wt, Hs, Ws)
+
+
+class UFCLayer(nn.Module):
+    """aggregation.UFCLayer (aggregation.py:146-356)."""
+
+    def __init__(self, fs: int, f2c: Tuple[int, int, int], nhead: int = 8, d: int = 256):
+        super().__init__()
+        self.fs, self.nhead, self.dim = fs, nhead, d // nhead
+        self.q_proj = nn.Linear(d + 256 * nhead, d)
+        self.k_proj = nn.Linear(d + 256 * nhead, d)
+        self.v_proj = nn.Linear(d, d)
+        self.v_proj_corr = Encoder4D((nhead, nhead))
+        self.mlp = nn.Sequential(nn.Linear(d, 4 * d), _DWConv(4 * d, fs), nn.GELU(), nn.Linear(4 * d, d))
+        self.mlp_corr = Encoder4D((nhead, 4 * nhead, nhead))
+        self.mlp_cross = nn.Sequential(nn.Linear(d, 4 * d), _DWConv(4 * d, fs), nn.GELU(), nn.Linear(4 * d, d))
+        self.mlp_refine_corr = Encoder4D((nhead, 4 * nhead, nhead))
+        self.mlp_refine_corr2 = Encoder4D((nhead, 4 * nhead, nhead))
+        self.feat_to_corr1 = Encoder4D((1, nhead), *f2c)
+        self.feat_to_corr2 = Encoder4D((1, nhead), *f2c)
+        self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.v_cross = nn.Linear(d, d)
+        self.norm_cross1, self.norm_cross2 = nn.LayerNorm(d), nn.LayerNorm(d)
+        self.pos_embed = nn.Parameter(torch.zeros(1, fs * fs, 1, self.dim))
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+
+    def _attention(self, corr, feat, ops):              # aggregation.py:269-310
+        B, H, Hs, Ws, Ht, Wt = corr.shape
+        fs = self.fs
+        feat_r = feat
+        feat = self.norm1(feat)
+        cc = F.interpolate(_corr_to_maps(corr), size=(fs, fs), mode="bilinear", align_corners=True)
+        cf = torch.cat((_map_to_tokens(cc), feat), dim=-1)
+        q = self.q_proj(cf).view(B, -1, self.nhead, self.dim) + self.pos_embed
+        k = self.k_proj(cf).view(B, -1, self.nhead, self.dim) + self.pos_embed
+        vf = self.v_proj(feat).view(B, -1, self.nhead, self.dim)
+        vc = F.interpolate(_corr_to_maps(self.v_proj_corr(corr, ops)), size=(fs, fs), mode="bilinear",
+                           align_corners=True)
+        vc = vc.reshape(B, H, Ht * Wt, fs * fs).permute(0, 3, 1, 2)                  # (B, L, H, Ht*Wt)
+        msg_feat = _linear_attention(q, k, vf).view(B, -1, self.nhead * self.dim)
+        msg_corr = _linear_attention(q, k, vc)                                       # (B, L, H, Ht*Wt)
+        msg_corr = msg_corr.permute(0, 2, 3, 1).reshape(B, H * Ht * Wt, fs, fs)
+        msg_corr = F.interpolate(msg_corr, size=(Hs, Ws), mode="bilinear", align_corners=True)
+        msg_corr = msg_corr.reshape(B, H, Ht, Wt, Hs, Ws).permute(0, 1, 4, 5, 2, 3)
+        msg_feat = feat_r + msg_feat
+        msg_corr = corr + msg_corr
+        msg_feat = msg_feat + self.mlp(self.norm2(msg_feat))
+        msg_corr = msg_corr + self.mlp_corr(msg_corr, ops)
+        return msg_corr, msg_feat
+
+    def _cross(self, corr, src, trg):                   # aggregation.py:312-340
+        B, H, Hs, Ws, Ht, Wt = corr.shape
+        fs = self.fs
+        c = corr.reshape(B, H, Hs * Ws, Ht * Wt)
+        pool = lambda t, hh: _map_to_tokens(F.avg_pool2d(_tokens_to_map(t, fs), fs // hh))
+        trg_v = self.v_cross(self.norm_cross1(pool(trg, Ht))).view(B, -1, self.nhead, self.dim)
+        src_v = self.v_cross(self.norm_cross1(pool(src, Hs))).view(B, -1, self.nhead, self.dim)
+        src_attn = torch.einsum("bhst,bthc->bshc", c.softmax(-1), trg_v).reshape(B, -1, self.nhead * self.dim)
+        trg_attn = torch.einsum("bhst,bshc->bthc", c.softmax(-2), src_v).reshape(B, -1, self.nhead * self.dim)
+        up = lambda t, hh: _map_to_tokens(_tokens_to_map(t, hh).repeat_interleave(fs // hh, 2)
+                                          .repeat_interleave(fs // hh, 3))
+        src = src + up(src_attn, Hs)
+        trg = trg + up(trg_attn, Ht)
+        src = src + self.mlp_cross(self.norm_cross2(src))
+        trg = trg + self.mlp_cross(self.norm_cross2(trg))
+        return src, trg
+
+    def forward(self, corr, src, trg, ops):             # aggregation.py:342-356
+        t4 = lambda x: x.permute(0, 1, 4, 5, 2, 3)
+        corr_src, src_r = self._attention(corr, src, ops)
+        corr_trg, trg_r = self._attention(t4(corr).contiguous(), trg, ops)
+        corr_r = corr_src + t4(corr_trg)
+        corr_r = corr_r + self.feat_to_corr1(ops.correlation_tokens(src_r, trg_r, self.fs), ops)
+        corr_r = corr_r + self.mlp_refine_corr(corr_r, ops)
+        src_r, trg_r = self._cross(corr_r, src_r, trg_r)
+        corr_r = corr_r + self.feat_to_corr2(ops.correlation_tokens(src_r, trg_r, self.fs), ops)
+        corr_r = corr_r + self.mlp_refine_corr2(corr_r, ops)
+        return corr_r, src_r, trg_r
+
+
+def _interp_tokens(x, size):                             # aggregation.py:58-63
+    h = int(math.isqrt(x.shape[1]))
+    return _map_to_tokens(F.interpolate(_tokens_to_map(x, h), size=(size, size), mode="bilinear", align_corners=True))
+
+
+def _interp4d(x, n):                                     # aggregation.py:49-56, x (B,1,h,h,h,h) -> (B,1,n,n,n,n)
+    B, C, Hs, Ws, Ht, Wt = x.shape
+    y = F.interpolate(x.reshape(B, C * Hs * Ws, Ht, Wt), size=(n, n), mode="bilinear", align_corners=True)
+    y = y.reshape(B, C, Hs, Ws, n, n).permute(0, 1, 4, 5, 2, 3).reshape(B, C * n * n, Hs, Ws)
+    y = F.interpolate(y, size=(n, n), mode="bilinear", align_corners=True)
+    return y.reshape(B, C, n, n, n, n).permute(0, 1, 4, 5, 2, 3)
+
+
+def _mapping_to_flow(m):                                 # aggregation.py:30-48
+    B, _, H, W = m.shape
+    xs = torch.arange(W, device=m.device, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
+    ys = torch.arange(H, device=m.device, dtype=torch.float32).view(1, 1, H, 1).expand(B, 1, H, W)
+    fx = (m[:, 0:1].float() + 1) * (W - 1) / 2.0 - xs
+    fy = (m[:, 1:2].float() + 1) * (H - 1) / 2.0 - ys
+    return torch.cat((fx, fy), 1)
+
+
+class UFC(nn.Module):
+    """aggregation.UFC (aggregation.py:358-562): coarse-to-fine schedule [2, 2, 1] layers at 16^2 / 32^2 / 64^2 tokens."""
+
+    def __init__(self, nhead: int = 8):
+        super().__init__()
+        cfg = [(16, (3, 1, 1), 2), (32, (3, 2, 1), 2), (64, (5, 4, 2), 1)]
+        self.layers = nn.ModuleList([nn.ModuleList([UFCLayer(fs, f2c, nhead) for _ in range(n)]) for fs, f2c, n in cfg])
+        self.embedding = nn.ModuleList([Encoder4D((1, nhead), *f2c) for _, f2c, _ in cfg])
+        self.proj_feat = nn.ModuleList([nn.Sequential(nn.Linear(c, 256), nn.ReLU()) for c in (512, 256, 128)])
+
+    def forward(self, feat: Sequence[torch.Tensor], nview: int, ops):
+        B2 = feat[0].shape[0]
+        B = B2 // nview
+        take = lambda i, v: self.proj_feat[i](_map_to_tokens(feat[i].view(B, nview, *feat[i].shape[1:])[:, v]))
+        src_f = [take(i, 0) for i in range(3)]
+        trg_f = [take(i, 1) for i in range(3)]
+        feats, corrs = [], []
+        corr = src = trg = None
+        for lvl, fs in enumerate((16, 32, 64)):
+            emb = self.embedding[lvl](ops.correlation_tokens(src_f[lvl], trg_f[lvl], fs), ops)
+            if lvl == 0:
+                corr, src, trg = emb, src_f[0], trg_f[0]
+            else:
+                corr = corr + emb
+                src = _interp_tokens(src, fs) + src_f[lvl]
+                trg = _interp_tokens(trg, fs) + trg_f[lvl]
+            for layer in self.layers[lvl]:
+                corr, src, trg = layer(corr, src, trg, ops)
+            feats.append(_tokens_to_map(torch.stack((src, trg), dim=1).flatten(0, 1), fs))
+            corrs.append(ops.correlation_tokens(src, trg, fs))
+        c = sum(_interp4d(x, 64) for x in corrs) / len(corrs)                          # (B,1,64,64,64,64)
+        t_to_s, s_to_t = ops.soft_argmax_pair(c)                                      # (B,2,64,64) each
+        return feats, (_mapping_to_flow(t_to_s), _mapping_to_flow(s_to_t), t_to_s, s_to_t), c
+
+
+# ----------------------------------------------------------------------------------------------
+# pose head (out of the render/aggregation scope; stock ops) — backbone.py:209-428
+# ----------------------------------------------------------------------------------------------
+def positional_encodings(fx, fy, cx, cy, n: int = 64):
+    """(x^2, y^2, xy, x, y, 1) of K^-1-normalised pixel coordinates, index = col*n + row.
+    Closed form of the 4096-iteration Python loop of backbone.get_positional_encodings (backbone.py:209-278)."""
+    B = fx.shape[0]
+    dev = fx.device
+    hp, wp = cy * 2, cx * 2
+    K = torch.zeros(B, 3, 3, device=dev)
+    K[:, 0, 0] = ((fx / wp) * 2).squeeze(-1)
+    K[:, 1, 1] = ((fy / hp) * 2).squeeze(-1)
+    K[:, 0, 2] = ((cx / wp) * 2 - 1).squeeze(-1)
+    K[:, 1, 2] = ((cy / hp) * 2 - 1).squeeze(-1)
+    K[:, 2, 2] = 1
+    Kinv = torch.inverse(K)
+    lin = torch.linspace(-1, 1, steps=n, device=dev)
+    xs = lin.repeat_interleave(n)                       # index k*n + j -> xs[k]
+    ys = lin.repeat(n)                                  #               -> ys[j]
+    pts = torch.stack((xs, ys, torch.ones_like(xs)), 0)                                  # (3, n*n)
+    w = Kinv @ pts                                                                       # (B,3,n*n)
+    p4, p3 = w[:, 0] / w[:, 2], w[:, 1] / w[:, 2]
+    return torch.stack((p3 * p3, p4 * p4, p3 * p4, p3, p4, torch.ones_like(p3)), dim=2)  # (B, n*n, 6)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, d: int, hidden: int):
+        super().__init__()
+        self.fc1, self.act, self.fc2 = nn.Linear(d, hidden), nn.GELU(), nn.Linear(hidden, d)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class _CrossAttention(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)          # unused upstream too (backbone.py:296); checkpoint key
+        self.proj_fundamental = nn.Linear(dim + 6, dim)
+
+    def forward(self, x1, x2, corr, intr):
+        B = x1.shape[0]
+        a1 = corr.reshape(B, corr.shape[-4] * corr.shape[-3], -1)                       # (B, src, trg)
+        a2 = a1.transpose(-2, -1)
+        f1 = a1.softmax(dim=-1) * a1.softmax(dim=-2)
+        f2 = a2.softmax(dim=-1) * a2.softmax(dim=-2)
+        pos = positional_encodings(*intr, n=int(math.isqrt(x1.shape[1]))).to(x1.dtype)
+        v1, v2 = torch.cat([x1, pos], dim=2), torch.cat([x2, pos], dim=2)
+        F1 = ((v1.transpose(-2, -1) @ f1) @ v1).transpose(-2, -1)
+        F2 = ((v2.transpose(-2, -1) @ f2) @ v2).transpose(-2, -1)
+        return self.proj_fundamental(F2), self.proj_fundamental(F1)
+
+
+class CrossBlock(nn.Module):
+    def __init__(self, dim: int = 256):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.cross_attn = _CrossAttention(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _Mlp(dim, 4 * dim)
+        self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x, corr, intr):
+        b_s, hw, nf = x.shape
+        x = x.reshape(-1, 2, hw, nf)
+        fa, fb = self.cross_attn(self.norm1(x[:, 0]), self.norm1(x[:, 1]), corr, intr)
+        f = torch.cat([fa.unsqueeze(1), fb.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)
+        f = f + self.mlp(self.norm2(f))
+        return self.norm(f)
+
+
+def r6d_to_matrix(d6):
+    """Zhou et al. 6-D rotation -> rows of R (CoPoNeRF.py:106-126)."""
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = F.normalize(a1, dim=-1)
+    b2 = F.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
+    return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
+
+
+def imagenet_normalise(x):
+    mean = x.new_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = x.new_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+def make_pose_heads():
+    mlp = lambda dims: [m for i in range(len(dims) - 1) for m in (nn.ReLU(), nn.Linear(dims[i], dims[i + 1]))]
+    pose = nn.Sequential(nn.Linear((16 * 16 + 6) * 256 * 2, 512), nn.ReLU(), nn.Linear(512, 256), nn.ReLU(),
+                         nn.Linear(256, 128 * 2), nn.ReLU())
+    return pose, nn.Sequential(*mlp([128, 64, 32, 6])), nn.Sequential(*mlp([128, 64, 32, 3]))
+
+
+def get_z(model, input, ops):
+    """Body of CoPoNeRF.get_z (CoPoNeRF.py:159-206) on the sub-modules of `model`."""
+    rgb = input["context"]["rgb"]
+    B, V, H, W, _ = rgb.shape
+    if (H, W) != (256, 256):
+        raise ValueError("get_z supports 256x256 context images only, like the reference (SURVEY.md §0)")
+    model.H, model.W = H, W
+    x = imagenet_normalise((rgb.flatten(0, 1).permute(0, 3, 1, 2) + 1) / 2.)
+    z = model.encoder(x)[:3]
+    z_conv = model.conv_map(x)
+    feats, flows, c = model.feature_cost_aggregation(z, model.n_view, ops)
+    Kn = input["context"]["intrinsics"].clone()
+    Kn[:, :, :2, :] = Kn[:, :, :2, :] / H
+    intr = (Kn[:, 0, 0, 0, None], Kn[:, 0, 1, 1, None], Kn[:, 0, 0, 2, None], Kn[:, 0, 1, 2, None])
+    pose_feat = model.cross_attention(feats[-1].flatten(-2, -1).transpose(-1, -2), c, intr).reshape(B, -1)
+    lat = model.pose_regressor(pose_feat)[:, :128]
+    R = r6d_to_matrix(model.rotation_regressor(lat))[:, :3, :3]
+    t = model.translation_regressor(lat)
+    bottom = torch.tensor([0., 0., 0., 1.], device=t.device).expand(B, 1, -1)
+    rel_pose = torch.cat((torch.cat((R, t.unsqueeze(-1)), dim=-1), bottom), dim=1)
+    return feats + [z_conv], rel_pose, flows

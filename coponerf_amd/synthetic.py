@@ -197,3 +197,29 @@ def make_render_weights(seed: int = 7, gain: float = 1.0) -> Dict[str, torch.Ten
         bound = gain / math.sqrt(fan_in)
         out[name] = uniform(shape, seed, -bound, bound, stream=100 + i)
     return out
+
+
+def make_full_weights(shapes: Dict[str, Tuple], seed: int = 11) -> Dict[str, torch.Tensor]:
+    """Deterministic values for EVERY state_dict entry (name -> shape), at scales that keep the 256x256 get_z stack
+    numerically tame: matrices/kernels U(+-1/sqrt(fan_in)), norm scales 1 +- 0.1, biases +-0.05, BatchNorm running
+    statistics (mean +-0.05, var in [0.8, 1.2])."""
+    out = {}
+    for i, name in enumerate(sorted(shapes)):
+        shape = tuple(shapes[name])
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            out[name] = torch.zeros(shape, dtype=torch.int64)
+        elif leaf == "running_var":
+            out[name] = uniform(shape, seed, 0.8, 1.2, stream=1000 + i)
+        elif leaf == "running_mean":
+            out[name] = uniform(shape, seed, -0.05, 0.05, stream=1000 + i)
+        elif leaf == "pos_embed":
+            out[name] = uniform(shape, seed, -0.04, 0.04, stream=1000 + i)
+        elif len(shape) >= 2:
+            bound = 1.0 / math.sqrt(int(np.prod(shape[1:])))
+            out[name] = uniform(shape, seed, -bound, bound, stream=1000 + i)
+        elif leaf == "weight":                                   # 1-D weight = normalisation scale
+            out[name] = uniform(shape, seed, 0.9, 1.1, stream=1000 + i)
+        else:
+            out[name] = uniform(shape, seed, -0.05, 0.05, stream=1000 + i)
+    return out

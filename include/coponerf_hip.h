@@ -122,6 +122,30 @@ int cpn_linear_f32(const float* X, int ldx, const float* W, int ldw, const float
 int cpn_mask_rgb(const float* rgb_raw, int ld, const uint8_t* overlaps, int B, int V, int R,
                  float* rgb, float* valid, void* stream);
 
+/* ==== get_z path: the 4-D operators of UFC =========================== */
+
+/* ---- K6: Conv4d (+ MaxPool4d when stride > 1) + GroupNorm(1 group) + ReLU in one pass --------------
+ * replaces conv4d.Conv4d / MaxPool4d / Encoder4D (models/conv4d.py:7-30, 57-163) and the einops rearrange copies
+ * around them.  x (B,Cin,Hq,Wq,Hs,Ws) fp32; wq/ws (Cout,Cin,k,k), bq/bs (Cout): query / support 2-D kernels;
+ * y (B,Cout,Hq',Wq',Hs',Ws') with n' = (n + 2p - k)/s + 1; gn_w/gn_b (Cout) GroupNorm affine;
+ * stats (B,2) float64 scratch that MUST be zero on entry (sum, sum of squares per sample).                  */
+int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
+                       const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout,
+                       int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream);
+
+/* ---- K7: cosine correlation of two token sets ------------------------------------------------------
+ * replaces aggregation.correlation / correlation_token (models/aggregation.py:70-80):
+ * out[b,s,t] = <src[b,s]/(|src[b,s]|+eps), trg[b,t]/(|trg[b,t]|+eps)>; src, trg (B,L,C), C % 16 == 0;
+ * src_n, trg_n (B,L,C) scratch for the normalised tokens; out (B,L,L) == (B,1,h,w,h,w).                    */
+int cpn_correlation(const float* src, const float* trg, int B, int L, int C, float eps,
+                    float* src_n, float* trg_n, float* out, void* stream);
+
+/* ---- K8: soft-argmax with temperature over the 4-D correlation, both directions --------------------
+ * replaces aggregation.soft_argmax + softmax_with_temperature (models/aggregation.py:119-144, 555-560).
+ * c (B, h*h source, h*h target); t_to_s[b,:,s] = E_{t ~ softmax_t(c[b,s,:]/beta)}[(x_t, y_t)],
+ * s_to_t[b,:,t] = E_{s ~ softmax_s(c[b,:,t]/beta)}[(x_s, y_s)], coordinates linspace(-1,1,h); outputs (B,2,h,h). */
+int cpn_soft_argmax_pair(const float* c, int B, int h, float beta, float* t_to_s, float* s_to_t, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

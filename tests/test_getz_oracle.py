@@ -1,0 +1,75 @@
+"""get_z: the oracle's UFC operators and the product's (stock-op) glue against fixtures of the upstream model (CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from coponerf_amd import CoPoNeRF, synthetic as syn
+from coponerf_amd.getz import Encoder4D, _linear_attention, positional_encodings
+from oracle.ufc_ref import TorchOps
+from tests.helpers import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def ops_gold():
+    return dict(np.load(os.path.join(GOLDEN, "ufc_ops.npz")))
+
+
+def test_oracle_ufc_operators_match_reference(ops_gold):
+    for tag, (cin, mid, k, s, p, n) in {"k3s1": (3, 5, 3, 1, 1, 6), "k3s2": (1, 8, 3, 2, 1, 10), "k5s4": (1, 8, 5, 4, 2, 16)}.items():
+        enc = Encoder4D((cin, mid), k, s, p)
+        shp = {kk: tuple(v.shape) for kk, v in enc.state_dict().items()}
+        enc.load_state_dict(syn.make_full_weights(shp, seed=70 + s))
+        x = syn.normal((2, cin, n, n, n, n), seed=80 + s)
+        with torch.no_grad():
+            y = enc(x, TorchOps)
+        assert (y - torch.from_numpy(ops_gold[f"enc4d_{tag}"])).abs().max() <= 2e-5, tag
+    a, b = syn.normal((2, 36, 24), seed=90), syn.normal((2, 36, 24), seed=91)
+    corr = TorchOps.correlation_tokens(a, b, 6)
+    assert (corr[:, 0] - torch.from_numpy(ops_gold["correlation"])).abs().max() <= 1e-6
+    c = syn.normal((2, 1, 6, 6, 6, 6), seed=92) * 0.2
+    t2s, s2t = TorchOps.soft_argmax_pair(c)
+    assert (t2s - torch.from_numpy(ops_gold["t_to_s"])).abs().max() <= 1e-5
+    assert (s2t - torch.from_numpy(ops_gold["s_to_t"])).abs().max() <= 1e-5
+    q, k_, v = syn.normal((2, 30, 4, 8), 93), syn.normal((2, 30, 4, 8), 94), syn.normal((2, 30, 4, 12), 95)
+    assert (_linear_attention(q, k_, v) - torch.from_numpy(ops_gold["linear_attention"])).abs().max() <= 1e-5
+
+
+def test_positional_encodings_closed_form():
+    """The vectorised table equals the reference's 4096-iteration loop formula (backbone.py:209-278) on a few entries."""
+    fx, fy, cx, cy = (torch.tensor([[v]]) for v in (0.8, 0.8, 0.5, 0.5))
+    pos = positional_encodings(fx, fy, cx, cy, n=64)
+    assert pos.shape == (1, 4096, 6)
+    lin = torch.linspace(-1, 1, 64)
+    K = torch.tensor([[[1.6, 0.0, 0.0], [0.0, 1.6, 0.0], [0.0, 0.0, 1.0]]])
+    for (j, k) in [(0, 0), (5, 17), (63, 2), (31, 63)]:
+        w = torch.inverse(K) @ torch.tensor([lin[k], lin[j], 1.0])
+        p3, p4 = (w[:, 1] / w[:, 2]).item(), (w[:, 0] / w[:, 2]).item()
+        got = pos[0, k * 64 + j]
+        assert torch.allclose(got, torch.tensor([p3 * p3, p4 * p4, p3 * p4, p3, p4, 1.0]), atol=1e-6)
+
+
+def test_get_z_glue_matches_reference():
+    """Product get_z with the oracle's CPU operators plugged in == upstream get_z (same 744-entry state_dict)."""
+    gold = dict(np.load(os.path.join(GOLDEN, "getz.npz")))
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model.eval()
+    inp = syn.make_inputs(1, 256, 256, 64, seed=41)
+    with torch.no_grad():
+        z, rel_pose, flows = model.get_z(inp, ops=TorchOps)
+    assert model.H == 256 and model.W == 256
+    assert [tuple(t.shape) for t in z] == [(2, 256, 16, 16), (2, 256, 32, 32), (2, 256, 64, 64), (2, 64, 256, 256)]
+    strides = [(4, 2), (8, 4), (16, 8), (8, 16)]
+    for i, t in enumerate(z):
+        cs, ss = strides[i]
+        g = torch.from_numpy(gold[f"z{i}_sample"])
+        assert (t[:, ::cs, ::ss, ::ss] - g).abs().max() <= 2e-3 * max(1.0, float(g.abs().max())), i
+        assert abs(float(t.mean()) - gold[f"z{i}_stats"][0]) <= 1e-3
+    for i, f in enumerate(flows):
+        g = torch.from_numpy(gold[f"flow{i}"])
+        assert f.shape == g.shape == (1, 2, 64, 64)
+        assert (f - g).abs().max() <= (5e-2 if i < 2 else 2e-3), i          # pixel units / normalised units
+    assert (rel_pose - torch.from_numpy(gold["rel_pose"])).abs().max() <= 2e-3

@@ -1,0 +1,86 @@
+"""get_z on the MI355X: the HIP UFC operators against the CPU oracle, and the whole get_z against upstream fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from coponerf_amd import synthetic as syn
+from tests.helpers import GOLDEN, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")
+
+
+def test_ufc_operators_against_oracle(dev):
+    from coponerf_amd.getz import Encoder4D
+    from coponerf_amd.ufc_ops import HipOps
+    from oracle.ufc_ref import TorchOps
+    gold = dict(np.load(os.path.join(GOLDEN, "ufc_ops.npz")))
+    hip = HipOps()
+    for tag, (cin, mid, k, s, p, n) in {"k3s1": (3, 5, 3, 1, 1, 6), "k3s2": (1, 8, 3, 2, 1, 10), "k5s4": (1, 8, 5, 4, 2, 16)}.items():
+        enc = Encoder4D((cin, mid), k, s, p)
+        shp = {kk: tuple(v.shape) for kk, v in enc.state_dict().items()}
+        enc.load_state_dict(syn.make_full_weights(shp, seed=70 + s))
+        x = syn.normal((2, cin, n, n, n, n), seed=80 + s)
+        with torch.no_grad():
+            want = enc(x, TorchOps)
+            got = enc.to(dev)(x.to(dev), hip).cpu()
+        assert got.shape == want.shape
+        assert (got - want).abs().max() <= 2e-5, tag
+        assert (got - torch.from_numpy(gold[f"enc4d_{tag}"])).abs().max() <= 3e-5, tag     # upstream itself
+    # the shapes UFC really uses: 8 -> 32 -> 8 channels on a 16^4 volume, residual-sized values
+    enc = Encoder4D((8, 32, 8))
+    shp = {kk: tuple(v.shape) for kk, v in enc.state_dict().items()}
+    enc.load_state_dict(syn.make_full_weights(shp, seed=77))
+    x = syn.normal((1, 8, 16, 16, 16, 16), seed=78)
+    with torch.no_grad():
+        want = enc(x, TorchOps)
+        got = enc.to(dev)(x.to(dev), hip).cpu()
+    assert (got - want).abs().max() <= 5e-5
+    # correlation and soft-argmax
+    a, b = syn.normal((2, 256, 64), seed=90), syn.normal((2, 256, 64), seed=91)
+    want = TorchOps.correlation_tokens(a, b, 16)
+    got = hip.correlation_tokens(a.to(dev), b.to(dev), 16).cpu()
+    assert (got - want).abs().max() <= 2e-6
+    for h, seed in ((6, 92), (16, 93)):
+        c = syn.normal((2, 1, h, h, h, h), seed=seed) * 0.2
+        w1, w2 = TorchOps.soft_argmax_pair(c)
+        g1, g2 = hip.soft_argmax_pair(c.to(dev))
+        assert (g1.cpu() - w1).abs().max() <= 2e-5 and (g2.cpu() - w2).abs().max() <= 2e-5
+    c = syn.normal((2, 1, 6, 6, 6, 6), seed=92) * 0.2
+    g1, g2 = hip.soft_argmax_pair(c.to(dev))
+    assert (g1.cpu() - torch.from_numpy(gold["t_to_s"])).abs().max() <= 2e-5
+    assert (g2.cpu() - torch.from_numpy(gold["s_to_t"])).abs().max() <= 2e-5
+
+
+def test_get_z_and_render_end_to_end(dev):
+    """get_z through the HIP operators == upstream get_z fixture; its outputs feed the HIP render path."""
+    from coponerf_amd import CoPoNeRF
+    gold = dict(np.load(os.path.join(GOLDEN, "getz.npz")))
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev).eval()
+    inp = to_device(syn.make_inputs(1, 256, 256, 64, seed=41), dev)
+    with torch.no_grad():
+        z, rel_pose, flows = model.get_z(inp)
+    strides = [(4, 2), (8, 4), (16, 8), (8, 16)]
+    for i, t in enumerate(z):
+        cs, ss = strides[i]
+        g = torch.from_numpy(gold[f"z{i}_sample"])
+        assert (t[:, ::cs, ::ss, ::ss].cpu() - g).abs().max() <= 5e-3 * max(1.0, float(g.abs().max())), i
+    for i, f in enumerate(flows):
+        assert (f.cpu() - torch.from_numpy(gold[f"flow{i}"])).abs().max() <= (1e-1 if i < 2 else 4e-3), i
+    assert (rel_pose.cpu() - torch.from_numpy(gold["rel_pose"])).abs().max() <= 5e-3
+    with torch.no_grad():
+        out = model(inp, z=z, rel_pose=rel_pose, val=True, flow=flows)
+        out2 = model(inp, val=True) if False else None
+    assert out["rgb"].shape == (1, 1, 64, 3) and torch.isfinite(out["rgb"]).all()
+    assert out["pixel_val"].shape == (2, 64, 64, 2)
