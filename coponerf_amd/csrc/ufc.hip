@@ -91,6 +91,82 @@ __global__ __launch_bounds__(256) void conv4d_kernel(const float* __restrict__ x
     }
 }
 
+// stride-1 3x3x3x3 fast path (57 of the 63 Conv4d calls of a get_z): one thread computes ALL output channels of
+// its position, so every input value is read once per tap instead of once per (tap, output channel); the weights
+// are staged in LDS as [cin][tap][branch][cout] and read as wave-uniform (broadcast) 16-byte vectors.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv4d_k3s1_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                          const float* __restrict__ bq, const float* __restrict__ ws,
+                                                          const float* __restrict__ bs, int Cin, int Hq, int Wq,
+                                                          int Hs, int Ws, float* __restrict__ y,
+                                                          double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];        // Cin * 9 * 2 * COUT floats
+    const int b = blockIdx.z;
+    for (int i = threadIdx.x; i < Cin * 9 * 2 * COUT; i += 256) {
+        const int o = i % COUT;
+        int t = i / COUT;
+        const int br = t & 1; t >>= 1;
+        const int tap = t % 9, c = t / 9;
+        wl[i] = (br ? ws : wq)[((size_t)o * Cin + c) * 9 + tap];
+    }
+    __syncthreads();
+    const long long npos = (long long)Hq * Wq * Hs * Ws;
+    const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = pos < npos;
+    double s1 = 0.0, s2 = 0.0;
+    if (active) {
+        const int sx = (int)(pos % Ws);
+        long long t = pos / Ws;
+        const int sy = (int)(t % Hs); t /= Hs;
+        const int qx = (int)(t % Wq);
+        const int qy = (int)(t / Wq);
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = bq[o] + bs[o];
+        const size_t cstride = (size_t)npos;
+        const float* xb = x + (size_t)b * Cin * cstride;
+        for (int c = 0; c < Cin; ++c) {
+            const float* xc = xb + c * cstride;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int Y = qy + i - 1, X = qx + j - 1, U = sy + i - 1, Vv = sx + j - 1;
+                    const float vq = (Y >= 0 && Y < Hq && X >= 0 && X < Wq)
+                                         ? xc[(((size_t)Y * Wq + X) * Hs + sy) * Ws + sx] : 0.0f;
+                    const float vs = (U >= 0 && U < Hs && Vv >= 0 && Vv < Ws)
+                                         ? xc[(((size_t)qy * Wq + qx) * Hs + U) * Ws + Vv] : 0.0f;
+                    const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ((c * 9 + i * 3 + j) * 2) * COUT);
+#pragma unroll
+                    for (int o4 = 0; o4 < COUT / 4; ++o4) {
+                        const f32x4 a = w4[o4], bb = w4[COUT / 4 + o4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[o4 * 4 + e] += a[e] * vq + bb[e] * vs;
+                    }
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            y[((size_t)b * COUT + o) * npos + pos] = acc[o];
+            s1 += (double)acc[o];
+            s2 += (double)acc[o] * acc[o];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(stats + b * 2, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(stats + b * 2 + 1, red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_relu_kernel(float* __restrict__ y, const double* __restrict__ stats,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, int Cout, long long npos) {
@@ -244,7 +320,46 @@ __global__ __launch_bounds__(256) void soft_argmax_cols_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bilinear resize with align_corners=True of `planes` independent (h, w) images: F.interpolate as used by
+// interpolate4d / forward_attention (aggregation.py:49-56, 285, 293, 299).  thread = output pixel; HBM-bound.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_bilinear_ac_kernel(const float* __restrict__ src,
+                                                                 float* __restrict__ dst, long long planes, int h,
+                                                                 int w, int H, int W) {
+    const long long total = planes * H * W;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int X = (int)(idx % W);
+        const long long t = idx / W;
+        const int Y = (int)(t % H);
+        const long long pl = t / H;
+        const float fy = sy * (float)Y, fx = sx * (float)X;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p = src + pl * h * w;
+        const float top = p[y0 * w + x0] * (1.0f - lx) + p[y0 * w + x1] * lx;
+        const float bot = p[y1 * w + x0] * (1.0f - lx) + p[y1 * w + x1] * lx;
+        dst[idx] = top * (1.0f - ly) + bot * ly;
+    }
+}
+
 }  // namespace
+
+extern "C" int cpn_resize_bilinear_ac(const float* src, float* dst, long long planes, int h, int w, int H, int W,
+                                      void* stream) {
+    CPN_REQUIRE(src && dst, CPN_E_ARG, "cpn_resize_bilinear_ac: null pointer");
+    CPN_REQUIRE(planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, CPN_E_SHAPE, "cpn_resize_bilinear_ac: bad shape");
+    const long long total = planes * H * W;
+    const unsigned blocks = (unsigned)(cpn_cdiv(total, 256) < 65536u ? cpn_cdiv(total, 256) : 65536u);
+    hipLaunchKernelGGL(resize_bilinear_ac_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, planes,
+                       h, w, H, W);
+    CPN_LAUNCH_CHECK("cpn_resize_bilinear_ac");
+    return 0;
+}
 
 extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
                                   const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout, int Hq,
@@ -260,8 +375,19 @@ extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* 
     const long long npos = (long long)Oq * Pq_ * Os * Ps_;
     const hipStream_t st = (hipStream_t)stream;
     dim3 grid(cpn_cdiv(npos, 256), Cout, B);
-    hipLaunchKernelGGL(conv4d_kernel, grid, dim3(256), 0, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, k, s, p, Oq, Pq_,
-                       Os, Ps_, y, stats);
+    const size_t wbytes = (size_t)Cin * 9 * 2 * Cout * sizeof(float);
+    if (k == 3 && s == 1 && p == 1 && (Cout == 8 || Cout == 32) && wbytes <= 64 * 1024) {
+        dim3 g1(cpn_cdiv(npos, 256), 1, B);
+        if (Cout == 8)
+            hipLaunchKernelGGL(conv4d_k3s1_kernel<8>, g1, dim3(256), wbytes, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs,
+                               Ws, y, stats);
+        else
+            hipLaunchKernelGGL(conv4d_k3s1_kernel<32>, g1, dim3(256), wbytes, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs,
+                               Ws, y, stats);
+    } else {
+        hipLaunchKernelGGL(conv4d_kernel, grid, dim3(256), 0, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, k, s, p, Oq,
+                           Pq_, Os, Ps_, y, stats);
+    }
     CPN_LAUNCH_CHECK("cpn_conv4d_gn_relu(conv)");
     hipLaunchKernelGGL(gn_relu_kernel, grid, dim3(256), 0, st, y, stats, gn_w, gn_b, eps, Cout, npos);
     CPN_LAUNCH_CHECK("cpn_conv4d_gn_relu(norm)");

@@ -175,18 +175,17 @@ class UFCLayer(nn.Module):
         fs = self.fs
         feat_r = feat
         feat = self.norm1(feat)
-        cc = F.interpolate(_corr_to_maps(corr), size=(fs, fs), mode="bilinear", align_corners=True)
+        cc = ops.resize_bilinear(_corr_to_maps(corr), fs)
         cf = torch.cat((_map_to_tokens(cc), feat), dim=-1)
         q = self.q_proj(cf).view(B, -1, self.nhead, self.dim) + self.pos_embed
         k = self.k_proj(cf).view(B, -1, self.nhead, self.dim) + self.pos_embed
         vf = self.v_proj(feat).view(B, -1, self.nhead, self.dim)
-        vc = F.interpolate(_corr_to_maps(self.v_proj_corr(corr, ops)), size=(fs, fs), mode="bilinear",
-                           align_corners=True)
+        vc = ops.resize_bilinear(_corr_to_maps(self.v_proj_corr(corr, ops)), fs)
         vc = vc.reshape(B, H, Ht * Wt, fs * fs).permute(0, 3, 1, 2)                  # (B, L, H, Ht*Wt)
         msg_feat = _linear_attention(q, k, vf).view(B, -1, self.nhead * self.dim)
         msg_corr = _linear_attention(q, k, vc)                                       # (B, L, H, Ht*Wt)
         msg_corr = msg_corr.permute(0, 2, 3, 1).reshape(B, H * Ht * Wt, fs, fs)
-        msg_corr = F.interpolate(msg_corr, size=(Hs, Ws), mode="bilinear", align_corners=True)
+        msg_corr = ops.resize_bilinear(msg_corr, Hs)
         msg_corr = msg_corr.reshape(B, H, Ht, Wt, Hs, Ws).permute(0, 1, 4, 5, 2, 3)
         msg_feat = feat_r + msg_feat
         msg_corr = corr + msg_corr
@@ -224,16 +223,18 @@ class UFCLayer(nn.Module):
         return corr_r, src_r, trg_r
 
 
-def _interp_tokens(x, size):                             # aggregation.py:58-63
+def _interp_tokens(x, size, ops):                        # aggregation.py:58-63
     h = int(math.isqrt(x.shape[1]))
-    return _map_to_tokens(F.interpolate(_tokens_to_map(x, h), size=(size, size), mode="bilinear", align_corners=True))
+    return _map_to_tokens(ops.resize_bilinear(_tokens_to_map(x, h), size))
 
 
-def _interp4d(x, n):                                     # aggregation.py:49-56, x (B,1,h,h,h,h) -> (B,1,n,n,n,n)
+def _interp4d(x, n, ops):                                # aggregation.py:49-56, x (B,1,h,h,h,h) -> (B,1,n,n,n,n)
     B, C, Hs, Ws, Ht, Wt = x.shape
-    y = F.interpolate(x.reshape(B, C * Hs * Ws, Ht, Wt), size=(n, n), mode="bilinear", align_corners=True)
+    if Hs == n and Ht == n:
+        return x
+    y = ops.resize_bilinear(x.reshape(B, C * Hs * Ws, Ht, Wt), n)
     y = y.reshape(B, C, Hs, Ws, n, n).permute(0, 1, 4, 5, 2, 3).reshape(B, C * n * n, Hs, Ws)
-    y = F.interpolate(y, size=(n, n), mode="bilinear", align_corners=True)
+    y = ops.resize_bilinear(y, n)
     return y.reshape(B, C, n, n, n, n).permute(0, 1, 4, 5, 2, 3)
 
 
@@ -270,13 +271,13 @@ class UFC(nn.Module):
                 corr, src, trg = emb, src_f[0], trg_f[0]
             else:
                 corr = corr + emb
-                src = _interp_tokens(src, fs) + src_f[lvl]
-                trg = _interp_tokens(trg, fs) + trg_f[lvl]
+                src = _interp_tokens(src, fs, ops) + src_f[lvl]
+                trg = _interp_tokens(trg, fs, ops) + trg_f[lvl]
             for layer in self.layers[lvl]:
                 corr, src, trg = layer(corr, src, trg, ops)
             feats.append(_tokens_to_map(torch.stack((src, trg), dim=1).flatten(0, 1), fs))
             corrs.append(ops.correlation_tokens(src, trg, fs))
-        c = sum(_interp4d(x, 64) for x in corrs) / len(corrs)                          # (B,1,64,64,64,64)
+        c = sum(_interp4d(x, 64, ops) for x in corrs) / len(corrs)                          # (B,1,64,64,64,64)
         t_to_s, s_to_t = ops.soft_argmax_pair(c)                                      # (B,2,64,64) each
         return feats, (_mapping_to_flow(t_to_s), _mapping_to_flow(s_to_t), t_to_s, s_to_t), c
 

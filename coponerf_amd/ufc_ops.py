@@ -54,3 +54,12 @@ class HipOps:
         s_to_t = torch.empty(B, 2, h, h, device=c.device, dtype=torch.float32)
         call("cpn_soft_argmax_pair", c.data_ptr(), B, h, 0.02, t_to_s.data_ptr(), s_to_t.data_ptr(), _stream())
         return t_to_s, s_to_t
+
+    def resize_bilinear(self, x, size):
+        """(N,C,h,w) -> (N,C,size,size), bilinear, align_corners=True."""
+        self._need_gpu(x)
+        x = x.contiguous().float()
+        N, C, h, w = x.shape
+        y = torch.empty(N, C, size, size, device=x.device, dtype=torch.float32)
+        call("cpn_resize_bilinear_ac", x.data_ptr(), y.data_ptr(), N * C, h, w, size, size, _stream())
+        return y

@@ -146,6 +146,11 @@ int cpn_correlation(const float* src, const float* trg, int B, int L, int C, flo
  * s_to_t[b,:,t] = E_{s ~ softmax_s(c[b,:,t]/beta)}[(x_s, y_s)], coordinates linspace(-1,1,h); outputs (B,2,h,h). */
 int cpn_soft_argmax_pair(const float* c, int B, int h, float beta, float* t_to_s, float* s_to_t, void* stream);
 
+/* ---- bilinear resize, align_corners=True, of `planes` independent (h,w) fp32 images -> (H,W) ----------
+ * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /
+ * interpolate2d_token (models/aggregation.py:49-63, 285, 293, 299).                                           */
+int cpn_resize_bilinear_ac(const float* src, float* dst, long long planes, int h, int w, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,10 @@ class TorchOps:
         return F.relu(F.group_norm(y, 1, gn_w, gn_b, eps))
 
     @staticmethod
+    def resize_bilinear(x, size):
+        return F.interpolate(x, size=(size, size), mode="bilinear", align_corners=True)
+
+    @staticmethod
     def correlation_tokens(src, trg, fs):
         B = src.shape[0]
         c = torch.einsum("bsc,btc->bst", l2_normalise_tokens(src), l2_normalise_tokens(trg))
