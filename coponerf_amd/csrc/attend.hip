@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void attend_kernel(const __half* __restrict__ 
         const float w = wts[row] * inv;
         wts[row] = w;
         if (at_wt) {                                           // (N,R,S) layout, n = b*V + v
-            const long long ray = ray0 + lray;
-            const int b = (int)(ray / R), r = (int)(ray % R);
+            const unsigned ray = (unsigned)ray0 + (unsigned)lray;
+            const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
             const int v = row / S, s = row - v * S;
             at_wt[(((size_t)(b * V + v)) * R + r) * S + s] = w;
         }
@@ -102,6 +102,91 @@ __global__ __launch_bounds__(256) void attend_kernel(const __half* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Folded variant: there is no non-linearity between query_encode_latent_2 and latent_value
+// (CoPoNeRF.py:387-404) and the softmax weights of a ray sum to 1, so
+//     sum_s w_s (Wv [W2 h_s0 + b2 ; W2 h_s1 + b2] + bv)  =  (Wv_a W2 | Wv_b W2) . sum_s w_s [h_s0 ; h_s1]  +  const.
+// This kernel therefore reduces the 2*832 = 1664 hidden activations per sample (fp16, post-ReLU) with the
+// softmax weights; the 1664 -> 416 value projection then runs once per RAY instead of once per sample.
+// thread = 8 hidden channels (16 B), rows streamed; per ray T x 3328 B read, fully coalesced.
+// ---------------------------------------------------------------------------------------------
+constexpr int HC = 1664;
+
+__global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __restrict__ qa,
+                                                            const __half* __restrict__ qb,
+                                                            const __half* __restrict__ hid, int V, int R, int S,
+                                                            int ray0, __half* __restrict__ hbar,
+                                                            float* __restrict__ at_wt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wts = reinterpret_cast<float*>(smem_raw);
+    float* red = wts + V * S;
+    const int T = V * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned lray = blockIdx.x;
+    const size_t row0 = (size_t)lray * T;
+
+    float lmax = -INFINITY;
+    for (int base = 0; base < T; base += 128) {
+        const int row = base + (tid >> 1);
+        if (row < T) {
+            const int hsel = tid & 1;
+            const half8* pa = reinterpret_cast<const half8*>(qa + (row0 + row) * 128 + hsel * 64);
+            const half8* pb = reinterpret_cast<const half8*>(qb + (row0 + row) * 128 + hsel * 64);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const half8 a = pa[k], b = pb[k];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)b[e];
+            }
+            acc += __shfl_xor(acc, 1);
+            const float logit = acc / 11.31f;
+            if (hsel == 0) wts[row] = logit;
+            lmax = fmaxf(lmax, logit);
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+    for (int row = tid; row < T; row += 256) {
+        const float e = __expf(wts[row] - gmax);
+        wts[row] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    for (int row = tid; row < T; row += 256) {
+        const float w = wts[row] * inv;
+        wts[row] = w;
+        if (at_wt) {
+            const unsigned ray = (unsigned)ray0 + lray;
+            const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
+            const int v = row / S, s = row - v * S;
+            at_wt[(((size_t)(b * V + v)) * R + r) * S + s] = w;
+        }
+    }
+    __syncthreads();
+    if (tid < HC / 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const __half* hp = hid + row0 * HC + tid * 8;
+#pragma unroll 4
+        for (int row = 0; row < T; ++row) {
+            const half8 h = *reinterpret_cast<const half8*>(hp + (size_t)row * HC);
+            const float w = wts[row];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += w * (float)h[e];
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[e];
+        *reinterpret_cast<half8*>(hbar + (size_t)lray * HC + tid * 8) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const float* zprev,
@@ -115,5 +200,18 @@ extern "C" int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* v
     hipLaunchKernelGGL(attend_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
                        (const __half*)qb, value, zprev, V, R, S, ray0, zout, at_wt);
     CPN_LAUNCH_CHECK("cpn_attend");
+    return 0;
+}
+
+extern "C" int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, int B, int V, int R,
+                                 int S, int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream) {
+    CPN_REQUIRE(qa && qb && hid && hbar, CPN_E_ARG, "cpn_attend_hidden: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && V * S <= 4096, CPN_E_SHAPE, "cpn_attend_hidden: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_attend_hidden: ray range outside B*R");
+    const size_t lds = (size_t)(V * S + 8) * sizeof(float);
+    hipLaunchKernelGGL(attend_hidden_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
+                       (const __half*)qb, (const __half*)hid, V, R, S, ray0, (__half*)hbar, at_wt);
+    CPN_LAUNCH_CHECK("cpn_attend_hidden");
     return 0;
 }

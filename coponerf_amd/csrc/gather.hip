@@ -86,17 +86,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     const __half* __restrict__ map3, int H, int W, const float* __restrict__ pixel_val,
     const float* __restrict__ sec_grid, const float* __restrict__ pe6, int V, int R, int S, int ray0,
     long long nrows, __half* __restrict__ xin) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long row = gid / CHUNKS_PER_ROW;
+    // 32-bit index arithmetic throughout (the host checks nrows * 108 < 2^31): 64-bit integer division is a
+    // ~100-instruction software routine on gfx950 and would dominate this otherwise load/store-bound kernel
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned row = gid / CHUNKS_PER_ROW;
     const int chunk = (int)(gid - row * CHUNKS_PER_ROW);
-    if (row >= nrows) return;
+    if (row >= (unsigned)nrows) return;
     // row = ((ray*V + v)*S + s)*2 + j  within the chunk of rays starting at ray0
     const int j = (int)(row & 1);
-    long long t = row >> 1;
-    const int s = (int)(t % S); t /= S;
-    const int v = (int)(t % V); t /= V;
-    const long long ray = ray0 + t;
-    const int b = (int)(ray / R), r = (int)(ray % R);
+    unsigned t = row >> 1;
+    const int s = (int)(t % (unsigned)S); t /= (unsigned)S;
+    const int v = (int)(t % (unsigned)V); t /= (unsigned)V;
+    const unsigned ray = (unsigned)ray0 + t;
+    const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
     const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + s;      // sample index in (N,R,S) arrays
 
     half8 out;
@@ -150,13 +152,12 @@ __global__ __launch_bounds__(256) void local_hidden_kernel(
 #pragma unroll
         for (int k = 0; k < 16; ++k) wr[e][k] = w[(size_t)(og * 8 + e) * ldw + k];
     }
-    for (long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); row < nrows;
-         row += (long long)gridDim.x * 16) {
-        long long t = row;
-        const int s = (int)(t % S); t /= S;
-        const int v = (int)(t % V); t /= V;
-        const long long ray = ray0 + t;
-        const int b = (int)(ray / R), r = (int)(ray % R);
+    for (unsigned row = blockIdx.x * 16 + (threadIdx.x >> 4); row < (unsigned)nrows; row += gridDim.x * 16) {
+        unsigned t = row;                                          // 32-bit: see gather_rows_kernel
+        const int s = (int)(t % (unsigned)S); t /= (unsigned)S;
+        const int v = (int)(t % (unsigned)V); t /= (unsigned)V;
+        const unsigned ray = (unsigned)ray0 + t;
+        const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
         const size_t nr = ((size_t)(b * V + v)) * R + r;
         const f32x4 l0 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8);
         const f32x4 l1 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8 + 4);
@@ -211,6 +212,8 @@ extern "C" int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const
                 "cpn_gather_rows: ray range [%d,%d) outside B*R=%lld", ray0, ray0 + nrays, (long long)B * R);
     const long long nrows = (long long)nrays * V * S * 2;
     const long long total = nrows * CHUNKS_PER_ROW;
+    CPN_REQUIRE(total < (1LL << 31) && (long long)B * R < (1LL << 31), CPN_E_SHAPE,
+                "cpn_gather_rows: chunk too large for 32-bit indexing (%lld work items)", total);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const __half*)map0, (const __half*)map1, (const __half*)map2, (const __half*)map3, H, W,
                        pixel_val, sec_grid, pe6, V, R, S, ray0, nrows, (__half*)xin);
@@ -226,7 +229,8 @@ extern "C" int cpn_local_hidden(const float* loc8, const float* coords9, const f
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_local_hidden: ray range outside B*R");
     const long long nrows = (long long)nrays * V * S;
-    const unsigned blocks = (unsigned)(cpn_cdiv(nrows, 16) < 8192u ? cpn_cdiv(nrows, 16) : 8192u);
+    CPN_REQUIRE(nrows * 16 < (1LL << 31), CPN_E_SHAPE, "cpn_local_hidden: chunk too large for 32-bit indexing");
+    const unsigned blocks = (unsigned)(cpn_cdiv(nrows, 16) < 512u ? cpn_cdiv(nrows, 16) : 512u);   // few blocks: each keeps its 128 weights in registers and strides over rows
     hipLaunchKernelGGL(local_hidden_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        loc8, coords9, w, ldw, bias, add, V, R, S, ray0, nrows, (__half*)out);
     CPN_LAUNCH_CHECK("cpn_local_hidden");

@@ -325,9 +325,8 @@ class _CrossAttention(nn.Module):
     def forward(self, x1, x2, corr, intr):
         B = x1.shape[0]
         a1 = corr.reshape(B, corr.shape[-4] * corr.shape[-3], -1)                       # (B, src, trg)
-        a2 = a1.transpose(-2, -1)
         f1 = a1.softmax(dim=-1) * a1.softmax(dim=-2)
-        f2 = a2.softmax(dim=-1) * a2.softmax(dim=-2)
+        f2 = f1.transpose(-2, -1)          # == a2.softmax(-1) * a2.softmax(-2) with a2 = a1^T: two softmaxes, not four
         pos = positional_encodings(*intr, n=int(math.isqrt(x1.shape[1]))).to(x1.dtype)
         v1, v2 = torch.cat([x1, pos], dim=2), torch.cat([x2, pos], dim=2)
         F1 = ((v1.transpose(-2, -1) @ f1) @ v1).transpose(-2, -1)

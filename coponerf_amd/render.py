@@ -97,8 +97,11 @@ class RenderEngine:
         "query_repeat_embed_2": (128, 128, 128),
     }
 
-    def __init__(self, chunk_rays: int = 2048):
+    def __init__(self, chunk_rays: int = 2048, fold_value: bool = True):
         self.chunk_rays = int(chunk_rays)
+        # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
+        # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it
+        self.fold_value = bool(fold_value)
         self._wkey = None
         self._w: Dict[str, torch.Tensor] = {}
         self._mkey = None
@@ -132,6 +135,23 @@ class RenderEngine:
             w[name + ".w16"] = dst
             w[name + ".b"] = params[name + ".bias"].detach().float().contiguous()
         f32 = lambda n: params[n].detach().float().contiguous()
+        # ---- folding: query_encode_latent_2 is linear and feeds only linear layers, so
+        #      key_map and latent_value act directly on the 2 x 832 hidden activations [h_own ; h_other]:
+        #      W' = [W_a . W2 | W_b . W2],  c' = W_a b2 + W_b b2 + b   (products in float64, then one rounding)
+        W2 = f32("query_encode_latent_2.weight").reshape(416, 832).double()
+        b2 = f32("query_encode_latent_2.bias").double()
+
+        def fold(wname, bname, n_out):
+            Wx = f32(wname).reshape(n_out, 832).double()
+            Wf = torch.cat((Wx[:, :416] @ W2, Wx[:, 416:] @ W2), dim=1)                  # (n_out, 1664)
+            cf = Wx[:, :416] @ b2 + Wx[:, 416:] @ b2 + f32(bname).double()
+            dst = torch.empty(n_out, 1664, dtype=torch.float16, device=dev)
+            src = Wf.float().contiguous()
+            call("cpn_pack_weight_f16", src.data_ptr(), n_out, 1664, dst.data_ptr(), 1664, s)
+            return dst, cf.float().contiguous()
+
+        w["key_fold.w16"], w["key_fold.b"] = fold("key_map.weight", "key_map.bias", 128)
+        w["value_fold.w16"], w["value_fold.b"] = fold("latent_value.weight", "latent_value.bias", 416)
         w["query_embed.w"] = f32("query_embed.weight").reshape(128, 16)
         w["query_embed.b"] = f32("query_embed.bias")
         wr = f32("query_repeat_embed.weight").reshape(128, 144)
@@ -232,8 +252,10 @@ class RenderEngine:
         T = V * S                       # rows per ray for the attention stage
         xin = self._buf("xin", (C * T * 2, _hip.XIN_STRIDE), f16, dev)
         hid = self._buf("hid", (C * T * 2, 832), f16, dev)
-        enc = self._buf("enc", (C * T, 832), f16, dev)
-        value = self._buf("value", (C * T, 416), f32, dev)
+        enc = value = None
+        if not self.fold_value:
+            enc = self._buf("enc", (C * T, 832), f16, dev)
+            value = self._buf("value", (C * T, 416), f32, dev)
         kh = self._buf("kh", (C * T, 128), f16, dev)
         key2 = self._buf("key2", (C * T, 128), f16, dev)
         hq = self._buf("hq", (C * T, 128), f16, dev)
@@ -242,6 +264,10 @@ class RenderEngine:
         z1 = self._buf("z1", (C, 416), f32, dev)
         ze = self._buf("ze", (C, 128), f32, dev)
         addq = self._buf("addq", (C, 128), f32, dev)
+
+        hbar = self._buf("hbar", (C, 1664), f16, dev)
+        zs = self._buf("zs", (C, 416), f32, dev)
+        GW = dict(self.GEMM_WEIGHTS, key_fold=(128, 1664, 1664), value_fold=(416, 1664, 1664))
 
         def gemm(a, lda, wname, out, ldc, m, n, k, relu, out_f32):
             prof = self.profile
@@ -252,8 +278,7 @@ class RenderEngine:
                  w[wname + ".b"].data_ptr(), out.data_ptr(), ldc, m, n, k, int(relu), int(out_f32), s)
             if prof is not None:
                 e1.record()
-                k_alg = self.GEMM_WEIGHTS[wname][1]                    # unpadded K: algorithmic FLOPs
-                prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * k_alg))
+                prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * GW[wname][1]))
 
         for ray0 in range(0, nray_total, C):
             n = min(C, nray_total - ray0)
@@ -262,16 +287,24 @@ class RenderEngine:
                  H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, ray0, n,
                  xin.data_ptr(), s)
             gemm(xin, _hip.XIN_STRIDE, "query_encode_latent", hid, 832, rows2, 832, _hip.XIN_K, True, False)
-            gemm(hid, 832, "query_encode_latent_2", enc, 416, rows2, 416, 832, False, False)   # (rows2,416)=(rows,832)
-            gemm(enc, 832, "latent_value", value, 416, rows, 416, 832, False, True)
-            gemm(enc, 832, "key_map", kh, 128, rows, 128, 832, True, False)
+            if self.fold_value:
+                gemm(hid, 1664, "key_fold", kh, 128, rows, 128, 1664, True, False)     # (rows2,832) == (rows,1664)
+            else:
+                gemm(hid, 832, "query_encode_latent_2", enc, 416, rows2, 416, 832, False, False)
+                gemm(enc, 832, "latent_value", value, 416, rows, 416, 832, False, True)
+                gemm(enc, 832, "key_map", kh, 128, rows, 128, 832, True, False)
             gemm(kh, 128, "key_map_2", key2, 128, rows, 128, 128, False, False)
             call("cpn_local_hidden", loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
                  w["query_embed.b"].data_ptr(), 0, B, V, R, S, ray0, n, hq.data_ptr(), s)
             gemm(hq, 128, "query_embed_2", ce, 128, rows, 128, 128, False, False)
             # round 1 (CoPoNeRF.py:450-461)
-            call("cpn_attend", key2.data_ptr(), ce.data_ptr(), value.data_ptr(), 0, B, V, R, S, ray0, n,
-                 z1.data_ptr(), at_wt.data_ptr(), s)
+            if self.fold_value:
+                call("cpn_attend_hidden", key2.data_ptr(), ce.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
+                     hbar.data_ptr(), at_wt.data_ptr(), s)
+                gemm(hbar, 1664, "value_fold", z1, 416, n, 416, 1664, False, True)
+            else:
+                call("cpn_attend", key2.data_ptr(), ce.data_ptr(), value.data_ptr(), 0, B, V, R, S, ray0, n,
+                     z1.data_ptr(), at_wt.data_ptr(), s)
             # round 2 (CoPoNeRF.py:467-485)
             call("cpn_linear_f32", z1.data_ptr(), 416, w["encode_latent.w"].data_ptr(), 416,
                  w["encode_latent.b"].data_ptr(), 0, 0, ze.data_ptr(), 128, n, 128, 416, 0, 0, s)
@@ -280,8 +313,15 @@ class RenderEngine:
             call("cpn_local_hidden", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
                  w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), B, V, R, S, ray0, n, hq.data_ptr(), s)
             gemm(hq, 128, "query_repeat_embed_2", q2, 128, rows, 128, 128, False, False)
-            call("cpn_attend", q2.data_ptr(), ce.data_ptr(), value.data_ptr(), z1.data_ptr(), B, V, R, S, ray0, n,
-                 zl[ray0:ray0 + n].data_ptr(), 0, s)
+            if self.fold_value:
+                call("cpn_attend_hidden", q2.data_ptr(), ce.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
+                     hbar.data_ptr(), 0, s)
+                gemm(hbar, 1664, "value_fold", zs, 416, n, 416, 1664, False, True)
+                # the round-1 vector sits in both view slots when the views are summed (CoPoNeRF.py:481-485)
+                torch.add(zs[:n], z1[:n], alpha=float(V), out=zl[ray0:ray0 + n])
+            else:
+                call("cpn_attend", q2.data_ptr(), ce.data_ptr(), value.data_ptr(), z1.data_ptr(), B, V, R, S, ray0, n,
+                     zl[ray0:ray0 + n].data_ptr(), 0, s)
 
         # ---- light-field decoder phi over all rays (lightfield.py:131-167), exact fp32
         c18 = torch.zeros(nray_total, 32, dtype=f32, device=dev)

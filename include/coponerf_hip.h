@@ -112,6 +112,12 @@ int cpn_gemm_f16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const f
 int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const float* zprev,
                int B, int V, int R, int S, int ray0, int nrays, float* zout, float* at_wt, void* stream);
 
+/* ---- K4': the same joint softmax, reducing the 1664 hidden activations [h_own ; h_other] of every sample ----
+ * (value projection folded through query_encode_latent_2 and applied once per ray afterwards)
+ *   hid (rays*V*S, 1664) fp16 = the (rows*2, 832) output of the first encoder layer; hbar (rays, 1664) fp16   */
+int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, int B, int V, int R, int S,
+                      int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream);
+
 /* ---- K5: exact-fp32 per-ray linear layer (MFMA 16x16x4 f32)  Y = act_out( act_in(X) . W^T + bias + res ) --
  * replaces nn.Conv1d encode_latent (CoPoNeRF.py:468) and lightfield.ResnetFC (models/lightfield.py:131-167).
  *   X (M, ldx), W (N, ldw), bias (N) or NULL, res (M, ldr) or NULL, Y (M, ldy); N <= 128; K multiple of 4      */

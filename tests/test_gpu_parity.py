@@ -87,6 +87,22 @@ def ref_keys():
             "rel_pose_flip", "gt_rel_pose", "gt_rel_pose_flip"]
 
 
+def test_layer_by_layer_mode_matches_folded_mode(model, dev, weights):
+    """RenderEngine(fold_value=False) evaluates query_encode_latent_2 / latent_value / key_map per sample exactly as
+    the reference orders them; the default folded evaluation must agree with it and with the oracle."""
+    cfg, gold = load_case("c1_val")
+    ref, out_fold = run_pair(model, dev, weights, cfg)
+    model._engine.fold_value = False
+    try:
+        _, out_plain = run_pair(model, dev, weights, cfg)
+    finally:
+        model._engine.fold_value = True
+    assert torch.equal(out_plain["pixel_val"], out_fold["pixel_val"])
+    assert (out_plain["rgb"] - out_fold["rgb"]).abs().max() <= 5e-4
+    assert (out_plain["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
+    assert (out_plain["at_wt"] - out_fold["at_wt"]).abs().max() <= 1e-3
+
+
 def test_stage_intermediates(model, dev, weights):
     """inter fixture: gathers / encoder / attention stages against the oracle AND the upstream intermediates."""
     cfg, gold = load_case("inter")
