@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--pairs", type=int, default=1, help="stereo pairs per GPU")
-    ap.add_argument("--chunk-rays", type=int, default=2048)
+    ap.add_argument("--chunk-rays", type=int, default=16384)
     ap.add_argument("--cpu-rays", type=int, default=4096, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 

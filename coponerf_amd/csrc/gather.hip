@@ -88,7 +88,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     long long nrows, __half* __restrict__ xin) {
     // 32-bit index arithmetic throughout (the host checks nrows * 108 < 2^31): 64-bit integer division is a
     // ~100-instruction software routine on gfx950 and would dominate this otherwise load/store-bound kernel
-    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware order: blocks are dispatched round-robin over the 8 XCDs; giving each XCD a contiguous range of
+    // rows (= neighbouring rays = overlapping texel footprints) keeps its private L2 on 1/8 of the feature maps
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, rem = nb & 7;
+    const unsigned lblock = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+    const unsigned gid = lblock * blockDim.x + threadIdx.x;
     const unsigned row = gid / CHUNKS_PER_ROW;
     const int chunk = (int)(gid - row * CHUNKS_PER_ROW);
     if (row >= (unsigned)nrows) return;

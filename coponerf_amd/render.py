@@ -97,7 +97,7 @@ class RenderEngine:
         "query_repeat_embed_2": (128, 128, 128),
     }
 
-    def __init__(self, chunk_rays: int = 2048, fold_value: bool = True):
+    def __init__(self, chunk_rays: int = 16384, fold_value: bool = True):
         self.chunk_rays = int(chunk_rays)
         # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
         # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it

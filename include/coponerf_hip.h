@@ -43,7 +43,8 @@ extern "C" {
 #define CPN_CAM_KO    72   /* fx fy cx cy of the other context view                                */
 #define CPN_CAM_KN    76   /* 9: K_v[:3,:3] with rows 0,1 divided by H      (CoPoNeRF.py:259-261) */
 
-/* padded K of the first encoder layer: 835 inputs -> 864 consumed (27 x 32), row stride 896 halves */
+/* padded K of the first encoder layer: 835 inputs -> 864 consumed (27 x 32); row stride 896 halves = 14 x 128 B:
+ * 128-byte-aligned rows are worth 10 % on the GEMM that reads them (808 vs 728 TFLOP/s, tools/gemm_ld.py) */
 #define CPN_XIN_K      864
 #define CPN_XIN_STRIDE 896
 
