@@ -116,8 +116,24 @@ def main():
         "config": {"workload": f"configs[1]: {H}x{H} stereo pair, full-image render {R} rays x {S} samples, "
                                f"{B} pair(s) per GPU, render path only (z/rel_pose/flow given, val=True)",
                    "chunk_rays": args.chunk_rays, "pairs_per_gpu": B},
-        "path_tflops": value * f_ray(S) / 1e12,
+        "path_tflops": value * f_ray(S) / 1e12,          # algorithmic FLOPs of the reference formulation
+        "executed_tflops": value * (S * 6637056.0 + 4300000.0) / 1e12,   # executed after folding the value/key projections
     }
+
+    # ---- secondary figure: the whole image pipeline (get_z once per pair + the render pass), SURVEY.md §8(d)
+    if H == 256:
+        with torch.no_grad():
+            for _ in range(2):
+                zz = model.get_z(inp)
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            for _ in range(3):
+                zz = model.get_z(inp)
+            torch.cuda.synchronize()
+            getz_ms = (time.perf_counter() - g0) / 3 * 1e3
+        line["get_z_ms"] = getz_ms
+        line["image_rays_per_s"] = rays_per_step / (getz_ms * 1e-3 + elapsed / args.steps)
+        del zz
 
     if rank == 0:
         # ---- roofline of the dominant kernel: first encoder GEMM (835 -> 832 + ReLU), 53 % of the path's FLOPs

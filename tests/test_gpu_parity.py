@@ -219,6 +219,25 @@ def test_full_size_properties(model, dev, weights):
     assert (full["rgb"][:, 0][invalid] == 1).all()
 
 
+@pytest.mark.parametrize("H,S,R,rig", [(256, 64, 192, "wide"), (512, 128, 96, "narrow")])
+def test_other_baseline_configs_against_oracle(H, S, R, rig, model, dev, weights):
+    """BASELINE configs 4 (ACID-like wide baseline, 256x256x64) and 5 (512x512, 128 samples per ray), render path:
+    same bars as the fixture cases — indices bit-identical to the oracle, rgb within 1e-3."""
+    from oracle import render_ref as orc
+    inp = syn.make_inputs(1, H, H, R, seed=33, rig=rig)
+    z, rel, flow = syn.make_latents(1, H, H, seed=34)
+    with torch.no_grad():
+        ref = orc.forward(inp, z, rel, flow, True, weights, npoints=S, keep=True)
+        model.npoints = S
+        out = model(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=True, flow=to_device(flow, dev),
+                    debug=True)
+    assert torch.equal(out["pixel_val"], ref["pixel_val"])
+    assert torch.equal(out["_core"]["pt"].cpu(), ref["pt"])
+    assert (out["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
+    assert (out["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+    assert torch.equal(out["valid_mask"].cpu(), ref["valid_mask"])
+
+
 def test_missing_library_is_loud(monkeypatch):
     from coponerf_amd import _hip
     monkeypatch.setattr(_hip, "_lib", None)
