@@ -113,15 +113,13 @@ class CoPoNeRF(nn.Module):
             raise NotImplementedError(f"the HIP render path is specialised for n_view=2 (got {self.n_view})")
         if z is None:
             z, rel_pose, flow = self.get_z(input)
-        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
-                                        or any(t.requires_grad for t in z)):
-            raise NotImplementedError(
-                "backward kernels of the render path are not built yet: call under torch.no_grad() "
-                "(validation / test.py path); training is SURVEY.md §8 config c3")
         ctx, qry = input["context"], input["query"]
         self.H, self.W = ctx["rgb"].shape[2], ctx["rgb"].shape[3]    # what get_z records (models/CoPoNeRF.py:180)
-        core = self._engine.render(self._render_params(), ctx["cam2world"], ctx["intrinsics"], qry["cam2world"],
-                                   qry["intrinsics"], qry["uv"], z, rel_pose, val, self.npoints, self.H, self.W)
+        rp = self._render_params()
+        train = torch.is_grad_enabled() and (any(p.requires_grad for p in rp.values()) or any(t.requires_grad for t in z))
+        run = self._engine.render_train if train else self._engine.render          # same forward kernels either way
+        core = run(rp, ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], z,
+                   rel_pose, val, self.npoints, self.H, self.W)
         out = {"flow": flow, "uv": qry["uv"], "coords": core["coords"]}
         out["pixel_val"] = core["pixel_val_cpu"]                  # models/CoPoNeRF.py:490 (callers expect a CPU tensor)
         out["at_wts"] = [core["at_wt"]]

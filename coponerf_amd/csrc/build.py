@@ -22,6 +22,7 @@ UNITS = [
     ("attend.hip", []),
     ("linear_f32.hip", []),
     ("ufc.hip", []),
+    ("backward.hip", []),
 ]
 
 

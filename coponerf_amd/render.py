@@ -189,6 +189,95 @@ class RenderEngine:
         self._maps, self._mkey = maps, key
         return maps
 
+    # ---- geometry shared by the inference and the training pass (never differentiated) ----------------
+    @torch.no_grad()
+    def _geometry(self, ctx_c2w, ctx_K, qry_c2w, qry_K, uv, rel_pose, val, S, H, W):
+        dev = uv.device
+        B, _, R, _ = uv.shape
+        N = B * V
+        s = _stream()
+        cam_cpu, Tq_cpu = build_camera_block(ctx_c2w.detach().float().cpu(), ctx_K.detach().float().cpu(),
+                                             qry_c2w.detach().float().cpu(), qry_K.detach().float().cpu(),
+                                             None if rel_pose is None else rel_pose.detach().float().cpu(), val, H)
+        cam = cam_cpu.to(dev)
+        ikey = (S, str(dev))
+        if ikey not in self._interval:
+            self._interval[ikey] = torch.linspace(0, 1, S).to(dev)
+        interval = self._interval[ikey]
+        uvc = uv.detach().float().reshape(B, R, 2).contiguous()
+        f32 = torch.float32
+        g = {"coords9": torch.empty(N, R, 9, dtype=f32, device=dev), "seg": torch.empty(N, R, 4, dtype=f32, device=dev),
+             "overlaps": torch.empty(N, R, dtype=torch.uint8, device=dev),
+             "pixel_val": torch.empty(N, R, S, 2, dtype=f32, device=dev), "pt": torch.empty(N, R, S, 3, dtype=f32, device=dev),
+             "sec_grid": torch.empty(N, R, S, 2, dtype=f32, device=dev), "pe6": torch.empty(N, R, S, 6, dtype=f32, device=dev),
+             "loc8": torch.empty(N, R, S, 8, dtype=f32, device=dev), "Tq": Tq_cpu.to(dev)}
+        call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), B, V, R, g["coords9"].data_ptr(), g["seg"].data_ptr(),
+             g["overlaps"].data_ptr(), s)
+        call("cpn_sample_geometry", cam.data_ptr(), g["coords9"].data_ptr(), g["seg"].data_ptr(), interval.data_ptr(),
+             B, V, R, S, H, W, g["pixel_val"].data_ptr(), g["pt"].data_ptr(), g["sec_grid"].data_ptr(),
+             g["pe6"].data_ptr(), g["loc8"].data_ptr(), s)
+        return g
+
+    # ---- the differentiable render pass (training; gradients to the render weights and to z) ------------
+    def render_train(self, params: Dict[str, torch.Tensor], ctx_c2w, ctx_K, qry_c2w, qry_K, uv,
+                     z: Sequence[torch.Tensor], rel_pose, val: bool, S: int, H: int, W: int) -> Dict[str, torch.Tensor]:
+        """Same forward kernels as render(), wrapped in autograd Functions (coponerf_amd/train_fns.py); all rays of
+        the call form one chunk (training uses <= 4096 rays per pair, /root/reference train.py:87)."""
+        from .train_fns import GemmFn, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn
+        dev = uv.device
+        if dev.type != "cuda":
+            raise RuntimeError("coponerf_amd renders on a HIP device only (got uv on %s)" % dev)
+        B, _, R, _ = uv.shape
+        if B * R > 32768:
+            raise ValueError("render_train keeps all activations of the call: at most 32768 rays per call")
+        g = self._geometry(ctx_c2w, ctx_K, qry_c2w, qry_K, uv, rel_pose, val, S, H, W)
+        dims = (B, V, R, S)
+        P = params
+        mat = lambda n, rows: P[n + ".weight"].reshape(rows, -1)
+        bias = lambda n: P[n + ".bias"]
+        xin = GatherFn.apply(z[0], z[1], z[2], z[3], g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W))
+        hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False)
+        hid2 = hid.view(-1, 1664)
+        W2, b2 = mat("query_encode_latent_2", 416), bias("query_encode_latent_2")
+
+        def fold(name, n_out):                                   # differentiable fp32 fold (DESIGN.md §4.2)
+            Wx = mat(name, n_out)
+            return (torch.cat((Wx[:, :416] @ W2, Wx[:, 416:] @ W2), dim=1),
+                    Wx[:, :416] @ b2 + Wx[:, 416:] @ b2 + bias(name))
+
+        Wkf, ckf = fold("key_map", 128)
+        Wvf, cvf = fold("latent_value", 416)
+        kh = GemmFn.apply(hid2, Wkf, ckf, True, False)
+        key2 = GemmFn.apply(kh, mat("key_map_2", 128), bias("key_map_2"), False, False)
+        hq = LocalHiddenFn.apply(g["loc8"], g["coords9"], mat("query_embed", 128), bias("query_embed"), None, dims)
+        ce = GemmFn.apply(hq, mat("query_embed_2", 128), bias("query_embed_2"), False, False)
+        hbar1, w1 = AttendHiddenFn.apply(key2, ce, hid2, dims)
+        z1 = GemmFn.apply(hbar1, Wvf, cvf, False, True)
+        ze = LinearF32Fn.apply(z1, mat("encode_latent", 128), bias("encode_latent"), None, False, False)
+        Wr = mat("query_repeat_embed", 128)
+        aq = LinearF32Fn.apply(ze, Wr[:, :128].contiguous(), None, None, False, False)
+        q2h = LocalHiddenFn.apply(g["loc8"], g["coords9"], Wr[:, 128:].contiguous(), bias("query_repeat_embed"), aq, dims)
+        q2 = GemmFn.apply(q2h, mat("query_repeat_embed_2", 128), bias("query_repeat_embed_2"), False, False)
+        hbar2, _ = AttendHiddenFn.apply(q2, ce, hid2, dims)
+        zs = GemmFn.apply(hbar2, Wvf, cvf, False, True)
+        zl = zs + float(V) * z1                                  # CoPoNeRF.py:481-485
+        nray = B * R
+        c18 = torch.zeros(nray, 32, dtype=torch.float32, device=dev)
+        c18[:, :18] = g["coords9"].view(B, V, R, 9).permute(0, 2, 1, 3).reshape(nray, 18)
+        x = LinearF32Fn.apply(c18, torch.nn.functional.pad(P["phi.lin_in.weight"], (0, 14)), P["phi.lin_in.bias"], None,
+                              False, False)
+        for k in range(3):
+            Wz = P[f"phi.lin_z.{k}.weight"]
+            x = LinearF32Fn.apply(zl, Wz[:, :416] + Wz[:, 416:], P[f"phi.lin_z.{k}.bias"], x, False, False)
+            net = LinearF32Fn.apply(x, P[f"phi.blocks.{k}.fc_0.weight"], P[f"phi.blocks.{k}.fc_0.bias"], None, True, False)
+            x = LinearF32Fn.apply(net, P[f"phi.blocks.{k}.fc_1.weight"], P[f"phi.blocks.{k}.fc_1.bias"], x, True, False)
+        raw = LinearF32Fn.apply(x, P["phi.lin_out.weight"], P["phi.lin_out.bias"], None, True, False)     # (nray, 3)
+        valid = g["overlaps"].view(B, V, R).any(dim=1).float()
+        rgb = raw.view(B, R, 3) * valid[..., None] + (1 - valid[..., None])
+        return {"rgb": rgb.view(B, 1, R, 3), "valid_mask": valid[..., None], "pixel_val": g["pixel_val"],
+                "pixel_val_cpu": g["pixel_val"].cpu(), "pt": g["pt"], "at_wt": w1, "coords": g["coords9"],
+                "z_local": zl, "Tq": g["Tq"], "sec_grid": g["sec_grid"], "rgb_raw": raw}
+
     # ---- the render pass -------------------------------------------------------------------------
     @torch.no_grad()
     def render(self, params: Dict[str, torch.Tensor], ctx_c2w, ctx_K, qry_c2w, qry_K, uv, z: Sequence[torch.Tensor],

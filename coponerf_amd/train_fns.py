@@ -1,0 +1,197 @@
+"""Autograd wrappers for the training path (BASELINE config 3; caller: /root/reference wrapper.py:107,138).
+
+Every forward below calls the SAME HIP kernel the inference path uses (one forward path); only the backward is new:
+  * plain GEMM gradients (dX = dY.W, dW = dY^T.X) are library GEMMs -> hipBLASLt via torch.matmul,
+  * the two fused non-GEMM stages have their own kernels (csrc/backward.hip): the joint-softmax / weighted hidden
+    sum and the bilinear gather (scatter-add into the feature maps),
+  * ReLU masks, bias sums and the per-ray fp32 layers are a few elementwise / small-matmul torch ops.
+No coordinate gradients exist on this path: sample coordinates derive from poses only and the 3-D points are
+detached in the reference (models/CoPoNeRF.py:244, 380-381, 433), so geometry runs outside autograd.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _hip
+from ._hip import call
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _mm_f32(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
+    """(P,M) fp16 @ (M,Q) fp16 -> fp32, accumulated in fp32; M can be millions of rows, so the product is formed in
+    slabs whose fp16 outputs are summed in fp32 (keeps hipBLASLt's fast fp16 path, avoids fp16 overflow/rounding
+    of a multi-million-term sum)."""
+    M = a16.shape[1]
+    slab = 1 << 18
+    out = torch.zeros(a16.shape[0], b16.shape[1], dtype=torch.float32, device=a16.device)
+    for m0 in range(0, M, slab):
+        out += torch.matmul(a16[:, m0:m0 + slab], b16[m0:m0 + slab]).float()
+    return out
+
+
+class GemmFn(Function):
+    """C = act(A . W^T + b) through cpn_gemm_f16.  A (M, lda) fp16 (row stride lda >= K), W (N, K) fp32, b (N)."""
+
+    @staticmethod
+    def forward(ctx, A16, W, b, relu: bool, out_f32: bool):
+        M, lda = A16.shape
+        N, K = W.shape
+        Kp = ((K + 31) // 32) * 32
+        assert Kp <= lda, (K, lda)
+        W16 = torch.zeros(N, lda, dtype=torch.float16, device=A16.device)
+        Wc = W.detach().contiguous().float()
+        call("cpn_pack_weight_f16", Wc.data_ptr(), N, K, W16.data_ptr(), lda, _stream())
+        bc = b.detach().contiguous().float()
+        C = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.float16, device=A16.device)
+        call("cpn_gemm_f16", A16.data_ptr(), lda, W16.data_ptr(), lda, bc.data_ptr(), C.data_ptr(), N, M, N, Kp,
+             int(relu), int(out_f32), _stream())
+        ctx.save_for_backward(A16, W16, C if relu else None)
+        ctx.relu, ctx.K = relu, K
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A16, W16, C = ctx.saved_tensors
+        d = dC
+        if ctx.relu:
+            d = d * (C > 0)
+        d16 = d.to(torch.float16)
+        dA = torch.matmul(d16, W16) if ctx.needs_input_grad[0] else None            # (M, lda): pad columns get 0
+        dW = _mm_f32(d16.t(), A16)[:, :ctx.K] if ctx.needs_input_grad[1] else None
+        db = d.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        return dA, dW, db, None, None
+
+
+class LinearF32Fn(Function):
+    """Y = act_out(act_in(X) . W^T + b + res) through cpn_linear_f32 (exact fp32).  K % 16 == 0, N <= 128."""
+
+    @staticmethod
+    def forward(ctx, X, W, b, res, relu_in: bool, relu_out: bool):
+        M, K = X.shape
+        N = W.shape[0]
+        Xc, Wc = X.detach().contiguous().float(), W.detach().contiguous().float()
+        bc = None if b is None else b.detach().contiguous().float()
+        rc = None if res is None else res.detach().contiguous().float()
+        Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
+        call("cpn_linear_f32", Xc.data_ptr(), K, Wc.data_ptr(), K, 0 if bc is None else bc.data_ptr(),
+             0 if rc is None else rc.data_ptr(), N, Y.data_ptr(), N, M, N, K, int(relu_in), int(relu_out), _stream())
+        ctx.save_for_backward(Xc, Wc, Y if relu_out else None)
+        ctx.relu_in, ctx.relu_out = relu_in, relu_out
+        ctx.has_b, ctx.has_res = b is not None, res is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W, Y = ctx.saved_tensors
+        d = dY * (Y > 0) if ctx.relu_out else dY
+        Xa = torch.relu(X) if ctx.relu_in else X
+        dX = d @ W
+        if ctx.relu_in:
+            dX = dX * (X > 0)
+        return dX, d.t() @ Xa, (d.sum(0) if ctx.has_b else None), (d if ctx.has_res else None), None, None
+
+
+def build_local_coords(loc8, coords9, B, V, R, S):
+    """(B*V,R,S,8), (B*V,R,9) -> L (B*R*V*S, 16) in the GEMM row order; channel order of CoPoNeRF.py:445."""
+    lc = loc8.view(B, V, R, S, 8).permute(0, 2, 1, 3, 4)                       # (B,R,V,S,8)
+    c9 = coords9.view(B, V, R, 9).permute(0, 2, 1, 3)[:, :, :, None, :].expand(-1, -1, -1, S, -1)
+    z3 = torch.zeros_like(lc[..., :3])
+    L = torch.cat([lc[..., 0:3], z3, c9[..., 0:3], lc[..., 3:7], c9[..., 6:9]], dim=-1)
+    return L.reshape(B * R * V * S, 16)
+
+
+class LocalHiddenFn(Function):
+    """out = fp16(relu(W . L(row) + b + add[ray])) through cpn_local_hidden."""
+
+    @staticmethod
+    def forward(ctx, loc8, coords9, W, b, add, dims):
+        B, V, R, S = dims
+        nrays = B * R
+        Wc, bc = W.detach().contiguous().float(), b.detach().contiguous().float()
+        ac = None if add is None else add.detach().contiguous().float()
+        out = torch.empty(nrays * V * S, 128, dtype=torch.float16, device=loc8.device)
+        call("cpn_local_hidden", loc8.data_ptr(), coords9.data_ptr(), Wc.data_ptr(), Wc.shape[1], bc.data_ptr(),
+             0 if ac is None else ac.data_ptr(), B, V, R, S, 0, nrays, out.data_ptr(), _stream())
+        ctx.save_for_backward(loc8, coords9, out)
+        ctx.dims, ctx.has_add = dims, add is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        loc8, coords9, out = ctx.saved_tensors
+        B, V, R, S = ctx.dims
+        d = (dout * (out > 0)).float()
+        L = build_local_coords(loc8, coords9, B, V, R, S)
+        dW = d.t() @ L
+        dadd = d.view(B * R, V * S, 128).sum(1) if ctx.has_add else None
+        return None, None, dW, d.sum(0), dadd, None
+
+
+class AttendHiddenFn(Function):
+    """(hbar fp16 (rays,1664), w fp32 (N,R,S)) = cpn_attend_hidden(qa, qb, hid)."""
+
+    @staticmethod
+    def forward(ctx, qa, qb, hid2, dims):
+        B, V, R, S = dims
+        nrays = B * R
+        hbar = torch.empty(nrays, 1664, dtype=torch.float16, device=qa.device)
+        w = torch.empty(B * V, R, S, dtype=torch.float32, device=qa.device)
+        call("cpn_attend_hidden", qa.data_ptr(), qb.data_ptr(), hid2.data_ptr(), B, V, R, S, 0, nrays, hbar.data_ptr(),
+             w.data_ptr(), _stream())
+        ctx.save_for_backward(qa, qb, hid2, w)
+        ctx.dims = dims
+        return hbar, w
+
+    @staticmethod
+    def backward(ctx, dhbar, dw):
+        qa, qb, hid2, w = ctx.saved_tensors
+        B, V, R, S = ctx.dims
+        nrays = B * R
+        dh = dhbar.float().contiguous()
+        dwc = None if dw is None else dw.float().contiguous()
+        dqa, dqb, dhid = torch.empty_like(qa), torch.empty_like(qb), torch.empty_like(hid2)
+        call("cpn_attend_hidden_bwd", qa.data_ptr(), qb.data_ptr(), hid2.data_ptr(), w.data_ptr(), dh.data_ptr(),
+             0 if dwc is None else dwc.data_ptr(), B, V, R, S, 0, nrays, dqa.data_ptr(), dqb.data_ptr(),
+             dhid.data_ptr(), _stream())
+        return dqa, dqb, dhid, None
+
+
+class GatherFn(Function):
+    """xin fp16 (rows2, 896) = cpn_gather_rows(NHWC fp16 copies of z0..z3); backward scatters into the maps."""
+
+    @staticmethod
+    def forward(ctx, z0, z1, z2, z3, pixel_val, sec_grid, pe6, dims, HW):
+        B, V, R, S = dims
+        H, W = HW
+        s = _stream()
+        maps = []
+        for t in (z0, z1, z2, z3):
+            src = t.detach().float().contiguous()
+            n, c, h, w_ = src.shape
+            dst = torch.empty(n, h, w_, c, dtype=torch.float16, device=src.device)
+            call("cpn_nchw_to_nhwc_f16", src.data_ptr(), dst.data_ptr(), n, c, h, w_, s)
+            maps.append(dst)
+        nrays = B * R
+        xin = torch.empty(nrays * V * S * 2, _hip.XIN_STRIDE, dtype=torch.float16, device=z0.device)
+        call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, W,
+             pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, 0, nrays, xin.data_ptr(), s)
+        ctx.save_for_backward(pixel_val, sec_grid)
+        ctx.dims, ctx.HW = dims, HW
+        ctx.shapes = [tuple(t.shape) for t in (z0, z1, z2, z3)]
+        return xin
+
+    @staticmethod
+    def backward(ctx, dxin):
+        pixel_val, sec_grid = ctx.saved_tensors
+        B, V, R, S = ctx.dims
+        H, W = ctx.HW
+        d = dxin.contiguous()
+        dmaps = [torch.zeros(n, h, w_, c, dtype=torch.float32, device=d.device) for (n, c, h, w_) in ctx.shapes]
+        call("cpn_gather_rows_bwd", d.data_ptr(), d.shape[1], H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V, R, S,
+             0, B * R, dmaps[0].data_ptr(), dmaps[1].data_ptr(), dmaps[2].data_ptr(), dmaps[3].data_ptr(), _stream())
+        g = [m.permute(0, 3, 1, 2).contiguous() for m in dmaps]
+        return g[0], g[1], g[2], g[3], None, None, None, None, None

@@ -129,6 +129,20 @@ int cpn_linear_f32(const float* X, int ldx, const float* W, int ldw, const float
 int cpn_mask_rgb(const float* rgb_raw, int ld, const uint8_t* overlaps, int B, int V, int R,
                  float* rgb, float* valid, void* stream);
 
+/* ==== training: backward of the two non-GEMM stages (plain GEMM gradients use hipBLASLt via torch.matmul) ==== */
+
+/* gradient of cpn_attend_hidden: dhbar (rays,1664) fp32, dw_ext (N,R,S) fp32 or NULL (external gradient on the
+ * softmax weights), at_wt (N,R,S) the forward weights -> dqa, dqb (rays*V*S,128) fp16, dhid (rays*V*S,1664) fp16   */
+int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, const float* at_wt,
+                          const float* dhbar, const float* dw_ext, int B, int V, int R, int S, int ray0, int nrays,
+                          uint16_t* dqa, uint16_t* dqb, uint16_t* dhid, void* stream);
+
+/* gradient of cpn_gather_rows w.r.t. the feature maps: dxin (rows, ldx) fp16 -> atomically accumulated into
+ * dmap0..3 (N,h,w,C) fp32 NHWC, which the caller zeroes first.  No coordinate gradient (CoPoNeRF.py:380-381).    */
+int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float* pixel_val, const float* sec_grid,
+                        int B, int V, int R, int S, int ray0, int nrays,
+                        float* dmap0, float* dmap1, float* dmap2, float* dmap3, void* stream);
+
 /* ==== get_z path: the 4-D operators of UFC =========================== */
 
 /* ---- K6: Conv4d (+ MaxPool4d when stride > 1) + GroupNorm(1 group) + ReLU in one pass --------------

@@ -1,0 +1,94 @@
+"""Training path on the MI355X: gradients of the HIP render path against autograd through the CPU oracle."""
+import pytest
+import torch
+
+from coponerf_amd import synthetic as syn
+from tests.helpers import to_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")
+
+
+def _loss(out, coef, cw):
+    return (out["rgb"] * coef).sum() + (out["at_wt"] * cw).sum()
+
+
+def test_render_gradients_match_oracle_autograd(dev):
+    from coponerf_amd import CoPoNeRF
+    from oracle import render_ref as orc
+    B, H, R, S = 2, 64, 80, 32
+    weights = syn.make_render_weights(seed=17)
+    inp = syn.make_inputs(B, H, H, R, seed=51)
+    z, rel, flow = syn.make_latents(B, H, H, seed=52)
+    coef = syn.normal((B, 1, R, 3), seed=53)
+    cw = syn.normal((2 * B, R, S), seed=54) * 0.3
+    # ---- oracle gradients (float32 autograd on the CPU)
+    w_ref = {k: v.clone().requires_grad_(True) for k, v in weights.items()}
+    z_ref = [t.clone().requires_grad_(True) for t in z]
+    out_ref = orc.forward(inp, z_ref, rel, flow, False, w_ref, npoints=S)
+    _loss(out_ref, coef, cw).backward()
+    # ---- HIP path
+    model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+    model.load_state_dict(weights, strict=False)
+    model = model.to(dev)
+    model.train()
+    z_hip = [t.to(dev).requires_grad_(True) for t in z]
+    out = model(to_device(inp, dev), z=z_hip, rel_pose=rel.to(dev), val=False, flow=to_device(flow, dev))
+    assert out["rgb"].requires_grad and out["at_wt"].requires_grad
+    assert (out["rgb"].detach().cpu() - out_ref["rgb"].detach()).abs().max() <= 1e-3
+    _loss(out, coef.to(dev), cw.to(dev)).backward()
+    params = dict(model.named_parameters())
+
+    report = []
+
+    def close(name, got, want):
+        # fp16 activations flip a few ReLU masks relative to the fp32 oracle, which moves single entries of the
+        # small per-ray layers by ~1/rays; judge the whole tensor (relative L2) and bound the worst entry loosely.
+        got = got.cpu()
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        rel = float((got - want).norm() / (want.norm() + 1e-12))
+        report.append((name, rel, err, scale))
+        return rel <= 3e-2 and err <= 0.1 * scale + 1e-6
+
+    for name, wr in w_ref.items():
+        assert params[name].grad is not None, name
+    ok = [close(name, params[name].grad, wr.grad) for name, wr in w_ref.items()]
+    ok += [close(f"z[{i}]", zh.grad, zr.grad) for i, (zh, zr) in enumerate(zip(z_hip, z_ref))]
+    table = "\n".join(f"{n:48s} relL2 {r:.3e} maxerr {e:.3e} scale {s_:.3e}" for n, r, e, s_ in report)
+    print(table)
+    assert all(ok), table
+    # layers the render path never touches stay without gradient (skip-None contract of wrapper.py:26)
+    assert params["corr_embed.weight"].grad is None
+
+
+def test_full_training_step_end_to_end(dev):
+    """get_z + render + backward + SGD step at 256x256: gradients reach encoder, UFC and render weights, loss moves."""
+    from coponerf_amd import CoPoNeRF
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev).train()
+    inp = to_device(syn.make_inputs(1, 256, 256, 128, seed=61), dev)
+    target = inp["query"]["rgb"]
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = model(inp, val=False)
+        loss = (out["rgb"] - target).abs().mean()
+        loss.backward()
+        losses.append(float(loss))
+        opt.step()
+    P = dict(model.named_parameters())
+    for name in ("query_encode_latent.weight", "phi.lin_out.weight", "encoder.model.conv1.weight", "conv_map.weight",
+                 "feature_cost_aggregation.layers.0.0.q_proj.weight",
+                 "feature_cost_aggregation.embedding.2.conv4d.0.0.query_conv.weight"):
+        assert P[name].grad is not None and torch.isfinite(P[name].grad).all() and float(P[name].grad.abs().max()) > 0, name
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
