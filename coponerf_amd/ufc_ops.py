@@ -1,13 +1,92 @@
-"""HIP bindings of the UFC 4-D operators (the `ops` interface used by coponerf_amd.getz)."""
+"""HIP bindings of the UFC 4-D operators (the `ops` interface used by coponerf_amd.getz).
+
+Forward values ALWAYS come from the HIP kernels (csrc/ufc.hip).  When a caller trains (BASELINE config 3) the
+operators are wrapped in `_HipForwardVjp`: the backward pass evaluates the vector-Jacobian product of the same
+operator written with library ops (MIOpen conv2d / pooling / group_norm, hipBLASLt einsum) at the saved inputs.
+That restatement is never used to produce a forward value.
+"""
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
+from torch.autograd import Function
 
 from ._hip import call
 
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+class _HipForwardVjp(Function):
+    """forward: `hip_fn(*tensors)` (HIP kernels);  backward: VJP of `vjp_fn` (library ops) at the same inputs."""
+
+    @staticmethod
+    def forward(ctx, hip_fn, vjp_fn, *tensors):
+        out = hip_fn(*tensors)
+        ctx.vjp_fn = vjp_fn
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        need = ctx.needs_input_grad[2:]
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(n) for t, n in zip(ctx.saved_tensors, need)]
+            outs = ctx.vjp_fn(*ins)
+            outs = outs if isinstance(outs, tuple) else (outs,)
+            wanted = [t for t, n in zip(ins, need) if n]
+            pairs = [(o, g) for o, g in zip(outs, gouts) if g is not None]
+            got = torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True)
+        it = iter(got)
+        return (None, None) + tuple(next(it) if n else None for n in need)
+
+
+def _wants_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+
+
+def _pool_pair(x, s, support: bool):
+    """MaxPool4d of models/conv4d.py:7-30 over one pair of dims (kernel = stride = s, ceil_mode)."""
+    if s == 1:
+        return x
+    B, C, Hq, Wq, Hs, Ws = x.shape
+    if support:
+        y = F.max_pool2d(x.reshape(B * C * Hq * Wq, 1, Hs, Ws), s, s, 0, ceil_mode=True)
+        return y.reshape(B, C, Hq, Wq, y.shape[-2], y.shape[-1])
+    y = F.max_pool2d(x.permute(0, 1, 4, 5, 2, 3).reshape(B * C * Hs * Ws, 1, Hq, Wq), s, s, 0, ceil_mode=True)
+    return y.reshape(B, C, Hs, Ws, y.shape[-2], y.shape[-1]).permute(0, 1, 4, 5, 2, 3)
+
+
+def _conv4d_gn_relu_lib(x, wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps):
+    B, Cin = x.shape[:2]
+    xq, xs = _pool_pair(x, s, True), _pool_pair(x, s, False)
+    Hq, Wq, Hs2, Ws2 = xq.shape[2:]
+    yq = F.conv2d(xq.permute(0, 4, 5, 1, 2, 3).reshape(B * Hs2 * Ws2, Cin, Hq, Wq), wq, bq, stride=s, padding=p)
+    yq = yq.reshape(B, Hs2, Ws2, -1, yq.shape[-2], yq.shape[-1]).permute(0, 3, 4, 5, 1, 2)
+    Hq2, Wq2, Hs, Ws = xs.shape[2:]
+    ys = F.conv2d(xs.permute(0, 2, 3, 1, 4, 5).reshape(B * Hq2 * Wq2, Cin, Hs, Ws), ws, bs, stride=s, padding=p)
+    ys = ys.reshape(B, Hq2, Wq2, -1, ys.shape[-2], ys.shape[-1]).permute(0, 3, 1, 2, 4, 5)
+    return F.relu(F.group_norm(yq + ys, 1, gn_w, gn_b, eps))
+
+
+def _correlation_lib(src, trg, fs):
+    n = lambda t: t / (t.norm(dim=-1, p=2, keepdim=True) + 1e-5)
+    return torch.einsum("bsc,btc->bst", n(src), n(trg)).reshape(src.shape[0], 1, fs, fs, fs, fs)
+
+
+def _soft_argmax_lib(corr, beta=0.02):
+    b, _, h, w = corr.shape
+    pr = torch.softmax(corr / beta, dim=1).view(-1, h, w, h, w)
+    xn = torch.linspace(-1, 1, w, device=corr.device).view(1, w, 1, 1)
+    yn = torch.linspace(-1, 1, h, device=corr.device).view(1, h, 1, 1)
+    gx = (pr.sum(dim=1) * xn).sum(dim=1, keepdim=True)
+    gy = (pr.sum(dim=2) * yn).sum(dim=1, keepdim=True)
+    return torch.cat((gx, gy), dim=1)
+
+
+def _soft_argmax_pair_lib(c):
+    return _soft_argmax_lib(c.permute(0, 1, 4, 5, 2, 3).flatten(1, 3)), _soft_argmax_lib(c.flatten(1, 3))
 
 
 class HipOps:
@@ -20,6 +99,10 @@ class HipOps:
 
     def conv4d_gn_relu(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps):
         self._need_gpu(x)
+        if _wants_grad(x, wq, bq, ws, bs, gn_w, gn_b):
+            hip = lambda x_, wq_, bq_, ws_, bs_, gw_, gb_: self.conv4d_gn_relu(x_, wq_, bq_, ws_, bs_, k, s, p, gw_, gb_, eps)
+            lib = lambda *t: _conv4d_gn_relu_lib(*t, k, s, p, eps)
+            return _HipForwardVjp.apply(hip, lib, x.float(), wq, bq, ws, bs, gn_w, gn_b)
         x = x.contiguous().float()
         B, Cin, Hq, Wq, Hs, Ws = x.shape
         Cout = wq.shape[0]
@@ -36,6 +119,9 @@ class HipOps:
 
     def correlation_tokens(self, src, trg, fs):
         self._need_gpu(src)
+        if _wants_grad(src, trg):
+            return _HipForwardVjp.apply(lambda a, b: self.correlation_tokens(a, b, fs),
+                                        lambda a, b: _correlation_lib(a, b, fs), src.float(), trg.float())
         B, L, C = src.shape
         s_ = src.contiguous().float()
         t_ = trg.contiguous().float()
@@ -47,6 +133,8 @@ class HipOps:
 
     def soft_argmax_pair(self, c):
         self._need_gpu(c)
+        if _wants_grad(c):
+            return _HipForwardVjp.apply(self.soft_argmax_pair, _soft_argmax_pair_lib, c.float())
         c = c.contiguous().float()
         B = c.shape[0]
         h = c.shape[-1]
@@ -58,6 +146,9 @@ class HipOps:
     def resize_bilinear(self, x, size):
         """(N,C,h,w) -> (N,C,size,size), bilinear, align_corners=True."""
         self._need_gpu(x)
+        if _wants_grad(x):
+            return _HipForwardVjp.apply(lambda t: self.resize_bilinear(t, size), lambda t: F.interpolate(
+                t, size=(size, size), mode="bilinear", align_corners=True), x.float())
         x = x.contiguous().float()
         N, C, h, w = x.shape
         y = torch.empty(N, C, size, size, device=x.device, dtype=torch.float32)

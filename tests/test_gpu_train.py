@@ -84,7 +84,7 @@ def test_full_training_step_end_to_end(dev):
         out = model(inp, val=False)
         loss = (out["rgb"] - target).abs().mean()
         loss.backward()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         opt.step()
     P = dict(model.named_parameters())
     for name in ("query_encode_latent.weight", "phi.lin_out.weight", "encoder.model.conv1.weight", "conv_map.weight",
@@ -92,3 +92,37 @@ def test_full_training_step_end_to_end(dev):
                  "feature_cost_aggregation.embedding.2.conv4d.0.0.query_conv.weight"):
         assert P[name].grad is not None and torch.isfinite(P[name].grad).all() and float(P[name].grad.abs().max()) > 0, name
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+
+
+def test_ufc_operator_gradients_match_oracle(dev):
+    """HipOps forward (HIP) + library-op VJP against autograd through the CPU oracle operators."""
+    from coponerf_amd.ufc_ops import HipOps
+    from oracle.ufc_ref import TorchOps
+    hip, ref = HipOps(), TorchOps()
+
+    def both(fn_name, tensors, extra_hip, extra_ref=None):
+        extra_ref = extra_hip if extra_ref is None else extra_ref
+        a = [t.clone().requires_grad_(True) for t in tensors]
+        b = [t.clone().to(dev).requires_grad_(True) for t in tensors]
+        oa = extra_ref(getattr(ref, fn_name), a)
+        ob = extra_hip(getattr(hip, fn_name), b)
+        oa = oa if isinstance(oa, tuple) else (oa,)
+        ob = ob if isinstance(ob, tuple) else (ob,)
+        la = sum((o * syn.normal(tuple(o.shape), seed=90 + i)).sum() for i, o in enumerate(oa))
+        lb = sum((o * syn.normal(tuple(o.shape), seed=90 + i).to(dev)).sum() for i, o in enumerate(ob))
+        la.backward(), lb.backward()
+        for i, (x, y) in enumerate(zip(a, b)):
+            rel = float((y.grad.cpu() - x.grad).norm() / (x.grad.norm() + 1e-12))
+            assert rel <= 2e-3, (fn_name, i, rel)
+
+    x = syn.normal((1, 4, 8, 8, 8, 8), seed=81)
+    for k, s, p, cout in ((3, 1, 1, 8), (3, 2, 1, 6)):
+        wq, ws = syn.normal((cout, 4, k, k), seed=82) * 0.2, syn.normal((cout, 4, k, k), seed=83) * 0.2
+        bq, bs = syn.normal((cout,), seed=84) * 0.1, syn.normal((cout,), seed=85) * 0.1
+        gw, gb = 1 + 0.1 * syn.normal((cout,), seed=86), 0.1 * syn.normal((cout,), seed=87)
+        both("conv4d_gn_relu", [x, wq, bq, ws, bs, gw, gb],
+             lambda f, t: f(t[0], t[1], t[2], t[3], t[4], k, s, p, t[5], t[6], 1e-5))
+    src, trg = syn.normal((2, 64, 32), seed=88), syn.normal((2, 64, 32), seed=89)
+    both("correlation_tokens", [src, trg], lambda f, t: f(t[0], t[1], 8))
+    both("soft_argmax_pair", [syn.normal((2, 1, 8, 8, 8, 8), seed=80) * 0.05], lambda f, t: f(t[0]))
+    both("resize_bilinear", [syn.normal((2, 3, 8, 8), seed=79)], lambda f, t: f(t[0], 16))
