@@ -30,7 +30,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_linear_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
-    "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "cpn_soft_argmax_pair": [_P, _I, _I, _F, _P, _P, _P],
@@ -79,6 +79,8 @@ def lib() -> ctypes.CDLL:
         fn.restype = ctypes.c_int
     handle.cpn_abi_version.argtypes = []
     handle.cpn_abi_version.restype = ctypes.c_int
+    handle.cpn_gather_bwd_chunks.argtypes = [_I, _I]
+    handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
     handle.cpn_last_error.argtypes = []
     handle.cpn_last_error.restype = ctypes.c_char_p
     got = handle.cpn_abi_version()

@@ -8,7 +8,11 @@
 //   cpn_gather_rows_bwd    gradient of the bilinear multi-scale gather w.r.t. the feature maps (scatter-add),
 //                          i.e. of F.grid_sample at models/CoPoNeRF.py:312 / 370 (no coordinate gradient: all sample
 //                          coordinates derive from poses only and `pt` is detached, CoPoNeRF.py:380-381, 433)
+#include <algorithm>
+
 #include "common.h"
+
+extern "C" long long cpn_gather_bwd_chunks(int R, int S);
 
 namespace {
 
@@ -135,39 +139,224 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int Wl, int Hl, bo
     return t;
 }
 
-// thread = (row, 16-byte chunk < 104) like the forward; 4 taps x 8 channels of float atomics into NHWC fp32 maps
-__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(
+// Scatter-add of the gather gradient without atomic contention.
+// Global fp32 atomics collapse here (millions of rows land on a few hundred coarse pixels: 316 ms per training step)
+// and ds_add_f32 is ~10x slower than a plain LDS write on gfx950 (measured, tools/gbwd_bench.py), so accumulation is
+// made exclusive instead: ONE WAVE owns one (image, level, 8x8-pixel tile, 64-channel slice) accumulator in LDS
+// (16 KB fp32) with lane = channel, so its read-modify-writes need no atomics at all.
+//   pass 1 (gather_bbox_kernel): per 64-row chunk and level, the pixel bounding box of the rows' 2x2 footprints.
+//   pass 2 (gather_rows_bwd_kernel): the wave
+//     A) tests 64 chunk boxes at a time against its tile (lane = chunk), and for the chunks that may touch it
+//        evaluates the rows (lane = row) and queues a 16-byte descriptor per row that really does,
+//     B) drains the queue NB rows at a time: the 128-byte channel slices of dxin for the NEXT NB rows are in flight
+//        while the current NB are accumulated.
+// Coarse levels are additionally split G ways over the rows; tiles are flushed once with global atomics.
+constexpr int TP = 8;        // tile side (pixels)
+constexpr int TC = 64;       // channels per slice = lanes
+constexpr int QCAP = 128;    // descriptor queue entries per wave
+constexpr int NB = 16;       // rows per drain batch
+constexpr int WAVES = 2;     // waves (= roles) per workgroup
+struct GatherBwdPlan {
+    int lvl, tiles_x, tiles, slices, G;                    // roles of this launch: (img, g, tile, slice), slice fastest
+    int maxchunks;                                         // chunk slots per image in the bbox scratch
+};
+
+// the rows that read image `img`: idx in [0, 2*nr*S) -> (first j=0: own view at pixel_val, then j=1: other view at
+// sec_grid); same enumeration in both passes
+struct RowRef {
+    unsigned row;      // row of dxin
+    float2 g;          // normalised sample coordinate
+    int j;
+};
+__device__ __forceinline__ RowRef row_of(int idx, int per, int S, bool s_pow2, int s_shift, int rlo, int b, int vi, int V,
+                                         int R, int ray0, const float* __restrict__ pixel_val,
+                                         const float* __restrict__ sec_grid) {
+    RowRef o;
+    o.j = idx >= per;
+    const int rem = idx - o.j * per;
+    const int rr = s_pow2 ? (rem >> s_shift) : (rem / S);
+    const int sm = rem - rr * S;
+    const int r = rlo + rr;
+    const int v = o.j ? (V - 1 - vi) : vi;
+    const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + sm;
+    o.g = *reinterpret_cast<const float2*>((o.j ? sec_grid : pixel_val) + sidx * 2);
+    o.row = ((((unsigned)(b * R + r - ray0)) * V + v) * S + sm) * 2 + o.j;
+    return o;
+}
+// pixel-space sample position at a level, with the clamps of make_taps
+__device__ __forceinline__ void level_xy(float2 g, int j, float fW, float fH, float& x, float& y) {
+    x = ((g.x + 1.0f) * fW - 1.0f) / 2.0f;
+    y = ((g.y + 1.0f) * fH - 1.0f) / 2.0f;
+    if (!j) {
+        x = fminf(fmaxf(x, 0.0f), fW - 1.0f);
+        y = fminf(fmaxf(y, 0.0f), fH - 1.0f);
+    } else {
+        x = fminf(fmaxf(x, -2.0f), fW + 1.0f);
+        y = fminf(fmaxf(y, -2.0f), fH + 1.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_bbox_kernel(
+    int H, int W, const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, int V, int R, int S,
+    int ray0, int nrays, int maxchunks, int nimg, int4* __restrict__ bbox) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int img = wid / maxchunks, c = wid - img * maxchunks;
+    if (img >= nimg) return;
+    const int b = img / V, vi = img - b * V;
+    const int rlo = max(ray0, b * R) - b * R, rhi = min(ray0 + nrays, (b + 1) * R) - b * R;
+    const int per = max(rhi - rlo, 0) * S, total = 2 * per;
+    const int idx = c * 64 + lane;
+    const bool live = idx < total;
+    RowRef rf;
+    if (live) rf = row_of(idx, per, S, (S & (S - 1)) == 0, 31 - __builtin_clz(S), rlo, b, vi, V, R, ray0, pixel_val, sec_grid);
+#pragma unroll
+    for (int lvl = 0; lvl < 4; ++lvl) {
+        const int shift = 4 - lvl - (lvl == 3);
+        int x0 = 1 << 30, y0 = 1 << 30, x1 = -(1 << 30), y1 = -(1 << 30);
+        if (live) {
+            float x, y;
+            level_xy(rf.g, rf.j, (float)(W >> shift), (float)(H >> shift), x, y);
+            x0 = (int)floorf(x); y0 = (int)floorf(y);
+            x1 = x0 + 1; y1 = y0 + 1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x0 = min(x0, __shfl_xor(x0, o)); y0 = min(y0, __shfl_xor(y0, o));
+            x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
+        }
+        if (lane == 0) bbox[((size_t)img * maxchunks + c) * 4 + lvl] = make_int4(x0, y0, x1, y1);
+    }
+}
+
+__global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
     const __half* __restrict__ dxin, int ldx, int H, int W, const float* __restrict__ pixel_val,
-    const float* __restrict__ sec_grid, int V, int R, int S, int ray0, long long nrows, float* __restrict__ dmap0,
-    float* __restrict__ dmap1, float* __restrict__ dmap2, float* __restrict__ dmap3) {
-    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned row = gid / 104u;
-    const int chunk = (int)(gid - row * 104u);
-    if (row >= (unsigned)nrows) return;
-    const int j = (int)(row & 1);
-    unsigned t = row >> 1;
-    const int s = (int)(t % (unsigned)S); t /= (unsigned)S;
-    const int v = (int)(t % (unsigned)V); t /= (unsigned)V;
-    const unsigned ray = (unsigned)ray0 + t;
-    const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
-    const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + s;
-    int lvl, c8;
-    if (chunk < 96) { lvl = chunk >> 5; c8 = chunk & 31; } else { lvl = 3; c8 = chunk - 96; }
+    const float* __restrict__ sec_grid, int V, int R, int S, int ray0, int nrays, float* __restrict__ dmap0,
+    float* __restrict__ dmap1, float* __restrict__ dmap2, float* __restrict__ dmap3, GatherBwdPlan plan,
+    int nroles, const int4* __restrict__ bbox) {
+    __shared__ float tiles_lds[WAVES][TP * TP * TC];
+    __shared__ uint4 queue_lds[WAVES][QCAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* tile = tiles_lds[wave];
+    uint4* queue = queue_lds[wave];
+    // waves that run at the same time share (img, g): they read neighbouring 128-byte slices of the SAME rows
+    int role = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
+    if (role >= nroles) return;
+    const int lvl = plan.lvl, G = plan.G;
+    const int slice = role % plan.slices; role /= plan.slices;
+    const int tidx = role % plan.tiles; role /= plan.tiles;
+    const int g = role % G;
+    const int img = role / G;
+    const int tx0 = (tidx % plan.tiles_x) * TP, ty0 = (tidx / plan.tiles_x) * TP;
     const int shift = 4 - lvl - (lvl == 3);
     const int Hl = H >> shift, Wl = W >> shift;
     const int C = (lvl == 3) ? 64 : 256;
+    const __half* dcol = dxin + (lvl == 3 ? 768 : lvl * 256) + slice * TC + lane;
     float* base = (lvl == 0) ? dmap0 : (lvl == 1) ? dmap1 : (lvl == 2) ? dmap2 : dmap3;
-    const float* g = (j == 0 ? pixel_val : sec_grid) + sidx * 2;
-    const int img = b * V + (j == 0 ? v : (V - 1 - v));
-    const Taps tp = make_taps(g[0], g[1], Wl, Hl, j == 0);
-    const half8 d = *reinterpret_cast<const half8*>(dxin + (size_t)row * ldx + chunk * 8);
-    float* m = base + (size_t)img * Hl * Wl * C + c8 * 8;
+
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (tp.w[k] == 0.0f) continue;
-        float* p = m + (size_t)tp.off[k] * C;
+    for (int i = 0; i < TP * TP; ++i) tile[i * TC + lane] = 0.0f;
+
+    const int b = img / V, vi = img - b * V;
+    const int rlo = max(ray0, b * R) - b * R, rhi = min(ray0 + nrays, (b + 1) * R) - b * R;
+    const int per = max(rhi - rlo, 0) * S, total = 2 * per;
+    const int nchunks = (total + 63) >> 6;
+    const int cpg = (nchunks + G - 1) / G;
+    const int c_end = min(nchunks, (g + 1) * cpg);
+    const bool s_pow2 = (S & (S - 1)) == 0;
+    const int s_shift = 31 - __builtin_clz(S);
+    const float fW = (float)Wl, fH = (float)Hl;
+    const int4* boxes = bbox + (size_t)img * plan.maxchunks * 4 + lvl;
+
+    auto drain = [&](int n) {
+        // raw halves are carried across the iteration and converted at use, so the loads of batch i+1 stay in
+        // flight during the accumulation of batch i (a conversion at the load would wait for it there)
+        __half cur[NB], nxt[NB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(p + e, (float)d[e] * tp.w[k]);
+        for (int u = 0; u < NB; ++u) {
+            nxt[u] = dcol[(size_t)queue[min(u, n - 1)].x * ldx];      // unconditional: no branch, no wait between loads
+        }
+        for (int i = 0; i < n; i += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                nxt[u] = dcol[(size_t)queue[min(i + NB + u, n - 1)].x * ldx];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (i + u >= n) break;
+                const float du = __half2float(cur[u]);
+                const uint4 q = queue[i + u];
+                const int pk = __builtin_amdgcn_readfirstlane((int)q.y);
+                const float hfx = __uint_as_float(q.z), hfy = __uint_as_float(q.w);
+                const int hx = (pk & 255) - 1, hy = ((pk >> 8) & 255) - 1;
+                float* t = tile + (hy * TP + hx) * TC + lane;
+                if (pk & (1 << 16)) t[0] += du * ((1.0f - hfx) * (1.0f - hfy));
+                if (pk & (2 << 16)) t[TC] += du * (hfx * (1.0f - hfy));
+                if (pk & (4 << 16)) t[TP * TC] += du * ((1.0f - hfx) * hfy);
+                if (pk & (8 << 16)) t[TP * TC + TC] += du * (hfx * hfy);
+            }
+        }
+    };
+
+    int qn = 0;
+    for (int cb = g * cpg; cb < c_end; cb += 64) {
+        // A1: lane = chunk, conservative box test
+        bool maybe = false;
+        if (cb + lane < c_end) {
+            const int4 bx = boxes[(size_t)(cb + lane) * 4];
+            maybe = (bx.z >= tx0) && (bx.x < tx0 + TP) && (bx.w >= ty0) && (bx.y < ty0 + TP);
+        }
+        unsigned long long cmask = __ballot(maybe);
+        while (cmask) {
+            const int c = cb + (int)__builtin_ctzll(cmask);
+            cmask &= cmask - 1;
+            // A2: lane = row of chunk c
+            const int idx = c * 64 + lane;
+            uint4 desc = make_uint4(0, 0, 0, 0);
+            int flags = 0;
+            if (idx < total) {
+                const RowRef rf = row_of(idx, per, S, s_pow2, s_shift, rlo, b, vi, V, R, ray0, pixel_val, sec_grid);
+                float x, y;
+                level_xy(rf.g, rf.j, fW, fH, x, y);
+                const float xf = floorf(x), yf = floorf(y);
+                const int x0 = (int)xf, y0 = (int)yf;
+                const float fx = x - xf, fy = y - yf;
+                const int hx = x0 - tx0, hy = y0 - ty0;
+                if (hx >= -1 && hx < TP && hy >= -1 && hy < TP) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int xi = x0 + (k & 1), yi = y0 + (k >> 1);
+                        const float wk = ((k & 1) ? fx : 1.0f - fx) * ((k >> 1) ? fy : 1.0f - fy);
+                        const bool in_img = (xi >= 0) && (xi < Wl) && (yi >= 0) && (yi < Hl);
+                        const bool in_tile = (xi >= tx0) && (xi < tx0 + TP) && (yi >= ty0) && (yi < ty0 + TP);
+                        if (in_img && in_tile && wk != 0.0f) flags |= 1 << k;
+                    }
+                    desc.x = rf.row;
+                    desc.y = (unsigned)((hx + 1) | ((hy + 1) << 8) | (flags << 16));
+                    desc.z = __float_as_uint(fx);
+                    desc.w = __float_as_uint(fy);
+                }
+            }
+            const unsigned long long mask = __ballot(flags != 0);
+            if (mask) {
+                const int pos =
+                    __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (flags) queue[qn + pos] = desc;
+                __builtin_amdgcn_wave_barrier();
+                qn += __builtin_popcountll(mask);
+                if (qn > QCAP - 64) { drain(qn); qn = 0; }
+            }
+        }
+    }
+    if (qn) drain(qn);
+
+    float* m = base + (size_t)img * Hl * Wl * C + slice * TC + lane;
+#pragma unroll 4
+    for (int pix = 0; pix < TP * TP; ++pix) {
+        const float v = tile[pix * TC + lane];
+        const int gy = ty0 + (pix >> 3), gx = tx0 + (pix & 7);
+        if (v != 0.0f && gy < Hl && gx < Wl) atomicAdd(m + ((size_t)gy * Wl + gx) * C, v);
     }
 }
 
@@ -190,19 +379,41 @@ extern "C" int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, con
 
 extern "C" int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float* pixel_val,
                                    const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays,
-                                   float* dmap0, float* dmap1, float* dmap2, float* dmap3, void* stream) {
-    CPN_REQUIRE(dxin && pixel_val && sec_grid && dmap0 && dmap1 && dmap2 && dmap3, CPN_E_ARG,
+                                   float* dmap0, float* dmap1, float* dmap2, float* dmap3, int32_t* chunk_boxes,
+                                   void* stream) {
+    CPN_REQUIRE(dxin && pixel_val && sec_grid && dmap0 && dmap1 && dmap2 && dmap3 && chunk_boxes, CPN_E_ARG,
                 "cpn_gather_rows_bwd: null pointer");
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && (H % 16) == 0 && (W % 16) == 0 && ldx >= 832,
                 CPN_E_SHAPE, "cpn_gather_rows_bwd: bad shape");
+    CPN_REQUIRE(H <= 1024 && W <= 1024, CPN_E_SHAPE, "cpn_gather_rows_bwd: maps larger than 1024 pixels a side");
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_gather_rows_bwd: ray range outside B*R");
     const long long nrows = (long long)nrays * V * S * 2;
-    const long long total = nrows * 104;
-    CPN_REQUIRE(total < (1LL << 31), CPN_E_SHAPE, "cpn_gather_rows_bwd: chunk too large for 32-bit indexing");
-    hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const __half*)dxin, ldx, H, W, pixel_val, sec_grid, V, R, S, ray0, nrows, dmap0, dmap1, dmap2,
-                       dmap3);
+    CPN_REQUIRE(nrows < (1LL << 31), CPN_E_SHAPE, "cpn_gather_rows_bwd: chunk too large for 32-bit indexing");
+    const int maxchunks = (int)cpn_gather_bwd_chunks(R, S);
+    const int nimg = B * V;
+    const long long nwaves = (long long)nimg * maxchunks;
+    hipLaunchKernelGGL(gather_bbox_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, H, W,
+                       pixel_val, sec_grid, V, R, S, ray0, nrays, maxchunks, nimg, (int4*)chunk_boxes);
+    const long long cand = 2LL * (long long)((nrays + B - 1) / B) * S;       // rows that read one image
+    for (int l = 0; l < 4; ++l) {
+        GatherBwdPlan plan;
+        const int shift = 4 - l - (l == 3);
+        const int Hl = H >> shift, Wl = W >> shift;
+        plan.lvl = l;
+        plan.maxchunks = maxchunks;
+        plan.tiles_x = (Wl + TP - 1) / TP;
+        plan.tiles = plan.tiles_x * ((Hl + TP - 1) / TP);
+        plan.slices = (l == 3 ? 64 : 256) / TC;
+        const long long hits = cand / plan.tiles;                            // expected rows landing on one tile
+        plan.G = (int)std::min<long long>(64, std::max<long long>(1, (hits + 1023) / 2048));
+        const int nroles = nimg * plan.G * plan.tiles * plan.slices;
+        hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((nroles + WAVES - 1) / WAVES), dim3(64 * WAVES), 0,
+                           (hipStream_t)stream, (const __half*)dxin, ldx, H, W, pixel_val, sec_grid, V, R, S, ray0,
+                           nrays, dmap0, dmap1, dmap2, dmap3, plan, nroles, (const int4*)chunk_boxes);
+    }
     CPN_LAUNCH_CHECK("cpn_gather_rows_bwd");
     return 0;
 }
+
+extern "C" long long cpn_gather_bwd_chunks(int R, int S) { return (2LL * R * S + 63) / 64; }

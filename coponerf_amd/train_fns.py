@@ -191,7 +191,9 @@ class GatherFn(Function):
         H, W = ctx.HW
         d = dxin.contiguous()
         dmaps = [torch.zeros(n, h, w_, c, dtype=torch.float32, device=d.device) for (n, c, h, w_) in ctx.shapes]
+        boxes = torch.empty(B * V * _hip.lib().cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=d.device)
         call("cpn_gather_rows_bwd", d.data_ptr(), d.shape[1], H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V, R, S,
-             0, B * R, dmaps[0].data_ptr(), dmaps[1].data_ptr(), dmaps[2].data_ptr(), dmaps[3].data_ptr(), _stream())
+             0, B * R, dmaps[0].data_ptr(), dmaps[1].data_ptr(), dmaps[2].data_ptr(), dmaps[3].data_ptr(),
+             boxes.data_ptr(), _stream())
         g = [m.permute(0, 3, 1, 2).contiguous() for m in dmaps]
         return g[0], g[1], g[2], g[3], None, None, None, None, None

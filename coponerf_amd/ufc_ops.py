@@ -58,7 +58,7 @@ def _pool_pair(x, s, support: bool):
     return y.reshape(B, C, Hs, Ws, y.shape[-2], y.shape[-1]).permute(0, 1, 4, 5, 2, 3)
 
 
-def _conv4d_gn_relu_lib(x, wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps):
+def _conv4d_lib(x, wq, bq, ws, bs, s, p):
     B, Cin = x.shape[:2]
     xq, xs = _pool_pair(x, s, True), _pool_pair(x, s, False)
     Hq, Wq, Hs2, Ws2 = xq.shape[2:]
@@ -67,7 +67,61 @@ def _conv4d_gn_relu_lib(x, wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps):
     Hq2, Wq2, Hs, Ws = xs.shape[2:]
     ys = F.conv2d(xs.permute(0, 2, 3, 1, 4, 5).reshape(B * Hq2 * Wq2, Cin, Hs, Ws), ws, bs, stride=s, padding=p)
     ys = ys.reshape(B, Hq2, Wq2, -1, ys.shape[-2], ys.shape[-1]).permute(0, 3, 1, 2, 4, 5)
-    return F.relu(F.group_norm(yq + ys, 1, gn_w, gn_b, eps))
+    return yq + ys
+
+
+class _Conv4dGnReluFn(Function):
+    """forward: cpn_conv4d_gn_relu.  backward: GroupNorm(1 group)+ReLU in closed form from the statistics the HIP
+    kernel accumulated (no group_norm re-evaluation), then the conv/pool VJP through MIOpen's conv2d backward."""
+
+    @staticmethod
+    def forward(ctx, ops, x, wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps):
+        out, stats = ops._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps)
+        n = out[0].numel()
+        mean = stats[:, 0] / n
+        rstd = torch.rsqrt((stats[:, 1] / n - mean * mean).clamp_min(0) + eps)
+        ctx.save_for_backward(x, wq, bq, ws, bs, gn_w, out, mean.float(), rstd.float())
+        ctx.cfg = (s, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wq, bq, ws, bs, gn_w, out, mean, rstd = ctx.saved_tensors
+        s, p = ctx.cfg
+        need = ctx.needs_input_grad[1:6]
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(n) for t, n in zip((x, wq, bq, ws, bs), need)]
+            y = _conv4d_lib(*ins, s, p)
+        B, C = y.shape[:2]
+        bshape, cshape = (B, 1, 1, 1, 1, 1), (1, C, 1, 1, 1, 1)
+        yh = (y.detach() - mean.view(bshape)) * rstd.view(bshape)
+        dz = dout * (out > 0)
+        sp = (0, 2, 3, 4, 5)
+        dgw = (dz * yh).sum(sp)
+        dgb = dz.sum(sp)
+        dyh = dz * gn_w.detach().view(cshape)
+        red = (1, 2, 3, 4, 5)
+        m1 = dyh.mean(red, keepdim=True)
+        m2 = (dyh * yh).mean(red, keepdim=True)
+        dy = (dyh - m1 - yh * m2) * rstd.view(bshape)
+        wanted = [t for t, n in zip(ins, need) if n]
+        got = iter(torch.autograd.grad(y, wanted, dy) if wanted else ())
+        gx, gwq, gbq, gws, gbs = (next(got) if n else None for n in need)
+        return None, gx, gwq, gbq, gws, gbs, dgw, dgb, None, None, None, None
+
+
+class _ResizeFn(Function):
+    """forward: cpn_resize_bilinear_ac.  backward: the adjoint of the (linear) interpolation, no forward re-run."""
+
+    @staticmethod
+    def forward(ctx, ops, x, size):
+        ctx.in_shape, ctx.size = tuple(x.shape), size
+        return ops.resize_bilinear(x, size)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return None, torch.ops.aten.upsample_bilinear2d_backward(dout.contiguous(), [ctx.size, ctx.size],
+                                                                 list(ctx.in_shape), True, None, None), None
 
 
 def _correlation_lib(src, trg, fs):
@@ -100,9 +154,10 @@ class HipOps:
     def conv4d_gn_relu(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps):
         self._need_gpu(x)
         if _wants_grad(x, wq, bq, ws, bs, gn_w, gn_b):
-            hip = lambda x_, wq_, bq_, ws_, bs_, gw_, gb_: self.conv4d_gn_relu(x_, wq_, bq_, ws_, bs_, k, s, p, gw_, gb_, eps)
-            lib = lambda *t: _conv4d_gn_relu_lib(*t, k, s, p, eps)
-            return _HipForwardVjp.apply(hip, lib, x.float(), wq, bq, ws, bs, gn_w, gn_b)
+            return _Conv4dGnReluFn.apply(self, x.float(), wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps)
+        return self._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps)[0]
+
+    def _conv4d_gn_relu_hip(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps):
         x = x.contiguous().float()
         B, Cin, Hq, Wq, Hs, Ws = x.shape
         Cout = wq.shape[0]
@@ -115,7 +170,7 @@ class HipOps:
         call("cpn_conv4d_gn_relu", x.data_ptr(), wq_.data_ptr(), bq_.data_ptr(), ws_.data_ptr(), bs_.data_ptr(),
              gw.data_ptr(), gb.data_ptr(), float(eps), B, Cin, Cout, Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(),
              stats.data_ptr(), _stream())
-        return y
+        return y, stats
 
     def correlation_tokens(self, src, trg, fs):
         self._need_gpu(src)
@@ -147,8 +202,7 @@ class HipOps:
         """(N,C,h,w) -> (N,C,size,size), bilinear, align_corners=True."""
         self._need_gpu(x)
         if _wants_grad(x):
-            return _HipForwardVjp.apply(lambda t: self.resize_bilinear(t, size), lambda t: F.interpolate(
-                t, size=(size, size), mode="bilinear", align_corners=True), x.float())
+            return _ResizeFn.apply(self, x.float(), size)
         x = x.contiguous().float()
         N, C, h, w = x.shape
         y = torch.empty(N, C, size, size, device=x.device, dtype=torch.float32)

@@ -137,11 +137,13 @@ int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, const uint16_t
                           const float* dhbar, const float* dw_ext, int B, int V, int R, int S, int ray0, int nrays,
                           uint16_t* dqa, uint16_t* dqb, uint16_t* dhid, void* stream);
 
-/* gradient of cpn_gather_rows w.r.t. the feature maps: dxin (rows, ldx) fp16 -> atomically accumulated into
- * dmap0..3 (N,h,w,C) fp32 NHWC, which the caller zeroes first.  No coordinate gradient (CoPoNeRF.py:380-381).    */
+/* gradient of cpn_gather_rows w.r.t. the feature maps: dxin (rows, ldx) fp16 -> accumulated into dmap0..3
+ * (N,h,w,C) fp32 NHWC, which the caller zeroes first.  No coordinate gradient (CoPoNeRF.py:380-381).
+ * chunk_boxes: scratch of B*V*cpn_gather_bwd_chunks(R,S)*16 int32.                                                */
+long long cpn_gather_bwd_chunks(int R, int S);
 int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float* pixel_val, const float* sec_grid,
                         int B, int V, int R, int S, int ray0, int nrays,
-                        float* dmap0, float* dmap1, float* dmap2, float* dmap3, void* stream);
+                        float* dmap0, float* dmap1, float* dmap2, float* dmap3, int32_t* chunk_boxes, void* stream);
 
 /* ==== get_z path: the 4-D operators of UFC =========================== */
 

@@ -1,0 +1,55 @@
+"""Time one training step (BASELINE config 3 per-GPU share: batch=4 pairs, 4096 rays/pair, 64 samples) on one GPU."""
+import argparse
+import json
+import time
+
+import torch
+
+from coponerf_amd import CoPoNeRF, synthetic as syn
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev).train()
+    inp = syn.make_inputs(a.batch, 256, 256, a.rays, seed=61)
+    mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (o.to(dev) if torch.is_tensor(o) else o)
+    inp = mv(inp)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    parts = []
+    for it in range(a.warmup + a.steps):
+        if it == a.warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        ev[0].record()
+        z, rel, flow = model.get_z(inp, val=False)
+        ev[1].record()
+        out = model(inp, z=z, rel_pose=rel, val=False, flow=flow)
+        loss = (out["rgb"] - inp["query"]["rgb"]).abs().mean()
+        ev[2].record()
+        loss.backward()
+        ev[3].record()
+        opt.step()
+        if it >= a.warmup:
+            torch.cuda.synchronize()
+            parts.append([ev[i].elapsed_time(ev[i + 1]) for i in range(3)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    p = torch.tensor(parts).mean(0).tolist()
+    print(json.dumps({"train_ms_per_step": dt * 1e3, "rays_per_s": a.batch * a.rays / dt, "get_z_ms": p[0],
+                      "render_fwd_ms": p[1], "backward_ms": p[2], "peak_mem_GB": torch.cuda.max_memory_allocated() / 2**30,
+                      "batch": a.batch, "rays_per_pair": a.rays, "loss": float(loss.detach())}))
+
+
+if __name__ == "__main__":
+    main()
