@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--pairs", type=int, default=1, help="stereo pairs per GPU")
     ap.add_argument("--chunk-rays", type=int, default=16384)
+    ap.add_argument("--lanes", type=int, default=2, help="HIP streams the ray chunks are spread over")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -66,6 +67,7 @@ def main():
     model.load_state_dict(syn.make_render_weights(), strict=False)
     model = model.to(dev).eval()
     model._engine.chunk_rays = args.chunk_rays
+    model._engine.lanes = args.lanes
 
     def to(o):
         if torch.is_tensor(o):
@@ -115,7 +117,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"configs[1]: {H}x{H} stereo pair, full-image render {R} rays x {S} samples, "
                                f"{B} pair(s) per GPU, render path only (z/rel_pose/flow given, val=True)",
-                   "chunk_rays": args.chunk_rays, "pairs_per_gpu": B},
+                   "chunk_rays": args.chunk_rays, "lanes": args.lanes, "pairs_per_gpu": B},
         "path_tflops": value * f_ray(S) / 1e12,          # algorithmic FLOPs of the reference formulation
         "executed_tflops": value * (S * 6637056.0 + 4300000.0) / 1e12,   # executed after folding the value/key projections
     }

@@ -49,7 +49,14 @@ struct Cfg {
     static constexpr int UNITS_A = BM / 8;            // a unit = 8 rows x 128 B = one wave-wide 1 KiB DMA
     static constexpr int UNITS_B = BN / 8;
     static constexpr int UNITS = UNITS_A + UNITS_B;
-    static constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+    static constexpr int A_BYTES = BM * ROW_BYTES;      // one stage of activations
+    static constexpr int B_BYTES = BN * ROW_BYTES;      // one stage of weights
+    static constexpr int A_SLOTS = 3;                   // activations stream from HBM: prefetched two stages ahead
+    static constexpr int B_SLOTS = 2;                   // weights are L2-resident: one stage ahead is enough
+    // 26 weight units over 8 waves leave 6 waves one piece short: those issue an out-of-bounds (zero-fill, no
+    // memory traffic) piece into a per-wave 1 KiB dump instead of branching, so the DMA stays in one basic block
+    static constexpr int DUMP_BYTES = (UNITS_B % 8) ? 8 * 1024 : 0;
+    static constexpr int LDS_BYTES = A_SLOTS * A_BYTES + B_SLOTS * B_BYTES + DUMP_BYTES;
 };
 
 // blockIdx.x -> (m tile, n tile).  Blocks are dispatched round-robin over the 8 XCDs (private L2 each), so the
@@ -87,7 +94,6 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
     // 32 per round, so the source swizzle ((row>>1)&7) and hence the per-lane byte offset are round-invariant:
     // ONE voffset VGPR per operand, everything else in the scalar offset.  The A descriptor ends at row
     // min(BM, M-m0): rows past M read as zero (hardware bounds check) instead of being clamped.
-    constexpr int MAXU = (C_::UNITS + 7) / 8;
     constexpr int UA4 = C_::UNITS_A / 8;
     const int r0 = wave * 8 + (lane >> 3);
     const int lchunk = (lane & 7) ^ ((r0 >> 1) & 7);
@@ -98,19 +104,35 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
         (void*)(W + (size_t)n0 * ldw), 0, C_::BN * ldw * 2, 0x00020000);
     const int voff_a = (r0 * lda + lchunk * 8) * 2;
     const int voff_w = (r0 * ldw + lchunk * 8) * 2;
-    auto stage = [&](int kt, int buf) {
-        char* sbase = smem + buf * C_::STAGE_BYTES + wave * 1024;
+    char* const smem_b = smem + C_::A_SLOTS * C_::A_BYTES;
+    char* const dump = smem_b + C_::B_SLOTS * C_::B_BYTES + wave * 1024;
+    const int w_bytes = C_::BN * ldw * 2;
+    constexpr int UB = (C_::UNITS_B + 7) / 8;
+    // one DMA piece = one wave-wide 1 KiB buffer_load...lds.  Pieces 0..UB-1 are weights, UB..UB+UA4-1 activations.
+    auto piece_a = [&](int kt, int slot, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(smem + slot * C_::A_BYTES + wave * 1024 + i * 8192),
+                                                 16, voff_a, kt * BK * 2 + i * 128 * lda, 0, 0);
+    };
+    auto piece_b = [&](int kt, int slot, int i) {
+        char* sbase = smem_b + slot * C_::B_BYTES + wave * 1024;
         const int kbytes = kt * BK * 2;
-#pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-            if (wave + 8 * i >= C_::UNITS) break;
-            if (i < UA4)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(sbase + i * 8192), 16, voff_a,
-                                                         kbytes + i * 128 * lda, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(sbase + i * 8192), 16, voff_w,
-                                                         kbytes + (i - UA4) * 128 * ldw, 0, 0);
+        if ((i + 1) * 8 <= C_::UNITS_B) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(sbase + i * 8192), 16, voff_w,
+                                                     kbytes + i * 128 * ldw, 0, 0);
+        } else {
+            const bool live = wave + 8 * i < C_::UNITS_B;
+            char* dst = live ? sbase + i * 8192 : dump;
+            const int soff = live ? kbytes + i * 128 * ldw : w_bytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, voff_w, soff, 0, 0);
         }
+    };
+    auto stage_a = [&](int kt, int slot) {
+#pragma unroll
+        for (int i = 0; i < UA4; ++i) piece_a(kt, slot, i);
+    };
+    auto stage_b = [&](int kt, int slot) {
+#pragma unroll
+        for (int i = 0; i < UB; ++i) piece_b(kt, slot, i);
     };
 
     f32x4 acc[2][NT];
@@ -123,16 +145,16 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
     const int fk = lane >> 4;
     const int swz = (frow >> 1) & 7;
     const int xoff = (wave * 32 + frow) * ROW_BYTES;
-    const int woff = (BM + frow) * ROW_BYTES;
+    const int woff = frow * ROW_BYTES;
     const int coff0 = ((fk ^ swz) << 4), coff1 = (((4 + fk) ^ swz) << 4);
 
-    auto load_frags = [&](const char* sbase, int coff, half8 (&xa)[2], half8 (&wb)[NT]) {
+    auto load_frags = [&](const char* sa, const char* sb, int coff, half8 (&xa)[2], half8 (&wb)[NT]) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-            xa[mt] = *reinterpret_cast<const half8*>(sbase + xoff + mt * 16 * ROW_BYTES + coff);
+            xa[mt] = *reinterpret_cast<const half8*>(sa + xoff + mt * 16 * ROW_BYTES + coff);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            wb[nt] = *reinterpret_cast<const half8*>(sbase + woff + nt * 16 * ROW_BYTES + coff);
+            wb[nt] = *reinterpret_cast<const half8*>(sb + woff + nt * 16 * ROW_BYTES + coff);
     };
     auto mma = [&](const half8 (&xa)[2], const half8 (&wb)[NT]) {
 #pragma unroll
@@ -158,24 +180,65 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
 
     const int nfull = K32 >> 1;
     half8 xa0[2], wb0[NT], xa1[2], wb1[NT];
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
+    stage_a(0, 0);
+    stage_b(0, 0);
+    if (nk > 1) { stage_a(1, 1); stage_b(1, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    load_frags(smem, coff0, xa0, wb0);
-    for (int kt = 0; kt < nfull; ++kt) {
-        const char* scur = smem + (kt & 1) * C_::STAGE_BYTES;
-        const char* snxt = smem + ((kt + 1) & 1) * C_::STAGE_BYTES;
-        load_frags(scur, coff1, xa1, wb1);
+    if (nk > 2) stage_a(2, 2);
+    load_frags(smem, smem_b, coff0, xa0, wb0);
+    // Main part: stages kt+2 (weights) and kt+3 (activations) exist -> branch-free body.
+    //  * DMA pieces are spread between the MFMAs of phase B, one per MFMA pair: issued back to back right behind the
+    //    barrier they stall BOTH waves of a SIMD at the same moment and its MFMA pipe idles (~60-180 cycles a piece).
+    //  * raw s_barrier instead of __syncthreads(): the fence of __syncthreads() makes the compiler drain vmcnt to 0,
+    //    which would serialise the two-stage-ahead activation prefetch behind every barrier.  What the barrier must
+    //    order is spelled out instead: this wave's DMA of stage kt+1 has landed (in-order completion: all but the
+    //    youngest UA4 pieces), and its ds_reads of stage kt have returned before another wave's DMA reuses the slot.
+    constexpr int NDMA = UA4 + UB;
+    static_assert(NDMA <= NT, "one DMA piece per MFMA pair");
+    int sa = 0;                                        // activation slot of stage kt (kt mod 3)
+    int kt = 0;
+    for (; kt + 3 < nk && kt < nfull; ++kt) {
+        const int sa1 = (sa == 2) ? 0 : sa + 1;
+        const char* acur = smem + sa * C_::A_BYTES;
+        const char* anxt = smem + sa1 * C_::A_BYTES;
+        const char* bcur = smem_b + (kt & 1) * C_::B_BYTES;
+        const char* bnxt = smem_b + ((kt + 1) & 1) * C_::B_BYTES;
+        load_frags(acur, bcur, coff1, xa1, wb1);
         mma(xa0, wb0);
         CPN_INTERLEAVE_READS_MFMA();
-        // the compiler does not count buffer_load...lds against the barrier: drain this wave's DMA explicitly
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(UA4) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            wb0[nt] = *reinterpret_cast<const half8*>(bnxt + woff + nt * 16 * ROW_BYTES + coff0);
+            if (nt < 2) xa0[nt] = *reinterpret_cast<const half8*>(anxt + xoff + nt * 16 * ROW_BYTES + coff0);
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[nt], xa1[0], acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[nt], xa1[1], acc[1][nt], 0, 0, 0);
+            if (nt < UB) piece_b(kt + 2, kt & 1, nt);                  // weight slot of stage kt was just drained
+            else if (nt < NDMA) piece_a(kt + 3, sa, nt - UB);          // and so was its activation slot
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sa = sa1;
+    }
+    // tail: the last stages, nothing (or only weights) left to fetch
+    for (; kt < nfull; ++kt) {
+        const int sa1 = (sa == 2) ? 0 : sa + 1;
+        const char* acur = smem + sa * C_::A_BYTES;
+        const char* anxt = smem + sa1 * C_::A_BYTES;
+        const char* bcur = smem_b + (kt & 1) * C_::B_BYTES;
+        const char* bnxt = smem_b + ((kt + 1) & 1) * C_::B_BYTES;
+        load_frags(acur, bcur, coff1, xa1, wb1);
+        mma(xa0, wb0);
+        CPN_INTERLEAVE_READS_MFMA();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 2 < nk) stage(kt + 2, kt & 1);
-        load_frags(snxt, coff0, xa0, wb0);             // harmless garbage after the last stage
+        if (kt + 2 < nk) stage_b(kt + 2, kt & 1);
+        load_frags(anxt, bnxt, coff0, xa0, wb0);       // harmless garbage after the last stage
         mma(xa1, wb1);
         CPN_INTERLEAVE_READS_MFMA();
+        sa = sa1;
     }
     if (K32 & 1) mma(xa0, wb0);                        // odd trailing k32 step (already in set 0)
 #undef CPN_INTERLEAVE_READS_MFMA
@@ -239,7 +302,7 @@ template <int NT, bool OUT_F32, bool RELU>
 int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
            int K32, hipStream_t stream) {
     using C_ = Cfg<NT>;
-    const size_t lds = 2 * C_::STAGE_BYTES;
+    const size_t lds = C_::LDS_BYTES;
     auto kern = gemm_f16_kernel<NT, OUT_F32, RELU>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -97,8 +97,12 @@ class RenderEngine:
         "query_repeat_embed_2": (128, 128, 128),
     }
 
-    def __init__(self, chunk_rays: int = 16384, fold_value: bool = True):
+    def __init__(self, chunk_rays: int = 16384, fold_value: bool = True, lanes: int = 2):
         self.chunk_rays = int(chunk_rays)
+        # ray chunks are independent: `lanes` HIP streams, each with its own workspace, take the chunks round-robin so
+        # that the HBM-bound stages of one chunk (gather, hidden sums) run under the MFMA-bound GEMMs of another
+        self.lanes = max(1, int(lanes))
+        self._lane_streams: List[torch.cuda.Stream] = []
         # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
         # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it
         self.fold_value = bool(fold_value)
@@ -339,37 +343,41 @@ class RenderEngine:
         zl = torch.empty(nray_total, 416, dtype=f32, device=dev)
         C = min(self.chunk_rays, nray_total)
         T = V * S                       # rows per ray for the attention stage
-        xin = self._buf("xin", (C * T * 2, _hip.XIN_STRIDE), f16, dev)
-        hid = self._buf("hid", (C * T * 2, 832), f16, dev)
-        enc = value = None
-        if not self.fold_value:
-            enc = self._buf("enc", (C * T, 832), f16, dev)
-            value = self._buf("value", (C * T, 416), f32, dev)
-        kh = self._buf("kh", (C * T, 128), f16, dev)
-        key2 = self._buf("key2", (C * T, 128), f16, dev)
-        hq = self._buf("hq", (C * T, 128), f16, dev)
-        ce = self._buf("ce", (C * T, 128), f16, dev)
-        q2 = self._buf("q2", (C * T, 128), f16, dev)
-        z1 = self._buf("z1", (C, 416), f32, dev)
-        ze = self._buf("ze", (C, 128), f32, dev)
-        addq = self._buf("addq", (C, 128), f32, dev)
-
-        hbar = self._buf("hbar", (C, 1664), f16, dev)
-        zs = self._buf("zs", (C, 416), f32, dev)
         GW = dict(self.GEMM_WEIGHTS, key_fold=(128, 1664, 1664), value_fold=(416, 1664, 1664))
+        nchunks = (nray_total + C - 1) // C
+        nlanes = min(self.lanes, nchunks)
+        if nlanes > 1 and (len(self._lane_streams) < nlanes or self._lane_streams[0].device != dev):
+            self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(nlanes)]
+        main = torch.cuda.current_stream()
 
-        def gemm(a, lda, wname, out, ldc, m, n, k, relu, out_f32):
-            prof = self.profile
-            if prof is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            call("cpn_gemm_f16", a.data_ptr(), lda, w[wname + ".w16"].data_ptr(), w[wname + ".w16"].shape[1],
-                 w[wname + ".b"].data_ptr(), out.data_ptr(), ldc, m, n, k, int(relu), int(out_f32), s)
-            if prof is not None:
-                e1.record()
-                prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * GW[wname][1]))
+        def lane_buffers(lane):
+            t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
+            bufs = {"xin": t("xin", (C * T * 2, _hip.XIN_STRIDE), f16), "hid": t("hid", (C * T * 2, 832), f16),
+                    "kh": t("kh", (C * T, 128), f16), "key2": t("key2", (C * T, 128), f16),
+                    "hq": t("hq", (C * T, 128), f16), "ce": t("ce", (C * T, 128), f16), "q2": t("q2", (C * T, 128), f16),
+                    "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
+                    "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
+            if not self.fold_value:
+                bufs["enc"] = t("enc", (C * T, 832), f16)
+                bufs["value"] = t("value", (C * T, 416), f32)
+            return bufs
 
-        for ray0 in range(0, nray_total, C):
+        def run_chunk(ray0, bf, s):
+            xin, hid, kh, key2, hq, ce, q2 = (bf[k] for k in ("xin", "hid", "kh", "key2", "hq", "ce", "q2"))
+            z1, ze, addq, hbar, zs = (bf[k] for k in ("z1", "ze", "addq", "hbar", "zs"))
+            enc, value = bf.get("enc"), bf.get("value")
+
+            def gemm(a, lda, wname, out, ldc, m, n, k, relu, out_f32):
+                prof = self.profile
+                if prof is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                call("cpn_gemm_f16", a.data_ptr(), lda, w[wname + ".w16"].data_ptr(), w[wname + ".w16"].shape[1],
+                     w[wname + ".b"].data_ptr(), out.data_ptr(), ldc, m, n, k, int(relu), int(out_f32), s)
+                if prof is not None:
+                    e1.record()
+                    prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * GW[wname][1]))
+
             n = min(C, nray_total - ray0)
             rows, rows2 = n * T, n * T * 2
             call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
@@ -411,6 +419,27 @@ class RenderEngine:
             else:
                 call("cpn_attend", q2.data_ptr(), ce.data_ptr(), value.data_ptr(), z1.data_ptr(), B, V, R, S, ray0, n,
                      zl[ray0:ray0 + n].data_ptr(), 0, s)
+
+        if nlanes == 1:
+            bf = lane_buffers(0)
+            for ray0 in range(0, nray_total, C):
+                run_chunk(ray0, bf, s)
+        else:
+            for lane in range(nlanes):
+                self._lane_streams[lane].wait_event(geom_done)          # geometry + zl allocation precede this point
+            ready = torch.cuda.Event()
+            ready.record()                                              # weights / maps / zl exist on the main stream
+            for ci, ray0 in enumerate(range(0, nray_total, C)):
+                lane = ci % nlanes
+                st = self._lane_streams[lane]
+                if ci < nlanes:
+                    st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    run_chunk(ray0, lane_buffers(lane), st.cuda_stream)
+            for lane in range(nlanes):
+                done = torch.cuda.Event()
+                done.record(self._lane_streams[lane])
+                main.wait_event(done)
 
         # ---- light-field decoder phi over all rays (lightfield.py:131-167), exact fp32
         c18 = torch.zeros(nray_total, 32, dtype=f32, device=dev)
