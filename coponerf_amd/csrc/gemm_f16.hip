@@ -32,6 +32,8 @@
 // byte vs 2500 TFLOP/s / 6.3 TB/s = 397): it is bounded by MFMA issue AND by streaming the (M,K) input and (M,N)
 // output once.  Algorithmic FLOPs per launch = 2*M*N*K; measured main-loop rate 1050 TFLOP/s, 765 TFLOP/s with
 // the tile prologue/epilogue (profiles/, tools/gemm_k.py).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -59,16 +61,24 @@ struct Cfg {
     static constexpr int LDS_BYTES = A_SLOTS * A_BYTES + B_SLOTS * B_BYTES + DUMP_BYTES;
 };
 
-// blockIdx.x -> (m tile, n tile).  Blocks are dispatched round-robin over the 8 XCDs (private L2 each), so the
-// linear id is first remapped to give every XCD a contiguous range of logical tiles (bijective for any grid size),
-// then the N tile index runs fastest: the n_tiles workgroups that share one 256-row activation tile execute
-// back to back on the same XCD and hit its L2 instead of re-streaming the tile from HBM.
-__device__ __forceinline__ void tile_of_block(int n_tiles, int& m_tile, int& n_tile) {
+// Persistent workgroups: the grid is one workgroup per CU and each walks a list of output tiles.  Workgroups are
+// dispatched round-robin over the 8 XCDs (private L2 each): XCD x owns a contiguous range of logical tiles and its
+// workgroups take them in lock step with the N index fastest, so the n_tiles workgroups that share one 256-row
+// activation tile run at the same time on the same L2 instead of re-streaming the tile from HBM.
+struct TileWalk {
+    int begin, end, step, cur;      // logical tiles [begin, end) of this XCD, this workgroup takes begin+i, +step, ...
+};
+__device__ __forceinline__ TileWalk tile_walk(int total) {
     const int nwg = gridDim.x, b = blockIdx.x;
-    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    n_tile = logical % n_tiles;
-    m_tile = logical / n_tiles;
+    const int xcd = b & 7, idx = b >> 3;
+    const int wg_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);            // workgroups on this XCD
+    const int q = total >> 3, r = total & 7;
+    TileWalk t;
+    t.begin = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    t.end = t.begin + q + (xcd < r ? 1 : 0);
+    t.step = wg_x;
+    t.cur = t.begin + idx;
+    return t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -78,68 +88,65 @@ template <int NT, bool OUT_F32, bool RELU>
 __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict__ A, int lda,
                                                              const __half* __restrict__ W, int ldw,
                                                              const float* __restrict__ bias,
-                                                             void* __restrict__ Cv, int ldc, int M, int K32, int n_tiles) {
+                                                             void* __restrict__ Cv, int ldc, int M, int K32, int n_tiles,
+                                                             int total_tiles) {
     using C_ = Cfg<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int m_tile, n_tile;
-    tile_of_block(n_tiles, m_tile, n_tile);
-    const int m0 = m_tile * BM;
-    const int n0 = n_tile * C_::BN;
     const int nk = (K32 + 1) >> 1;
+    const int nfull = K32 >> 1;
 
-    // DMA (buffer_load ... lds): wave w moves units w, w+4, ...; unit u = image rows [8u, 8u+8).  Rows advance by
-    // 32 per round, so the source swizzle ((row>>1)&7) and hence the per-lane byte offset are round-invariant:
+    // DMA (buffer_load ... lds): wave w moves units w, w+8, ...; unit u = image rows [8u, 8u+8).  Rows advance by
+    // 64 per round, so the source swizzle ((row>>1)&7) and hence the per-lane byte offset are round-invariant:
     // ONE voffset VGPR per operand, everything else in the scalar offset.  The A descriptor ends at row
     // min(BM, M-m0): rows past M read as zero (hardware bounds check) instead of being clamped.
     constexpr int UA4 = C_::UNITS_A / 8;
+    constexpr int UB = (C_::UNITS_B + 7) / 8;
+    constexpr int NDMA = UA4 + UB;
+    static_assert(NDMA <= NT, "one DMA piece per MFMA pair");
     const int r0 = wave * 8 + (lane >> 3);
     const int lchunk = (lane & 7) ^ ((r0 >> 1) & 7);
-    const int rows_valid = (M - m0) < BM ? (M - m0) : BM;
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(A + (size_t)m0 * lda), 0, rows_valid * lda * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(W + (size_t)n0 * ldw), 0, C_::BN * ldw * 2, 0x00020000);
     const int voff_a = (r0 * lda + lchunk * 8) * 2;
     const int voff_w = (r0 * ldw + lchunk * 8) * 2;
     char* const smem_b = smem + C_::A_SLOTS * C_::A_BYTES;
     char* const dump = smem_b + C_::B_SLOTS * C_::B_BYTES + wave * 1024;
     const int w_bytes = C_::BN * ldw * 2;
-    constexpr int UB = (C_::UNITS_B + 7) / 8;
-    // one DMA piece = one wave-wide 1 KiB buffer_load...lds.  Pieces 0..UB-1 are weights, UB..UB+UA4-1 activations.
-    auto piece_a = [&](int kt, int slot, int i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void*)(smem + slot * C_::A_BYTES + wave * 1024 + i * 8192),
+
+    // one DMA piece = one wave-wide 1 KiB buffer_load...lds
+    auto piece_a = [&](const __amdgpu_buffer_rsrc_t& ra, int kt, int slot, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(smem + slot * C_::A_BYTES + wave * 1024 + i * 8192),
                                                  16, voff_a, kt * BK * 2 + i * 128 * lda, 0, 0);
     };
-    auto piece_b = [&](int kt, int slot, int i) {
+    auto piece_b = [&](const __amdgpu_buffer_rsrc_t& rw, int kt, int slot, int i) {
         char* sbase = smem_b + slot * C_::B_BYTES + wave * 1024;
         const int kbytes = kt * BK * 2;
         if ((i + 1) * 8 <= C_::UNITS_B) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(sbase + i * 8192), 16, voff_w,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(sbase + i * 8192), 16, voff_w,
                                                      kbytes + i * 128 * ldw, 0, 0);
         } else {
             const bool live = wave + 8 * i < C_::UNITS_B;
             char* dst = live ? sbase + i * 8192 : dump;
             const int soff = live ? kbytes + i * 128 * ldw : w_bytes;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)dst, 16, voff_w, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)dst, 16, voff_w, soff, 0, 0);
         }
     };
-    auto stage_a = [&](int kt, int slot) {
+    auto stage_a = [&](const __amdgpu_buffer_rsrc_t& ra, int kt, int slot) {
 #pragma unroll
-        for (int i = 0; i < UA4; ++i) piece_a(kt, slot, i);
+        for (int i = 0; i < UA4; ++i) piece_a(ra, kt, slot, i);
     };
-    auto stage_b = [&](int kt, int slot) {
+    auto stage_b = [&](const __amdgpu_buffer_rsrc_t& rw, int kt, int slot) {
 #pragma unroll
-        for (int i = 0; i < UB; ++i) piece_b(kt, slot, i);
+        for (int i = 0; i < UB; ++i) piece_b(rw, kt, slot, i);
     };
-
-    f32x4 acc[2][NT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto rsrc_of_a = [&](int m0) {
+        const int rows_valid = (M - m0) < BM ? (M - m0) : BM;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, rows_valid * lda * 2, 0x00020000);
+    };
+    auto rsrc_of_w = [&](int n0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * ldw), 0, w_bytes, 0x00020000);
+    };
 
     const int frow = lane & 15;
     const int fk = lane >> 4;
@@ -156,21 +163,12 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
         for (int nt = 0; nt < NT; ++nt)
             wb[nt] = *reinterpret_cast<const half8*>(sb + woff + nt * 16 * ROW_BYTES + coff);
     };
-    auto mma = [&](const half8 (&xa)[2], const half8 (&wb)[NT]) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[nt], xa[mt], acc[mt][nt], 0, 0, 0);
-    };
 
-    // Software pipeline (one wave per SIMD has no partner wave to hide LDS latency behind):
+    // Software pipeline per 64-deep stage:
     //   phase A  MFMAs on fragment set 0 (stage kt, first k32)  ||  ds_reads of set 1 (stage kt, second k32)
     //   barrier  -> stage kt+1 has landed for every wave, every wave is done reading stage kt
-    //   phase B  DMA of stage kt+2 into the buffer just freed;
-    //            MFMAs on set 1  ||  ds_reads of set 0 for stage kt+1
+    //   phase B  MFMAs on set 1  ||  ds_reads of set 0 for stage kt+1  ||  DMA of weights(kt+2), activations(kt+3)
     // so the barrier sits between two MFMA blocks whose operands are already in registers.
-    // sched_group_barrier pins the interleave to 1 ds_read per 3 MFMAs (17 reads under 52 MFMAs).
 #define CPN_INTERLEAVE_READS_MFMA()                                             \
     _Pragma("unroll") for (int q_ = 0; q_ < NT; ++q_) {                         \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* 1 DS read */      \
@@ -178,124 +176,183 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
     }                                                                           \
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 
-    const int nfull = K32 >> 1;
-    half8 xa0[2], wb0[NT], xa1[2], wb1[NT];
-    stage_a(0, 0);
-    stage_b(0, 0);
-    if (nk > 1) { stage_a(1, 1); stage_b(1, 1); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nk > 2) stage_a(2, 2);
-    load_frags(smem, smem_b, coff0, xa0, wb0);
-    // Main part: stages kt+2 (weights) and kt+3 (activations) exist -> branch-free body.
-    //  * DMA pieces are spread between the MFMAs of phase B, one per MFMA pair: issued back to back right behind the
-    //    barrier they stall BOTH waves of a SIMD at the same moment and its MFMA pipe idles (~60-180 cycles a piece).
-    //  * raw s_barrier instead of __syncthreads(): the fence of __syncthreads() makes the compiler drain vmcnt to 0,
-    //    which would serialise the two-stage-ahead activation prefetch behind every barrier.  What the barrier must
-    //    order is spelled out instead: this wave's DMA of stage kt+1 has landed (in-order completion: all but the
-    //    youngest UA4 pieces), and its ds_reads of stage kt have returned before another wave's DMA reuses the slot.
-    constexpr int NDMA = UA4 + UB;
-    static_assert(NDMA <= NT, "one DMA piece per MFMA pair");
-    int sa = 0;                                        // activation slot of stage kt (kt mod 3)
-    int kt = 0;
-    for (; kt + 3 < nk && kt < nfull; ++kt) {
-        const int sa1 = (sa == 2) ? 0 : sa + 1;
-        const char* acur = smem + sa * C_::A_BYTES;
-        const char* anxt = smem + sa1 * C_::A_BYTES;
-        const char* bcur = smem_b + (kt & 1) * C_::B_BYTES;
-        const char* bnxt = smem_b + ((kt + 1) & 1) * C_::B_BYTES;
-        load_frags(acur, bcur, coff1, xa1, wb1);
-        mma(xa0, wb0);
-        CPN_INTERLEAVE_READS_MFMA();
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(UA4) : "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            wb0[nt] = *reinterpret_cast<const half8*>(bnxt + woff + nt * 16 * ROW_BYTES + coff0);
-            if (nt < 2) xa0[nt] = *reinterpret_cast<const half8*>(anxt + xoff + nt * 16 * ROW_BYTES + coff0);
-            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[nt], xa1[0], acc[0][nt], 0, 0, 0);
-            acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[nt], xa1[1], acc[1][nt], 0, 0, 0);
-            if (nt < UB) piece_b(kt + 2, kt & 1, nt);                  // weight slot of stage kt was just drained
-            else if (nt < NDMA) piece_a(kt + 3, sa, nt - UB);          // and so was its activation slot
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        sa = sa1;
+    TileWalk walk = tile_walk(total_tiles);
+    if (walk.cur >= walk.end) return;
+    // stage 0 of the first tile; later tiles get theirs issued under the previous tile's epilogue
+    {
+        const int t = walk.cur;
+        stage_a(rsrc_of_a((t / n_tiles) * BM), 0, 0);
+        stage_b(rsrc_of_w((t % n_tiles) * C_::BN), 0, 0);
     }
-    // tail: the last stages, nothing (or only weights) left to fetch
-    for (; kt < nfull; ++kt) {
-        const int sa1 = (sa == 2) ? 0 : sa + 1;
-        const char* acur = smem + sa * C_::A_BYTES;
-        const char* anxt = smem + sa1 * C_::A_BYTES;
-        const char* bcur = smem_b + (kt & 1) * C_::B_BYTES;
-        const char* bnxt = smem_b + ((kt + 1) & 1) * C_::B_BYTES;
-        load_frags(acur, bcur, coff1, xa1, wb1);
-        mma(xa0, wb0);
-        CPN_INTERLEAVE_READS_MFMA();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 2 < nk) stage_b(kt + 2, kt & 1);
-        load_frags(anxt, bnxt, coff0, xa0, wb0);       // harmless garbage after the last stage
-        mma(xa1, wb1);
-        CPN_INTERLEAVE_READS_MFMA();
-        sa = sa1;
-    }
-    if (K32 & 1) mma(xa0, wb0);                        // odd trailing k32 step (already in set 0)
-#undef CPN_INTERLEAVE_READS_MFMA
 
-    if constexpr (!OUT_F32) {
-        // fp16 epilogue through LDS: the accumulator layout gives a lane 4 consecutive columns (8 B) of one row, i.e.
-        // 32-B row segments per store; staging the wave's 32 x BN tile in the (now idle) ring and reading it back
-        // row-contiguously turns 2*NT 8-byte stores into NT 16-byte stores that cover whole 416-B rows.
-        constexpr int RS = C_::BN * 2 + 16;                       // padded row stride: conflict-free ds_write_b64
-        constexpr int CPR = C_::BN / 8;                           // 16-byte chunks per row
-        __syncthreads();                                          // every wave is done reading the ring
-        char* cw = smem + wave * (32 * RS);
+    for (; walk.cur < walk.end; walk.cur += walk.step) {
+        const int m0 = (walk.cur / n_tiles) * BM;
+        const int n0 = (walk.cur % n_tiles) * C_::BN;
+        const __amdgpu_buffer_rsrc_t rsrc_a = rsrc_of_a(m0);
+        const __amdgpu_buffer_rsrc_t rsrc_w = rsrc_of_w(n0);
+
+        f32x4 acc[2][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + nt * 16 + (lane >> 4) * 4);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                f32x4 v = acc[mt][nt] + bv;
-                if (RELU) {
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        half8 xa0[2], wb0[NT], xa1[2], wb1[NT];
+        // slower waves may still be reading the previous tile's C staging out of activation slots 1-2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nk > 1) { stage_a(rsrc_a, 1, 1); stage_b(rsrc_w, 1, 1); }
+        // stage 0 landed (and the previous tile's stores have left: on gfx9 they share vmcnt with the loads and may
+        // retire out of order against them, so the count cannot single out the DMA); stage 1 may stay in flight
+        if (nk > 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nk > 2) stage_a(rsrc_a, 2, 2);
+        load_frags(smem, smem_b, coff0, xa0, wb0);
+
+        // Main part: stages kt+2 (weights) and kt+3 (activations) exist -> branch-free body.
+        //  * DMA pieces are spread between the MFMAs of phase B, one per MFMA pair: issued back to back right behind
+        //    the barrier they stall BOTH waves of a SIMD at the same moment and its MFMA pipe idles.
+        //  * raw s_barrier instead of __syncthreads(): the fence of __syncthreads() makes the compiler drain vmcnt
+        //    to 0, which would serialise the two-stage-ahead activation prefetch behind every barrier.  What the
+        //    barrier must order is spelled out instead: this wave's DMA of stage kt+1 has landed (in-order
+        //    completion: all but the youngest UA4 pieces), and its ds_reads of stage kt have returned before another
+        //    wave's DMA reuses the slot.
+        int sa = 0;                                        // activation slot of stage kt (kt mod 3)
+        int kt = 0;
+        for (; kt + 3 < nk && kt < nfull; ++kt) {
+            const int sa1 = (sa == 2) ? 0 : sa + 1;
+            const char* acur = smem + sa * C_::A_BYTES;
+            const char* anxt = smem + sa1 * C_::A_BYTES;
+            const char* bcur = smem_b + (kt & 1) * C_::B_BYTES;
+            const char* bnxt = smem_b + ((kt + 1) & 1) * C_::B_BYTES;
+            load_frags(acur, bcur, coff1, xa1, wb1);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
-                }
-                half4 h;
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[i];
-                *reinterpret_cast<half4*>(cw + (mt * 16 + (lane & 15)) * RS + (nt * 16 + (lane >> 4) * 4) * 2) = h;
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[nt], xa0[mt], acc[mt][nt], 0, 0, 0);
+            CPN_INTERLEAVE_READS_MFMA();
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(UA4) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                wb0[nt] = *reinterpret_cast<const half8*>(bnxt + woff + nt * 16 * ROW_BYTES + coff0);
+                if (nt < 2) xa0[nt] = *reinterpret_cast<const half8*>(anxt + xoff + nt * 16 * ROW_BYTES + coff0);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[nt], xa1[0], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[nt], xa1[1], acc[1][nt], 0, 0, 0);
+                if (nt < UB) piece_b(rsrc_w, kt + 2, kt & 1, nt);              // weight slot of stage kt just drained
+                else if (nt < NDMA) piece_a(rsrc_a, kt + 3, sa, nt - UB);      // and so was its activation slot
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sa = sa1;
+        }
+        // tail: the last stages, nothing (or only weights) left to fetch
+        for (; kt < nfull; ++kt) {
+            const int sa1 = (sa == 2) ? 0 : sa + 1;
+            const char* acur = smem + sa * C_::A_BYTES;
+            const char* anxt = smem + sa1 * C_::A_BYTES;
+            const char* bcur = smem_b + (kt & 1) * C_::B_BYTES;
+            const char* bnxt = smem_b + ((kt + 1) & 1) * C_::B_BYTES;
+            load_frags(acur, bcur, coff1, xa1, wb1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[nt], xa0[mt], acc[mt][nt], 0, 0, 0);
+            CPN_INTERLEAVE_READS_MFMA();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage_b(rsrc_w, kt + 2, kt & 1);
+            load_frags(anxt, bnxt, coff0, xa0, wb0);       // harmless garbage after the last stage
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[nt], xa1[mt], acc[mt][nt], 0, 0, 0);
+            CPN_INTERLEAVE_READS_MFMA();
+            sa = sa1;
+        }
+        if (K32 & 1) {                                     // odd trailing k32 step (already in set 0)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[nt], xa0[mt], acc[mt][nt], 0, 0, 0);
+        }
+
+        // every wave is done with the ring: stage 0 of the NEXT tile starts now and flies under this tile's epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int t = walk.cur + walk.step;
+            if (t < walk.end) {
+                stage_a(rsrc_of_a((t / n_tiles) * BM), 0, 0);
+                stage_b(rsrc_of_w((t % n_tiles) * C_::BN), 0, 0);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __half* cbase = (__half*)Cv + (size_t)(m0 + wave * 32) * ldc + n0;
-#pragma unroll
-        for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
-            const int q = lane + 64 * i;
-            const int r = q / CPR, c = q - r * CPR;
-            if (q < 32 * CPR && m0 + wave * 32 + r < M) {
-                const half8 val = *reinterpret_cast<const half8*>(cw + r * RS + c * 16);
-                *reinterpret_cast<half8*>(cbase + (size_t)r * ldc + c * 8) = val;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = n0 + nt * 16 + (lane >> 4) * 4;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+
+        if constexpr (!OUT_F32) {
+            // fp16 epilogue through LDS (activation slots 1 and 2; slot 0 is receiving the next tile): the accumulator
+            // layout gives a lane 4 consecutive columns (8 B) of one row, i.e. 32-B row segments per store; staging
+            // 16 x BN per wave and reading it back row-contiguously turns them into 16-byte stores that cover whole
+            // 416-B rows.  Two halves of 16 rows keep the staging inside 64 KiB.
+            constexpr int RS = C_::BN * 2 + 16;                       // padded row stride: conflict-free ds_write_b64
+            constexpr int CPR = C_::BN / 8;                           // 16-byte chunks per row
+            static_assert(8 * 16 * RS <= 2 * C_::A_BYTES, "staging must fit activation slots 1-2");
+            char* cw = smem + C_::A_BYTES + wave * (16 * RS);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
-                if (m >= M) continue;
-                f32x4 v = acc[mt][nt] + bv;
-                if (RELU) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + nt * 16 + (lane >> 4) * 4);
+                    f32x4 v = acc[mt][nt] + bv;
+                    if (RELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+                    }
+                    half4 h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[i];
+                    *reinterpret_cast<half4*>(cw + (lane & 15) * RS + (nt * 16 + (lane >> 4) * 4) * 2) = h;
                 }
-                *reinterpret_cast<f32x4*>((float*)Cv + (size_t)m * ldc + n) = v;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const int rbase = m0 + wave * 32 + mt * 16;
+                __half* cbase = (__half*)Cv + (size_t)rbase * ldc + n0;
+#pragma unroll
+                for (int i = 0; i < (16 * CPR + 63) / 64; ++i) {
+                    const int q = lane + 64 * i;
+                    const int r = q / CPR, c = q - r * CPR;
+                    if (q < 16 * CPR && rbase + r < M) {
+                        const half8 val = *reinterpret_cast<const half8*>(cw + r * RS + c * 16);
+                        *reinterpret_cast<half8*>(cbase + (size_t)r * ldc + c * 8) = val;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + nt * 16 + (lane >> 4) * 4;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
+                    if (m >= M) continue;
+                    f32x4 v = acc[mt][nt] + bv;
+                    if (RELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+                    }
+                    *reinterpret_cast<f32x4*>((float*)Cv + (size_t)m * ldc + n) = v;
+                }
             }
         }
     }
+#undef CPN_INTERLEAVE_READS_MFMA
 }
 
 template <int NT, bool OUT_F32, bool RELU>
@@ -314,8 +371,21 @@ int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias
         attr_set = true;
     }
     const int n_tiles = N / C_::BN;
-    dim3 grid(cpn_cdiv(M, BM) * n_tiles);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles);
+    const long long total = (long long)cpn_cdiv(M, BM) * n_tiles;
+    if (total >= (1LL << 31)) {
+        cpn_set_error("cpn_gemm_f16: %lld output tiles exceed the 32-bit tile index", total);
+        return CPN_E_SHAPE;
+    }
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        num_cu = n;
+    }
+    dim3 grid((unsigned)std::min<long long>(total, num_cu));       // persistent: one workgroup per CU
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles, (int)total);
     CPN_LAUNCH_CHECK("cpn_gemm_f16");
     return 0;
 }

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from coponerf_amd._hip import call
 dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
-M, N, ld = 524288, 832, 896
+M, N, ld = int(sys.argv[1]) if len(sys.argv) > 1 else 524288, 832, 896
 A = (torch.randn(M, ld, device=dev) * 0.5).half(); W = (torch.randn(N, ld, device=dev) * 0.05).half()
 b = torch.randn(N, device=dev); C = torch.empty(M, N, device=dev, dtype=torch.float16)
 for K in (64, 128, 256, 448, 864):
