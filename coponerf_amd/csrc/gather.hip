@@ -9,6 +9,8 @@
 // wave reads 4 x 1 KiB fully-coalesced segments and writes 1 KiB of the row.  HBM/L2-bound:
 // per output row 4 taps x 832 ch x 2 B = 6.5 KiB read (mostly L2 hits: 44.6 MB fp32 -> 22.3 MB fp16
 // per pair at 256^2, neighbouring samples share texels) and 1.75 KiB written.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -79,22 +81,26 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int Wl, int Hl, bo
 }
 
 // 108 16-byte chunks per row: 32 | 32 | 32 (levels 0-2, 256 ch) | 8 (level 3, 64 ch) | 1 (pe) | 3 (zero)
-constexpr int CHUNKS_PER_ROW = CPN_XIN_K / 8;
+constexpr int LANES_PER_ROW = 32;       // 4 levels x 8 lanes
 
+// thread = (row, level, sub): the row decomposition and the level's bilinear taps (~140 VALU instructions) are
+// computed once and amortised over the 4 chunks sub, sub+8, sub+16, sub+24 of that level (one chunk per thread was
+// VALU-bound on exactly that index arithmetic: 3.7 ms per 16 384-ray launch).  8 neighbouring lanes read / write 128
+// contiguous bytes.  Level-3 threads own one chunk (64 channels) and, for sub < 4, the pe / zero-pad chunk 104+sub.
 __global__ __launch_bounds__(256) void gather_rows_kernel(
     const __half* __restrict__ map0, const __half* __restrict__ map1, const __half* __restrict__ map2,
     const __half* __restrict__ map3, int H, int W, const float* __restrict__ pixel_val,
     const float* __restrict__ sec_grid, const float* __restrict__ pe6, int V, int R, int S, int ray0,
     long long nrows, __half* __restrict__ xin) {
-    // 32-bit index arithmetic throughout (the host checks nrows * 108 < 2^31): 64-bit integer division is a
-    // ~100-instruction software routine on gfx950 and would dominate this otherwise load/store-bound kernel
+    // 32-bit index arithmetic throughout (the host checks nrows * 32 < 2^31): 64-bit integer division is a
+    // ~100-instruction software routine on gfx950.
     // XCD-aware order: blocks are dispatched round-robin over the 8 XCDs; giving each XCD a contiguous range of
     // rows (= neighbouring rays = overlapping texel footprints) keeps its private L2 on 1/8 of the feature maps
     const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, rem = nb & 7;
     const unsigned lblock = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
     const unsigned gid = lblock * blockDim.x + threadIdx.x;
-    const unsigned row = gid / CHUNKS_PER_ROW;
-    const int chunk = (int)(gid - row * CHUNKS_PER_ROW);
+    const unsigned row = gid / LANES_PER_ROW;
+    const int lvl = (int)(gid >> 3) & 3, sub = (int)gid & 7;
     if (row >= (unsigned)nrows) return;
     // row = ((ray*V + v)*S + s)*2 + j  within the chunk of rays starting at ray0
     const int j = (int)(row & 1);
@@ -105,80 +111,112 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
     const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
     const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + s;      // sample index in (N,R,S) arrays
 
-    half8 out;
-    if (chunk < 104) {
-        int lvl, c8;
-        if (chunk < 96) { lvl = chunk >> 5; c8 = chunk & 31; } else { lvl = 3; c8 = chunk - 96; }
-        const int shift = 4 - lvl - (lvl == 3);                       // H/16, H/8, H/4, H
-        const int Hl = H >> shift, Wl = W >> shift;
-        const int C = (lvl == 3) ? 64 : 256;
-        const __half* base = (lvl == 0) ? map0 : (lvl == 1) ? map1 : (lvl == 2) ? map2 : map3;
-        // j = 0: own image at the epipolar sample (border); j = 1: other image at the reprojected point (zeros)
-        const float* g = (j == 0 ? pixel_val : sec_grid) + sidx * 2;
-        const int img = b * V + (j == 0 ? v : (V - 1 - v));
-        const Taps tp = make_taps(g[0], g[1], Wl, Hl, j == 0);
-        const __half* m = base + (size_t)img * Hl * Wl * C + c8 * 8;
+    const int shift = 4 - lvl - (lvl == 3);                           // H/16, H/8, H/4, H
+    const int Hl = H >> shift, Wl = W >> shift;
+    const int C = (lvl == 3) ? 64 : 256;
+    const __half* base = (lvl == 0) ? map0 : (lvl == 1) ? map1 : (lvl == 2) ? map2 : map3;
+    // j = 0: own image at the epipolar sample (border); j = 1: other image at the reprojected point (zeros)
+    const float* g = (j == 0 ? pixel_val : sec_grid) + sidx * 2;
+    const int img = b * V + (j == 0 ? v : (V - 1 - v));
+    const Taps tp = make_taps(g[0], g[1], Wl, Hl, j == 0);
+    const __half* m = base + (size_t)img * Hl * Wl * C + sub * 8;
+    __half* orow = xin + (size_t)row * CPN_XIN_STRIDE;
+    __half* o = orow + (lvl == 3 ? 768 : lvl * 256) + sub * 8;
+    const int iters = (lvl == 3) ? 1 : 4;
+    for (int it = 0; it < iters; ++it) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const half8 tv = *reinterpret_cast<const half8*>(m + (size_t)tp.off[k] * C);
+            const half8 tv = *reinterpret_cast<const half8*>(m + (size_t)tp.off[k] * C + it * 64);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += (float)tv[e] * tp.w[k];
         }
+        half8 out;
 #pragma unroll
         for (int e = 0; e < 8; ++e) out[e] = (_Float16)acc[e];
-    } else {
+        *reinterpret_cast<half8*>(o + it * 64) = out;
+    }
+    if (lvl == 3 && sub < 4) {
+        half8 out;
 #pragma unroll
         for (int e = 0; e < 8; ++e) out[e] = (_Float16)0.0f;
-        if (chunk == 104) {
+        if (sub == 0) {
             const float* pe = pe6 + sidx * 6 + j * 3;
             out[0] = (_Float16)pe[0]; out[1] = (_Float16)pe[1]; out[2] = (_Float16)pe[2];
         }
+        *reinterpret_cast<half8*>(orow + (104 + sub) * 8) = out;
     }
-    *reinterpret_cast<half8*>(xin + (size_t)row * CPN_XIN_STRIDE + chunk * 8) = out;
 }
 
 // ---------------------------------------------------------------------------------------------
-// first (16 -> 128) layer of query_embed / query_repeat_embed in exact fp32, output fp16 rows.
-// thread = (row, group of 8 outputs): 16 threads per row, 16-B coalesced stores.
+// first (16 -> 128) layer of query_embed / query_repeat_embed in fp32, output fp16 rows.
+// One wave = 16 rows per step on the fp32 matrix cores: D(128 ch x 16 rows) = W(128 x 16) . L^T(16 x 16 rows) as 8 output
+// tiles x 4 v_mfma_f32_16x16x4_f32 (the VALU form, 128 FMA per 16-byte store, ran at 20 % of the fp32 VALU peak:
+// 0.54 ms per launch).  Weights are the MFMA A operand and stay in registers for the whole kernel; the rows of tile
+// t = 2p+h are assigned to channels p*32 + (a/4)*8 + h*4 + a%4, so a lane ends up with 8 CONSECUTIVE channels of one
+// row per tile pair (16-byte stores, 64 contiguous bytes per row and pair).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void local_hidden_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w, int ldw,
     const float* __restrict__ bias, const float* __restrict__ add, int V, int R, int S, int ray0,
     long long nrows, __half* __restrict__ out) {
-    // thread = (row lane, group of 8 outputs); the 8 x 16 weights of the group live in registers and the
-    // block strides over rows, so the kernel is FMA-bound (128 FMA per 16-byte store) instead of load-bound.
-    const int og = threadIdx.x & 15;
-    float wr[8][16], br[8];
+    const int lane = threadIdx.x & 63;
+    const int a = lane & 15, fg = lane >> 4;
+    f32x4 wv[8];                  // wv[t][e] = W[channel(t, a)][fg*4 + e]
+    f32x4 bv[8];                  // bias of the 4 channels this lane owns in tile t
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        br[e] = bias[og * 8 + e];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wr[e][k] = w[(size_t)(og * 8 + e) * ldw + k];
+    for (int t = 0; t < 8; ++t) {
+        const int p = t >> 1, h = t & 1;
+        const int ch_a = p * 32 + (a >> 2) * 8 + h * 4 + (a & 3);
+        wv[t] = *reinterpret_cast<const f32x4*>(w + (size_t)ch_a * ldw + fg * 4);
+        bv[t] = *reinterpret_cast<const f32x4*>(bias + p * 32 + fg * 8 + h * 4);
     }
-    for (unsigned row = blockIdx.x * 16 + (threadIdx.x >> 4); row < (unsigned)nrows; row += gridDim.x * 16) {
-        unsigned t = row;                                          // 32-bit: see gather_rows_kernel
-        const int s = (int)(t % (unsigned)S); t /= (unsigned)S;
-        const int v = (int)(t % (unsigned)V); t /= (unsigned)V;
-        const unsigned ray = (unsigned)ray0 + t;
+    const unsigned ngroups = (unsigned)((nrows + 15) >> 4);
+    const unsigned wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (unsigned grp = wave_id; grp < ngroups; grp += nwaves) {
+        const unsigned row = grp * 16 + a;
+        const bool live = row < (unsigned)nrows;
+        unsigned t_ = live ? row : (unsigned)nrows - 1;            // 32-bit: see gather_rows_kernel
+        const int s = (int)(t_ % (unsigned)S); t_ /= (unsigned)S;
+        const int v = (int)(t_ % (unsigned)V); t_ /= (unsigned)V;
+        const unsigned ray = (unsigned)ray0 + t_;
         const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
         const size_t nr = ((size_t)(b * V + v)) * R + r;
         const f32x4 l0 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8);
         const f32x4 l1 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8 + 4);
         const float* c9 = coords9 + nr * 9;
-        // local_coords channel order (CoPoNeRF.py:445): ctx dir 0-2, zeros 3-5, query dir 6-8, depth 9-12, origin 13-15
-        const float L[16] = {l0[0], l0[1], l0[2], 0.f, 0.f, 0.f, c9[0], c9[1], c9[2],
-                             l0[3], l1[0], l1[1], l1[2], c9[6], c9[7], c9[8]};
-        half8 o;
+        // local_coords channel order (CoPoNeRF.py:445): ctx dir 0-2, zeros 3-5, query dir 6-8, depth 9-12, origin 13-15;
+        // this lane feeds k = fg*4 .. fg*4+3
+        f32x4 lv;
+        if (fg == 0) lv = f32x4{l0[0], l0[1], l0[2], 0.f};
+        else if (fg == 1) lv = f32x4{0.f, 0.f, c9[0], c9[1]};
+        else if (fg == 2) lv = f32x4{c9[2], l0[3], l1[0], l1[1]};
+        else lv = f32x4{l1[2], c9[6], c9[7], c9[8]};
+        f32x4 acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float acc = br[e];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc += wr[e][k] * L[k];
-            if (add) acc += add[(size_t)t * 128 + og * 8 + e];
-            o[e] = (_Float16)fmaxf(acc, 0.0f);
+        for (int t = 0; t < 8; ++t) {
+            acc[t] = bv[t];
+            if (add) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(add + (size_t)t_ * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+                acc[t] += av;
+            }
         }
-        *reinterpret_cast<half8*>(out + (size_t)row * 128 + og * 8) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], lv[e], acc[t], 0, 0, 0);
+        if (live) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                half8 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = (_Float16)fmaxf(acc[2 * p][i], 0.0f);
+                    o[4 + i] = (_Float16)fmaxf(acc[2 * p + 1][i], 0.0f);
+                }
+                *reinterpret_cast<half8*>(out + (size_t)row * 128 + p * 32 + fg * 8) = o;
+            }
+        }
     }
 }
 
@@ -215,7 +253,7 @@ extern "C" int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_gather_rows: ray range [%d,%d) outside B*R=%lld", ray0, ray0 + nrays, (long long)B * R);
     const long long nrows = (long long)nrays * V * S * 2;
-    const long long total = nrows * CHUNKS_PER_ROW;
+    const long long total = nrows * LANES_PER_ROW;
     CPN_REQUIRE(total < (1LL << 31) && (long long)B * R < (1LL << 31), CPN_E_SHAPE,
                 "cpn_gather_rows: chunk too large for 32-bit indexing (%lld work items)", total);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -234,7 +272,8 @@ extern "C" int cpn_local_hidden(const float* loc8, const float* coords9, const f
                 "cpn_local_hidden: ray range outside B*R");
     const long long nrows = (long long)nrays * V * S;
     CPN_REQUIRE(nrows * 16 < (1LL << 31), CPN_E_SHAPE, "cpn_local_hidden: chunk too large for 32-bit indexing");
-    const unsigned blocks = (unsigned)(cpn_cdiv(nrows, 16) < 512u ? cpn_cdiv(nrows, 16) : 512u);   // few blocks: each keeps its 128 weights in registers and strides over rows
+    const long long groups = cpn_cdiv(nrows, 16);                   // 16 rows per wave step, 4 waves per block
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(groups, 4), 2048);
     hipLaunchKernelGGL(local_hidden_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        loc8, coords9, w, ldw, bias, add, V, R, S, ray0, nrows, (__half*)out);
     CPN_LAUNCH_CHECK("cpn_local_hidden");
