@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--pairs", type=int, default=1, help="stereo pairs per GPU")
     ap.add_argument("--chunk-rays", type=int, default=16384)
-    ap.add_argument("--lanes", type=int, default=2, help="HIP streams the ray chunks are spread over")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="HIP streams the ray chunks are spread over (2: +2.5 % rays/s, but kernels of different "
+                         "chunks then share the GPU and the per-kernel roofline timing is no longer clean)")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -146,9 +148,22 @@ def main():
             flops = evs[0][2]
             avg_ms = sum(ms) / len(ms)
             achieved = flops / (avg_ms * 1e-3) / 1e12
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (they cannot be
+            # read live); the committed record is used only when it was taken on this launch shape
+            traffic, mfma_busy = None, None
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v4_traffic.json")
+            rows_per_launch = int(round(flops / (2.0 * 832 * 835)))
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    rec = json.load(f)
+                if rec["shape"]["M"] == rows_per_launch:
+                    traffic, mfma_busy = rec["hbm_bytes"], rec["mfma"]["mfma_busy_fraction"]
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel<13> (query_encode_latent 835->832)",
                                 "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": None,
+                                "frac": achieved / F16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                                "traffic_source": "profiles/r01_v4_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                                  "WRITE_SIZE, per launch)" if traffic else None,
+                                "mfma_busy_pmc": mfma_busy,
                                 "avg_launch_ms": avg_ms, "launches": len(ms), "flops_per_launch": flops}
             kern = {}
             for k, v in prof.items():

@@ -97,7 +97,7 @@ class RenderEngine:
         "query_repeat_embed_2": (128, 128, 128),
     }
 
-    def __init__(self, chunk_rays: int = 16384, fold_value: bool = True, lanes: int = 2):
+    def __init__(self, chunk_rays: int = 16384, fold_value: bool = True, lanes: int = 1):
         self.chunk_rays = int(chunk_rays)
         # ray chunks are independent: `lanes` HIP streams, each with its own workspace, take the chunks round-robin so
         # that the HBM-bound stages of one chunk (gather, hidden sums) run under the MFMA-bound GEMMs of another
