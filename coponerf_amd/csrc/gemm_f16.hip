@@ -8,30 +8,36 @@
 //     128, so the workgroup tile is 256 (M) x 16*NT (N) with NT = 13 (N = 832, 416) or 8 (N = 128); 32x32 tiles
 //     would need per-wave N splits that 13 does not allow without 7.7 % zero padding.
 //   * 8 waves = 512 threads, wave w owns rows [32w, 32w+32) x all NT column tiles.  Everything lives in the VGPR
-//     file (2*NT*4 accumulators + two fragment sets <= 234 registers): two waves per SIMD, no VGPR<->AGPR copies
+//     file (2*NT*4 accumulators + two fragment sets, 229 registers): two waves per SIMD, no VGPR<->AGPR copies
 //     (one-wave-per-SIMD variants with 4*NT*4 accumulators were measured slower — the allocator shuttles the
-//     accumulators between the two register files every K step — and a 4-wave / 128-row / two-workgroups-per-CU
-//     form with a 3-slot ring was measured at 807 vs 832 TFLOP/s: overlapping one tile's store phase with
-//     another tile's main loop does not pay, the tile order already keeps the memory system busy).
+//     accumulators between the two register files every K step).
 //   * operands are swapped (MFMA A-operand = weights, B-operand = activations) so a lane ends up holding 4
-//     CONSECUTIVE output columns of one row; fp16 results are staged through the (idle) LDS ring and leave as
-//     16-byte row-contiguous stores covering whole 416-B rows (C-tile store phase 0.39 -> 0.29 ms per launch).
+//     CONSECUTIVE output columns of one row; fp16 results are staged through LDS and leave as 16-byte
+//     row-contiguous stores covering whole 416-B rows.
 //   * both tiles are K-contiguous (activations (M,K), weights (N,K)) and are staged by buffer_load_dwordx4 ... lds
 //     (LDS-DMA, no VGPR round trip; the descriptor's bounds check zero-fills rows past M and reads past the end)
-//     into a 2-slot ring of [rows][64] fp16 images.  The LDS image is lane-linear, so the bank-conflict XOR swizzle
-//     is applied to the per-lane SOURCE offset (chunk c of row r lives at physical chunk c ^ ((r >> 1) & 7)) and to
-//     the fragment reads: every ds_read_b128 lane group touches 16 distinct 16-B slots (SQ_LDS_BANK_CONFLICT = 0).
+//     as [rows][64] fp16 images.  The LDS image is lane-linear, so the bank-conflict XOR swizzle is applied to the
+//     per-lane SOURCE offset (chunk c of row r lives at physical chunk c ^ ((r >> 1) & 7)) and to the fragment
+//     reads: every ds_read_b128 lane group touches 16 distinct 16-B slots.
+//   * asymmetric ring: 3 slots for activations (they stream from HBM, prefetched TWO stages ahead) and 2 for
+//     weights (L2-resident, one stage ahead) = 96 + 53 KiB; a symmetric 3-slot ring does not fit 160 KiB.
+//     The barrier is a raw s_barrier with a counted s_waitcnt vmcnt(UA4): DMA completes in issue order, so all but
+//     the youngest activation pieces must have landed — __syncthreads() would drain vmcnt to 0 at every K step.
 //   * two-phase software pipeline per 64-deep stage: each block of 2*NT MFMAs runs on fragments that were read
-//     from LDS one phase earlier (sched_group_barrier pins 1 ds_read per 2 MFMAs); the workgroup barrier sits
-//     between two MFMA blocks whose operands are already in registers, and the DMA of stage t+2 is issued right
-//     behind it into the slot that was just drained.
-//   * XCD-aware tile order: the linear block id is remapped so that each XCD (private L2) owns a contiguous range
-//     of logical tiles with the N index fastest -> the N tiles sharing one 256-row activation tile run back to
-//     back on one L2 (566 -> 670 TFLOP/s on the 835 -> 832 layer).
+//     from LDS one phase earlier; the barrier sits between two MFMA blocks whose operands are already in
+//     registers.  The DMA pieces of the next stages are issued ONE PER MFMA PAIR inside phase B (sched_barrier
+//     pinned): back to back behind the barrier they stall both waves of a SIMD at once and its MFMA pipe idles.
+//   * persistent workgroups (one per CU) walk the tile list; the first stage of the NEXT tile is issued before the
+//     epilogue of the current one, which stages C in the two activation slots that stage does not use, so the
+//     DMA latency of a tile start and the C-store phase overlap instead of adding up (875 -> 919 TFLOP/s).
+//   * XCD-aware tile order: each XCD (private L2) owns a contiguous range of logical tiles and its workgroups take
+//     them in lock step with the N index fastest -> the N tiles sharing one 256-row activation tile run together
+//     on one L2.  rocprofv3 still shows 1.46x the algorithmic activation bytes fetched (profiles/r01_v4_traffic.json).
 // Roofline: at K ~ N ~ 832 the GEMM sits on the ridge of the MI355X roofline (2*K*N/(2*(K+N)) = 416 FLOP per HBM
 // byte vs 2500 TFLOP/s / 6.3 TB/s = 397): it is bounded by MFMA issue AND by streaming the (M,K) input and (M,N)
-// output once.  Algorithmic FLOPs per launch = 2*M*N*K; measured main-loop rate 1050 TFLOP/s, 765 TFLOP/s with
-// the tile prologue/epilogue (profiles/, tools/gemm_k.py).
+// output once.  Algorithmic FLOPs per launch = 2*M*N*K.  Measured on the 835->832 layer at M = 4.19 M rows:
+// 915 TFLOP/s = 36.6 % of the 2.5 PFLOP/s spec peak, SQ_VALU_MFMA_BUSY_CYCLES = 48.9 % of the SIMD cycles (the
+// clock sits near 1.85 GHz under this load); history 604 -> 765 -> 828 -> 875 -> 919 (profiles/, tools/gemm_k.py).
 #include <algorithm>
 
 #include "common.h"
