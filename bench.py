@@ -59,6 +59,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
+        # the host side of a step is a few O(B) 4x4 products: keep N ranks from oversubscribing the host cores
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -173,7 +175,7 @@ def main():
         # ---- CPU baseline: the oracle on a bounded sample of the same workload on the host cores.  PyTorch CPU ops
         #      stop scaling (and regress) far below a 256-thread host, so the thread count is probed first and the
         #      best one is used and reported; the sample is sized for ~20 s of CPU work.
-        if args.cpu_rays > 0:
+        if args.cpu_rays > 0 and world == 1:          # CPU baseline: rank 0 at N = 1 only
             from oracle import render_ref as orc
             w = syn.make_render_weights()
 
