@@ -22,15 +22,9 @@ def _stream() -> int:
 
 
 def _mm_f32(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
-    """(P,M) fp16 @ (M,Q) fp16 -> fp32, accumulated in fp32; M can be millions of rows, so the product is formed in
-    slabs whose fp16 outputs are summed in fp32 (keeps hipBLASLt's fast fp16 path, avoids fp16 overflow/rounding
-    of a multi-million-term sum)."""
-    M = a16.shape[1]
-    slab = 1 << 18
-    out = torch.zeros(a16.shape[0], b16.shape[1], dtype=torch.float32, device=a16.device)
-    for m0 in range(0, M, slab):
-        out += torch.matmul(a16[:, m0:m0 + slab], b16[m0:m0 + slab]).float()
-    return out
+    """(P,M) fp16 @ (M,Q) fp16 -> fp32 with fp32 accumulation AND fp32 output (hipBLASLt): M is millions of rows, an
+    fp16 result would overflow / lose the tail of the sum."""
+    return torch.mm(a16, b16, out_dtype=torch.float32)
 
 
 class GemmFn(Function):

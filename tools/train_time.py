@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--detach-z", action="store_true", help="stop the gradient at z (times the render backward alone)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = CoPoNeRF.CoPoNeRF(n_view=2)
@@ -33,6 +34,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         ev[0].record()
         z, rel, flow = model.get_z(inp, val=False)
+        if a.detach_z:
+            z, rel, flow = [t.detach() for t in z], rel.detach(), [f.detach() for f in flow]
         ev[1].record()
         out = model(inp, z=z, rel_pose=rel, val=False, flow=flow)
         loss = (out["rgb"] - inp["query"]["rgb"]).abs().mean()
