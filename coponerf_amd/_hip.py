@@ -32,6 +32,9 @@ SIGNATURES: Dict[str, List] = {
     "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_gn_relu": [_P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P],
+    "cpn_gn_relu_bwd": [_P, _P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "cpn_soft_argmax_pair": [_P, _I, _I, _F, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],

@@ -10,6 +10,8 @@
 // the volume with direct 6-D indexing — no transposed copies.  All of it is HBM/L2-bound streaming work
 // (volumes 16^4 x {8,32} ch = 2-8 MB, raw correlations up to 64^4 = 67 MB): coalescing along the innermost
 // support axis, one scalar-broadcast weight per (out-channel, in-channel, tap).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -167,9 +169,9 @@ __global__ __launch_bounds__(256) void conv4d_k3s1_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void gn_relu_kernel(float* __restrict__ y, const double* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const double* __restrict__ stats,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, int Cout, long long npos) {
+                                                      float eps, int Cout, long long npos, float* out) {
     const int b = blockIdx.z, o = blockIdx.y;
     const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= npos) return;
@@ -179,7 +181,75 @@ __global__ __launch_bounds__(256) void gn_relu_kernel(float* __restrict__ y, con
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const size_t idx = ((size_t)b * Cout + o) * npos + pos;
     const float v = (y[idx] - (float)mean) * rstd * gamma[o] + beta[o];
-    y[idx] = fmaxf(v, 0.0f);
+    out[idx] = fmaxf(v, 0.0f);
+}
+
+// ---- backward of GroupNorm(1 group) + ReLU, two passes over the volume ---------------------------------------
+//   dz = dout * [out > 0],  yh = (y - mean_b) * rstd_b
+//   pass 1: S1_b = sum dz*g_c, S2_b = sum dz*g_c*yh (over channels and positions);  dgamma_c = sum dz*yh, dbeta_c = sum dz
+//   pass 2: dy = rstd_b * (dz*g_c - S1_b/n - yh*S2_b/n)
+// red: (B*2 + C*2) doubles, zero on entry.
+__device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, double n, float eps, float& mean, float& rstd) {
+    const double m = stats[b * 2] / n;
+    const double var = stats[b * 2 + 1] / n - m * m;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(
+    const float* __restrict__ y, const float* __restrict__ out, const float* __restrict__ dout,
+    const double* __restrict__ stats, const float* __restrict__ gamma, float eps, int B, int Cout, long long npos,
+    double* __restrict__ red) {
+    const int b = blockIdx.z, o = blockIdx.y;
+    float mean, rstd;
+    gn_mean_rstd(stats, b, (double)Cout * (double)npos, eps, mean, rstd);
+    const float g = gamma[o];
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const size_t base = ((size_t)b * Cout + o) * npos;
+    for (long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x; pos < npos;
+         pos += (long long)gridDim.x * blockDim.x) {
+        const float dz = out[base + pos] > 0.0f ? dout[base + pos] : 0.0f;
+        const float yh = (y[base + pos] - mean) * rstd;
+        a[0] += (double)(dz * g);
+        a[1] += (double)(dz * g * yh);
+        a[2] += (double)(dz * yh);
+        a[3] += (double)dz;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[i] += __shfl_xor(a[i], off);
+    __shared__ double sh[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int i = 0; i < 4; ++i) sh[wave][i] = a[i];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        double* dst = threadIdx.x < 2 ? red + b * 2 + threadIdx.x : red + 2 * B + o * 2 + (threadIdx.x - 2);
+        atomicAdd(dst, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(
+    const float* __restrict__ y, const float* __restrict__ out, const float* __restrict__ dout,
+    const double* __restrict__ stats, const float* __restrict__ gamma, float eps, int B, int Cout, long long npos,
+    const double* __restrict__ red, float* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int b = blockIdx.z, o = blockIdx.y;
+    const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+        dgamma[o] = (float)red[2 * B + o * 2];
+        dbeta[o] = (float)red[2 * B + o * 2 + 1];
+    }
+    if (pos >= npos) return;
+    const double n = (double)Cout * (double)npos;
+    float mean, rstd;
+    gn_mean_rstd(stats, b, n, eps, mean, rstd);
+    const float m1 = (float)(red[b * 2] / n), m2 = (float)(red[b * 2 + 1] / n);
+    const size_t idx = ((size_t)b * Cout + o) * npos + pos;
+    const float dz = out[idx] > 0.0f ? dout[idx] : 0.0f;
+    const float yh = (y[idx] - mean) * rstd;
+    dy[idx] = rstd * (dz * gamma[o] - m1 - yh * m2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -361,17 +431,17 @@ extern "C" int cpn_resize_bilinear_ac(const float* src, float* dst, long long pl
     return 0;
 }
 
-extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
-                                  const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout, int Hq,
-                                  int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream) {
-    CPN_REQUIRE(x && wq && bq && ws && bs && gn_w && gn_b && y && stats, CPN_E_ARG, "cpn_conv4d_gn_relu: null pointer");
+extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, const float* ws, const float* bs, int B,
+                          int Cin, int Cout, int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y,
+                          double* stats, void* stream) {
+    CPN_REQUIRE(x && wq && bq && ws && bs && y && stats, CPN_E_ARG, "cpn_conv4d: null pointer");
     CPN_REQUIRE(B > 0 && B < 65536 && Cin > 0 && Cout > 0 && Cout < 65536 && k > 0 && s > 0 && p >= 0, CPN_E_SHAPE,
-                "cpn_conv4d_gn_relu: bad shape");
+                "cpn_conv4d: bad shape");
     auto co = [&](int n) { return (n + 2 * p - k) / s + 1; };
     auto po = [&](int n) { return (n + s - 1) / s; };
     const int Oq = co(Hq), Pq_ = co(Wq), Os = co(Hs), Ps_ = co(Ws);
     CPN_REQUIRE(Oq == po(Hq) && Pq_ == po(Wq) && Os == po(Hs) && Ps_ == po(Ws), CPN_E_SHAPE,
-                "cpn_conv4d_gn_relu: conv output (%d) and pooled size (%d) of the two branches disagree", Oq, po(Hq));
+                "cpn_conv4d: conv output (%d) and pooled size (%d) of the two branches disagree", Oq, po(Hq));
     const long long npos = (long long)Oq * Pq_ * Os * Ps_;
     const hipStream_t st = (hipStream_t)stream;
     dim3 grid(cpn_cdiv(npos, 256), Cout, B);
@@ -388,9 +458,45 @@ extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* 
         hipLaunchKernelGGL(conv4d_kernel, grid, dim3(256), 0, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, k, s, p, Oq,
                            Pq_, Os, Ps_, y, stats);
     }
-    CPN_LAUNCH_CHECK("cpn_conv4d_gn_relu(conv)");
-    hipLaunchKernelGGL(gn_relu_kernel, grid, dim3(256), 0, st, y, stats, gn_w, gn_b, eps, Cout, npos);
-    CPN_LAUNCH_CHECK("cpn_conv4d_gn_relu(norm)");
+    CPN_LAUNCH_CHECK("cpn_conv4d");
+    return 0;
+}
+
+extern "C" int cpn_gn_relu(const float* y, const double* stats, const float* gn_w, const float* gn_b, float eps, int B,
+                           int C, long long npos, float* out, void* stream) {
+    CPN_REQUIRE(y && stats && gn_w && gn_b && out, CPN_E_ARG, "cpn_gn_relu: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && C > 0 && C < 65536 && npos > 0, CPN_E_SHAPE, "cpn_gn_relu: bad shape");
+    dim3 grid(cpn_cdiv(npos, 256), C, B);
+    hipLaunchKernelGGL(gn_relu_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, stats, gn_w, gn_b, eps, C, npos, out);
+    CPN_LAUNCH_CHECK("cpn_gn_relu");
+    return 0;
+}
+
+extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
+                                  const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout, int Hq,
+                                  int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream) {
+    CPN_REQUIRE(gn_w && gn_b, CPN_E_ARG, "cpn_conv4d_gn_relu: null pointer");
+    int rc = cpn_conv4d(x, wq, bq, ws, bs, B, Cin, Cout, Hq, Wq, Hs, Ws, k, s, p, y, stats, stream);
+    if (rc) return rc;
+    auto co = [&](int n) { return (n + 2 * p - k) / s + 1; };
+    const long long npos = (long long)co(Hq) * co(Wq) * co(Hs) * co(Ws);
+    return cpn_gn_relu(y, stats, gn_w, gn_b, eps, B, Cout, npos, y, stream);
+}
+
+extern "C" int cpn_gn_relu_bwd(const float* y, const float* out, const float* dout, const double* stats,
+                               const float* gn_w, float eps, int B, int C, long long npos, double* red, float* dy,
+                               float* dgn_w, float* dgn_b, void* stream) {
+    CPN_REQUIRE(y && out && dout && stats && gn_w && red && dy && dgn_w && dgn_b, CPN_E_ARG,
+                "cpn_gn_relu_bwd: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && C > 0 && C < 65536 && npos > 0, CPN_E_SHAPE, "cpn_gn_relu_bwd: bad shape");
+    const hipStream_t st = (hipStream_t)stream;
+    const unsigned bx = (unsigned)std::min<long long>(cpn_cdiv(npos, 256), 64);
+    hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel, dim3(bx, C, B), dim3(256), 0, st, y, out, dout, stats, gn_w, eps, B, C,
+                       npos, red);
+    CPN_LAUNCH_CHECK("cpn_gn_relu_bwd(reduce)");
+    hipLaunchKernelGGL(gn_relu_bwd_apply_kernel, dim3(cpn_cdiv(npos, 256), C, B), dim3(256), 0, st, y, out, dout, stats,
+                       gn_w, eps, B, C, npos, red, dy, dgn_w, dgn_b);
+    CPN_LAUNCH_CHECK("cpn_gn_relu_bwd(apply)");
     return 0;
 }
 

@@ -71,42 +71,63 @@ def _conv4d_lib(x, wq, bq, ws, bs, s, p):
 
 
 class _Conv4dGnReluFn(Function):
-    """forward: cpn_conv4d_gn_relu.  backward: GroupNorm(1 group)+ReLU in closed form from the statistics the HIP
-    kernel accumulated (no group_norm re-evaluation), then the conv/pool VJP through MIOpen's conv2d backward."""
+    """forward: cpn_conv4d + cpn_gn_relu, keeping the pre-normalisation volume.
+    backward: GroupNorm(1 group)+ReLU on the HIP kernel cpn_gn_relu_bwd (two passes over the volume, sums from the
+    forward); the data gradient of a stride-1 Conv4d is a Conv4d with flipped, transposed kernels -> the same HIP conv
+    kernel; weight gradients through MIOpen's conv2d weight-gradient on the two separable branches.  Strided layers
+    (max-pool routing) take the library VJP of the conv/pool graph."""
 
     @staticmethod
     def forward(ctx, ops, x, wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps):
-        out, stats = ops._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps)
-        n = out[0].numel()
-        mean = stats[:, 0] / n
-        rstd = torch.rsqrt((stats[:, 1] / n - mean * mean).clamp_min(0) + eps)
-        ctx.save_for_backward(x, wq, bq, ws, bs, gn_w, out, mean.float(), rstd.float())
-        ctx.cfg = (s, p)
+        y, out, stats = ops._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps, keep_pre=True)
+        ctx.save_for_backward(x, wq, bq, ws, bs, gn_w, y, out, stats)
+        ctx.cfg = (k, s, p, eps)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, wq, bq, ws, bs, gn_w, out, mean, rstd = ctx.saved_tensors
-        s, p = ctx.cfg
-        need = ctx.needs_input_grad[1:6]
-        with torch.enable_grad():
-            ins = [t.detach().requires_grad_(n) for t, n in zip((x, wq, bq, ws, bs), need)]
-            y = _conv4d_lib(*ins, s, p)
+        x, wq, bq, ws, bs, gn_w, y, out, stats = ctx.saved_tensors
+        k, s, p, eps = ctx.cfg
         B, C = y.shape[:2]
-        bshape, cshape = (B, 1, 1, 1, 1, 1), (1, C, 1, 1, 1, 1)
-        yh = (y.detach() - mean.view(bshape)) * rstd.view(bshape)
-        dz = dout * (out > 0)
-        sp = (0, 2, 3, 4, 5)
-        dgw = (dz * yh).sum(sp)
-        dgb = dz.sum(sp)
-        dyh = dz * gn_w.detach().view(cshape)
-        red = (1, 2, 3, 4, 5)
-        m1 = dyh.mean(red, keepdim=True)
-        m2 = (dyh * yh).mean(red, keepdim=True)
-        dy = (dyh - m1 - yh * m2) * rstd.view(bshape)
-        wanted = [t for t, n in zip(ins, need) if n]
-        got = iter(torch.autograd.grad(y, wanted, dy) if wanted else ())
-        gx, gwq, gbq, gws, gbs = (next(got) if n else None for n in need)
+        npos = y[0, 0].numel()
+        dev = y.device
+        dout = dout.contiguous().float()
+        red = torch.zeros(B * 2 + C * 2, dtype=torch.float64, device=dev)
+        dy = torch.empty_like(y)
+        dgw = torch.empty(C, dtype=torch.float32, device=dev)
+        dgb = torch.empty(C, dtype=torch.float32, device=dev)
+        gw = gn_w.detach().contiguous().float()
+        call("cpn_gn_relu_bwd", y.data_ptr(), out.data_ptr(), dout.data_ptr(), stats.data_ptr(), gw.data_ptr(), float(eps),
+             B, C, npos, red.data_ptr(), dy.data_ptr(), dgw.data_ptr(), dgb.data_ptr(), _stream())
+        need_x, need_w = ctx.needs_input_grad[1], any(ctx.needs_input_grad[2:6])
+        gx = gwq = gbq = gws = gbs = None
+        if k == 3 and s == 1 and p == 1:
+            Bx, Cin, Hq, Wq, Hs, Ws = x.shape
+            if need_x:
+                flip = lambda w: w.detach().float().flip(-1, -2).transpose(0, 1).contiguous()
+                zb = torch.zeros(Cin, dtype=torch.float32, device=dev)
+                gx = torch.empty_like(x)
+                scratch = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+                wq_t, ws_t = flip(wq), flip(ws)
+                call("cpn_conv4d", dy.data_ptr(), wq_t.data_ptr(), zb.data_ptr(), ws_t.data_ptr(), zb.data_ptr(), B, C, Cin,
+                     Hq, Wq, Hs, Ws, 3, 1, 1, gx.data_ptr(), scratch.data_ptr(), _stream())
+            if need_w:
+                cb = torch.ops.aten.convolution_backward
+                xq = x.permute(0, 4, 5, 1, 2, 3).reshape(B * Hs * Ws, Cin, Hq, Wq)
+                dq = dy.permute(0, 4, 5, 1, 2, 3).reshape(B * Hs * Ws, C, Hq, Wq)
+                _, gwq, gbq = cb(dq, xq, wq.detach(), [C], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, True])
+                xs = x.permute(0, 2, 3, 1, 4, 5).reshape(B * Hq * Wq, Cin, Hs, Ws)
+                ds = dy.permute(0, 2, 3, 1, 4, 5).reshape(B * Hq * Wq, C, Hs, Ws)
+                _, gws, _ = cb(ds, xs, ws.detach(), [C], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])
+                gbs = gbq
+        else:
+            need = ctx.needs_input_grad[1:6]
+            with torch.enable_grad():
+                ins = [t.detach().requires_grad_(n) for t, n in zip((x, wq, bq, ws, bs), need)]
+                yy = _conv4d_lib(*ins, s, p)
+            wanted = [t for t, n in zip(ins, need) if n]
+            got = iter(torch.autograd.grad(yy, wanted, dy) if wanted else ())
+            gx, gwq, gbq, gws, gbs = (next(got) if n else None for n in need)
         return None, gx, gwq, gbq, gws, gbs, dgw, dgb, None, None, None, None
 
 
@@ -157,7 +178,7 @@ class HipOps:
             return _Conv4dGnReluFn.apply(self, x.float(), wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps)
         return self._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps)[0]
 
-    def _conv4d_gn_relu_hip(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps):
+    def _conv4d_gn_relu_hip(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps, keep_pre=False):
         x = x.contiguous().float()
         B, Cin, Hq, Wq, Hs, Ws = x.shape
         Cout = wq.shape[0]
@@ -167,6 +188,13 @@ class HipOps:
         stats = torch.zeros(B, 2, device=x.device, dtype=torch.float64)
         f = lambda t: t.detach().contiguous().float()
         wq_, bq_, ws_, bs_, gw, gb = f(wq), f(bq), f(ws), f(bs), f(gn_w), f(gn_b)
+        if keep_pre:                                  # training: pre-normalisation volume kept for the backward pass
+            call("cpn_conv4d", x.data_ptr(), wq_.data_ptr(), bq_.data_ptr(), ws_.data_ptr(), bs_.data_ptr(), B, Cin, Cout,
+                 Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(), stats.data_ptr(), _stream())
+            out = torch.empty_like(y)
+            call("cpn_gn_relu", y.data_ptr(), stats.data_ptr(), gw.data_ptr(), gb.data_ptr(), float(eps), B, Cout,
+                 y[0, 0].numel(), out.data_ptr(), _stream())
+            return y, out, stats
         call("cpn_conv4d_gn_relu", x.data_ptr(), wq_.data_ptr(), bq_.data_ptr(), ws_.data_ptr(), bs_.data_ptr(),
              gw.data_ptr(), gb.data_ptr(), float(eps), B, Cin, Cout, Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(),
              stats.data_ptr(), _stream())

@@ -156,6 +156,19 @@ int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const f
                        const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout,
                        int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream);
 
+/* the two halves of K6 on their own (training keeps the pre-normalisation volume; the data gradient of a stride-1
+ * Conv4d is a Conv4d with flipped, transposed kernels): conv (+pool) -> y and the GroupNorm sums; y -> out           */
+int cpn_conv4d(const float* x, const float* wq, const float* bq, const float* ws, const float* bs, int B, int Cin,
+               int Cout, int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream);
+int cpn_gn_relu(const float* y, const double* stats, const float* gn_w, const float* gn_b, float eps, int B, int C,
+                long long npos, float* out, void* stream);
+/* backward of GroupNorm(1 group) + ReLU (autograd of models/conv4d.py:150-158): y pre-normalisation volume, out the
+ * forward output, dout its gradient, stats the forward sums; red (B*2 + C*2) float64 scratch, zero on entry ->
+ * dy (B,C,npos), dgn_w (C), dgn_b (C)                                                                              */
+int cpn_gn_relu_bwd(const float* y, const float* out, const float* dout, const double* stats, const float* gn_w,
+                    float eps, int B, int C, long long npos, double* red, float* dy, float* dgn_w, float* dgn_b,
+                    void* stream);
+
 /* ---- K7: cosine correlation of two token sets ------------------------------------------------------
  * replaces aggregation.correlation / correlation_token (models/aggregation.py:70-80):
  * out[b,s,t] = <src[b,s]/(|src[b,s]|+eps), trg[b,t]/(|trg[b,t]|+eps)>; src, trg (B,L,C), C % 16 == 0;
