@@ -35,6 +35,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_gn_relu": [_P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P],
     "cpn_gn_relu_bwd": [_P, _P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
+    "cpn_conv_wgrad_planes": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_dwconv3x3_wgrad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "cpn_soft_argmax_pair": [_P, _I, _I, _F, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
@@ -84,6 +86,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_abi_version.restype = ctypes.c_int
     handle.cpn_gather_bwd_chunks.argtypes = [_I, _I]
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
+    handle.cpn_conv_wgrad_scratch.argtypes = [_I, _I]
+    handle.cpn_conv_wgrad_scratch.restype = ctypes.c_longlong
     handle.cpn_last_error.argtypes = []
     handle.cpn_last_error.restype = ctypes.c_char_p
     got = handle.cpn_abi_version()

@@ -253,6 +253,166 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// weight gradient of a 3x3 / stride 1 / pad 1 convolution over the LAST two dims of (B, C, G, H, W) volumes:
+//   dW[o][c][i][j] = sum_{b,g,y,x} dy[b,o,g,y,x] * X[b,c,g,y+i-1,x+j-1],   db[o] = sum dy[b,o,...]
+// i.e. one separable branch of Conv4d (the other branch is the same call on the volumes with the two index pairs
+// swapped).  As a GEMM it is Cout x (Cin*9) with the contraction over millions of positions: MIOpen's choice for it
+// ran 1.9 ms per call.  Here a workgroup walks (b,g) planes: the Cin input planes (1-pixel zero halo, so the nine
+// shifted reads need no bounds logic) and the Cout gradient planes are staged in LDS; a wave owns one 16(o) x 16(c)
+// output tile for all nine taps (9 accumulator tiles), dy is the MFMA A operand read once per 4 positions and reused
+// by the nine v_mfma_f32_16x16x4_f32; partial sums leave once per workgroup with atomics.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_MAXC = 32;           // Cin, Cout <= 32
+constexpr int WG_MAXP = 256;          // H * W <= 256
+constexpr int WG_BLOCKS = 256;        // workgroups (= partial sums) per call
+__global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, int Cin, int Cout, int G, int H, int W, int nplanes,
+    float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float wgl[];
+    const int P = H * W, HP = (H + 2) * (W + 2);
+    const int XS = HP + ((HP & 31) == 5 ? 0 : ((37 - (HP & 31)) & 31));     // plane stride = 5 (mod 32)
+    const int DS = P + ((P & 31) == 4 ? 0 : ((36 - (P & 31)) & 31));        // row stride   = 4 (mod 32)
+    const int CT = (Cin + 15) >> 4, MT = (Cout + 15) >> 4;
+    float* xs = wgl;                                  // [CT*16][XS]   haloed input planes
+    float* ds = wgl + CT * 16 * XS;                   // [MT*16][DS]   gradient planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < CT * 16 * XS + MT * 16 * DS; i += 256) wgl[i] = 0.0f;     // halo + padding rows stay zero
+
+    const int npairs = MT * CT;                       // 1, 2 or 4 output tiles
+    const int pair = wave % npairs, kpart = wave / npairs, kparts = 4 / npairs;
+    const int mt = pair % MT, ct = pair / MT;
+    const int ln = lane & 15, lk = lane >> 4;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const int ksteps = (P + 3) >> 2;
+    const int k_lo = kpart * ksteps / kparts, k_hi = (kpart + 1) * ksteps / kparts;
+    const float* arow = ds + (mt * 16 + ln) * DS;
+    const float* brow = xs + (ct * 16 + ln) * XS;
+    // staging: P <= 256, so thread tid owns position tid of every plane
+    const bool stg = tid < P;
+    const int sy = stg ? tid / W : 0, sx = stg ? tid - sy * W : 0;
+    const int hoff = (sy + 1) * (W + 2) + sx + 1;
+    const int y0 = (k_lo * 4 + lk) / W, x0 = (k_lo * 4 + lk) - y0 * W;
+
+    for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
+        const int b = pl / G, g = pl - b * G;
+        __syncthreads();                              // previous plane fully consumed (and the zero fill done)
+        if (stg) {
+            const float* xp = x + (((size_t)b * Cin) * G + g) * P + tid;
+            const float* dp = dy + (((size_t)b * Cout) * G + g) * P + tid;
+            const size_t cs = (size_t)G * P;
+            for (int c = 0; c < Cin; ++c) xs[c * XS + hoff] = xp[c * cs];
+            for (int o = 0; o < Cout; ++o) ds[o * DS + tid] = dp[o * cs];
+        }
+        __syncthreads();
+        int yy = y0, xx = x0;
+        for (int ks = k_lo; ks < k_hi; ++ks) {
+            const int pos = ks * 4 + lk;
+            const bool live = pos < P;
+            const float av = live ? arow[pos] : 0.0f;
+            bsum += av;
+            const float* bp = brow + yy * (W + 2) + xx;          // tap (0,0) of the haloed plane
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float bv = live ? bp[i * (W + 2) + j] : 0.0f;
+                    acc[i * 3 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i * 3 + j], 0, 0, 0);
+                }
+            xx += 4;
+            while (xx >= W) { xx -= W; ++yy; }
+        }
+    }
+    // partial sums of this workgroup: [Cout*Cin*9 weights | Cout biases]; D[m = lk*4 + e][n = ln]: m -> output
+    // channel, n -> input channel.  Waves that split the positions of one tile (kparts > 1) combine with LDS atomics.
+    const int nw = Cout * Cin * 9;
+    float* mine = partial + (size_t)blockIdx.x * (nw + Cout);
+    __syncthreads();
+    float* red = wgl;                                 // reuse LDS: nw + Cout floats <= 32*32*9 + 32
+    for (int i = tid; i < nw + Cout; i += 256) red[i] = 0.0f;
+    __syncthreads();
+    const int c = ct * 16 + ln;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = mt * 16 + lk * 4 + e;
+            if (o < Cout && c < Cin) {
+                if (kparts > 1) atomicAdd(red + ((size_t)o * Cin + c) * 9 + t, acc[t][e]);
+                else red[((size_t)o * Cin + c) * 9 + t] = acc[t][e];
+            }
+        }
+    if (ct == 0) {                                    // bias: lanes (ln = o, lk) hold disjoint position subsets
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        const int o = mt * 16 + ln;
+        if (lk == 0 && o < Cout) atomicAdd(red + nw + o, bsum);
+    }
+    __syncthreads();
+    for (int i = tid; i < nw + Cout; i += 256) mine[i] = red[i];
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw,
+                                                                int Cout, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+    // 64 outputs per workgroup, the partial sums of the nblocks producers split over 4 waves
+    __shared__ float sh[4][64];
+    const int j = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + j;
+    float sacc = 0.0f;
+    if (i < nw + Cout)
+        for (int b = part; b < nblocks; b += 4) sacc += partial[(size_t)b * (nw + Cout) + i];
+    sh[part][j] = sacc;
+    __syncthreads();
+    if (part == 0 && i < nw + Cout) {
+        const float v = sh[0][j] + sh[1][j] + sh[2][j] + sh[3][j];
+        if (i < nw) dw[i] = v;
+        else if (db) db[i - nw] = v;
+    }
+}
+
+// weight / bias gradient of a depthwise 3x3, stride 1, pad 1 convolution (the DWConv of the UFC feed-forward blocks,
+// models/aggregation.py): dw[c][i][j] = sum_{n,y,x} dy[n,c,y,x] * X[n,c,y+i-1,x+j-1],  db[c] = sum dy[n,c].
+// Ten sums over N*H*W values per channel — MIOpen's batched-GEMM weight-gradient took 1.9 ms for it.
+// One workgroup per channel.
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              int N, int C, int H, int W, float* __restrict__ dw,
+                                                              float* __restrict__ db) {
+    const int c = blockIdx.x, P = H * W;
+    float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int idx = threadIdx.x; idx < N * P; idx += 256) {
+        const int n = idx / P, pos = idx - n * P;
+        const int yy = pos / W, xx = pos - yy * W;
+        const size_t base = ((size_t)n * C + c) * P;
+        const float g = dy[base + pos];
+        a[9] += g;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int Y = yy + i - 1, X = xx + j - 1;
+                if (Y >= 0 && Y < H && X >= 0 && X < W) a[i * 3 + j] += g * x[base + (size_t)Y * W + X];
+            }
+    }
+    __shared__ float sh[4][10];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[t] += __shfl_xor(a[t], off);
+        if (lane == 0) sh[wave][t] = a[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        if (threadIdx.x < 9) dw[c * 9 + threadIdx.x] = v;
+        else if (db) db[c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // correlation: tokens (B, L, C) -> x / (||x|| + eps), then C[b] = S_n[b] . T_n[b]^T with the exact-f32 MFMA
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -497,6 +657,57 @@ extern "C" int cpn_gn_relu_bwd(const float* y, const float* out, const float* do
     hipLaunchKernelGGL(gn_relu_bwd_apply_kernel, dim3(cpn_cdiv(npos, 256), C, B), dim3(256), 0, st, y, out, dout, stats,
                        gn_w, eps, B, C, npos, red, dy, dgn_w, dgn_b);
     CPN_LAUNCH_CHECK("cpn_gn_relu_bwd(apply)");
+    return 0;
+}
+
+extern "C" long long cpn_conv_wgrad_scratch(int Cin, int Cout) {
+    return (long long)WG_BLOCKS * ((long long)Cout * Cin * 9 + Cout);
+}
+
+extern "C" int cpn_conv_wgrad_planes(const float* x, const float* dy, int B, int Cin, int Cout, int G, int H, int W,
+                                     float* partial, float* dw, float* db, void* stream) {
+    CPN_REQUIRE(x && dy && dw && partial, CPN_E_ARG, "cpn_conv_wgrad_planes: null pointer");
+    CPN_REQUIRE(B > 0 && G > 0 && H > 0 && W >= 4 && Cin > 0 && Cout > 0, CPN_E_SHAPE,
+                "cpn_conv_wgrad_planes: bad shape");
+    CPN_REQUIRE(Cin <= WG_MAXC && Cout <= WG_MAXC && H * W <= WG_MAXP, CPN_E_SHAPE,
+                "cpn_conv_wgrad_planes: supports Cin, Cout <= %d and H*W <= %d (got %d, %d, %d)", WG_MAXC, WG_MAXP, Cin,
+                Cout, H * W);
+    CPN_REQUIRE((long long)B * G < (1LL << 31), CPN_E_SHAPE, "cpn_conv_wgrad_planes: too many planes");
+    const int P = H * W, HP = (H + 2) * (W + 2);
+    const int XS = HP + ((HP & 31) == 5 ? 0 : ((37 - (HP & 31)) & 31));
+    const int DS = P + ((P & 31) == 4 ? 0 : ((36 - (P & 31)) & 31));
+    const int CT = (Cin + 15) / 16, MT = (Cout + 15) / 16;
+    const size_t lds = std::max((size_t)CT * 16 * XS + (size_t)MT * 16 * DS, (size_t)Cout * Cin * 9 + Cout) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) {
+            cpn_set_error("cpn_conv_wgrad_planes: cannot reserve LDS: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int nplanes = B * G;
+    const int blocks = std::min(nplanes, WG_BLOCKS);
+    const hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_planes_kernel, dim3(blocks), dim3(256), lds, st, x, dy, Cin, Cout, G, H, W, nplanes,
+                       partial);
+    CPN_LAUNCH_CHECK("cpn_conv_wgrad_planes");
+    const int nw = Cout * Cin * 9;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cpn_cdiv(nw + Cout, 64)), dim3(256), 0, st, partial, blocks, nw, Cout,
+                       dw, db);
+    CPN_LAUNCH_CHECK("cpn_conv_wgrad_planes(reduce)");
+    return 0;
+}
+
+extern "C" int cpn_dwconv3x3_wgrad(const float* x, const float* dy, int N, int C, int H, int W, float* dw, float* db,
+                                   void* stream) {
+    CPN_REQUIRE(x && dy && dw, CPN_E_ARG, "cpn_dwconv3x3_wgrad: null pointer");
+    CPN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (long long)N * H * W < (1LL << 31), CPN_E_SHAPE,
+                "cpn_dwconv3x3_wgrad: bad shape");
+    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, dy, N, C, H, W, dw, db);
+    CPN_LAUNCH_CHECK("cpn_dwconv3x3_wgrad");
     return 0;
 }
 

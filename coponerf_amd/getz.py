@@ -118,7 +118,12 @@ class _DWConv(nn.Module):
 
     def forward(self, x):                       # (B, L, C) tokens
         B, L, C = x.shape
-        y = self.dwconv(x.transpose(1, 2).reshape(B, C, self.size, self.size))
+        xm = x.transpose(1, 2).reshape(B, C, self.size, self.size)
+        if xm.is_cuda and torch.is_grad_enabled() and (xm.requires_grad or self.dwconv.weight.requires_grad):
+            from .ufc_ops import DwConv3x3Fn               # training on the GPU: HIP weight-gradient kernel
+            y = DwConv3x3Fn.apply(xm, self.dwconv.weight, self.dwconv.bias)
+        else:
+            y = self.dwconv(xm)
         return y.flatten(2).transpose(1, 2)
 
 

@@ -111,7 +111,23 @@ class _Conv4dGnReluFn(Function):
                 wq_t, ws_t = flip(wq), flip(ws)
                 call("cpn_conv4d", dy.data_ptr(), wq_t.data_ptr(), zb.data_ptr(), ws_t.data_ptr(), zb.data_ptr(), B, C, Cin,
                      Hq, Wq, Hs, Ws, 3, 1, 1, gx.data_ptr(), scratch.data_ptr(), _stream())
-            if need_w:
+            if need_w and Cin <= 32 and C <= 32 and Hs * Ws <= 256 and Hq * Wq <= 256 and min(Ws, Wq) >= 4:
+                # both separable branches on the HIP weight-gradient kernel; the query branch sees the volumes with
+                # the (query, support) index pairs swapped so that its 3x3 window runs over the last two dims too
+                from . import _hip
+                gwq = torch.empty(C, Cin, 3, 3, dtype=torch.float32, device=dev)
+                gws = torch.empty(C, Cin, 3, 3, dtype=torch.float32, device=dev)
+                gbs = torch.empty(C, dtype=torch.float32, device=dev)
+                part = torch.empty(_hip.lib().cpn_conv_wgrad_scratch(Cin, C), dtype=torch.float32, device=dev)
+                xf = x.detach().contiguous().float()
+                call("cpn_conv_wgrad_planes", xf.data_ptr(), dy.data_ptr(), B, Cin, C, Hq * Wq, Hs, Ws, part.data_ptr(),
+                     gws.data_ptr(), gbs.data_ptr(), _stream())
+                xt = xf.permute(0, 1, 4, 5, 2, 3).contiguous()
+                dt = dy.permute(0, 1, 4, 5, 2, 3).contiguous()
+                call("cpn_conv_wgrad_planes", xt.data_ptr(), dt.data_ptr(), B, Cin, C, Hs * Ws, Hq, Wq, part.data_ptr(),
+                     gwq.data_ptr(), 0, _stream())
+                gbq = gbs
+            elif need_w:
                 cb = torch.ops.aten.convolution_backward
                 xq = x.permute(0, 4, 5, 1, 2, 3).reshape(B * Hs * Ws, Cin, Hq, Wq)
                 dq = dy.permute(0, 4, 5, 1, 2, 3).reshape(B * Hs * Ws, C, Hq, Wq)
@@ -129,6 +145,32 @@ class _Conv4dGnReluFn(Function):
             got = iter(torch.autograd.grad(yy, wanted, dy) if wanted else ())
             gx, gwq, gbq, gws, gbs = (next(got) if n else None for n in need)
         return None, gx, gwq, gbq, gws, gbs, dgw, dgb, None, None, None, None
+
+
+class DwConv3x3Fn(Function):
+    """Depthwise 3x3 / stride 1 / pad 1 convolution of the UFC feed-forward blocks.  forward and data gradient are
+    library depthwise convolutions; the weight / bias gradient (ten sums per channel) runs on cpn_dwconv3x3_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return F.conv2d(x, w, b, 1, 1, 1, x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous().float()
+        dx = F.conv2d(dy, w.detach().flip(-1, -2), None, 1, 1, 1, C) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            xf = x.detach().contiguous().float()
+            dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=x.device)
+            db = torch.empty(C, dtype=torch.float32, device=x.device) if ctx.has_b else None
+            call("cpn_dwconv3x3_wgrad", xf.data_ptr(), dy.data_ptr(), N, C, H, W, dw.data_ptr(),
+                 0 if db is None else db.data_ptr(), _stream())
+        return dx, dw, db
 
 
 class _ResizeFn(Function):

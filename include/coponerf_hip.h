@@ -169,6 +169,20 @@ int cpn_gn_relu_bwd(const float* y, const float* out, const float* dout, const d
                     float eps, int B, int C, long long npos, double* red, float* dy, float* dgn_w, float* dgn_b,
                     void* stream);
 
+/* weight gradient of ONE separable branch of a 3x3 / stride-1 / pad-1 Conv4d (autograd of models/conv4d.py:108-135):
+ * x (B,Cin,G,H,W), dy (B,Cout,G,H,W), convolution over (H,W) -> dw (Cout,Cin,3,3) and db (Cout, may be NULL), both
+ * overwritten.  The support branch is the call on (B,C,Hq*Wq,Hs,Ws) as stored; the query branch the call on the
+ * volumes with the index pairs swapped.  Cin, Cout <= 32, H*W <= 256, W >= 4.
+ * partial: scratch of cpn_conv_wgrad_scratch(Cin, Cout) floats (per-workgroup partial sums).                        */
+long long cpn_conv_wgrad_scratch(int Cin, int Cout);
+int cpn_conv_wgrad_planes(const float* x, const float* dy, int B, int Cin, int Cout, int G, int H, int W,
+                          float* partial, float* dw, float* db, void* stream);
+
+/* weight / bias gradient of the depthwise 3x3 / stride-1 / pad-1 convolution of the UFC feed-forward blocks
+ * (DWConv, models/aggregation.py): x, dy (N,C,H,W) -> dw (C,1,3,3), db (C, may be NULL), overwritten.              */
+int cpn_dwconv3x3_wgrad(const float* x, const float* dy, int N, int C, int H, int W, float* dw, float* db,
+                        void* stream);
+
 /* ---- K7: cosine correlation of two token sets ------------------------------------------------------
  * replaces aggregation.correlation / correlation_token (models/aggregation.py:70-80):
  * out[b,s,t] = <src[b,s]/(|src[b,s]|+eps), trg[b,t]/(|trg[b,t]|+eps)>; src, trg (B,L,C), C % 16 == 0;

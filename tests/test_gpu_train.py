@@ -126,3 +126,37 @@ def test_ufc_operator_gradients_match_oracle(dev):
     both("correlation_tokens", [src, trg], lambda f, t: f(t[0], t[1], 8))
     both("soft_argmax_pair", [syn.normal((2, 1, 8, 8, 8, 8), seed=80) * 0.05], lambda f, t: f(t[0]))
     both("resize_bilinear", [syn.normal((2, 3, 8, 8), seed=79)], lambda f, t: f(t[0], 16))
+
+
+def test_conv_weight_gradient_kernels(dev):
+    """cpn_conv_wgrad_planes / cpn_dwconv3x3_wgrad against autograd of the stock convolutions (fp32, GPU)."""
+    import torch.nn.functional as F
+    from coponerf_amd import _hip
+    from coponerf_amd._hip import call
+    st = torch.cuda.current_stream().cuda_stream
+    for (B, Cin, Cout, G, H, W) in ((2, 32, 32, 9, 16, 16), (1, 4, 8, 5, 8, 8), (2, 8, 32, 3, 6, 10), (1, 1, 8, 4, 16, 16)):
+        x = syn.normal((B, Cin, G, H, W), seed=70).to(dev)
+        dy = syn.normal((B, Cout, G, H, W), seed=71).to(dev)
+        w = torch.zeros(Cout, Cin, 3, 3, device=dev, requires_grad=True)
+        b = torch.zeros(Cout, device=dev, requires_grad=True)
+        x2 = x.permute(0, 2, 1, 3, 4).reshape(B * G, Cin, H, W)
+        d2 = dy.permute(0, 2, 1, 3, 4).reshape(B * G, Cout, H, W)
+        (F.conv2d(x2, w, b, 1, 1) * d2).sum().backward()
+        part = torch.empty(_hip.lib().cpn_conv_wgrad_scratch(Cin, Cout), device=dev)
+        dw, db = torch.empty(Cout, Cin, 3, 3, device=dev), torch.empty(Cout, device=dev)
+        call("cpn_conv_wgrad_planes", x.data_ptr(), dy.data_ptr(), B, Cin, Cout, G, H, W, part.data_ptr(), dw.data_ptr(),
+             db.data_ptr(), st)
+        assert (dw - w.grad).abs().max() <= 2e-4 * (1 + w.grad.abs().max()), (B, Cin, Cout, G, H, W)
+        assert (db - b.grad).abs().max() <= 2e-4 * (1 + b.grad.abs().max())
+    from coponerf_amd.ufc_ops import DwConv3x3Fn
+    x = syn.normal((3, 40, 16, 16), seed=72).to(dev)
+    wa = (syn.normal((40, 1, 3, 3), seed=73) * 0.3).to(dev)
+    ba = (syn.normal((40,), seed=74) * 0.1).to(dev)
+    coef = syn.normal((3, 40, 16, 16), seed=75).to(dev)
+    grads = []
+    for fn in (lambda a, w_, b_: F.conv2d(a, w_, b_, 1, 1, 1, 40), DwConv3x3Fn.apply):
+        xs, ws, bs = (t.clone().requires_grad_(True) for t in (x, wa, ba))
+        (fn(xs, ws, bs) * coef).sum().backward()
+        grads.append((xs.grad, ws.grad, bs.grad))
+    for g_ref, g_hip in zip(*grads):
+        assert (g_ref - g_hip).abs().max() <= 2e-4 * (1 + g_ref.abs().max())
