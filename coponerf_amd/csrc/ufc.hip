@@ -660,6 +660,107 @@ extern "C" int cpn_gn_relu_bwd(const float* y, const float* out, const float* do
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// dual softmax of the "fundamental-matrix" cross attention (models/backbone.py:296-330):
+//   f[b,i,j] = softmax_j(a[b,i,:])[j] * softmax_i(a[b,:,j])[i]        a: (B, L, M), up to 4096 x 4096
+// torch runs two softmax kernels (the strided one at ~230 GB/s) and a product.  Here: row statistics (max, sum) with
+// one wave per row, column statistics with 64 coalesced columns per workgroup and an online softmax down the rows, and
+// one elementwise pass f = exp(2a - rmax_i - cmax_j) / (rsum_i * csum_j).  The statistics are kept for the backward:
+//   da = 2 f df - r * Srow_i - c * Scol_j,   Srow_i = sum_j f df,  Scol_j = sum_i f df,  r / c the two softmaxes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                        long long rows, int M, float* __restrict__ stat, int mode) {
+    // mode 0: stat[row] = (max, sum exp(a - max));  mode 1: stat[row] = sum a*w   (w = second operand, same shape)
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* ar = a + (size_t)row * M;
+    if (mode == 0) {
+        float m = -INFINITY;
+        for (int j = lane; j < M; j += 64) m = fmaxf(m, ar[j]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float se = 0.f;
+        for (int j = lane; j < M; j += 64) se += expf(ar[j] - m);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
+        if (lane == 0) { stat[row * 2] = m; stat[row * 2 + 1] = se; }
+    } else {
+        const float* wr = w + (size_t)row * M;
+        float sacc = 0.f;
+        for (int j = lane; j < M; j += 64) sacc += ar[j] * wr[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+        if (lane == 0) stat[row] = sacc;
+    }
+}
+
+// workgroup = 64 columns x 4 row groups (coalesced 256-byte row segments), 4 partials merged through LDS
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ a, const float* __restrict__ w, int L,
+                                                        int M, float* __restrict__ stat, int mode) {
+    const int b = blockIdx.y;
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + l;
+    __shared__ float part[4][2][64];
+    float m = -INFINITY, se = 0.f;
+    if (j < M) {
+        const float* col = a + (size_t)b * L * M + j;
+        if (mode == 0) {
+            for (int i = g; i < L; i += 4) {
+                const float v = col[(size_t)i * M];
+                if (v > m) { se *= expf(m - v); m = v; }
+                se += expf(v - m);
+            }
+        } else {
+            const float* wc = w + (size_t)b * L * M + j;
+            for (int i = g; i < L; i += 4) se += col[(size_t)i * M] * wc[(size_t)i * M];
+        }
+    }
+    part[g][0][l] = m; part[g][1][l] = se;
+    __syncthreads();
+    if (g == 0 && j < M) {
+        if (mode == 0) {
+            const float Mx = fmaxf(fmaxf(part[0][0][l], part[1][0][l]), fmaxf(part[2][0][l], part[3][0][l]));
+            float E = 0.f;
+            for (int q = 0; q < 4; ++q) E += part[q][1][l] * expf(part[q][0][l] - Mx);
+            stat[((size_t)b * M + j) * 2] = Mx;
+            stat[((size_t)b * M + j) * 2 + 1] = E;
+        } else {
+            stat[(size_t)b * M + j] = (part[0][1][l] + part[1][1][l]) + (part[2][1][l] + part[3][1][l]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dual_softmax_apply_kernel(const float* __restrict__ a,
+                                                                 const float* __restrict__ rstat,
+                                                                 const float* __restrict__ cstat, int L, int M,
+                                                                 long long total, float* __restrict__ f) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % M);
+        const long long row = i / M;                 // = b*L + i
+        const long long b = row / L;
+        const float rm = rstat[row * 2], rs = rstat[row * 2 + 1];
+        const float cm = cstat[(b * M + j) * 2], cs = cstat[(b * M + j) * 2 + 1];
+        const float v = a[i];
+        f[i] = (expf(v - rm) / rs) * (expf(v - cm) / cs);
+    }
+}
+
+__global__ __launch_bounds__(256) void dual_softmax_bwd_apply_kernel(
+    const float* __restrict__ a, const float* __restrict__ rstat, const float* __restrict__ cstat,
+    const float* __restrict__ df, const float* __restrict__ srow, const float* __restrict__ scol, int L, int M,
+    long long total, float* __restrict__ da) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % M);
+        const long long row = i / M;
+        const long long b = row / L;
+        const float v = a[i];
+        const float r = expf(v - rstat[row * 2]) / rstat[row * 2 + 1];
+        const float c = expf(v - cstat[(b * M + j) * 2]) / cstat[(b * M + j) * 2 + 1];
+        da[i] = 2.0f * r * c * df[i] - r * srow[row] - c * scol[b * M + j];
+    }
+}
+
 extern "C" long long cpn_conv_wgrad_scratch(int Cin, int Cout) {
     return (long long)WG_BLOCKS * ((long long)Cout * Cin * 9 + Cout);
 }
@@ -708,6 +809,36 @@ extern "C" int cpn_dwconv3x3_wgrad(const float* x, const float* dy, int N, int C
                 "cpn_dwconv3x3_wgrad: bad shape");
     hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, dy, N, C, H, W, dw, db);
     CPN_LAUNCH_CHECK("cpn_dwconv3x3_wgrad");
+    return 0;
+}
+
+extern "C" int cpn_dual_softmax(const float* a, int B, int L, int M, float* rstat, float* cstat, float* f,
+                                void* stream) {
+    CPN_REQUIRE(a && rstat && cstat && f, CPN_E_ARG, "cpn_dual_softmax: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && L > 0 && M > 0, CPN_E_SHAPE, "cpn_dual_softmax: bad shape");
+    const hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)B * L, total = rows * M;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, a, (const float*)nullptr, rows, M, rstat, 0);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(cpn_cdiv(M, 64), B), dim3(256), 0, st, a, (const float*)nullptr, L, M, cstat, 0);
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(total, 256), 16384);
+    hipLaunchKernelGGL(dual_softmax_apply_kernel, dim3(blocks), dim3(256), 0, st, a, rstat, cstat, L, M, total, f);
+    CPN_LAUNCH_CHECK("cpn_dual_softmax");
+    return 0;
+}
+
+extern "C" int cpn_dual_softmax_bwd(const float* a, const float* rstat, const float* cstat, const float* f,
+                                    const float* df, int B, int L, int M, float* srow, float* scol, float* da,
+                                    void* stream) {
+    CPN_REQUIRE(a && rstat && cstat && f && df && srow && scol && da, CPN_E_ARG, "cpn_dual_softmax_bwd: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && L > 0 && M > 0, CPN_E_SHAPE, "cpn_dual_softmax_bwd: bad shape");
+    const hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)B * L, total = rows * M;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, f, df, rows, M, srow, 1);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(cpn_cdiv(M, 64), B), dim3(256), 0, st, f, df, L, M, scol, 1);
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(total, 256), 16384);
+    hipLaunchKernelGGL(dual_softmax_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, a, rstat, cstat, df, srow, scol, L, M,
+                       total, da);
+    CPN_LAUNCH_CHECK("cpn_dual_softmax_bwd");
     return 0;
 }
 

@@ -327,10 +327,10 @@ class _CrossAttention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=False)          # unused upstream too (backbone.py:296); checkpoint key
         self.proj_fundamental = nn.Linear(dim + 6, dim)
 
-    def forward(self, x1, x2, corr, intr):
+    def forward(self, x1, x2, corr, intr, ops):
         B = x1.shape[0]
         a1 = corr.reshape(B, corr.shape[-4] * corr.shape[-3], -1)                       # (B, src, trg)
-        f1 = a1.softmax(dim=-1) * a1.softmax(dim=-2)
+        f1 = ops.dual_softmax(a1)                                  # a1.softmax(-1) * a1.softmax(-2)
         f2 = f1.transpose(-2, -1)          # == a2.softmax(-1) * a2.softmax(-2) with a2 = a1^T: two softmaxes, not four
         pos = positional_encodings(*intr, n=int(math.isqrt(x1.shape[1]))).to(x1.dtype)
         v1, v2 = torch.cat([x1, pos], dim=2), torch.cat([x2, pos], dim=2)
@@ -348,10 +348,10 @@ class CrossBlock(nn.Module):
         self.mlp = _Mlp(dim, 4 * dim)
         self.norm = nn.LayerNorm(dim)
 
-    def forward(self, x, corr, intr):
+    def forward(self, x, corr, intr, ops):
         b_s, hw, nf = x.shape
         x = x.reshape(-1, 2, hw, nf)
-        fa, fb = self.cross_attn(self.norm1(x[:, 0]), self.norm1(x[:, 1]), corr, intr)
+        fa, fb = self.cross_attn(self.norm1(x[:, 0]), self.norm1(x[:, 1]), corr, intr, ops)
         f = torch.cat([fa.unsqueeze(1), fb.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)
         f = f + self.mlp(self.norm2(f))
         return self.norm(f)
@@ -392,7 +392,7 @@ def get_z(model, input, ops):
     Kn = input["context"]["intrinsics"].clone()
     Kn[:, :, :2, :] = Kn[:, :, :2, :] / H
     intr = (Kn[:, 0, 0, 0, None], Kn[:, 0, 1, 1, None], Kn[:, 0, 0, 2, None], Kn[:, 0, 1, 2, None])
-    pose_feat = model.cross_attention(feats[-1].flatten(-2, -1).transpose(-1, -2), c, intr).reshape(B, -1)
+    pose_feat = model.cross_attention(feats[-1].flatten(-2, -1).transpose(-1, -2), c, intr, ops).reshape(B, -1)
     lat = model.pose_regressor(pose_feat)[:, :128]
     R = r6d_to_matrix(model.rotation_regressor(lat))[:, :3, :3]
     t = model.translation_regressor(lat)

@@ -147,6 +147,34 @@ class _Conv4dGnReluFn(Function):
         return None, gx, gwq, gbq, gws, gbs, dgw, dgb, None, None, None, None
 
 
+class _DualSoftmaxFn(Function):
+    """f = softmax(a, -1) * softmax(a, -2) on cpn_dual_softmax / cpn_dual_softmax_bwd."""
+
+    @staticmethod
+    def forward(ctx, a):
+        a = a.contiguous().float()
+        B, L, M = a.shape
+        dev = a.device
+        rstat = torch.empty(B, L, 2, dtype=torch.float32, device=dev)
+        cstat = torch.empty(B, M, 2, dtype=torch.float32, device=dev)
+        f = torch.empty_like(a)
+        call("cpn_dual_softmax", a.data_ptr(), B, L, M, rstat.data_ptr(), cstat.data_ptr(), f.data_ptr(), _stream())
+        ctx.save_for_backward(a, rstat, cstat, f)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        a, rstat, cstat, f = ctx.saved_tensors
+        B, L, M = a.shape
+        df = df.contiguous().float()
+        srow = torch.empty(B, L, dtype=torch.float32, device=a.device)
+        scol = torch.empty(B, M, dtype=torch.float32, device=a.device)
+        da = torch.empty_like(a)
+        call("cpn_dual_softmax_bwd", a.data_ptr(), rstat.data_ptr(), cstat.data_ptr(), f.data_ptr(), df.data_ptr(), B, L, M,
+             srow.data_ptr(), scol.data_ptr(), da.data_ptr(), _stream())
+        return da
+
+
 class DwConv3x3Fn(Function):
     """Depthwise 3x3 / stride 1 / pad 1 convolution of the UFC feed-forward blocks.  forward and data gradient are
     library depthwise convolutions; the weight / bias gradient (ten sums per channel) runs on cpn_dwconv3x3_wgrad."""
@@ -267,6 +295,11 @@ class HipOps:
         s_to_t = torch.empty(B, 2, h, h, device=c.device, dtype=torch.float32)
         call("cpn_soft_argmax_pair", c.data_ptr(), B, h, 0.02, t_to_s.data_ptr(), s_to_t.data_ptr(), _stream())
         return t_to_s, s_to_t
+
+    def dual_softmax(self, a):
+        """(B,L,M) -> softmax(a,-1) * softmax(a,-2)."""
+        self._need_gpu(a)
+        return _DualSoftmaxFn.apply(a)
 
     def resize_bilinear(self, x, size):
         """(N,C,h,w) -> (N,C,size,size), bilinear, align_corners=True."""

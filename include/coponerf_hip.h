@@ -183,6 +183,13 @@ int cpn_conv_wgrad_planes(const float* x, const float* dy, int B, int Cin, int C
 int cpn_dwconv3x3_wgrad(const float* x, const float* dy, int N, int C, int H, int W, float* dw, float* db,
                         void* stream);
 
+/* dual softmax of the pose branch's cross attention (models/backbone.py:296-330), a (B,L,M) fp32:
+ * f = softmax(a, dim=-1) * softmax(a, dim=-2); rstat (B,L,2) / cstat (B,M,2) receive (max, sum exp) per row / column
+ * and feed the backward: da from df with srow (B,L), scol (B,M) scratch.                                            */
+int cpn_dual_softmax(const float* a, int B, int L, int M, float* rstat, float* cstat, float* f, void* stream);
+int cpn_dual_softmax_bwd(const float* a, const float* rstat, const float* cstat, const float* f, const float* df,
+                         int B, int L, int M, float* srow, float* scol, float* da, void* stream);
+
 /* ---- K7: cosine correlation of two token sets ------------------------------------------------------
  * replaces aggregation.correlation / correlation_token (models/aggregation.py:70-80):
  * out[b,s,t] = <src[b,s]/(|src[b,s]|+eps), trg[b,t]/(|trg[b,t]|+eps)>; src, trg (B,L,C), C % 16 == 0;

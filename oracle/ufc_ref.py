@@ -57,6 +57,11 @@ class TorchOps:
         return F.relu(F.group_norm(y, 1, gn_w, gn_b, eps))
 
     @staticmethod
+    def dual_softmax(a):
+        """models/backbone.py:296-330: the product of the row-wise and the column-wise softmax."""
+        return a.softmax(dim=-1) * a.softmax(dim=-2)
+
+    @staticmethod
     def resize_bilinear(x, size):
         return F.interpolate(x, size=(size, size), mode="bilinear", align_corners=True)
 

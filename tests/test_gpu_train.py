@@ -126,6 +126,7 @@ def test_ufc_operator_gradients_match_oracle(dev):
     both("correlation_tokens", [src, trg], lambda f, t: f(t[0], t[1], 8))
     both("soft_argmax_pair", [syn.normal((2, 1, 8, 8, 8, 8), seed=80) * 0.05], lambda f, t: f(t[0]))
     both("resize_bilinear", [syn.normal((2, 3, 8, 8), seed=79)], lambda f, t: f(t[0], 16))
+    both("dual_softmax", [syn.normal((2, 70, 130), seed=78) * 2.0], lambda f, t: f(t[0]))
 
 
 def test_conv_weight_gradient_kernels(dev):
