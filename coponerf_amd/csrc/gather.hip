@@ -239,6 +239,106 @@ __global__ __launch_bounds__(256) void local_hidden_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// query_embed / query_repeat_embed as ONE kernel: out = W2 . relu(W1 . L + b1 + add) + b2  (16 -> 128 -> 128), the
+// hidden layer never leaves the registers.  Stage 1 is local_hidden_kernel's fp32 MFMA; its accumulator layout
+// (lane = row ln, channels p*32 + fg*8 + 0..7) IS the B-operand layout of v_mfma_f32_16x16x32_f16 for K block p, so
+// after ReLU and the fp16 rounding (the same rounding the stored hidden layer had) the second layer runs straight
+// off the registers against W2 fragments held in LDS (lane-linear 16-byte slots, 32 KiB).  Output rows use the
+// same channel permutation: 16-byte stores, 64 contiguous bytes per row and tile pair.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void local_mlp_kernel(
+    const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
+    const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
+    const float* __restrict__ b2, int V, int R, int S, int ray0, long long nrows, __half* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) half8 w2l[8 * 4 * 64];        // [tile t][k block p][lane]
+    __shared__ __attribute__((aligned(16))) half8 ostage[4][16 * 17];
+    const int lane = threadIdx.x & 63;
+    const int a = lane & 15, fg = lane >> 4;
+    for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) {
+        const int l = i & 63, p = (i >> 6) & 3, t = i >> 8;
+        const int ch = (t >> 1) * 32 + ((l & 15) >> 2) * 8 + (t & 1) * 4 + (l & 3);       // output channel of tile row
+        w2l[i] = *reinterpret_cast<const half8*>(w2 + (size_t)ch * ldw2 + p * 32 + (l >> 4) * 8);
+    }
+    f32x4 wv[8], bv[8], b2v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int p = t >> 1, h = t & 1;
+        wv[t] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(p * 32 + (a >> 2) * 8 + h * 4 + (a & 3)) * ldw1 + fg * 4);
+        bv[t] = *reinterpret_cast<const f32x4*>(b1 + p * 32 + fg * 8 + h * 4);
+        b2v[t] = *reinterpret_cast<const f32x4*>(b2 + p * 32 + fg * 8 + h * 4);
+    }
+    __syncthreads();
+    const unsigned ngroups = (unsigned)((nrows + 15) >> 4);
+    const unsigned wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (unsigned grp = wave_id; grp < ngroups; grp += nwaves) {
+        const unsigned row = grp * 16 + a;
+        const bool live = row < (unsigned)nrows;
+        unsigned t_ = live ? row : (unsigned)nrows - 1;
+        const int s = (int)(t_ % (unsigned)S); t_ /= (unsigned)S;
+        const int v = (int)(t_ % (unsigned)V); t_ /= (unsigned)V;
+        const unsigned ray = (unsigned)ray0 + t_;
+        const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
+        const size_t nr = ((size_t)(b * V + v)) * R + r;
+        const f32x4 l0 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8);
+        const f32x4 l1 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8 + 4);
+        const float* c9 = coords9 + nr * 9;
+        f32x4 lv;
+        if (fg == 0) lv = f32x4{l0[0], l0[1], l0[2], 0.f};
+        else if (fg == 1) lv = f32x4{0.f, 0.f, c9[0], c9[1]};
+        else if (fg == 2) lv = f32x4{c9[2], l0[3], l1[0], l1[1]};
+        else lv = f32x4{l1[2], c9[6], c9[7], c9[8]};
+        f32x4 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            acc[t] = bv[t];
+            if (add) acc[t] += *reinterpret_cast<const f32x4*>(add + (size_t)t_ * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], lv[e], acc[t], 0, 0, 0);
+        // hidden layer -> fp16 B operands: K block p = channels p*32 .. p*32+31, this lane holds fg*8 .. fg*8+7 of it
+        half8 hb[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hb[p][i] = (_Float16)fmaxf(acc[2 * p][i], 0.0f);
+                hb[p][4 + i] = (_Float16)fmaxf(acc[2 * p + 1][i], 0.0f);
+            }
+        f32x4 o2[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            o2[t] = b2v[t];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                o2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[(t * 4 + p) * 64 + lane], hb[p], o2[t], 0, 0, 0);
+        }
+        // stage the wave's 16 x 128 tile in LDS and write whole 256-byte rows (4 rows per store instruction)
+        half8* stg = ostage[threadIdx.x >> 6];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            half8 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i] = (_Float16)o2[2 * p][i];
+                o[4 + i] = (_Float16)o2[2 * p + 1][i];
+            }
+            stg[a * 17 + p * 4 + fg] = o;                       // row a, 16-byte slot p*4+fg (row stride 17 slots)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = q * 4 + (lane >> 4), slot = lane & 15;
+            const unsigned orow = grp * 16 + rr;
+            const half8 o = stg[rr * 17 + slot];
+            if (orow < (unsigned)nrows) *reinterpret_cast<half8*>(out + (size_t)orow * 128 + slot * 8) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+}
+
 }  // namespace
 
 extern "C" int cpn_nchw_to_nhwc_f16(const float* src, uint16_t* dst, int N, int C, int h, int w, void* stream) {
@@ -297,5 +397,23 @@ extern "C" int cpn_local_hidden(const float* loc8, const float* coords9, const f
     hipLaunchKernelGGL(local_hidden_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        loc8, coords9, w, ldw, bias, add, V, R, S, ray0, nrows, (__half*)out);
     CPN_LAUNCH_CHECK("cpn_local_hidden");
+    return 0;
+}
+
+extern "C" int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
+                             const float* add, const uint16_t* w2, int ldw2, const float* b2, int B, int V, int R, int S,
+                             int ray0, int nrays, uint16_t* out, void* stream) {
+    CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && out, CPN_E_ARG, "cpn_local_mlp: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && ldw1 >= 16 && ldw2 >= 128 && (ldw2 % 8) == 0, CPN_E_SHAPE,
+                "cpn_local_mlp: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_local_mlp: ray range outside B*R");
+    const long long nrows = (long long)nrays * V * S;
+    CPN_REQUIRE(nrows * 16 < (1LL << 31), CPN_E_SHAPE, "cpn_local_mlp: chunk too large for 32-bit indexing");
+    const long long groups = cpn_cdiv(nrows, 16);
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(groups, 4), 2048);
+    hipLaunchKernelGGL(local_mlp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+                       (const __half*)w2, ldw2, b2, V, R, S, ray0, nrows, (__half*)out);
+    CPN_LAUNCH_CHECK("cpn_local_mlp");
     return 0;
 }

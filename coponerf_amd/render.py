@@ -391,9 +391,9 @@ class RenderEngine:
                 gemm(enc, 832, "latent_value", value, 416, rows, 416, 832, False, True)
                 gemm(enc, 832, "key_map", kh, 128, rows, 128, 832, True, False)
             gemm(kh, 128, "key_map_2", key2, 128, rows, 128, 128, False, False)
-            call("cpn_local_hidden", loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
-                 w["query_embed.b"].data_ptr(), 0, B, V, R, S, ray0, n, hq.data_ptr(), s)
-            gemm(hq, 128, "query_embed_2", ce, 128, rows, 128, 128, False, False)
+            call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
+                 w["query_embed.b"].data_ptr(), 0, w["query_embed_2.w16"].data_ptr(), 128,
+                 w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, ce.data_ptr(), s)
             # round 1 (CoPoNeRF.py:450-461)
             if self.fold_value:
                 call("cpn_attend_hidden", key2.data_ptr(), ce.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
@@ -407,9 +407,9 @@ class RenderEngine:
                  w["encode_latent.b"].data_ptr(), 0, 0, ze.data_ptr(), 128, n, 128, 416, 0, 0, s)
             call("cpn_linear_f32", ze.data_ptr(), 128, w["query_repeat_embed.w_z"].data_ptr(), 128, 0, 0, 0,
                  addq.data_ptr(), 128, n, 128, 128, 0, 0, s)
-            call("cpn_local_hidden", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
-                 w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), B, V, R, S, ray0, n, hq.data_ptr(), s)
-            gemm(hq, 128, "query_repeat_embed_2", q2, 128, rows, 128, 128, False, False)
+            call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
+                 w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
+                 w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, q2.data_ptr(), s)
             if self.fold_value:
                 call("cpn_attend_hidden", q2.data_ptr(), ce.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
                      hbar.data_ptr(), 0, s)

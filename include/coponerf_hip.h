@@ -97,6 +97,12 @@ int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const uint16_t* 
 int cpn_local_hidden(const float* loc8, const float* coords9, const float* w, int ldw, const float* bias,
                      const float* add, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out, void* stream);
 
+/* both layers of query_embed / query_repeat_embed in one pass (CoPoNeRF.py:446, 472-473):
+ * out[row, 0:128] = fp16( W2 . fp16(relu(W1[:, 0:16] . L(row) + b1 + add[ray])) + b2 ), W2 (128, ldw2) fp16 packed   */
+int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
+                  const float* add, const uint16_t* w2, int ldw2, const float* b2, int B, int V, int R, int S,
+                  int ray0, int nrays, uint16_t* out, void* stream);
+
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).
  *   A (M, lda) fp16, W (N, ldw) fp16 (both K-contiguous), bias (N) fp32, K multiple of 32, N multiple of 16*tile

@@ -32,10 +32,27 @@ def call(name, *a):
     if name in ("cpn_sample_geometry", "cpn_mask_rgb") or (name == "cpn_gather_rows" and "g" not in seen):
         tick("before " + name)
         seen.add("g") if name == "cpn_gather_rows" else None
-    if name == "cpn_linear_f32" and a[-5] == 32 and "phi" not in seen:   # K = 32: phi.lin_in
+    if name == "cpn_linear_f32" and a[10] == 32 and "phi" not in seen:   # K = 32: phi.lin_in
         tick("chunks done"); seen.add("phi")
     return orig_call(name, *a)
 R.call = call
+import coponerf_amd.CoPoNeRF as CM
+orig_aux = CM.aux_outputs
+def aux(*a, **k):
+    tick("before aux_outputs")
+    out = orig_aux(*a, **k)
+    tick("aux_outputs")
+    return out
+CM.aux_outputs = aux
+orig_empty = torch.empty
+def empty(*a, **k):
+    if k.get("pin_memory"):
+        tick("before pinned alloc")
+        out = orig_empty(*a, **k)
+        tick("pinned alloc")
+        return out
+    return orig_empty(*a, **k)
+R.torch.empty = empty
 
 with torch.no_grad():
     for it in range(4):
