@@ -124,8 +124,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
 
     half8 tv[4][4];                     // [chunk][tap] texel vectors of the previous sample
     int prev[4] = {-1, -1, -1, -1};
+    float2 gnext = g[0];
     for (int s = 0; s < S; ++s) {
-        const float2 gq = g[s];
+        const float2 gq = gnext;
+        if (s + 1 < S) gnext = g[s + 1];              // the next coordinate is in flight while this sample's texels load
         const Taps tp = make_taps(gq.x, gq.y, Wl, Hl, j == 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -144,11 +146,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             if (it > 0 && !coarse) break;
+            // acc[e] = fma(f32(texel), w, acc[e]) with the fp16 -> fp32 conversion inside the FMA (v_fma_mix_f32):
+            // 128 instructions per sample instead of 128 conversions + 64 packed FMAs, same bits
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 tq = __builtin_bit_cast(u32x4, tv[it][k]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (float)tv[it][k][e] * tp.w[k];
+                for (int i = 0; i < 4; ++i) {
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * i]) : "v"(tq[i]), "v"(tp.w[k]));
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                        : "+v"(acc[2 * i + 1]) : "v"(tq[i]), "v"(tp.w[k]));
+                }
+            }
             half8 out;
 #pragma unroll
             for (int e = 0; e < 8; ++e) out[e] = (_Float16)acc[e];
