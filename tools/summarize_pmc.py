@@ -3,7 +3,7 @@
 import csv, re, sys, collections
 
 def short(name):
-    m = re.search(r"(gemm_f16_w4_kernel|gemm_f16_p8_kernel|gemm_f16_p4_kernel|gemm_f16_ring_kernel|gemm_f16_kernel|gather_rows_kernel|attend_kernel|attend_hidden_kernel|attend_hidden_bwd_kernel|gather_rows_bwd_kernel|gather_bbox_kernel|local_hidden_kernel|"
+    m = re.search(r"(gemm_f16_w4_kernel|gemm_f16_p8_kernel|gemm_f16_p4_kernel|gemm_f16_ring_kernel|gemm_f16_kernel|gather_rows_kernel|attend_kernel|attend_hidden_kernel|attend_hidden_bwd_kernel|gather_rows_bwd_kernel|gather_bbox_kernel|local_hidden_kernel|local_mlp_kernel|row_stats_kernel|col_stats_kernel|dual_softmax_apply_kernel|dual_softmax_bwd_apply_kernel|conv_wgrad_planes_kernel|conv_wgrad_reduce_kernel|dwconv3x3_wgrad_kernel|gn_relu_bwd_reduce_kernel|gn_relu_bwd_apply_kernel|conv4d_k3s1_kernel|resize_bilinear_ac_kernel|"
                   r"linear_f32_kernel|conv4d_kernel|gn_relu_kernel|gemm_nt_f32_kernel|l2norm_rows_kernel|soft_argmax_rows_kernel|soft_argmax_cols_kernel|sample_geometry_kernel|project_rays_kernel|nchw_to_nhwc_f16_kernel|"
                   r"mask_rgb_kernel|pack_weight_f16_kernel|ray_mlp_kernel|fused_\w+)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else None
