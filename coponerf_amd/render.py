@@ -354,7 +354,7 @@ class RenderEngine:
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
             bufs = {"xin": t("xin", (C * T * 2, _hip.XIN_STRIDE), f16), "hid": t("hid", (C * T * 2, 832), f16),
                     "kh": t("kh", (C * T, 128), f16), "key2": t("key2", (C * T, 128), f16),
-                    "hq": t("hq", (C * T, 128), f16), "ce": t("ce", (C * T, 128), f16), "q2": t("q2", (C * T, 128), f16),
+                    "ce": t("ce", (C * T, 128), f16), "q2": t("q2", (C * T, 128), f16),
                     "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
             if not self.fold_value:
@@ -363,7 +363,7 @@ class RenderEngine:
             return bufs
 
         def run_chunk(ray0, bf, s):
-            xin, hid, kh, key2, hq, ce, q2 = (bf[k] for k in ("xin", "hid", "kh", "key2", "hq", "ce", "q2"))
+            xin, hid, kh, key2, ce, q2 = (bf[k] for k in ("xin", "hid", "kh", "key2", "ce", "q2"))
             z1, ze, addq, hbar, zs = (bf[k] for k in ("z1", "ze", "addq", "hbar", "zs"))
             enc, value = bf.get("enc"), bf.get("value")
 

@@ -66,6 +66,11 @@ def test_render_gradients_match_oracle_autograd(dev):
     assert all(ok), table
     # layers the render path never touches stay without gradient (skip-None contract of wrapper.py:26)
     assert params["corr_embed.weight"].grad is None
+    # ... and against the upstream reference's own gradients on the same case (tests/golden/grads.npz)
+    from tests.test_oracle_grads import check_against_fixture
+    grads = {name: params[name].grad for name in w_ref}
+    grads.update({f"z{i}": t.grad for i, t in enumerate(z_hip)})
+    check_against_fixture(grads, rel_l2=5e-2, rel_max=0.1)          # fixture holds a 1-in-61 sample per tensor
 
 
 def test_full_training_step_end_to_end(dev):
