@@ -296,13 +296,15 @@ def positional_encodings(fx, fy, cx, cy, n: int = 64):
     B = fx.shape[0]
     dev = fx.device
     hp, wp = cy * 2, cx * 2
-    K = torch.zeros(B, 3, 3, device=dev)
-    K[:, 0, 0] = ((fx / wp) * 2).squeeze(-1)
-    K[:, 1, 1] = ((fy / hp) * 2).squeeze(-1)
-    K[:, 0, 2] = ((cx / wp) * 2 - 1).squeeze(-1)
-    K[:, 1, 2] = ((cy / hp) * 2 - 1).squeeze(-1)
-    K[:, 2, 2] = 1
-    Kinv = torch.inverse(K)
+    # K = [[a,0,c],[0,b,d],[0,0,1]] in normalised coordinates; its inverse in closed form (the library inverse
+    # synchronises with the host, which also rules out HIP-graph capture of get_z)
+    a = ((fx / wp) * 2).squeeze(-1)
+    b = ((fy / hp) * 2).squeeze(-1)
+    c = ((cx / wp) * 2 - 1).squeeze(-1)
+    d = ((cy / hp) * 2 - 1).squeeze(-1)
+    zero, one = torch.zeros_like(a), torch.ones_like(a)
+    Kinv = torch.stack((torch.stack((1 / a, zero, -c / a), -1), torch.stack((zero, 1 / b, -d / b), -1),
+                        torch.stack((zero, zero, one), -1)), -2)                         # (B,3,3)
     lin = torch.linspace(-1, 1, steps=n, device=dev)
     xs = lin.repeat_interleave(n)                       # index k*n + j -> xs[k]
     ys = lin.repeat(n)                                  #               -> ys[j]
@@ -365,9 +367,21 @@ def r6d_to_matrix(d6):
     return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
 
 
+_CONSTS = {}
+
+
+def _const(device, values):
+    """Small constant tensors, uploaded once per device (a host->device copy inside get_z would also make the call
+    impossible to capture into a HIP graph)."""
+    key = (str(device), tuple(values))
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor(values, dtype=torch.float32, device=device)
+    return _CONSTS[key]
+
+
 def imagenet_normalise(x):
-    mean = x.new_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
-    std = x.new_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    mean = _const(x.device, (0.485, 0.456, 0.406)).view(1, 3, 1, 1)
+    std = _const(x.device, (0.229, 0.224, 0.225)).view(1, 3, 1, 1)
     return (x - mean) / std
 
 
@@ -396,6 +410,6 @@ def get_z(model, input, ops):
     lat = model.pose_regressor(pose_feat)[:, :128]
     R = r6d_to_matrix(model.rotation_regressor(lat))[:, :3, :3]
     t = model.translation_regressor(lat)
-    bottom = torch.tensor([0., 0., 0., 1.], device=t.device).expand(B, 1, -1)
+    bottom = _const(t.device, (0., 0., 0., 1.)).expand(B, 1, -1)
     rel_pose = torch.cat((torch.cat((R, t.unsqueeze(-1)), dim=-1), bottom), dim=1)
     return feats + [z_conv], rel_pose, flows
