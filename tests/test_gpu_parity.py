@@ -238,6 +238,29 @@ def test_other_baseline_configs_against_oracle(H, S, R, rig, model, dev, weights
     assert torch.equal(out["valid_mask"].cpu(), ref["valid_mask"])
 
 
+@pytest.mark.parametrize("B,H,S,R,val", [(3, 96, 24, 77, True), (2, 48, 40, 33, False), (1, 64, 7, 129, True)])
+def test_ragged_shapes_against_oracle(B, H, S, R, val, model, dev, weights):
+    """Sizes that are multiples of nothing convenient: odd ray counts, sample counts that are not powers of two (7, 24,
+    40), batch 3, ray chunks that end in the middle of a batch element (chunk_rays = 50)."""
+    from oracle import render_ref as orc
+    inp = syn.make_inputs(B, H, H, R, seed=91)
+    z, rel, flow = syn.make_latents(B, H, H, seed=92)
+    old_chunk, old_s = model._engine.chunk_rays, model.npoints
+    try:
+        with torch.no_grad():
+            ref = orc.forward(inp, z, rel, flow, val, weights, npoints=S, keep=True)
+            model.npoints, model._engine.chunk_rays = S, 50
+            out = model(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=val,
+                        flow=to_device(flow, dev), debug=True)
+    finally:
+        model._engine.chunk_rays, model.npoints = old_chunk, old_s
+    assert torch.equal(out["pixel_val"], ref["pixel_val"])
+    assert torch.equal(out["_core"]["pt"].cpu(), ref["pt"])
+    assert (out["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
+    assert (out["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+    assert torch.equal(out["valid_mask"].cpu(), ref["valid_mask"])
+
+
 def test_missing_library_is_loud(monkeypatch):
     from coponerf_amd import _hip
     monkeypatch.setattr(_hip, "_lib", None)
