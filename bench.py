@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=1,
                     help="HIP streams the ray chunks are spread over (2: +2.5 % rays/s, but kernels of different "
                          "chunks then share the GPU and the per-kernel roofline timing is no longer clean)")
-    ap.add_argument("--cpu-rays", type=int, default=4096, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=8192, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
