@@ -1,4 +1,4 @@
-"""GPU microbenchmark of cpn_gemm_f16 on the three dominant shapes (set CPN_GEMM_VARIANT=0/1 before launch)."""
+"""GPU microbenchmark of cpn_gemm_f16 on the dominant shapes of the render path (argument: rays per launch)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,4 +27,4 @@ for name, M, N, K, ld, kalg, relu, f32 in shapes:
     ref = A[:4096, :K].float() @ W[:, :K].float().t() + b
     if relu: ref = ref.clamp_min(0)
     err = (C[:4096].float() - ref).abs().max().item()
-    print(f"variant={os.environ.get('CPN_GEMM_VARIANT','0')} {name:22s} M={M} {ms:8.3f} ms  {2.0*M*N*kalg/ms/1e9:8.1f} TFLOP/s (alg)  maxerr {err:.2e}")
+    print(f"{name:22s} M={M} {ms:8.3f} ms  {2.0*M*N*kalg/ms/1e9:8.1f} TFLOP/s (alg)  maxerr {err:.2e}")

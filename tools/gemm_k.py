@@ -1,3 +1,5 @@
+"""K sweep of cpn_gemm_f16 at fixed M, N = 832: time = a + b*K separates the main-loop rate from the K-independent
+C-store phase (argument: M)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,4 +15,4 @@ for K in (64, 128, 256, 448, 864):
     e0.record()
     for _ in range(20): f()
     e1.record(); torch.cuda.synchronize()
-    print(f"variant={os.environ.get('CPN_GEMM_VARIANT','0')} ablate={os.environ.get('CPN_ABLATE','0')} K={K:4d} {e0.elapsed_time(e1)/20:.3f} ms")
+    print(f"K={K:4d} {e0.elapsed_time(e1)/20:.3f} ms")
