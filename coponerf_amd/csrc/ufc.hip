@@ -660,6 +660,78 @@ extern "C" int cpn_gn_relu_bwd(const float* y, const float* out, const float* do
     return 0;
 }
 
+// backward of the two soft-argmax directions: with p = softmax over the reduced index of c / beta and (ox, oy) the
+// forward outputs, d c = p / beta * (gx * (x - ox) + gy * (y - oy)).  Rows first (writes dc), columns second (adds).
+__global__ __launch_bounds__(256) void soft_argmax_rows_bwd_kernel(const float* __restrict__ c, int h, float beta,
+                                                                   const float* __restrict__ out,
+                                                                   const float* __restrict__ gout,
+                                                                   float* __restrict__ dc) {
+    const int T = h * h;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const float* row = c + ((size_t)b * T + s) * T;
+    float* drow = dc + ((size_t)b * T + s) * T;
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int t = threadIdx.x; t < T; t += 256) m = fmaxf(m, row[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float se = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) se += expf((row[t] - m) / beta);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
+    if (lane == 0) red[4 + wave] = se;
+    __syncthreads();
+    const float inv = 1.0f / (((red[4] + red[5]) + (red[6] + red[7])) * beta);
+    const float ox = out[((size_t)b * 2 + 0) * T + s], oy = out[((size_t)b * 2 + 1) * T + s];
+    const float gx = gout[((size_t)b * 2 + 0) * T + s], gy = gout[((size_t)b * 2 + 1) * T + s];
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float p = expf((row[t] - m) / beta) * inv;
+        drow[t] = p * (gx * (lin11(t % h, h) - ox) + gy * (lin11(t / h, h) - oy));
+    }
+}
+
+__global__ __launch_bounds__(256) void soft_argmax_cols_bwd_kernel(const float* __restrict__ c, int h, float beta,
+                                                                   const float* __restrict__ out,
+                                                                   const float* __restrict__ gout,
+                                                                   float* __restrict__ dc) {
+    const int T = h * h;
+    const int b = blockIdx.y;
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + l;
+    __shared__ float part[4][2][64];
+    __shared__ float fin[2][64];
+    float m = -INFINITY, se = 0.f;
+    const float* col = c + (size_t)b * T * T + t;
+    if (t < T)
+        for (int s = g; s < T; s += 4) {
+            const float v = col[(size_t)s * T];
+            if (v > m) { se *= expf((m - v) / beta); m = v; }
+            se += expf((v - m) / beta);
+        }
+    part[g][0][l] = m; part[g][1][l] = se;
+    __syncthreads();
+    if (g == 0) {
+        const float M = fmaxf(fmaxf(part[0][0][l], part[1][0][l]), fmaxf(part[2][0][l], part[3][0][l]));
+        float E = 0.f;
+        for (int q = 0; q < 4; ++q) E += part[q][1][l] * expf((part[q][0][l] - M) / beta);
+        fin[0][l] = M; fin[1][l] = 1.0f / (E * beta);
+    }
+    __syncthreads();
+    if (t >= T) return;
+    const float M = fin[0][l], inv = fin[1][l];
+    const float ox = out[((size_t)b * 2 + 0) * T + t], oy = out[((size_t)b * 2 + 1) * T + t];
+    const float gx = gout[((size_t)b * 2 + 0) * T + t], gy = gout[((size_t)b * 2 + 1) * T + t];
+    float* dcol = dc + (size_t)b * T * T + t;
+    for (int s = g; s < T; s += 4) {
+        const float q = expf((col[(size_t)s * T] - M) / beta) * inv;
+        dcol[(size_t)s * T] += q * (gx * (lin11(s % h, h) - ox) + gy * (lin11(s / h, h) - oy));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dual softmax of the "fundamental-matrix" cross attention (models/backbone.py:296-330):
 //   f[b,i,j] = softmax_j(a[b,i,:])[j] * softmax_i(a[b,:,j])[i]        a: (B, L, M), up to 4096 x 4096
@@ -867,5 +939,19 @@ extern "C" int cpn_soft_argmax_pair(const float* c, int B, int h, float beta, fl
     hipLaunchKernelGGL(soft_argmax_rows_kernel, dim3(T, B), dim3(256), 0, st, c, h, beta, t_to_s);
     hipLaunchKernelGGL(soft_argmax_cols_kernel, dim3(cpn_cdiv(T, 64), B), dim3(256), 0, st, c, h, beta, s_to_t);
     CPN_LAUNCH_CHECK("cpn_soft_argmax_pair");
+    return 0;
+}
+
+extern "C" int cpn_soft_argmax_pair_bwd(const float* c, int B, int h, float beta, const float* t_to_s,
+                                        const float* s_to_t, const float* g_t_to_s, const float* g_s_to_t, float* dc,
+                                        void* stream) {
+    CPN_REQUIRE(c && t_to_s && s_to_t && g_t_to_s && g_s_to_t && dc, CPN_E_ARG, "cpn_soft_argmax_pair_bwd: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && h > 1 && beta > 0.f, CPN_E_SHAPE, "cpn_soft_argmax_pair_bwd: bad shape");
+    const hipStream_t st = (hipStream_t)stream;
+    const int T = h * h;
+    hipLaunchKernelGGL(soft_argmax_rows_bwd_kernel, dim3(T, B), dim3(256), 0, st, c, h, beta, t_to_s, g_t_to_s, dc);
+    hipLaunchKernelGGL(soft_argmax_cols_bwd_kernel, dim3(cpn_cdiv(T, 64), B), dim3(256), 0, st, c, h, beta, s_to_t,
+                       g_s_to_t, dc);
+    CPN_LAUNCH_CHECK("cpn_soft_argmax_pair_bwd");
     return 0;
 }

@@ -175,6 +175,27 @@ class _DualSoftmaxFn(Function):
         return da
 
 
+class _SoftArgmaxPairFn(Function):
+    """cpn_soft_argmax_pair / cpn_soft_argmax_pair_bwd."""
+
+    @staticmethod
+    def forward(ctx, ops, c):
+        t_to_s, s_to_t = ops._soft_argmax_pair_hip(c)
+        ctx.save_for_backward(c, t_to_s, s_to_t)
+        return t_to_s, s_to_t
+
+    @staticmethod
+    def backward(ctx, g_ts, g_st):
+        c, t_to_s, s_to_t = ctx.saved_tensors
+        B, h = c.shape[0], c.shape[-1]
+        zero = lambda g, like: torch.zeros_like(like) if g is None else g.contiguous().float()
+        g_ts, g_st = zero(g_ts, t_to_s), zero(g_st, s_to_t)
+        dc = torch.empty_like(c)
+        call("cpn_soft_argmax_pair_bwd", c.data_ptr(), B, h, 0.02, t_to_s.data_ptr(), s_to_t.data_ptr(), g_ts.data_ptr(),
+             g_st.data_ptr(), dc.data_ptr(), _stream())
+        return None, dc
+
+
 class DwConv3x3Fn(Function):
     """Depthwise 3x3 / stride 1 / pad 1 convolution of the UFC feed-forward blocks.  forward and data gradient are
     library depthwise convolutions; the weight / bias gradient (ten sums per channel) runs on cpn_dwconv3x3_wgrad."""
@@ -219,19 +240,6 @@ def _correlation_lib(src, trg, fs):
     n = lambda t: t / (t.norm(dim=-1, p=2, keepdim=True) + 1e-5)
     return torch.einsum("bsc,btc->bst", n(src), n(trg)).reshape(src.shape[0], 1, fs, fs, fs, fs)
 
-
-def _soft_argmax_lib(corr, beta=0.02):
-    b, _, h, w = corr.shape
-    pr = torch.softmax(corr / beta, dim=1).view(-1, h, w, h, w)
-    xn = torch.linspace(-1, 1, w, device=corr.device).view(1, w, 1, 1)
-    yn = torch.linspace(-1, 1, h, device=corr.device).view(1, h, 1, 1)
-    gx = (pr.sum(dim=1) * xn).sum(dim=1, keepdim=True)
-    gy = (pr.sum(dim=2) * yn).sum(dim=1, keepdim=True)
-    return torch.cat((gx, gy), dim=1)
-
-
-def _soft_argmax_pair_lib(c):
-    return _soft_argmax_lib(c.permute(0, 1, 4, 5, 2, 3).flatten(1, 3)), _soft_argmax_lib(c.flatten(1, 3))
 
 
 class HipOps:
@@ -287,7 +295,10 @@ class HipOps:
     def soft_argmax_pair(self, c):
         self._need_gpu(c)
         if _wants_grad(c):
-            return _HipForwardVjp.apply(self.soft_argmax_pair, _soft_argmax_pair_lib, c.float())
+            return _SoftArgmaxPairFn.apply(self, c.contiguous().float())
+        return self._soft_argmax_pair_hip(c)
+
+    def _soft_argmax_pair_hip(self, c):
         c = c.contiguous().float()
         B = c.shape[0]
         h = c.shape[-1]

@@ -208,6 +208,9 @@ int cpn_correlation(const float* src, const float* trg, int B, int L, int C, flo
  * c (B, h*h source, h*h target); t_to_s[b,:,s] = E_{t ~ softmax_t(c[b,s,:]/beta)}[(x_t, y_t)],
  * s_to_t[b,:,t] = E_{s ~ softmax_s(c[b,:,t]/beta)}[(x_s, y_s)], coordinates linspace(-1,1,h); outputs (B,2,h,h). */
 int cpn_soft_argmax_pair(const float* c, int B, int h, float beta, float* t_to_s, float* s_to_t, void* stream);
+/* backward of K8: t_to_s / s_to_t are the forward outputs, g_* their gradients (B,2,h*h) -> dc (B,h*h,h*h), overwritten */
+int cpn_soft_argmax_pair_bwd(const float* c, int B, int h, float beta, const float* t_to_s, const float* s_to_t,
+                             const float* g_t_to_s, const float* g_s_to_t, float* dc, void* stream);
 
 /* ---- bilinear resize, align_corners=True, of `planes` independent (h,w) fp32 images -> (H,W) ----------
  * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /

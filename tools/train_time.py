@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--detach-z", action="store_true", help="stop the gradient at z (times the render backward alone)")
+    ap.add_argument("--flow-loss", action="store_true", help="add a flow / pose term to the loss (the reference's cycle, "
+                                                            "ssim and pose losses send gradients through those heads)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = CoPoNeRF.CoPoNeRF(n_view=2)
@@ -39,6 +41,8 @@ def main():
         ev[1].record()
         out = model(inp, z=z, rel_pose=rel, val=False, flow=flow)
         loss = (out["rgb"] - inp["query"]["rgb"]).abs().mean()
+        if a.flow_loss:
+            loss = loss + 0.1 * sum(f.abs().mean() for f in flow) + 0.1 * (rel - out["gt_rel_pose"]).abs().mean()
         ev[2].record()
         loss.backward()
         ev[3].record()
