@@ -52,13 +52,30 @@ def _reproject(kp, depth, Ki, Kj, T):
     return r[..., :-1] / (r[..., -1:] + 1e-6)
 
 
+_FLOW_CACHE: Dict[str, tuple] = {}
+
+
+def _flow_products(flow: Sequence[torch.Tensor], width: int):
+    """(cycle mask of view 2, flow upsampled to 256x256): functions of the flows alone, so a full-image render that
+    calls forward() once per ray chunk with the same `flow` computes them once (keyed on storage and version)."""
+    key = tuple((f.data_ptr(), f._version, tuple(f.shape)) for f in flow[:2]) + (width,)
+    hit = _FLOW_CACHE.get("entry")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    _, mask2 = cycle_masks(flow, width)
+    flow_up = F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])
+    if not any(f.requires_grad for f in flow[:2]):
+        _FLOW_CACHE["entry"] = (key, mask2, flow_up)
+    return mask2, flow_up
+
+
 def aux_outputs(inp: Dict, flow: Sequence[torch.Tensor], at_wt: torch.Tensor, pt: torch.Tensor,
                 Tq: torch.Tensor) -> Dict[str, torch.Tensor]:
     ctx, qry = inp["context"], inp["query"]
     B, V = ctx["rgb"].shape[:2]
     R = qry["uv"].shape[2]
     dev = at_wt.device
-    _, mask2 = cycle_masks(flow, ctx["rgb"].shape[-2])
+    mask2, flow_up = _flow_products(flow, ctx["rgb"].shape[-2])
     at_max = at_wt.argmax(dim=-1)[..., None]
     expected = (at_wt[..., None] * torch.clamp(pt, -100, 100)).sum(dim=-2).view(B, V, R, 3).sum(dim=1)
     hom = torch.cat((expected, torch.ones(B, R, 1, device=dev)), dim=2).permute(0, 2, 1)
@@ -71,7 +88,6 @@ def aux_outputs(inp: Dict, flow: Sequence[torch.Tensor], at_wt: torch.Tensor, pt
     kp = torch.clamp(tl.transpose(1, 2), 0, 255)                          # (B,2,R): x row 0, y row 1
     bidx = torch.arange(B, device=dev)[:, None]
     match_mask = mask2[bidx, kp[:, 1], kp[:, 0]]
-    flow_up = F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])
     cidx = torch.arange(2, device=dev)[None, :, None]
     src = kp + flow_up[bidx[:, :, None], cidx, kp[:, 1:2], kp[:, 0:1]]
     inb = (0 <= tl) & (tl < 256)
