@@ -114,6 +114,7 @@ constexpr int HC = 1664;
 
 __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __restrict__ qa,
                                                             const __half* __restrict__ qb,
+                                                            const float* __restrict__ logits,
                                                             const __half* __restrict__ hid, int V, int R, int S,
                                                             int ray0, __half* __restrict__ hbar,
                                                             float* __restrict__ at_wt) {
@@ -126,6 +127,20 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
     const size_t row0 = (size_t)lray * T;
 
     float lmax = -INFINITY;
+    if (logits) {                                         // row dot products already formed by the producing kernel
+        for (int row = tid; row < T; row += 256) {
+            const float logit = logits[row0 + row] / 11.31f;
+            wts[row] = logit;
+            lmax = fmaxf(lmax, logit);
+        }
+    } else
+    if (logits) {                                         // row dot products already formed by the producing kernel
+        for (int row = tid; row < T; row += 256) {
+            const float logit = logits[row0 + row] / 11.31f;
+            wts[row] = logit;
+            lmax = fmaxf(lmax, logit);
+        }
+    } else
     for (int base = 0; base < T; base += 128) {
         const int row = base + (tid >> 1);
         if (row < T) {
@@ -203,15 +218,15 @@ extern "C" int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* v
     return 0;
 }
 
-extern "C" int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, int B, int V, int R,
-                                 int S, int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream) {
-    CPN_REQUIRE(qa && qb && hid && hbar, CPN_E_ARG, "cpn_attend_hidden: null pointer");
+extern "C" int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const float* logits, const uint16_t* hid, int B,
+                                 int V, int R, int S, int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream) {
+    CPN_REQUIRE(((qa && qb) || logits) && hid && hbar, CPN_E_ARG, "cpn_attend_hidden: null pointer");
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && V * S <= 4096, CPN_E_SHAPE, "cpn_attend_hidden: bad shape");
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_attend_hidden: ray range outside B*R");
     const size_t lds = (size_t)(V * S + 8) * sizeof(float);
     hipLaunchKernelGGL(attend_hidden_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
-                       (const __half*)qb, (const __half*)hid, V, R, S, ray0, (__half*)hbar, at_wt);
+                       (const __half*)qb, logits, (const __half*)hid, V, R, S, ray0, (__half*)hbar, at_wt);
     CPN_LAUNCH_CHECK("cpn_attend_hidden");
     return 0;
 }

@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void local_hidden_kernel(
 __global__ __launch_bounds__(256) void local_mlp_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
     const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
-    const float* __restrict__ b2, int V, int R, int S, int ray0, long long nrows, __half* __restrict__ out) {
+    const float* __restrict__ b2, int V, int R, int S, int ray0, long long nrows, __half* __restrict__ out,
+    const __half* __restrict__ dot_with, float* __restrict__ logits_out) {
     __shared__ __attribute__((aligned(16))) half8 w2l[8 * 4 * 64];        // [tile t][k block p][lane]
     __shared__ __attribute__((aligned(16))) half8 ostage[4][16 * 17];
     const int lane = threadIdx.x & 63;
@@ -324,6 +325,26 @@ __global__ __launch_bounds__(256) void local_mlp_kernel(
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 o2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[(t * 4 + p) * 64 + lane], hb[p], o2[t], 0, 0, 0);
+        }
+        if (logits_out) {
+            // the consumer only needs <out[row], dot_with[row]>: form it here from the fp16-rounded outputs (the values
+            // a stored row would have had) and write 4 bytes per row instead of 256
+            float dsum = 0.0f;
+            if (live) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const half8 cv = *reinterpret_cast<const half8*>(dot_with + (size_t)row * 128 + p * 32 + fg * 8);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        dsum += (float)(_Float16)o2[2 * p][i] * (float)cv[i];
+                        dsum += (float)(_Float16)o2[2 * p + 1][i] * (float)cv[4 + i];
+                    }
+                }
+            }
+            dsum += __shfl_xor(dsum, 16);
+            dsum += __shfl_xor(dsum, 32);
+            if (live && fg == 0) logits_out[row] = dsum;
+            continue;
         }
         // stage the wave's 16 x 128 tile in LDS and write whole 256-byte rows (4 rows per store instruction)
         half8* stg = ostage[threadIdx.x >> 6];
@@ -412,8 +433,11 @@ extern "C" int cpn_local_hidden(const float* loc8, const float* coords9, const f
 
 extern "C" int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
                              const float* add, const uint16_t* w2, int ldw2, const float* b2, int B, int V, int R, int S,
-                             int ray0, int nrays, uint16_t* out, void* stream) {
-    CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && out, CPN_E_ARG, "cpn_local_mlp: null pointer");
+                             int ray0, int nrays, uint16_t* out, const uint16_t* dot_with, float* logits_out,
+                             void* stream) {
+    CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && (out || (dot_with && logits_out)), CPN_E_ARG,
+                "cpn_local_mlp: null pointer");
+    CPN_REQUIRE(!logits_out || dot_with, CPN_E_ARG, "cpn_local_mlp: logits_out needs dot_with");
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && ldw1 >= 16 && ldw2 >= 128 && (ldw2 % 8) == 0, CPN_E_SHAPE,
                 "cpn_local_mlp: bad shape");
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
@@ -423,7 +447,7 @@ extern "C" int cpn_local_mlp(const float* loc8, const float* coords9, const floa
     const long long groups = cpn_cdiv(nrows, 16);
     const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(groups, 4), 2048);
     hipLaunchKernelGGL(local_mlp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
-                       (const __half*)w2, ldw2, b2, V, R, S, ray0, nrows, (__half*)out);
+                       (const __half*)w2, ldw2, b2, V, R, S, ray0, nrows, (__half*)out, (const __half*)dot_with, logits_out);
     CPN_LAUNCH_CHECK("cpn_local_mlp");
     return 0;
 }

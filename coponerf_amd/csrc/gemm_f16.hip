@@ -90,12 +90,15 @@ __device__ __forceinline__ TileWalk tile_walk(int total) {
 // ---------------------------------------------------------------------------------------------
 // The kernel (design notes at the top of the file).
 // ---------------------------------------------------------------------------------------------
-template <int NT, bool OUT_F32, bool RELU>
+// DOT: instead of storing C, store logits[m] = <fp16(C[m, :]), Q[m, :]> (one workgroup tile must span all N columns):
+// the consumer of key_map_2 only needs that row dot product (attention logits), 4 bytes per row instead of 256.
+template <int NT, bool OUT_F32, bool RELU, bool DOT = false>
 __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict__ A, int lda,
                                                              const __half* __restrict__ W, int ldw,
                                                              const float* __restrict__ bias,
                                                              void* __restrict__ Cv, int ldc, int M, int K32, int n_tiles,
-                                                             int total_tiles) {
+                                                             int total_tiles, const __half* __restrict__ Q = nullptr,
+                                                             int ldq = 0) {
     using C_ = Cfg<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -301,7 +304,29 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
             }
         }
 
-        if constexpr (!OUT_F32) {
+        if constexpr (DOT) {
+            float dsum[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
+                const __half* qrow = Q + (size_t)(m < M ? m : M - 1) * ldq + n0 + (lane >> 4) * 4;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + nt * 16 + (lane >> 4) * 4);
+                    f32x4 v = acc[mt][nt] + bv;
+                    if (RELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+                    }
+                    const half4 qv = *reinterpret_cast<const half4*>(qrow + nt * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsum[mt] += (float)(_Float16)v[i] * (float)qv[i];
+                }
+                dsum[mt] += __shfl_xor(dsum[mt], 16);
+                dsum[mt] += __shfl_xor(dsum[mt], 32);
+                if (lane < 16 && m < M) ((float*)Cv)[m] = dsum[mt];
+            }
+        } else if constexpr (!OUT_F32) {
             // fp16 epilogue through LDS (activation slots 1 and 2; slot 0 is receiving the next tile): the accumulator
             // layout gives a lane 4 consecutive columns (8 B) of one row, i.e. 32-B row segments per store; staging
             // 16 x BN per wave and reading it back row-contiguously turns them into 16-byte stores that cover whole
@@ -391,8 +416,41 @@ int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias
         num_cu = n;
     }
     dim3 grid((unsigned)std::min<long long>(total, num_cu));       // persistent: one workgroup per CU
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles, (int)total);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles, (int)total,
+                       (const __half*)nullptr, 0);
     CPN_LAUNCH_CHECK("cpn_gemm_f16");
+    return 0;
+}
+
+// key_map_2-style launch: N == 16*NT (one tile spans the row), logits (M) fp32 out
+template <int NT>
+int launch_rowdot(const __half* A, int lda, const __half* W, int ldw, const float* bias, const __half* Q, int ldq,
+                  float* logits, int M, int K32, hipStream_t stream) {
+    using C_ = Cfg<NT>;
+    const size_t lds = C_::LDS_BYTES;
+    auto kern = gemm_f16_kernel<NT, false, false, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            cpn_set_error("cpn_gemm_f16_rowdot: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const long long total = cpn_cdiv(M, BM);
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        num_cu = n;
+    }
+    dim3 grid((unsigned)std::min<long long>(total, num_cu));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, (void*)logits, 0, M, K32, 1, (int)total, Q,
+                       ldq);
+    CPN_LAUNCH_CHECK("cpn_gemm_f16_rowdot");
     return 0;
 }
 
@@ -429,4 +487,18 @@ extern "C" int cpn_gemm_f16(const uint16_t* A, int lda, const uint16_t* W, int l
     if (N % 128 == 0) return dispatch<8>(a, lda, w, ldw, bias, C, ldc, M, N, K / 32, relu, out_f32, s);
     cpn_set_error("cpn_gemm_f16: N=%d is neither a multiple of 208 nor of 128", N);
     return CPN_E_SHAPE;
+}
+
+extern "C" int cpn_gemm_f16_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                                   const uint16_t* Q, int ldq, float* logits, int M, int N, int K, void* stream) {
+    CPN_REQUIRE(A && W && bias && Q && logits, CPN_E_ARG, "cpn_gemm_f16_rowdot: null pointer");
+    CPN_REQUIRE(M > 0 && N == 128 && K > 0 && (K % 32) == 0, CPN_E_SHAPE, "cpn_gemm_f16_rowdot: need N == 128, K %% 32 == 0");
+    CPN_REQUIRE(lda >= K && ldw >= K && (lda % 8) == 0 && (ldw % 8) == 0 && ldq >= N && (ldq % 4) == 0, CPN_E_SHAPE,
+                "cpn_gemm_f16_rowdot: bad leading dimension");
+    CPN_REQUIRE((long long)256 * lda * 2 < (1LL << 31) && (long long)N * ldw * 2 < (1LL << 31), CPN_E_SHAPE,
+                "cpn_gemm_f16_rowdot: tile exceeds the 32-bit buffer offset range");
+    CPN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)Q % 8) == 0 &&
+                    ((uintptr_t)bias % 16) == 0, CPN_E_ARG, "cpn_gemm_f16_rowdot: pointers must be aligned");
+    return launch_rowdot<8>((const __half*)A, lda, (const __half*)W, ldw, bias, (const __half*)Q, ldq, logits, M, K / 32,
+                            (hipStream_t)stream);
 }

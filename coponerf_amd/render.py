@@ -353,19 +353,21 @@ class RenderEngine:
         def lane_buffers(lane):
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
             bufs = {"xin": t("xin", (C * T * 2, _hip.XIN_STRIDE), f16), "hid": t("hid", (C * T * 2, 832), f16),
-                    "kh": t("kh", (C * T, 128), f16), "key2": t("key2", (C * T, 128), f16),
-                    "ce": t("ce", (C * T, 128), f16), "q2": t("q2", (C * T, 128), f16),
+                    "kh": t("kh", (C * T, 128), f16), "ce": t("ce", (C * T, 128), f16),
+                    "lg": t("lg", (C * T,), f32),
                     "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
             if not self.fold_value:
                 bufs["enc"] = t("enc", (C * T, 832), f16)
                 bufs["value"] = t("value", (C * T, 416), f32)
+                bufs["key2"] = t("key2", (C * T, 128), f16)
+                bufs["q2"] = t("q2", (C * T, 128), f16)
             return bufs
 
         def run_chunk(ray0, bf, s):
-            xin, hid, kh, key2, ce, q2 = (bf[k] for k in ("xin", "hid", "kh", "key2", "ce", "q2"))
+            xin, hid, kh, ce, lg = (bf[k] for k in ("xin", "hid", "kh", "ce", "lg"))
             z1, ze, addq, hbar, zs = (bf[k] for k in ("z1", "ze", "addq", "hbar", "zs"))
-            enc, value = bf.get("enc"), bf.get("value")
+            enc, value, key2, q2 = bf.get("enc"), bf.get("value"), bf.get("key2"), bf.get("q2")
 
             def gemm(a, lda, wname, out, ldc, m, n, k, relu, out_f32):
                 prof = self.profile
@@ -390,16 +392,19 @@ class RenderEngine:
                 gemm(hid, 832, "query_encode_latent_2", enc, 416, rows2, 416, 832, False, False)
                 gemm(enc, 832, "latent_value", value, 416, rows, 416, 832, False, True)
                 gemm(enc, 832, "key_map", kh, 128, rows, 128, 832, True, False)
-            gemm(kh, 128, "key_map_2", key2, 128, rows, 128, 128, False, False)
             call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
                  w["query_embed.b"].data_ptr(), 0, w["query_embed_2.w16"].data_ptr(), 128,
-                 w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, ce.data_ptr(), s)
+                 w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, ce.data_ptr(), 0, 0, s)
             # round 1 (CoPoNeRF.py:450-461)
             if self.fold_value:
-                call("cpn_attend_hidden", key2.data_ptr(), ce.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
+                # key_map_2 and the logit <key, coords_embed> in one pass: the (rows,128) key never reaches HBM
+                call("cpn_gemm_f16_rowdot", kh.data_ptr(), 128, w["key_map_2.w16"].data_ptr(), 128,
+                     w["key_map_2.b"].data_ptr(), ce.data_ptr(), 128, lg.data_ptr(), rows, 128, 128, s)
+                call("cpn_attend_hidden", 0, 0, lg.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
                      hbar.data_ptr(), at_wt.data_ptr(), s)
                 gemm(hbar, 1664, "value_fold", z1, 416, n, 416, 1664, False, True)
             else:
+                gemm(kh, 128, "key_map_2", key2, 128, rows, 128, 128, False, False)
                 call("cpn_attend", key2.data_ptr(), ce.data_ptr(), value.data_ptr(), 0, B, V, R, S, ray0, n,
                      z1.data_ptr(), at_wt.data_ptr(), s)
             # round 2 (CoPoNeRF.py:467-485)
@@ -407,16 +412,19 @@ class RenderEngine:
                  w["encode_latent.b"].data_ptr(), 0, 0, ze.data_ptr(), 128, n, 128, 416, 0, 0, s)
             call("cpn_linear_f32", ze.data_ptr(), 128, w["query_repeat_embed.w_z"].data_ptr(), 128, 0, 0, 0,
                  addq.data_ptr(), 128, n, 128, 128, 0, 0, s)
-            call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
-                 w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
-                 w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, q2.data_ptr(), s)
             if self.fold_value:
-                call("cpn_attend_hidden", q2.data_ptr(), ce.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
-                     hbar.data_ptr(), 0, s)
+                # the second query only enters through <query2, coords_embed>: local_mlp writes that logit directly
+                call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
+                     w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
+                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, 0, ce.data_ptr(), lg.data_ptr(), s)
+                call("cpn_attend_hidden", 0, 0, lg.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n, hbar.data_ptr(), 0, s)
                 gemm(hbar, 1664, "value_fold", zs, 416, n, 416, 1664, False, True)
                 # the round-1 vector sits in both view slots when the views are summed (CoPoNeRF.py:481-485)
                 torch.add(zs[:n], z1[:n], alpha=float(V), out=zl[ray0:ray0 + n])
             else:
+                call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
+                     w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
+                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, q2.data_ptr(), 0, 0, s)
                 call("cpn_attend", q2.data_ptr(), ce.data_ptr(), value.data_ptr(), z1.data_ptr(), B, V, R, S, ray0, n,
                      zl[ray0:ray0 + n].data_ptr(), 0, s)
 

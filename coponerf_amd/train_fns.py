@@ -134,7 +134,7 @@ class AttendHiddenFn(Function):
         nrays = B * R
         hbar = torch.empty(nrays, 1664, dtype=torch.float16, device=qa.device)
         w = torch.empty(B * V, R, S, dtype=torch.float32, device=qa.device)
-        call("cpn_attend_hidden", qa.data_ptr(), qb.data_ptr(), hid2.data_ptr(), B, V, R, S, 0, nrays, hbar.data_ptr(),
+        call("cpn_attend_hidden", qa.data_ptr(), qb.data_ptr(), 0, hid2.data_ptr(), B, V, R, S, 0, nrays, hbar.data_ptr(),
              w.data_ptr(), _stream())
         ctx.save_for_backward(qa, qb, hid2, w)
         ctx.dims = dims

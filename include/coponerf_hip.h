@@ -97,11 +97,17 @@ int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const uint16_t* 
 int cpn_local_hidden(const float* loc8, const float* coords9, const float* w, int ldw, const float* bias,
                      const float* add, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out, void* stream);
 
+/* key_map_2 + the attention logit in one pass (CoPoNeRF.py:408, 450): logits[m] = <fp16(A[m] . W^T + bias), Q[m]>,
+ * N = 128 (one tile spans the row), A (M,lda), W (128,ldw), Q (M,ldq) fp16, logits (M) fp32                          */
+int cpn_gemm_f16_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* Q,
+                        int ldq, float* logits, int M, int N, int K, void* stream);
+
 /* both layers of query_embed / query_repeat_embed in one pass (CoPoNeRF.py:446, 472-473):
  * out[row, 0:128] = fp16( W2 . fp16(relu(W1[:, 0:16] . L(row) + b1 + add[ray])) + b2 ), W2 (128, ldw2) fp16 packed   */
+/* dot_with (rows,128) fp16 + logits_out (rows) fp32, both or neither: write <out[row], dot_with[row]> instead of out */
 int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
                   const float* add, const uint16_t* w2, int ldw2, const float* b2, int B, int V, int R, int S,
-                  int ray0, int nrays, uint16_t* out, void* stream);
+                  int ray0, int nrays, uint16_t* out, const uint16_t* dot_with, float* logits_out, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).
@@ -122,8 +128,10 @@ int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const
 /* ---- K4': the same joint softmax, reducing the 1664 hidden activations [h_own ; h_other] of every sample ----
  * (value projection folded through query_encode_latent_2 and applied once per ray afterwards)
  *   hid (rays*V*S, 1664) fp16 = the (rows*2, 832) output of the first encoder layer; hbar (rays, 1664) fp16   */
-int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, int B, int V, int R, int S,
-                      int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream);
+/*   logits (rays*V*S) fp32 or NULL: the row dot products <qa[row], qb[row]> when the producing kernel already
+ *   formed them (cpn_gemm_f16_rowdot / cpn_local_mlp with logits_out); then qa, qb may be NULL                 */
+int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const float* logits, const uint16_t* hid, int B, int V,
+                      int R, int S, int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream);
 
 /* ---- K5: exact-fp32 per-ray linear layer (MFMA 16x16x4 f32)  Y = act_out( act_in(X) . W^T + bias + res ) --
  * replaces nn.Conv1d encode_latent (CoPoNeRF.py:468) and lightfield.ResnetFC (models/lightfield.py:131-167).
