@@ -207,6 +207,16 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         half8 xa0[2], wb0[NT], xa1[2], wb1[NT];
+        half4 qv[DOT ? 2 : 1][DOT ? NT : 1];               // DOT: the Q rows of this tile, in flight under the main loop
+        if constexpr (DOT) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
+                const __half* qrow = Q + (size_t)(m < M ? m : M - 1) * ldq + n0 + (lane >> 4) * 4;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) qv[mt][nt] = *reinterpret_cast<const half4*>(qrow + nt * 16);
+            }
+        }
         // slower waves may still be reading the previous tile's C staging out of activation slots 1-2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -309,7 +319,6 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
-                const __half* qrow = Q + (size_t)(m < M ? m : M - 1) * ldq + n0 + (lane >> 4) * 4;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + nt * 16 + (lane >> 4) * 4);
@@ -318,9 +327,8 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
                     }
-                    const half4 qv = *reinterpret_cast<const half4*>(qrow + nt * 16);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dsum[mt] += (float)(_Float16)v[i] * (float)qv[i];
+                    for (int i = 0; i < 4; ++i) dsum[mt] += (float)(_Float16)v[i] * (float)qv[mt][nt][i];
                 }
                 dsum[mt] += __shfl_xor(dsum[mt], 16);
                 dsum[mt] += __shfl_xor(dsum[mt], 32);
