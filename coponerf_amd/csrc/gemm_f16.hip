@@ -90,15 +90,20 @@ __device__ __forceinline__ TileWalk tile_walk(int total) {
 // ---------------------------------------------------------------------------------------------
 // The kernel (design notes at the top of the file).
 // ---------------------------------------------------------------------------------------------
-// DOT: instead of storing C, store logits[m] = <fp16(C[m, :]), Q[m, :]> (one workgroup tile must span all N columns):
+// DOT = 1: instead of storing C, store logits[m] = <fp16(C[m, :]), Q[m, :]> (one workgroup tile must span all N columns):
 // the consumer of key_map_2 only needs that row dot product (attention logits), 4 bytes per row instead of 256.
-template <int NT, bool OUT_F32, bool RELU, bool DOT = false>
+// DOT = 2: additionally chain a second 128 -> 128 layer in the epilogue, C2 = W2 . fp16(act(C)) + b2, and dot THAT with
+// Q (key_map -> ReLU -> key_map_2 -> logit in one kernel).  The accumulator layout of the first layer (lane = row,
+// columns nt*16 + fk*4 + 0..3) serves directly as the MFMA B operand of K block p = tile pair (2p, 2p+1); the W2
+// fragments are laid out in LDS for exactly that k order (k = 32p + fk*4 + e, 32p + 16 + fk*4 + e).
+template <int NT, bool OUT_F32, bool RELU, int DOT = 0>
 __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict__ A, int lda,
                                                              const __half* __restrict__ W, int ldw,
                                                              const float* __restrict__ bias,
                                                              void* __restrict__ Cv, int ldc, int M, int K32, int n_tiles,
                                                              int total_tiles, const __half* __restrict__ Q = nullptr,
-                                                             int ldq = 0) {
+                                                             int ldq = 0, const __half* __restrict__ W2 = nullptr,
+                                                             int ldw2 = 0, const float* __restrict__ bias2 = nullptr) {
     using C_ = Cfg<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -185,6 +190,16 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
     }                                                                           \
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 
+    half8* const w2l = reinterpret_cast<half8*>(smem + C_::LDS_BYTES);       // DOT == 2: [tile t][k block p][lane]
+    if constexpr (DOT == 2) {
+        for (int i = tid; i < NT * 4 * 64; i += 512) {
+            const int l = i & 63, p = (i >> 6) & 3, t = i >> 8;
+            const __half* src = W2 + (size_t)(t * 16 + (l & 15)) * ldw2 + p * 32 + (l >> 4) * 4;
+            const half4 lo = *reinterpret_cast<const half4*>(src), hi = *reinterpret_cast<const half4*>(src + 16);
+            w2l[i] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        __syncthreads();
+    }
     TileWalk walk = tile_walk(total_tiles);
     if (walk.cur >= walk.end) return;
     // stage 0 of the first tile; later tiles get theirs issued under the previous tile's epilogue
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
 
         half8 xa0[2], wb0[NT], xa1[2], wb1[NT];
         half4 qv[DOT ? 2 : 1][DOT ? NT : 1];               // DOT: the Q rows of this tile, in flight under the main loop
-        if constexpr (DOT) {
+        if constexpr (DOT != 0) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
@@ -314,22 +329,42 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
             }
         }
 
-        if constexpr (DOT) {
+        if constexpr (DOT != 0) {
             float dsum[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
+                f32x4 v[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + nt * 16 + (lane >> 4) * 4);
-                    f32x4 v = acc[mt][nt] + bv;
+                    v[nt] = acc[mt][nt] + *reinterpret_cast<const f32x4*>(bias + n0 + nt * 16 + (lane >> 4) * 4);
                     if (RELU) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+                        for (int i = 0; i < 4; ++i) v[nt][i] = fmaxf(v[nt][i], 0.0f);
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dsum[mt] += (float)(_Float16)v[i] * (float)qv[mt][nt][i];
                 }
+                if constexpr (DOT == 2) {
+                    half8 hb[NT / 2];
+#pragma unroll
+                    for (int p = 0; p < NT / 2; ++p)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            hb[p][i] = (_Float16)v[2 * p][i];
+                            hb[p][4 + i] = (_Float16)v[2 * p + 1][i];
+                        }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        f32x4 o2 = *reinterpret_cast<const f32x4*>(bias2 + t * 16 + (lane >> 4) * 4);
+#pragma unroll
+                        for (int p = 0; p < NT / 2; ++p)
+                            o2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[(t * 4 + p) * 64 + lane], hb[p], o2, 0, 0, 0);
+                        v[t] = o2;
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsum[mt] += (float)(_Float16)v[nt][i] * (float)qv[mt][nt][i];
                 dsum[mt] += __shfl_xor(dsum[mt], 16);
                 dsum[mt] += __shfl_xor(dsum[mt], 32);
                 if (lane < 16 && m < M) ((float*)Cv)[m] = dsum[mt];
@@ -425,18 +460,18 @@ int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias
     }
     dim3 grid((unsigned)std::min<long long>(total, num_cu));       // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles, (int)total,
-                       (const __half*)nullptr, 0);
+                       (const __half*)nullptr, 0, (const __half*)nullptr, 0, (const float*)nullptr);
     CPN_LAUNCH_CHECK("cpn_gemm_f16");
     return 0;
 }
 
-// key_map_2-style launch: N == 16*NT (one tile spans the row), logits (M) fp32 out
-template <int NT>
+// row-dot launches: N == 16*NT (one tile spans the row), logits (M) fp32 out; CHAIN adds the second 128 -> 128 layer
+template <int NT, bool RELU, int DOT>
 int launch_rowdot(const __half* A, int lda, const __half* W, int ldw, const float* bias, const __half* Q, int ldq,
-                  float* logits, int M, int K32, hipStream_t stream) {
+                  float* logits, int M, int K32, const __half* W2, int ldw2, const float* bias2, hipStream_t stream) {
     using C_ = Cfg<NT>;
-    const size_t lds = C_::LDS_BYTES;
-    auto kern = gemm_f16_kernel<NT, false, false, true>;
+    const size_t lds = C_::LDS_BYTES + (DOT == 2 ? NT * 4 * 64 * 16 : 0);
+    auto kern = gemm_f16_kernel<NT, false, RELU, DOT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -457,7 +492,7 @@ int launch_rowdot(const __half* A, int lda, const __half* W, int ldw, const floa
     }
     dim3 grid((unsigned)std::min<long long>(total, num_cu));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, (void*)logits, 0, M, K32, 1, (int)total, Q,
-                       ldq);
+                       ldq, W2, ldw2, bias2);
     CPN_LAUNCH_CHECK("cpn_gemm_f16_rowdot");
     return 0;
 }
@@ -507,6 +542,22 @@ extern "C" int cpn_gemm_f16_rowdot(const uint16_t* A, int lda, const uint16_t* W
                 "cpn_gemm_f16_rowdot: tile exceeds the 32-bit buffer offset range");
     CPN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)Q % 8) == 0 &&
                     ((uintptr_t)bias % 16) == 0, CPN_E_ARG, "cpn_gemm_f16_rowdot: pointers must be aligned");
-    return launch_rowdot<8>((const __half*)A, lda, (const __half*)W, ldw, bias, (const __half*)Q, ldq, logits, M, K / 32,
-                            (hipStream_t)stream);
+    return launch_rowdot<8, false, 1>((const __half*)A, lda, (const __half*)W, ldw, bias, (const __half*)Q, ldq, logits, M,
+                                      K / 32, nullptr, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cpn_gemm_f16_chain_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                                         const uint16_t* W2, int ldw2, const float* bias2, const uint16_t* Q, int ldq,
+                                         float* logits, int M, int K, void* stream) {
+    CPN_REQUIRE(A && W && bias && W2 && bias2 && Q && logits, CPN_E_ARG, "cpn_gemm_f16_chain_rowdot: null pointer");
+    CPN_REQUIRE(M > 0 && K > 0 && (K % 32) == 0, CPN_E_SHAPE, "cpn_gemm_f16_chain_rowdot: K %% 32 != 0");
+    CPN_REQUIRE(lda >= K && ldw >= K && (lda % 8) == 0 && (ldw % 8) == 0 && ldq >= 128 && (ldq % 4) == 0 && ldw2 >= 128 &&
+                    (ldw2 % 4) == 0, CPN_E_SHAPE, "cpn_gemm_f16_chain_rowdot: bad leading dimension");
+    CPN_REQUIRE((long long)256 * lda * 2 < (1LL << 31) && (long long)128 * ldw * 2 < (1LL << 31), CPN_E_SHAPE,
+                "cpn_gemm_f16_chain_rowdot: tile exceeds the 32-bit buffer offset range");
+    CPN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)Q % 8) == 0 && ((uintptr_t)W2 % 8) == 0 &&
+                    ((uintptr_t)bias % 16) == 0 && ((uintptr_t)bias2 % 16) == 0, CPN_E_ARG,
+                "cpn_gemm_f16_chain_rowdot: pointers must be aligned");
+    return launch_rowdot<8, true, 2>((const __half*)A, lda, (const __half*)W, ldw, bias, (const __half*)Q, ldq, logits, M,
+                                     K / 32, (const __half*)W2, ldw2, bias2, (hipStream_t)stream);
 }

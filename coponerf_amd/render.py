@@ -353,21 +353,21 @@ class RenderEngine:
         def lane_buffers(lane):
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
             bufs = {"xin": t("xin", (C * T * 2, _hip.XIN_STRIDE), f16), "hid": t("hid", (C * T * 2, 832), f16),
-                    "kh": t("kh", (C * T, 128), f16), "ce": t("ce", (C * T, 128), f16),
-                    "lg": t("lg", (C * T,), f32),
+                    "ce": t("ce", (C * T, 128), f16), "lg": t("lg", (C * T,), f32),
                     "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
             if not self.fold_value:
                 bufs["enc"] = t("enc", (C * T, 832), f16)
                 bufs["value"] = t("value", (C * T, 416), f32)
+                bufs["kh"] = t("kh", (C * T, 128), f16)
                 bufs["key2"] = t("key2", (C * T, 128), f16)
                 bufs["q2"] = t("q2", (C * T, 128), f16)
             return bufs
 
         def run_chunk(ray0, bf, s):
-            xin, hid, kh, ce, lg = (bf[k] for k in ("xin", "hid", "kh", "ce", "lg"))
+            xin, hid, ce, lg = (bf[k] for k in ("xin", "hid", "ce", "lg"))
             z1, ze, addq, hbar, zs = (bf[k] for k in ("z1", "ze", "addq", "hbar", "zs"))
-            enc, value, key2, q2 = bf.get("enc"), bf.get("value"), bf.get("key2"), bf.get("q2")
+            enc, value, kh, key2, q2 = (bf.get(k) for k in ("enc", "value", "kh", "key2", "q2"))
 
             def gemm(a, lda, wname, out, ldc, m, n, k, relu, out_f32):
                 prof = self.profile
@@ -386,9 +386,7 @@ class RenderEngine:
                  H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, ray0, n,
                  xin.data_ptr(), s)
             gemm(xin, _hip.XIN_STRIDE, "query_encode_latent", hid, 832, rows2, 832, _hip.XIN_K, True, False)
-            if self.fold_value:
-                gemm(hid, 1664, "key_fold", kh, 128, rows, 128, 1664, True, False)     # (rows2,832) == (rows,1664)
-            else:
+            if not self.fold_value:
                 gemm(hid, 832, "query_encode_latent_2", enc, 416, rows2, 416, 832, False, False)
                 gemm(enc, 832, "latent_value", value, 416, rows, 416, 832, False, True)
                 gemm(enc, 832, "key_map", kh, 128, rows, 128, 832, True, False)
@@ -397,9 +395,18 @@ class RenderEngine:
                  w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, ce.data_ptr(), 0, 0, s)
             # round 1 (CoPoNeRF.py:450-461)
             if self.fold_value:
-                # key_map_2 and the logit <key, coords_embed> in one pass: the (rows,128) key never reaches HBM
-                call("cpn_gemm_f16_rowdot", kh.data_ptr(), 128, w["key_map_2.w16"].data_ptr(), 128,
-                     w["key_map_2.b"].data_ptr(), ce.data_ptr(), 128, lg.data_ptr(), rows, 128, 128, s)
+                # folded key_map -> ReLU -> key_map_2 -> <key, coords_embed> in ONE kernel over hid viewed as (rows,1664):
+                # neither the 128-wide hidden layer nor the key reaches HBM, only 4 bytes of logit per row
+                prof = self.profile
+                if prof is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                call("cpn_gemm_f16_chain_rowdot", hid.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664,
+                     w["key_fold.b"].data_ptr(), w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(),
+                     ce.data_ptr(), 128, lg.data_ptr(), rows, 1664, s)
+                if prof is not None:
+                    e1.record()
+                    prof.setdefault("gemm_f16:key_fold+key_map_2", []).append((e0, e1, 2.0 * rows * 128 * (1664 + 128)))
                 call("cpn_attend_hidden", 0, 0, lg.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
                      hbar.data_ptr(), at_wt.data_ptr(), s)
                 gemm(hbar, 1664, "value_fold", z1, 416, n, 416, 1664, False, True)

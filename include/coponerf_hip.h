@@ -102,6 +102,12 @@ int cpn_local_hidden(const float* loc8, const float* coords9, const float* w, in
 int cpn_gemm_f16_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* Q,
                         int ldq, float* logits, int M, int N, int K, void* stream);
 
+/* key_map (folded) -> ReLU -> key_map_2 -> logit in one kernel (CoPoNeRF.py:404-408, 450):
+ * logits[m] = < fp16( W2 . fp16(relu(A[m] . W^T + bias)) + bias2 ), Q[m] >, W (128,ldw), W2 (128,ldw2), Q (M,ldq) fp16  */
+int cpn_gemm_f16_chain_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                              const uint16_t* W2, int ldw2, const float* bias2, const uint16_t* Q, int ldq,
+                              float* logits, int M, int K, void* stream);
+
 /* both layers of query_embed / query_repeat_embed in one pass (CoPoNeRF.py:446, 472-473):
  * out[row, 0:128] = fp16( W2 . fp16(relu(W1[:, 0:16] . L(row) + b1 + add[ray])) + b2 ), W2 (128, ldw2) fp16 packed   */
 /* dot_with (rows,128) fp16 + logits_out (rows) fp32, both or neither: write <out[row], dot_with[row]> instead of out */
