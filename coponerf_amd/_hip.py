@@ -34,8 +34,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gn_relu": [_P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P],
     "cpn_gn_relu_bwd": [_P, _P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "cpn_conv_wgrad_planes": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -92,6 +92,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_abi_version.restype = ctypes.c_int
     handle.cpn_gather_bwd_chunks.argtypes = [_I, _I]
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
+    handle.cpn_conv4d_scratch.argtypes = [_I] * 7
+    handle.cpn_conv4d_scratch.restype = ctypes.c_longlong
     handle.cpn_conv_wgrad_scratch.argtypes = [_I, _I]
     handle.cpn_conv_wgrad_scratch.restype = ctypes.c_longlong
     handle.cpn_last_error.argtypes = []

@@ -93,6 +93,106 @@ __global__ __launch_bounds__(256) void conv4d_kernel(const float* __restrict__ x
     }
 }
 
+// Strided layers (k3 s2 on 32^4, k5 s4 on 64^4): the kernel above re-evaluates the s x s max-pool window for every tap
+// (k*k*s*s reads per output, channel and branch).  With a scratch buffer the two pooled volumes are formed once
+//   Ps[b,c,Y,X,sy',sx'] = max_{dy,dx<s} x[b,c,Y,X,sy'*s+dy,sx'*s+dx]     (query branch: support dims pooled)
+//   Pq[b,c,qy',qx',U,V] = max_{dy,dx<s} x[b,c,qy'*s+dy,qx'*s+dx,U,V]     (support branch: query dims pooled)
+// and the convolution reads k*k values per output, channel and branch.
+__global__ __launch_bounds__(256) void pool_support_kernel(const float* __restrict__ x, int Hs, int Ws, int s, int Os,
+                                                           int Ps_, long long planes, float* __restrict__ out) {
+    // planes = B*Cin*Hq*Wq, each an (Hs,Ws) -> (Os,Ps_) max-pool with ceil mode
+    const long long total = planes * Os * Ps_;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int sx = (int)(i % Ps_);
+        long long t = i / Ps_;
+        const int sy = (int)(t % Os);
+        const long long pl = t / Os;
+        const float* base = x + pl * Hs * Ws;
+        float m = -INFINITY;
+        for (int dy = 0; dy < s; ++dy)
+            for (int dx = 0; dx < s; ++dx) {
+                const int yy = sy * s + dy, xx = sx * s + dx;
+                if (yy < Hs && xx < Ws) m = fmaxf(m, base[(size_t)yy * Ws + xx]);
+            }
+        out[i] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_query_kernel(const float* __restrict__ x, int Hq, int Wq, int Hs, int Ws,
+                                                         int s, int Oq, int Pq_, long long bc, float* __restrict__ out) {
+    // out[bc, qy', qx', U, V]; consecutive threads walk (U,V): contiguous reads of s*s planes
+    const long long P = (long long)Hs * Ws, total = bc * Oq * Pq_ * P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long uv = i % P;
+        long long t = i / P;
+        const int qx = (int)(t % Pq_); t /= Pq_;
+        const int qy = (int)(t % Oq);
+        const long long c = t / Oq;
+        const float* base = x + c * Hq * Wq * P + uv;
+        float m = -INFINITY;
+        for (int dy = 0; dy < s; ++dy)
+            for (int dx = 0; dx < s; ++dx) {
+                const int yy = qy * s + dy, xx = qx * s + dx;
+                if (yy < Hq && xx < Wq) m = fmaxf(m, base[((size_t)yy * Wq + xx) * P]);
+            }
+        out[i] = m;
+    }
+}
+
+// same contract as conv4d_kernel, reading the pooled volumes
+__global__ __launch_bounds__(256) void conv4d_pooled_kernel(const float* __restrict__ ps, const float* __restrict__ pq,
+                                                            const float* __restrict__ wq, const float* __restrict__ bq,
+                                                            const float* __restrict__ ws, const float* __restrict__ bs,
+                                                            int Cin, int Hq, int Wq, int Hs, int Ws, int k, int s, int p,
+                                                            int Oq, int Pq_, int Os, int Ps_, float* __restrict__ y,
+                                                            double* __restrict__ stats) {
+    const int o = blockIdx.y, b = blockIdx.z, Cout = gridDim.y;
+    const long long npos = (long long)Oq * Pq_ * Os * Ps_;
+    const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float val = 0.0f;
+    const bool active = pos < npos;
+    if (active) {
+        int sx = (int)(pos % Ps_);
+        long long t = pos / Ps_;
+        const int sy = (int)(t % Os); t /= Os;
+        const int qx = (int)(t % Pq_);
+        const int qy = (int)(t / Pq_);
+        const size_t ps_c = (size_t)Hq * Wq * Os * Ps_, pq_c = (size_t)Oq * Pq_ * Hs * Ws;
+        const float* psb = ps + (size_t)b * Cin * ps_c;
+        const float* pqb = pq + (size_t)b * Cin * pq_c;
+        float acc = bq[o] + bs[o];
+        for (int c = 0; c < Cin; ++c) {
+            const float* wqc = wq + ((size_t)o * Cin + c) * k * k;
+            const float* wsc = ws + ((size_t)o * Cin + c) * k * k;
+            for (int i = 0; i < k; ++i)
+                for (int j = 0; j < k; ++j) {
+                    const int Y = qy * s + i - p, X = qx * s + j - p;
+                    if (Y >= 0 && Y < Hq && X >= 0 && X < Wq)
+                        acc += wqc[i * k + j] * psb[c * ps_c + (((size_t)Y * Wq + X) * Os + sy) * Ps_ + sx];
+                    const int U = sy * s + i - p, Vv = sx * s + j - p;
+                    if (U >= 0 && U < Hs && Vv >= 0 && Vv < Ws)
+                        acc += wsc[i * k + j] * pqb[c * pq_c + (((size_t)qy * Pq_ + qx) * Hs + U) * Ws + Vv];
+                }
+        }
+        val = acc;
+        y[((size_t)b * Cout + o) * npos + pos] = acc;
+    }
+    double s1 = active ? (double)val : 0.0, s2 = active ? (double)val * val : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(stats + b * 2, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(stats + b * 2 + 1, red[1] + red[3] + red[5] + red[7]);
+    }
+}
+
 // stride-1 3x3x3x3 fast path (57 of the 63 Conv4d calls of a get_z): one thread computes ALL output channels of
 // its position, so every input value is read once per tap instead of once per (tap, output channel); the weights
 // are staged in LDS as [cin][tap][branch][cout] and read as wave-uniform (broadcast) 16-byte vectors.
@@ -591,9 +691,15 @@ extern "C" int cpn_resize_bilinear_ac(const float* src, float* dst, long long pl
     return 0;
 }
 
+extern "C" long long cpn_conv4d_scratch(int B, int Cin, int Hq, int Wq, int Hs, int Ws, int s) {
+    if (s <= 1) return 0;
+    auto po = [&](int n) { return (long long)((n + s - 1) / s); };
+    return (long long)B * Cin * ((long long)Hq * Wq * po(Hs) * po(Ws) + po(Hq) * po(Wq) * (long long)Hs * Ws);
+}
+
 extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, const float* ws, const float* bs, int B,
                           int Cin, int Cout, int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y,
-                          double* stats, void* stream) {
+                          double* stats, float* scratch, void* stream) {
     CPN_REQUIRE(x && wq && bq && ws && bs && y && stats, CPN_E_ARG, "cpn_conv4d: null pointer");
     CPN_REQUIRE(B > 0 && B < 65536 && Cin > 0 && Cout > 0 && Cout < 65536 && k > 0 && s > 0 && p >= 0, CPN_E_SHAPE,
                 "cpn_conv4d: bad shape");
@@ -614,6 +720,17 @@ extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, cons
         else
             hipLaunchKernelGGL(conv4d_k3s1_kernel<32>, g1, dim3(256), wbytes, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs,
                                Ws, y, stats);
+    } else if (s > 1 && scratch) {
+        float* psv = scratch;
+        float* pqv = scratch + (size_t)B * Cin * Hq * Wq * Os * Ps_;
+        const long long planes = (long long)B * Cin * Hq * Wq;
+        const long long n1 = planes * Os * Ps_, n2 = (long long)B * Cin * Oq * Pq_ * Hs * Ws;
+        hipLaunchKernelGGL(pool_support_kernel, dim3((unsigned)std::min<long long>(cpn_cdiv(n1, 256), 65536)), dim3(256), 0,
+                           st, x, Hs, Ws, s, Os, Ps_, planes, psv);
+        hipLaunchKernelGGL(pool_query_kernel, dim3((unsigned)std::min<long long>(cpn_cdiv(n2, 256), 65536)), dim3(256), 0,
+                           st, x, Hq, Wq, Hs, Ws, s, Oq, Pq_, (long long)B * Cin, pqv);
+        hipLaunchKernelGGL(conv4d_pooled_kernel, grid, dim3(256), 0, st, psv, pqv, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, k, s,
+                           p, Oq, Pq_, Os, Ps_, y, stats);
     } else {
         hipLaunchKernelGGL(conv4d_kernel, grid, dim3(256), 0, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, k, s, p, Oq,
                            Pq_, Os, Ps_, y, stats);
@@ -634,9 +751,10 @@ extern "C" int cpn_gn_relu(const float* y, const double* stats, const float* gn_
 
 extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
                                   const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout, int Hq,
-                                  int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream) {
+                                  int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, float* scratch,
+                                  void* stream) {
     CPN_REQUIRE(gn_w && gn_b, CPN_E_ARG, "cpn_conv4d_gn_relu: null pointer");
-    int rc = cpn_conv4d(x, wq, bq, ws, bs, B, Cin, Cout, Hq, Wq, Hs, Ws, k, s, p, y, stats, stream);
+    int rc = cpn_conv4d(x, wq, bq, ws, bs, B, Cin, Cout, Hq, Wq, Hs, Ws, k, s, p, y, stats, scratch, stream);
     if (rc) return rc;
     auto co = [&](int n) { return (n + 2 * p - k) / s + 1; };
     const long long npos = (long long)co(Hq) * co(Wq) * co(Hs) * co(Ws);

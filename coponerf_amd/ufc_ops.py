@@ -110,7 +110,7 @@ class _Conv4dGnReluFn(Function):
                 scratch = torch.zeros(B, 2, dtype=torch.float64, device=dev)
                 wq_t, ws_t = flip(wq), flip(ws)
                 call("cpn_conv4d", dy.data_ptr(), wq_t.data_ptr(), zb.data_ptr(), ws_t.data_ptr(), zb.data_ptr(), B, C, Cin,
-                     Hq, Wq, Hs, Ws, 3, 1, 1, gx.data_ptr(), scratch.data_ptr(), _stream())
+                     Hq, Wq, Hs, Ws, 3, 1, 1, gx.data_ptr(), scratch.data_ptr(), 0, _stream())
             if need_w and Cin <= 32 and C <= 32 and Hs * Ws <= 256 and Hq * Wq <= 256 and min(Ws, Wq) >= 4:
                 # both separable branches on the HIP weight-gradient kernel; the query branch sees the volumes with
                 # the (query, support) index pairs swapped so that its 3x3 window runs over the last two dims too
@@ -266,16 +266,20 @@ class HipOps:
         stats = torch.zeros(B, 2, device=x.device, dtype=torch.float64)
         f = lambda t: t.detach().contiguous().float()
         wq_, bq_, ws_, bs_, gw, gb = f(wq), f(bq), f(ws), f(bs), f(gn_w), f(gn_b)
+        from . import _hip
+        nscr = _hip.lib().cpn_conv4d_scratch(B, Cin, Hq, Wq, Hs, Ws, s)      # pooled volumes of a strided layer
+        scr = torch.empty(nscr, dtype=torch.float32, device=x.device) if nscr else None
+        scr_p = scr.data_ptr() if scr is not None else 0
         if keep_pre:                                  # training: pre-normalisation volume kept for the backward pass
             call("cpn_conv4d", x.data_ptr(), wq_.data_ptr(), bq_.data_ptr(), ws_.data_ptr(), bs_.data_ptr(), B, Cin, Cout,
-                 Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(), stats.data_ptr(), _stream())
+                 Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(), stats.data_ptr(), scr_p, _stream())
             out = torch.empty_like(y)
             call("cpn_gn_relu", y.data_ptr(), stats.data_ptr(), gw.data_ptr(), gb.data_ptr(), float(eps), B, Cout,
                  y[0, 0].numel(), out.data_ptr(), _stream())
             return y, out, stats
         call("cpn_conv4d_gn_relu", x.data_ptr(), wq_.data_ptr(), bq_.data_ptr(), ws_.data_ptr(), bs_.data_ptr(),
              gw.data_ptr(), gb.data_ptr(), float(eps), B, Cin, Cout, Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(),
-             stats.data_ptr(), _stream())
+             stats.data_ptr(), scr_p, _stream())
         return y, stats
 
     def correlation_tokens(self, src, trg, fs):

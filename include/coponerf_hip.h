@@ -171,15 +171,20 @@ int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float
  * replaces conv4d.Conv4d / MaxPool4d / Encoder4D (models/conv4d.py:7-30, 57-163) and the einops rearrange copies
  * around them.  x (B,Cin,Hq,Wq,Hs,Ws) fp32; wq/ws (Cout,Cin,k,k), bq/bs (Cout): query / support 2-D kernels;
  * y (B,Cout,Hq',Wq',Hs',Ws') with n' = (n + 2p - k)/s + 1; gn_w/gn_b (Cout) GroupNorm affine;
- * stats (B,2) float64 scratch that MUST be zero on entry (sum, sum of squares per sample).                  */
+ * stats (B,2) float64 scratch that MUST be zero on entry (sum, sum of squares per sample).
+ * scratch: cpn_conv4d_scratch(...) floats for the pooled volumes of a strided layer (0 for stride 1; NULL = no scratch,
+ * the pooling window is then re-evaluated per tap).                                                             */
+long long cpn_conv4d_scratch(int B, int Cin, int Hq, int Wq, int Hs, int Ws, int s);
 int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
                        const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout,
-                       int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream);
+                       int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, float* scratch,
+                       void* stream);
 
 /* the two halves of K6 on their own (training keeps the pre-normalisation volume; the data gradient of a stride-1
  * Conv4d is a Conv4d with flipped, transposed kernels): conv (+pool) -> y and the GroupNorm sums; y -> out           */
 int cpn_conv4d(const float* x, const float* wq, const float* bq, const float* ws, const float* bs, int B, int Cin,
-               int Cout, int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, void* stream);
+               int Cout, int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, float* scratch,
+               void* stream);
 int cpn_gn_relu(const float* y, const double* stats, const float* gn_w, const float* gn_b, float eps, int B, int C,
                 long long npos, float* out, void* stream);
 /* backward of GroupNorm(1 group) + ReLU (autograd of models/conv4d.py:150-158): y pre-normalisation volume, out the
