@@ -52,7 +52,7 @@ class GemmFn(Function):
         A16, W16, C = ctx.saved_tensors
         d = dC
         if ctx.relu:
-            d = d * (C > 0)
+            d = torch.ops.aten.threshold_backward(dC.contiguous(), C, 0)     # one pass: dC where C > 0
         d16 = d.to(torch.float16)
         dA = torch.matmul(d16, W16) if ctx.needs_input_grad[0] else None            # (M, lda): pad columns get 0
         dW = _mm_f32(d16.t(), A16)[:, :ctx.K] if ctx.needs_input_grad[1] else None
@@ -118,7 +118,7 @@ class LocalHiddenFn(Function):
     def backward(ctx, dout):
         loc8, coords9, out = ctx.saved_tensors
         B, V, R, S = ctx.dims
-        d = (dout * (out > 0)).float()
+        d = torch.ops.aten.threshold_backward(dout.contiguous(), out, 0).float()
         L = build_local_coords(loc8, coords9, B, V, R, S)
         dW = d.t() @ L
         dadd = d.view(B * R, V * S, 128).sum(1) if ctx.has_add else None
