@@ -99,6 +99,11 @@ class CoPoNeRF(nn.Module):
     def _render_params(self) -> Dict[str, torch.Tensor]:
         return {k: v for k, v in self.named_parameters() if k.split(".")[0] in RENDER_PARAM_PREFIXES}
 
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self._engine.invalidate()               # packed fp16 weights / tables are derived from the parameters
+        return out
+
     def get_z(self, input, val: bool = False, ops=None):
         """Features, estimated relative pose and flows (models/CoPoNeRF.py:159-206):
         ([(2B,256,16,16),(2B,256,32,32),(2B,256,64,64),(2B,64,256,256)], (B,4,4), 4 x (B,2,64,64)).

@@ -23,6 +23,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_nchw_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
     "cpn_pack_weight_f16": [_P, _I, _I, _P, _I, _P],
     "cpn_gather_rows": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_pack_encode_weights": [_P, _I, _P, _P, _P, _P, _P],
+    "cpn_encode_hidden": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
@@ -51,6 +53,7 @@ SIGNATURES: Dict[str, List] = {
 CAM_STRIDE = 96
 CAM_TQ, CAM_M, CAM_AOWN, CAM_AOTH, CAM_KQ, CAM_KC, CAM_KO, CAM_KN = 0, 16, 32, 48, 64, 68, 72, 76
 XIN_K, XIN_STRIDE = 864, 896
+TAB_LD, TAB_SLICE = 896, 224
 ABI_VERSION = 1
 
 

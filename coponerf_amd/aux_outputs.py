@@ -57,15 +57,17 @@ _FLOW_CACHE: Dict[str, tuple] = {}
 
 def _flow_products(flow: Sequence[torch.Tensor], width: int):
     """(cycle mask of view 2, flow upsampled to 256x256): functions of the flows alone, so a full-image render that
-    calls forward() once per ray chunk with the same `flow` computes them once (keyed on storage and version)."""
-    key = tuple((f.data_ptr(), f._version, tuple(f.shape)) for f in flow[:2]) + (width,)
+    calls forward() once per ray chunk with the same `flow` tensors computes them once."""
+    key = tuple((f._version, tuple(f.shape)) for f in flow[:2]) + (width,)
     hit = _FLOW_CACHE.get("entry")
-    if hit is not None and hit[0] == key:
+    # the entry holds the flow tensors themselves and is matched on IDENTITY (+ version): a new pair's flows that
+    # happen to be allocated at a freed pair's addresses can never hit it
+    if hit is not None and hit[0] == key and hit[3][0] is flow[0] and hit[3][1] is flow[1]:
         return hit[1], hit[2]
     _, mask2 = cycle_masks(flow, width)
     flow_up = F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])
     if not any(f.requires_grad for f in flow[:2]):
-        _FLOW_CACHE["entry"] = (key, mask2, flow_up)
+        _FLOW_CACHE["entry"] = (key, mask2, flow_up, (flow[0], flow[1]))
     return mask2, flow_up
 
 

@@ -134,13 +134,6 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
             lmax = fmaxf(lmax, logit);
         }
     } else
-    if (logits) {                                         // row dot products already formed by the producing kernel
-        for (int row = tid; row < T; row += 256) {
-            const float logit = logits[row0 + row] / 11.31f;
-            wts[row] = logit;
-            lmax = fmaxf(lmax, logit);
-        }
-    } else
     for (int base = 0; base < T; base += 128) {
         const int row = base + (tid >> 1);
         if (row < T) {

@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "taps.h"
 
 extern "C" long long cpn_gather_bwd_chunks(int R, int S);
 
@@ -104,39 +105,6 @@ __global__ __launch_bounds__(256) void attend_hidden_bwd_kernel(
             *reinterpret_cast<half8*>(dhid + (row0 + row) * HC + tid * 8) = o;
         }
     }
-}
-
-// ---- bilinear taps exactly as the forward gather (gather.hip: make_taps) -----------------------------------
-struct Taps {
-    int off[4];
-    float w[4];
-};
-__device__ __forceinline__ Taps make_taps(float gx, float gy, int Wl, int Hl, bool border) {
-    float x = ((gx + 1.0f) * (float)Wl - 1.0f) / 2.0f;
-    float y = ((gy + 1.0f) * (float)Hl - 1.0f) / 2.0f;
-    if (border) {
-        x = fminf(fmaxf(x, 0.0f), (float)(Wl - 1));
-        y = fminf(fmaxf(y, 0.0f), (float)(Hl - 1));
-    } else {
-        x = fminf(fmaxf(x, -2.0f), (float)Wl + 1.0f);
-        y = fminf(fmaxf(y, -2.0f), (float)Hl + 1.0f);
-    }
-    const float xf = floorf(x), yf = floorf(y);
-    const int x0 = (int)xf, y0 = (int)yf;
-    const float fx = x - xf, fy = y - yf;
-    Taps t;
-    const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy};
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int xi = x0 + i, yi = y0 + j;
-            const bool inside = (xi >= 0) && (xi <= Wl - 1) && (yi >= 0) && (yi <= Hl - 1);
-            const int xc = min(max(xi, 0), Wl - 1), yc = min(max(yi, 0), Hl - 1);
-            t.off[j * 2 + i] = yc * Wl + xc;
-            t.w[j * 2 + i] = inside ? wx[i] * wy[j] : 0.0f;
-        }
-    return t;
 }
 
 // Scatter-add of the gather gradient without atomic contention.

@@ -17,14 +17,16 @@ import torch
 import torch.distributed as dist
 
 
-def _buckets(tensors: List[torch.Tensor], bucket_bytes: int) -> List[List[torch.Tensor]]:
+def _buckets(items: List, bucket_bytes: int, key=lambda t: t) -> List[List]:
+    """Greedy split of `items` (tensors, or records whose tensor is key(item)) into same-dtype buckets."""
     out, cur, size = [], [], 0
-    for t in tensors:
+    for it in items:
+        t = key(it)
         nb = t.numel() * t.element_size()
-        if cur and (size + nb > bucket_bytes or t.dtype != cur[0].dtype):
+        if cur and (size + nb > bucket_bytes or t.dtype != key(cur[0]).dtype):
             out.append(cur)
             cur, size = [], 0
-        cur.append(t)
+        cur.append(it)
         size += nb
     if cur:
         out.append(cur)
@@ -36,31 +38,54 @@ def grads_finite(params: Iterable[torch.nn.Parameter], group=None) -> bool:
     grads = [p.grad for p in params if p.grad is not None]
     ok = torch.ones((), dtype=torch.float32, device=grads[0].device if grads else "cpu")
     if grads:
-        sq = torch.stack([g.detach().float().pow(2).sum() for g in grads]).sum()
-        ok = torch.isfinite(sq).float()
+        # isfinite per tensor (the reference tests isnan/isinf, wrapper.py:47-57): a sum of squares would overflow
+        # to inf on large-but-finite gradients and skip the step on every rank
+        ok = torch.stack([torch.isfinite(g.detach()).all() for g in grads]).all().float()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     return bool(ok.item() > 0)
 
 
 def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None) -> int:
-    """In-place gradient averaging across ranks; returns the number of collectives issued."""
+    """In-place gradient averaging across ranks; returns the number of data collectives issued.
+
+    Parameters without a gradient are skipped like wrapper.py:26 does.  The flat buckets need the SAME set of
+    gradients on every rank (the reference's per-parameter loop hangs just the same when one rank lacks a gradient
+    another has): one MAX all-reduce of the has-gradient mask establishes the union, and a rank missing one of those
+    gradients contributes zeros for it (its own `.grad` stays None)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     world = dist.get_world_size(group)
     if world == 1:
         return 0
-    grads = [p.grad.data for p in params if p.grad is not None]     # skip-None like wrapper.py:26
+    plist = [p for p in params]
+    if not plist:
+        return 0
+    dev = next((p.grad.device for p in plist if p.grad is not None), plist[0].device)
+    mask = torch.tensor([p.grad is not None for p in plist], dtype=torch.int32, device=dev)
+    dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
+    union = mask.bool().tolist()
+    grads, owned = [], []
+    for p, u in zip(plist, union):
+        if not u:
+            continue
+        if p.grad is not None:
+            grads.append(p.grad.data)
+            owned.append(True)
+        else:
+            grads.append(torch.zeros_like(p.data))
+            owned.append(False)
     handles = []
-    for bucket in _buckets(grads, bucket_bytes):
-        flat = torch.cat([g.reshape(-1) for g in bucket])
+    for bucket in _buckets(list(zip(grads, owned)), bucket_bytes, key=lambda t: t[0]):
+        flat = torch.cat([g.reshape(-1) for g, _ in bucket])
         handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, bucket))
     for work, flat, bucket in handles:
         work.wait()
         flat.div_(world)
         off = 0
-        for g in bucket:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
+        for g, mine in bucket:
+            if mine:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
     return len(handles)
 
@@ -79,6 +104,9 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, bucket_bytes: in
             t.copy_(flat[off:off + t.numel()].view_as(t))
             off += t.numel()
         n += 1
+    engine = getattr(module, "_engine", None)
+    if engine is not None:          # `.data` writes do not bump the version counters the weight cache is keyed on
+        engine.invalidate()
     return n
 
 

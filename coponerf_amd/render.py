@@ -97,8 +97,11 @@ class RenderEngine:
         "query_repeat_embed_2": (128, 128, 128),
     }
 
-    def __init__(self, chunk_rays: int = 16384, fold_value: bool = True, lanes: int = 1):
+    def __init__(self, chunk_rays: int = 16384, fold_value: bool = True, lanes: int = 1, tables: bool = True):
         self.chunk_rays = int(chunk_rays)
+        # tables=True: first encoder layer from pre-projected feature tables (cpn_encode_hidden, csrc/encode.hip);
+        # False: gather the 835-channel rows and run the 835 -> 832 GEMM on them (the form the training pass uses)
+        self.tables = bool(tables)
         # ray chunks are independent: `lanes` HIP streams, each with its own workspace, take the chunks round-robin so
         # that the HBM-bound stages of one chunk (gather, hidden sums) run under the MFMA-bound GEMMs of another
         self.lanes = max(1, int(lanes))
@@ -109,7 +112,10 @@ class RenderEngine:
         self._wkey = None
         self._w: Dict[str, torch.Tensor] = {}
         self._mkey = None
+        self._mrefs: Tuple[torch.Tensor, ...] = ()
         self._maps: List[torch.Tensor] = []
+        self._tabs: List[torch.Tensor] = []
+        self._wgen = 0                  # bumped whenever the packed weights are rebuilt (the tables depend on them)
         self._ws: Dict[str, torch.Tensor] = {}
         self._interval: Dict[Tuple[int, str], torch.Tensor] = {}
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops)
@@ -125,8 +131,17 @@ class RenderEngine:
             self._ws[name] = t
         return t[:n].view(*shape)
 
+    def invalidate(self) -> None:
+        """Drop the packed-weight / feature-map caches.  The caches are keyed on tensor identity and `_version`;
+        writes that bypass the version counter (`p.data.copy_`, `dist.broadcast(p.data)`: /root/reference
+        train.py:58-60) must be followed by this call — CoPoNeRF.load_state_dict and dist.broadcast_parameters do."""
+        self._wkey = None
+        self._mkey = None
+        self._mrefs = ()
+        self._maps, self._tabs = [], []
+
     def _weights(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        key = tuple((k, p.data_ptr(), p._version) for k, p in sorted(params.items()))
+        key = tuple((k, id(p), p.data_ptr(), p._version) for k, p in sorted(params.items()))
         if key == self._wkey:
             return self._w
         dev = params["query_encode_latent.weight"].device
@@ -176,22 +191,42 @@ class RenderEngine:
                 w[f"phi.blocks.{k}.{fc}.w"] = f32(f"phi.blocks.{k}.{fc}.weight")
                 w[f"phi.blocks.{k}.{fc}.b"] = f32(f"phi.blocks.{k}.{fc}.bias")
         w["phi.lin_out.w"], w["phi.lin_out.b"] = f32("phi.lin_out.weight"), f32("phi.lin_out.bias")
+        # ---- "project, then interpolate" form of the first layer (csrc/encode.hip): MFMA fragments of the
+        #      full-resolution / point-encoding columns and the table projection weights of the three coarse levels
+        W1 = f32("query_encode_latent.weight").reshape(832, 835)
+        w["enc.frag"] = torch.empty(4 * 3 * 13 * 64 * 8, dtype=torch.float16, device=dev)
+        w["enc.wtab"] = [torch.empty(_hip.TAB_LD, 256, dtype=torch.float16, device=dev) for _ in range(3)]
+        call("cpn_pack_encode_weights", W1.data_ptr(), 835, w["enc.frag"].data_ptr(), *(t.data_ptr() for t in w["enc.wtab"]), s)
+        w["enc.zero_bias"] = torch.zeros(_hip.TAB_LD, dtype=torch.float32, device=dev)
         self._w, self._wkey = w, key
+        self._wgen += 1
         return w
 
-    def _feature_maps(self, z: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in z)
-        if key == self._mkey:
-            return self._maps
-        maps, s = [], _stream()
+    def _feature_maps(self, z: Sequence[torch.Tensor], w: Dict[str, torch.Tensor]):
+        """NHWC fp16 copies of the four latent maps and, for the three coarse levels, their projection through the
+        first encoder layer (tables, csrc/encode.hip).  Cached per (z tensors, weight generation): the entry holds
+        strong references to the z tensors and compares identity, so a freed-and-reallocated tensor at the same
+        address can never hit it."""
+        key = tuple((t._version, tuple(t.shape)) for t in z) + (self._wgen if self.tables else -1,)
+        if key == self._mkey and len(self._mrefs) == len(z) and all(a is b for a, b in zip(self._mrefs, z)):
+            return self._maps, self._tabs
+        maps, tabs, s = [], [], _stream()
         for t in z:
             src = t.detach().float().contiguous()
             n, c, h, w_ = src.shape
             dst = torch.empty(n, h, w_, c, dtype=torch.float16, device=src.device)
             call("cpn_nchw_to_nhwc_f16", src.data_ptr(), dst.data_ptr(), n, c, h, w_, s)
             maps.append(dst)
-        self._maps, self._mkey = maps, key
-        return maps
+        if self.tables:
+            for lvl in range(3):
+                m = maps[lvl]
+                texels = m.shape[0] * m.shape[1] * m.shape[2]
+                tab = torch.empty(texels, _hip.TAB_LD, dtype=torch.float16, device=m.device)
+                call("cpn_gemm_f16", m.data_ptr(), 256, w["enc.wtab"][lvl].data_ptr(), 256, w["enc.zero_bias"].data_ptr(),
+                     tab.data_ptr(), _hip.TAB_LD, texels, _hip.TAB_LD, 256, 0, 0, s)
+                tabs.append(tab)
+        self._maps, self._tabs, self._mkey, self._mrefs = maps, tabs, key, tuple(z)
+        return maps, tabs
 
     # ---- geometry shared by the inference and the training pass (never differentiated) ----------------
     @torch.no_grad()
@@ -298,7 +333,7 @@ class RenderEngine:
         N = B * V
         s = _stream()
         w = self._weights(params)
-        maps = self._feature_maps(z)
+        maps, tabs = self._feature_maps(z, w)
 
         cam_cpu, Tq_cpu = build_camera_block(ctx_c2w.detach().float().cpu(), ctx_K.detach().float().cpu(),
                                              qry_c2w.detach().float().cpu(), qry_K.detach().float().cpu(),
@@ -352,10 +387,12 @@ class RenderEngine:
 
         def lane_buffers(lane):
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
-            bufs = {"xin": t("xin", (C * T * 2, _hip.XIN_STRIDE), f16), "hid": t("hid", (C * T * 2, 832), f16),
+            bufs = {"hid": t("hid", (C * T * 2, 832), f16),
                     "ce": t("ce", (C * T, 128), f16), "lg": t("lg", (C * T,), f32),
                     "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
+            if not self.tables:
+                bufs["xin"] = t("xin", (C * T * 2, _hip.XIN_STRIDE), f16)
             if not self.fold_value:
                 bufs["enc"] = t("enc", (C * T, 832), f16)
                 bufs["value"] = t("value", (C * T, 416), f32)
@@ -365,7 +402,8 @@ class RenderEngine:
             return bufs
 
         def run_chunk(ray0, bf, s):
-            xin, hid, ce, lg = (bf[k] for k in ("xin", "hid", "ce", "lg"))
+            hid, ce, lg = (bf[k] for k in ("hid", "ce", "lg"))
+            xin = bf.get("xin")
             z1, ze, addq, hbar, zs = (bf[k] for k in ("z1", "ze", "addq", "hbar", "zs"))
             enc, value, kh, key2, q2 = (bf.get(k) for k in ("enc", "value", "kh", "key2", "q2"))
 
@@ -382,10 +420,22 @@ class RenderEngine:
 
             n = min(C, nray_total - ray0)
             rows, rows2 = n * T, n * T * 2
-            call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
-                 H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, ray0, n,
-                 xin.data_ptr(), s)
-            gemm(xin, _hip.XIN_STRIDE, "query_encode_latent", hid, 832, rows2, 832, _hip.XIN_K, True, False)
+            if self.tables:
+                prof = self.profile
+                if prof is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                call("cpn_encode_hidden", tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), maps[3].data_ptr(),
+                     H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
+                     w["query_encode_latent.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), s)
+                if prof is not None:
+                    e1.record()
+                    prof.setdefault("encode_hidden", []).append((e0, e1, 2.0 * rows2 * 832 * 835))
+            else:
+                call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
+                     H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, ray0, n,
+                     xin.data_ptr(), s)
+                gemm(xin, _hip.XIN_STRIDE, "query_encode_latent", hid, 832, rows2, 832, _hip.XIN_K, True, False)
             if not self.fold_value:
                 gemm(hid, 832, "query_encode_latent_2", enc, 416, rows2, 416, 832, False, False)
                 gemm(enc, 832, "latent_value", value, 416, rows, 416, 832, False, True)

@@ -1,0 +1,75 @@
+"""One data-parallel training step of the drop-in model, as the reference's loop performs it.
+
+Mirrors /root/reference wrapper.py:104-151 for the default loss configuration (image loss only,
+models/loss_function.py:65-71, 105-108): forward with `val=False` (get_z inside), `|gt - rgb|.mean()`, backward,
+invalid-gradient guard, `clip_grad_norm_(max_norm=1)` BEFORE the exchange (wrapper.py:142-148), gradient averaging,
+Adam step.  The exchange and the guard are the RCCL-friendly forms of coponerf_amd/dist.py: one MIN-all-reduced finite
+flag (every rank takes the same branch: no deadlock) and a few flat buckets instead of <= 636 blocking per-parameter
+all-reduces.  One process per GPU; ranks draw independent batches (train.py:84-97 uses no DistributedSampler).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import dist as cdist
+
+
+class TrainStep:
+    def __init__(self, model: torch.nn.Module, lr: float = 5e-5 * 4, clip_grad: float = 1.0,
+                 bucket_bytes: int = 64 << 20, group=None):
+        self.model = model
+        self.params = [p for p in model.parameters()]
+        self.opt = torch.optim.Adam(self.params, lr=lr)                  # train.py:102-105 (both groups share lr)
+        self.clip_grad = clip_grad
+        self.bucket_bytes = bucket_bytes
+        self.group = group
+        self.timing: Optional[Dict[str, list]] = None                    # set to {} to collect HIP-event timings
+
+    def _ev(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def __call__(self, model_input: Dict, gt_rgb: torch.Tensor) -> Dict[str, object]:
+        """model_input: the reference's input dict on the device; gt_rgb (B,1,R,3).  Returns loss / bookkeeping."""
+        timed = self.timing is not None and torch.cuda.is_available()
+        e0 = self._ev() if timed else None
+        out = self.model(model_input, val=False)
+        zero = lambda t: torch.where(torch.isnan(t), torch.zeros_like(t), t)      # loss_function.py:66-69
+        loss = (zero(gt_rgb) - zero(out["rgb"])).abs().mean()
+        e1 = self._ev() if timed else None
+        loss.backward()
+        e2 = self._ev() if timed else None
+        stepped = cdist.grads_finite(self.params, group=self.group)      # same answer on every rank
+        ncoll, nbytes = 0, 0
+        if stepped:
+            if self.clip_grad:
+                torch.nn.utils.clip_grad_norm_(self.params, max_norm=float(self.clip_grad))
+            e3 = self._ev() if timed else None
+            ncoll = cdist.average_gradients(self.params, bucket_bytes=self.bucket_bytes, group=self.group)
+            if ncoll:
+                nbytes = sum(p.grad.numel() * p.grad.element_size() for p in self.params if p.grad is not None)
+            e4 = self._ev() if timed else None
+            self.opt.step()
+        else:
+            e3 = e4 = self._ev() if timed else None
+        self.opt.zero_grad(set_to_none=True)
+        e5 = self._ev() if timed else None
+        if timed:
+            self.timing.setdefault("events", []).append((e0, e1, e2, e3, e4, e5))
+        return {"loss": loss.detach(), "stepped": stepped, "collectives": ncoll, "allreduce_bytes": nbytes,
+                "at_wt": out["at_wt"].detach()}
+
+    def timing_summary(self) -> Dict[str, float]:
+        """Mean milliseconds per phase over the recorded steps (call after torch.cuda.synchronize())."""
+        ev = (self.timing or {}).get("events", [])
+        if not ev:
+            return {}
+        names = ("forward_ms", "backward_ms", "guard_clip_ms", "allreduce_ms", "optimizer_ms")
+        acc = [0.0] * 5
+        for e in ev:
+            for i in range(5):
+                acc[i] += e[i].elapsed_time(e[i + 1])
+        return {n: a / len(ev) for n, a in zip(names, acc)}

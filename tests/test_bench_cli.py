@@ -1,0 +1,35 @@
+"""bench.py launch contract on a box without a GPU: --gpus is honoured (round-1 verdict: it was parsed and ignored)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          env=e, timeout=300)
+
+
+def test_gpus_flag_spawns_or_refuses():
+    import torch
+    if torch.cuda.is_available():
+        return                                    # covered by the real bench run on the GPU box
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "--gpus 2 but only 0 HIP device(s) visible" in (r.stderr + r.stdout)
+
+
+def test_world_size_must_match_gpus():
+    r = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_modes_parse():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--mode", "train", "--gpus", "8"])
+    assert a.mode == "train" and a.gpus == 8 and a.train_rays == 4096
+    assert bench.parse_args([]).mode == "render"

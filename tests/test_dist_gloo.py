@@ -40,11 +40,20 @@ def _worker(rank, world, port, q):
     if rank == 1:
         next(model.parameters()).grad[0, 0] = float("nan")
     finite_after_nan = cd.grads_finite(model.parameters())   # False on BOTH ranks: same branch, no deadlock
+    # ---- ranks with DIFFERENT sets of gradients (rank 1 also trains the last Linear): no hang, the rank without the
+    #      gradient contributes zeros and keeps .grad None; large-but-finite gradients still count as finite
+    model.zero_grad(set_to_none=True)
+    (model(x) if rank == 1 else model[:3](x)).sum().backward()
+    local = None if model[3].weight.grad is None else model[3].weight.grad.clone()
+    cd.average_gradients(model.parameters(), bucket_bytes=512)
+    uneven_ok = (model[3].weight.grad is None) if rank == 0 else bool(torch.allclose(model[3].weight.grad, local / world))
+    model[0].weight.grad.fill_(1e30)                   # squares overflow fp32; the values themselves are finite
+    big_finite = cd.grads_finite(model.parameters())
     w0 = model[0].weight.detach().clone()
     gathered = [torch.zeros_like(w0) for _ in range(world)]
     dist.all_gather(gathered, w0)
     q.put((rank, ok, ncoll, nb, finite_all, finite_after_nan, bool(torch.equal(gathered[0], gathered[1])),
-           list(cd.shard_pairs(5, rank, world))))
+           uneven_ok, big_finite, list(cd.shard_pairs(5, rank, world))))
     dist.destroy_process_group()
 
 
@@ -59,8 +68,8 @@ def test_bucketed_allreduce_and_finite_flag_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, ncoll, nb, finite_all, finite_after_nan, synced, shard in res:
-        assert ok and synced
+    for rank, ok, ncoll, nb, finite_all, finite_after_nan, synced, uneven_ok, big_finite, shard in res:
+        assert ok and synced and uneven_ok and big_finite
         assert 1 <= ncoll < 6 and nb >= 1            # fewer collectives than the 6 gradient tensors
         assert finite_all is True and finite_after_nan is False
     assert res[0][-1] == [0, 2, 4] and res[1][-1] == [1, 3]

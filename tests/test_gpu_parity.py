@@ -267,3 +267,226 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libcoponerf_hip.so")
     with pytest.raises(_hip.HipLibraryError):
         _hip.lib()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2: the projected-table form of the first encoder layer (csrc/encode.hip) and the parity holes of round 1
+# ------------------------------------------------------------------------------------------------------------------
+def test_encode_hidden_against_torch(dev):
+    """cpn_encode_hidden (tables + K=96 MFMA) vs grid_sample + fp32 linear layer on the same fp16-rounded maps, and vs
+    the gather + GEMM form (cpn_gather_rows + cpn_gemm_f16); border + zeros padding, huge / on-texel coordinates,
+    a row count that is not a multiple of the 128-row tile."""
+    from coponerf_amd import _hip
+    from coponerf_amd._hip import call
+    from oracle.render_ref import gather_levels
+    torch.manual_seed(5)
+    B, V, R, S, H = 1, 2, 9, 20, 64                       # 9*2*20*2 = 720 rows = 5.6 tiles
+    N = B * V
+    z = [torch.randn(N, 256, H // 16, H // 16), torch.randn(N, 256, H // 8, H // 8),
+         torch.randn(N, 256, H // 4, H // 4), torch.randn(N, 64, H, H)]
+    z = [t.half().float() for t in z]
+    pv = torch.rand(N, R, S, 2) * 2.4 - 1.2
+    sg = torch.rand(N, R, S, 2) * 3 - 1.5
+    sg[0, 0, 0] = torch.tensor([1e10, -1e10])
+    sg[1, 0, 1] = torch.tensor([-1.0, 1.0])
+    pv[0, 1, 2] = torch.tensor([-1.0 + 1.0 / H, 1.0 - 1.0 / H])      # exactly on texel centres of the finest level
+    pe = torch.rand(N, R, S, 6) * 2 - 1
+    W1 = ((torch.rand(832, 835) * 2 - 1) / 835 ** 0.5)
+    b1 = (torch.rand(832) * 2 - 1) * 0.05
+    s = torch.cuda.current_stream().cuda_stream
+    maps = []
+    for t in z:
+        n, c, h, w = t.shape
+        d = torch.empty(n, h, w, c, dtype=torch.float16, device=dev)
+        src = t.to(dev).contiguous()
+        call("cpn_nchw_to_nhwc_f16", src.data_ptr(), d.data_ptr(), n, c, h, w, s)
+        maps.append(d)
+    W1d, b1d = W1.to(dev).contiguous(), b1.to(dev).contiguous()
+    frag = torch.empty(4 * 3 * 13 * 64 * 8, dtype=torch.float16, device=dev)
+    wtab = [torch.empty(_hip.TAB_LD, 256, dtype=torch.float16, device=dev) for _ in range(3)]
+    call("cpn_pack_encode_weights", W1d.data_ptr(), 835, frag.data_ptr(), *(t.data_ptr() for t in wtab), s)
+    zero_bias = torch.zeros(_hip.TAB_LD, device=dev)
+    tabs = []
+    for lvl in range(3):
+        m = maps[lvl]
+        texels = m.shape[0] * m.shape[1] * m.shape[2]
+        tab = torch.empty(texels, _hip.TAB_LD, dtype=torch.float16, device=dev)
+        call("cpn_gemm_f16", m.data_ptr(), 256, wtab[lvl].data_ptr(), 256, zero_bias.data_ptr(), tab.data_ptr(),
+             _hip.TAB_LD, texels, _hip.TAB_LD, 256, 0, 0, s)
+        tabs.append(tab)
+    pvd, sgd, ped = pv.to(dev), sg.to(dev), pe.to(dev)
+    rows = B * R * V * S * 2
+    hid = torch.full((rows, 832), float("nan"), dtype=torch.float16, device=dev)
+    call("cpn_encode_hidden", tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), maps[3].data_ptr(), H, H,
+         pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(), frag.data_ptr(), b1d.data_ptr(), B, V, R, S, 0, B * R,
+         hid.data_ptr(), s)
+    # ---- the gather + GEMM form on the same inputs
+    xin = torch.zeros(rows, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
+    call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, H,
+         pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(), B, V, R, S, 0, B * R, xin.data_ptr(), s)
+    W16 = torch.empty(832, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
+    call("cpn_pack_weight_f16", W1d.data_ptr(), 832, 835, W16.data_ptr(), _hip.XIN_STRIDE, s)
+    hid_g = torch.empty(rows, 832, dtype=torch.float16, device=dev)
+    call("cpn_gemm_f16", xin.data_ptr(), _hip.XIN_STRIDE, W16.data_ptr(), _hip.XIN_STRIDE, b1d.data_ptr(),
+         hid_g.data_ptr(), 832, rows, 832, _hip.XIN_K, 1, 0, s)
+    # ---- fp32 reference: grid_sample on the fp16-rounded maps, then the layer in float64
+    prim = gather_levels(z, pv, "border").view(B, V, R, S, 832)
+    z_swapped = [t.view(B, V, *t.shape[1:]).flip(1).reshape(t.shape) for t in z]
+    sec = gather_levels(z_swapped, sg, "zeros").view(B, V, R, S, 832)
+    pe5 = pe.view(B, V, R, S, 6)
+    x = torch.stack((torch.cat((prim, pe5[..., 0:3]), -1), torch.cat((sec, pe5[..., 3:6]), -1)), dim=4)   # (B,V,R,S,2,835)
+    x = x.permute(0, 2, 1, 3, 4, 5).reshape(rows, 835)                                                     # row order
+    want = torch.relu(x.double() @ W1.double().t() + b1.double()).float()
+    got, got_g = hid.float().cpu(), hid_g.float().cpu()
+    assert torch.isfinite(got).all()
+    scale = float(want.abs().max())
+    assert (got - want).abs().max() <= 4e-3 * max(1.0, scale), float((got - want).abs().max())
+    assert (got_g - want).abs().max() <= 4e-3 * max(1.0, scale)
+    # the two forms round differently (one fp16 rounding per table tap vs one per channel) but to the same accuracy
+    e_t = float((got - want).pow(2).mean().sqrt())
+    e_g = float((got_g - want).pow(2).mean().sqrt())
+    assert e_t <= 1.5 * e_g + 1e-5, (e_t, e_g)
+
+
+def test_table_mode_matches_gather_mode(model, dev, weights):
+    """RenderEngine(tables=False) materialises the gathered 835-channel rows and runs the 835 -> 832 GEMM on them
+    (round-1 form, still what the training pass differentiates); the default projected-table form must agree with it
+    and both with the oracle, on the narrow and the wide rig."""
+    for name in ("c1_val", "wide_val"):
+        cfg, gold = load_case(name)
+        ref, out_tab = run_pair(model, dev, weights, cfg)
+        model._engine.tables = False
+        try:
+            _, out_gat = run_pair(model, dev, weights, cfg)
+        finally:
+            model._engine.tables = True
+        assert torch.equal(out_tab["pixel_val"], out_gat["pixel_val"])
+        assert (out_tab["rgb"] - out_gat["rgb"]).abs().max() <= 5e-4
+        assert (out_tab["at_wt"] - out_gat["at_wt"]).abs().max() <= 1e-3
+        for o in (out_tab, out_gat):
+            assert (o["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
+            assert (o["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max() <= RGB_TOL
+
+
+def test_feature_cache_is_keyed_on_identity(model, dev, weights):
+    """a new pair's latents allocated at the freed addresses of the previous pair must not hit the NHWC / table
+    cache.  Render pair A, free its latents, render pair B (same shapes, likely the same addresses): B's image must be
+    B's, i.e. equal to a render of B through a fresh engine."""
+    from coponerf_amd.render import RenderEngine
+    cfg, _ = load_case("c1_val")
+    inp, zA, rel, flow = case_inputs(cfg)
+    _, zB, _, _ = case_inputs(dict(cfg, seed=cfg["seed"] + 100))
+    model.npoints = cfg["S"]
+    d_inp, d_flow = to_device(inp, dev), to_device(flow, dev)
+    with torch.no_grad():
+        z = to_device(zA, dev)
+        rgbA = model(d_inp, z=z, rel_pose=rel.to(dev), val=True, flow=d_flow)["rgb"].clone()
+        del z
+        z = to_device(zB, dev)                                    # the allocator hands back the freed blocks
+        rgbB = model(d_inp, z=z, rel_pose=rel.to(dev), val=True, flow=d_flow)["rgb"].clone()
+        old = model._engine
+        model._engine = RenderEngine()
+        try:
+            rgbB_fresh = model(d_inp, z=z, rel_pose=rel.to(dev), val=True, flow=d_flow)["rgb"].clone()
+        finally:
+            model._engine = old
+    assert torch.equal(rgbB, rgbB_fresh)
+    assert (rgbA - rgbB).abs().max() > 1e-3                       # the two pairs really differ
+
+
+def test_segment_clipper_edge_cases_on_device(dev):
+    """The 10 degenerate rays of tests/golden/edges.npz (camera at the origin, origin behind the image plane, ray
+    parallel to the image plane, miss, both ends inside, ...; models/epipolar.py:175-253) through cpn_project_rays:
+    bit-equal to the oracle on the same rays, equal to the upstream outputs within 1e-6 (NaN-aware)."""
+    from coponerf_amd import _hip
+    from coponerf_amd._hip import call
+    from oracle import render_ref as orc
+    import os
+    from tests.helpers import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "edges.npz")))
+    o, d, K = (torch.from_numpy(g[k]) for k in ("o", "d", "K"))
+    n = len(o)
+    # one camera per ray: T = [0 0 d | o], uv = (0,0), unit intrinsics -> direction normalize((d + o) - o)
+    T = torch.zeros(n, 4, 4)
+    T[:, :3, 2], T[:, :3, 3], T[:, 3, 3] = d, o, 1.0
+    Kq = torch.eye(4)[None].repeat(n, 1, 1)
+    uv = torch.zeros(n, 1, 2)
+    dir_o, mom_o, org_o = orc.plucker_rays(T, uv, Kq)
+    Kn = K[None].expand(n, -1, -1).contiguous()
+    xy0, xy1, ok, _, _ = orc.project_rays(org_o, dir_o, Kn)
+    cam = torch.zeros(n, 2, _hip.CAM_STRIDE)
+    cam[:, :, _hip.CAM_TQ:_hip.CAM_TQ + 16] = T.reshape(n, 1, 16)
+    cam[:, :, _hip.CAM_KQ:_hip.CAM_KQ + 4] = torch.tensor([1.0, 1.0, 0.0, 0.0])
+    cam[:, :, _hip.CAM_KN:_hip.CAM_KN + 9] = K.reshape(1, 1, 9)
+    camd, uvd = cam.reshape(2 * n, -1).to(dev).contiguous(), uv.reshape(n, 1, 2).to(dev).contiguous()
+    c9 = torch.empty(2 * n, 1, 9, device=dev)
+    seg = torch.empty(2 * n, 1, 4, device=dev)
+    ov = torch.empty(2 * n, 1, dtype=torch.uint8, device=dev)
+    call("cpn_project_rays", camd.data_ptr(), uvd.data_ptr(), n, 2, 1, c9.data_ptr(), seg.data_ptr(), ov.data_ptr(),
+         torch.cuda.current_stream().cuda_stream)
+    c9, seg, ov = c9.cpu().view(n, 2, 9), seg.cpu().view(n, 2, 4), ov.cpu().view(n, 2)
+    scrub = lambda t: torch.where(torch.isfinite(t), t, torch.zeros_like(t))
+    want_seg = torch.cat((scrub((xy0[:, 0] - 0.5) * 2.0), scrub((xy1[:, 0] - 0.5) * 2.0)), -1)
+    for v in range(2):
+        assert torch.equal(c9[:, v, 0:3], dir_o[:, 0]) and torch.equal(c9[:, v, 3:6], mom_o[:, 0])
+        assert torch.equal(seg[:, v], want_seg), (seg[:, v], want_seg)
+        assert torch.equal(ov[:, v].bool(), ok[:, 0])
+    # ... and against the upstream reference's own outputs
+    assert torch.equal(ov[:, 0].bool(), torch.from_numpy(g["overlaps_image"]))
+    up = torch.cat((scrub((torch.from_numpy(g["xy_min"]) - 0.5) * 2.0), scrub((torch.from_numpy(g["xy_max"]) - 0.5) * 2.0)), -1)
+    assert (seg[:, 0] - up).abs().max() <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["c1_val", "train_b2", "wide_val"])
+def test_aux_outputs_values_on_device(name, model, dev, weights):
+    """Row a20: the auxiliary outputs that feed the cycle loss / summaries, by VALUE on the GPU against the oracle and
+    the upstream fixture (round 1 only compared depth_ray, the two masks and the shape of at_wt_max)."""
+    cfg, gold = load_case(name)
+    ref, out = run_pair(model, dev, weights, cfg)
+    # at_wt_max: argmax over samples; a different index is only acceptable where the two largest weights tie to 1e-4
+    got, want = out["at_wt_max"].cpu()[..., 0], ref["at_wt_max"][..., 0]
+    diff = got != want
+    if diff.any():
+        w = ref["at_wt"]
+        gap = (w.gather(-1, want[..., None]) - w.gather(-1, got[..., None]))[..., 0][diff]
+        assert float(gap.abs().max()) <= 1e-4
+    assert diff.float().mean() <= 1e-2
+    for k in ("T_to_C1_pts", "T_to_C2_pts"):            # pixels (unbounded: points far outside the frame reach 1e4 px)
+        want_k = ref[k]
+        e = (out[k].cpu() - want_k).abs() / (1.0 + want_k.abs())
+        assert float(e.max()) <= 1e-3, (k, float(e.max()))            # the depth enters through fp16-weighted sums
+        if k in gold:
+            gk = torch.from_numpy(gold[k])
+            assert float(((out[k].cpu() - gk).abs() / (1.0 + gk.abs())).max()) <= 2e-3
+    # C2_pts_to_C1 = integer pixel + flow looked up there: equal unless the reprojected pixel moved across a pixel edge
+    c = (out["C2_pts_to_C1"].cpu() - ref["C2_pts_to_C1"]).abs().amax(-1)
+    assert (c > 1e-3).float().mean() <= 2e-2
+    assert (out["depth_ray"].cpu() - ref["depth_ray"]).abs().max() <= 2e-2
+
+
+def test_full_image_four_chunks_against_oracle(model, dev, weights):
+    """BASELINE configs[1] at its real size: 256x256, all 65 536 rays (4 chunks of 16 384), 64 samples.  The oracle
+    takes seconds per thousand rays, so a strided subset of 2 048 rays (every 32nd: touches all four chunks) is
+    rendered by the oracle on its own and compared with the same rays of the full-image HIP render."""
+    from oracle import render_ref as orc
+    H, S = 256, 64
+    inp = syn.make_inputs(1, H, H, 0, seed=41, full_image=True)
+    z, rel, flow = syn.make_latents(1, H, H, seed=42)
+    R = inp["query"]["uv"].shape[2]
+    assert R == 65536
+    sel = torch.arange(0, R, 32)
+    sub = {"context": inp["context"], "query": {k: (v[:, :, sel].contiguous() if k in ("uv", "rgb") else v)
+                                                for k, v in inp["query"].items()}}
+    model.npoints = S
+    old = model._engine.chunk_rays
+    model._engine.chunk_rays = 16384
+    try:
+        with torch.no_grad():
+            out = model(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=True, flow=to_device(flow, dev))
+            ref = orc.forward(sub, z, rel, flow, True, weights, npoints=S)
+    finally:
+        model._engine.chunk_rays = old
+    assert torch.equal(out["pixel_val"][:, sel], ref["pixel_val"])
+    assert (out["rgb"][:, :, sel].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
+    assert (out["at_wt"][:, sel].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+    assert torch.equal(out["valid_mask"][:, sel].cpu(), ref["valid_mask"])
