@@ -40,6 +40,12 @@
 #include "common.h"
 #include "taps.h"
 
+// timing-only ablations for tools/encode_ablate.py (results are wrong when non-zero; the product builds with 0):
+// 1 = no table taps, 2 = no hid stores, 4 = no MFMA phase, 8 = taps of level 0 only, 16 = every tap reads texel 0
+#ifndef CPN_ENCODE_ABLATE
+#define CPN_ENCODE_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int TILE_ROWS = 128;
@@ -50,9 +56,10 @@ constexpr int KSTEPS = 3;                 // K = 96 = 64 level-3 channels + 3 po
 constexpr int TAB_SLICE_BYTES = CPN_TAB_SLICE * 2;             // 448: 384 main + 64 tail (4 x {8 B used, 8 B pad})
 constexpr int TAB_ROW_BYTES = CPN_TAB_LD * 2;                  // 1792 per texel
 constexpr int TAPS_BYTES = TILE_ROWS * 4 * 32;                 // [row][level]{int off[4]; float w[4]}
-constexpr int AIMG_BYTES = KSTEPS * 4 * 2 * 1024;              // [k][wave][mt][lane] half8
+constexpr int AIMG_BYTES = 2 * 4 * 2 * 1024 + 4 * 2 * 256;     // [k < 2][wave][mt][lane] half8 + [wave][mt][r] half8 (k = 2, g = 0)
+constexpr int AIMG2_OFF = 2 * 4 * 2 * 1024;                    // third K step: only lane group 0 holds data (pt enc)
 constexpr int WIMG_BYTES = KSTEPS * NT * 1024;                 // [k][nt][lane] half8
-constexpr int LDS_BYTES = TAPS_BYTES + AIMG_BYTES + WIMG_BYTES;
+constexpr int LDS_BYTES = TAPS_BYTES + AIMG_BYTES + WIMG_BYTES + 832 * 4;
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -72,17 +79,42 @@ __device__ __forceinline__ float fma_mix_hi(float acc, unsigned packed, float w)
 }
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Which (ray, sample) a tile row is.  A tile = TG adjacent rays x TSB consecutive samples x {own, other image} of one
+// view = 128 rows; wave w takes samples 4w..4w+3 of the block and MFMA column r = (sample & 3)*4 + (ray & 3), so ONE
+// load instruction covers a 4 x 4 patch of (sample, ray): adjacent query pixels have almost the same epipolar line
+// and adjacent samples sit <= 1.5 texels apart, i.e. the 16 rows of an instruction share a handful of texels and
+// most of its 64-byte requests hit lines that a neighbouring lane just brought into the vector L1 (rays of a
+// full-image render are row-major pixels; any other ray order is still correct, only less cache friendly).
+constexpr int TG = 4;                     // rays per tile
+constexpr int TSB = 16;                   // samples per tile
+
+struct RowId {
+    bool live;
+    int j, s;
+    unsigned rayl;                        // ray inside this launch
+};
+__device__ __forceinline__ RowId tile_row(int row, unsigned group, int blk, int S, unsigned nrays) {
+    const int w = row >> 5, rl = row & 31, rs = rl >> 1;
+    RowId o;
+    o.j = rl & 1;
+    o.s = blk * TSB + w * 4 + (rs >> 2);
+    o.rayl = group * TG + (rs & 3);
+    o.live = (o.s < S) && (o.rayl < nrays);
+    return o;
+}
+
 __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
     const __half* __restrict__ tab0, const __half* __restrict__ tab1, const __half* __restrict__ tab2,
     long long tab0_bytes, long long tab1_bytes, long long tab2_bytes, const __half* __restrict__ map3, int H, int W,
     const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, const float* __restrict__ pe6,
-    const half8* __restrict__ wfrag, const float* __restrict__ bias, int V, int R, int S, int ray0, unsigned nrows,
-    __half* __restrict__ hid) {
+    const half8* __restrict__ wfrag, const float* __restrict__ bias, int V, int R, int S, int ray0, unsigned nrays,
+    int nblk, __half* __restrict__ hid) {
     // three separate LDS objects (not one dynamic array): the compiler then knows that reads of the tap records do
     // not alias the in-flight buffer_load ... lds of the weight image and does not drain vmcnt in front of them
     __shared__ __attribute__((aligned(16))) TapRec taps[TILE_ROWS * 4];
     __shared__ __attribute__((aligned(16))) char aimg[AIMG_BYTES];
     __shared__ __attribute__((aligned(16))) char wimg[WIMG_BYTES];
+    __shared__ __attribute__((aligned(16))) float bias_s[832];     // keeps the slice loop free of global loads up to the taps
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,7 +125,9 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
     // (= neighbouring rays = overlapping texel footprints), so its private L2 works on 1/8 of the tables
     const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, rem = nb & 7;
     const unsigned tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
-    const unsigned row0 = tile * TILE_ROWS;
+    const int blk = (int)(tile % (unsigned)nblk);
+    const int v = (int)((tile / (unsigned)nblk) % (unsigned)V);
+    const unsigned group = tile / (unsigned)(nblk * V);
 
     // weight fragments of slice n -> LDS (lane-linear 1 KiB pieces, wave w moves pieces w, w+4, ...)
     const __amdgpu_buffer_rsrc_t wrsrc =
@@ -109,31 +143,28 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
     };
 
     // ---- phase A: tap records, thread = (row, level pair) ----------------------------------------------------
+    for (int i = tid; i < 832 / 4; i += 256)
+        *reinterpret_cast<f32x4*>(bias_s + i * 4) = *reinterpret_cast<const f32x4*>(bias + i * 4);
     {
         const int row = tid >> 1, half = tid & 1;
-        const unsigned grow = row0 + row;
-        const bool live = grow < nrows;
-        unsigned t = (live ? grow : nrows - 1);
-        const int j = (int)(t & 1); t >>= 1;
-        const int s = (int)(t % (unsigned)S); t /= (unsigned)S;
-        const int v = (int)(t % (unsigned)V); t /= (unsigned)V;
-        const unsigned ray = (unsigned)ray0 + t;
+        const RowId id = tile_row(row, group, blk, S, nrays);
+        const unsigned ray = (unsigned)ray0 + (id.rayl < nrays ? id.rayl : nrays - 1);
         const int b = (int)(ray / (unsigned)R), rr = (int)(ray % (unsigned)R);
-        const size_t sidx = (((size_t)(b * V + v)) * R + rr) * S + s;
-        const float2 gq = *reinterpret_cast<const float2*>((j == 0 ? pixel_val : sec_grid) + sidx * 2);
-        const int img = b * V + (j == 0 ? v : (V - 1 - v));
+        const size_t sidx = (((size_t)(b * V + v)) * R + rr) * S + (id.s < S ? id.s : S - 1);
+        const float2 gq = *reinterpret_cast<const float2*>((id.j == 0 ? pixel_val : sec_grid) + sidx * 2);
+        const int img = b * V + (id.j == 0 ? v : (V - 1 - v));
 #pragma unroll
         for (int li = 0; li < 2; ++li) {
             const int lvl = half * 2 + li;
             const int shift = 4 - lvl - (lvl == 3);
             const int Hl = H >> shift, Wl = W >> shift;
-            const Taps tp = make_taps(gq.x, gq.y, Wl, Hl, j == 0);
+            const Taps tp = make_taps(gq.x, gq.y, Wl, Hl, id.j == 0);
             const int entry = (lvl == 3) ? 128 : TAB_ROW_BYTES;         // bytes per texel
             TapRec rec;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 rec.off[k] = (img * Hl * Wl + tp.off[k]) * entry;
-                rec.w[k] = live ? tp.w[k] : 0.0f;
+                rec.w[k] = id.live ? tp.w[k] : 0.0f;
             }
             taps[row * 4 + lvl] = rec;
         }
@@ -171,40 +202,40 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
             // chunk = half*4 + c: K step `half`, lane group g = c
             *reinterpret_cast<half8*>(aimg + (((half * 4 + w_) * 2 + mt) * 64 + c * 16 + rs) * 16) = o;
         }
-        // third K step: halves 64..66 = point encoding of this row, the rest zero; thread `half` writes groups 2h, 2h+1
-        {
-            const unsigned grow = row0 + row;
-            unsigned t = (grow < nrows ? grow : nrows - 1);
-            const int j = (int)(t & 1); t >>= 1;
-            const int s = (int)(t % (unsigned)S); t /= (unsigned)S;
-            const int v = (int)(t % (unsigned)V); t /= (unsigned)V;
-            const unsigned ray = (unsigned)ray0 + t;
-            const int b = (int)(ray / (unsigned)R), rr = (int)(ray % (unsigned)R);
-            const size_t sidx = (((size_t)(b * V + v)) * R + rr) * S + s;
-            half8 z8;
+        // third K step: halves 64..66 = point encoding of this row, the rest zero: only lane group g = 0 has data
+        if (half == 0) {
+            const RowId id = tile_row(row, group, blk, S, nrays);
+            half8 p8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) z8[e] = (_Float16)0.0f;
-            half8 p8 = z8;
-            if (half == 0 && grow < nrows) {
-                const float* pe = pe6 + sidx * 6 + j * 3;
+            for (int e = 0; e < 8; ++e) p8[e] = (_Float16)0.0f;
+            if (id.live) {
+                const unsigned ray = (unsigned)ray0 + id.rayl;
+                const int b = (int)(ray / (unsigned)R), rr = (int)(ray % (unsigned)R);
+                const size_t sidx = (((size_t)(b * V + v)) * R + rr) * S + id.s;
+                const float* pe = pe6 + sidx * 6 + id.j * 3;
                 p8[0] = (_Float16)pe[0]; p8[1] = (_Float16)pe[1]; p8[2] = (_Float16)pe[2];
             }
-            char* dst = aimg + (((2 * 4 + w_) * 2 + mt) * 64 + rs) * 16;
-            *reinterpret_cast<half8*>(dst + (half * 2) * 16 * 16) = p8;
-            *reinterpret_cast<half8*>(dst + (half * 2 + 1) * 16 * 16) = z8;
+            *reinterpret_cast<half8*>(aimg + AIMG2_OFF + ((w_ * 2 + mt) * 16 + rs) * 16) = p8;
         }
     }
     __syncthreads();          // (drains vmcnt: slice 0 of the weights has landed too)
 
     half8 xa[KSTEPS][2];
 #pragma unroll
-    for (int k = 0; k < KSTEPS; ++k)
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
             xa[k][mt] = *reinterpret_cast<const half8*>(aimg + (((k * 4 + wave) * 2 + mt) * 64 + lane) * 16);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const half8 p8 = *reinterpret_cast<const half8*>(aimg + AIMG2_OFF + ((wave * 2 + mt) * 16 + r) * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xa[2][mt][e] = (g == 0) ? p8[e] : (_Float16)0.0f;
+    }
 
-    // rows of this lane: tile row 32*wave + 2*r + mt
-    const unsigned lrow0 = row0 + wave * 32 + 2 * r;
+    // rows of this lane: tile rows 32*wave + 2*r + mt, mt = 0 (own image), 1 (other image)
+    const RowId lid = tile_row(wave * 32 + 2 * r, group, blk, S, nrays);
+    const size_t lrow0 = (((size_t)lid.rayl * V + v) * S + lid.s) * 2;                 // + mt
     const __amdgpu_buffer_rsrc_t trs0 = __builtin_amdgcn_make_buffer_rsrc((void*)tab0, 0, (int)tab0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t trs1 = __builtin_amdgcn_make_buffer_rsrc((void*)tab1, 0, (int)tab1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t trs2 = __builtin_amdgcn_make_buffer_rsrc((void*)tab2, 0, (int)tab2_bytes, 0x00020000);
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
         f32x4 acc[2][NT];
         // bias of the lane's 52 channels (natural channel order)
         {
-            const float* bp = bias + n * SLICE_CH;
+            const float* bp = bias_s + n * SLICE_CH;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 acc[0][2 * k] = *reinterpret_cast<const f32x4*>(bp + k * 32 + g * 8);
@@ -225,44 +256,55 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
         }
         // ---- K = 96 contraction of the full-resolution level + point encoding
 #pragma unroll
-        for (int k = 0; k < KSTEPS; ++k)
+        for (int k = 0; k < ((CPN_ENCODE_ABLATE & 4) ? 0 : KSTEPS); ++k)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const half8 wb = *reinterpret_cast<const half8*>(wimg + ((k * NT + nt) * 64 + lane) * 16);
                 acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xa[k][0], acc[0][nt], 0, 0, 0);
                 acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xa[k][1], acc[1][nt], 0, 0, 0);
             }
-        __syncthreads();                        // every wave has read this slice's fragments
+        // every wave has read this slice's fragments.  Raw s_barrier, not __syncthreads(): the fence of the latter
+        // drains vmcnt to 0, i.e. it would wait here for the previous slice's hid stores to reach memory
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (n + 1 < NSLICE) stage_w(n + 1);     // the next slice lands under the table taps below
 
-        // ---- 12 table taps per row, accumulated in fp32 on top of the MFMA result
+        // ---- 12 table taps per row, accumulated in fp32 on top of the MFMA result.  Order: 128-byte line (two
+        //      16-byte pieces per lane) outermost, the four taps inside: the taps of neighbouring rows that fall on
+        //      the same texel request the same cache line back to back
         const int col_off = n * TAB_SLICE_BYTES + g * 16;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int trow = wave * 32 + 2 * r + mt;
 #pragma unroll
-            for (int lvl = 0; lvl < 3; ++lvl) {
+            for (int lvl = 0; lvl < ((CPN_ENCODE_ABLATE & 1) ? 0 : (CPN_ENCODE_ABLATE & 8) ? 1 : 3); ++lvl) {
                 const TapRec rec = taps[trow * 4 + lvl];
                 const __amdgpu_buffer_rsrc_t rs = lvl == 0 ? trs0 : (lvl == 1 ? trs1 : trs2);
+                int vo[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vo[k] = ((CPN_ENCODE_ABLATE & 16) ? 0 : rec.off[k]) + col_off;
+#pragma unroll
+                for (int cp = 0; cp < 3; ++cp) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const u32x4 d0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k] + cp * 128, 0, 0);
+                        const u32x4 d1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k] + cp * 128 + 64, 0, 0);
+                        const float wk = rec.w[k];
+                        f32x4* a4 = &acc[mt][4 * cp];
+                        a4[0][0] = fma_mix_lo(a4[0][0], d0[0], wk); a4[0][1] = fma_mix_hi(a4[0][1], d0[0], wk);
+                        a4[0][2] = fma_mix_lo(a4[0][2], d0[1], wk); a4[0][3] = fma_mix_hi(a4[0][3], d0[1], wk);
+                        a4[1][0] = fma_mix_lo(a4[1][0], d0[2], wk); a4[1][1] = fma_mix_hi(a4[1][1], d0[2], wk);
+                        a4[1][2] = fma_mix_lo(a4[1][2], d0[3], wk); a4[1][3] = fma_mix_hi(a4[1][3], d0[3], wk);
+                        a4[2][0] = fma_mix_lo(a4[2][0], d1[0], wk); a4[2][1] = fma_mix_hi(a4[2][1], d1[0], wk);
+                        a4[2][2] = fma_mix_lo(a4[2][2], d1[1], wk); a4[2][3] = fma_mix_hi(a4[2][3], d1[1], wk);
+                        a4[3][0] = fma_mix_lo(a4[3][0], d1[2], wk); a4[3][1] = fma_mix_hi(a4[3][1], d1[2], wk);
+                        a4[3][2] = fma_mix_lo(a4[3][2], d1[3], wk); a4[3][3] = fma_mix_hi(a4[3][3], d1[3], wk);
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int vo = rec.off[k] + col_off;
-                    u32x4 d[6];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) d[c] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + c * 64, 0, 0);
-                    const u32x2 dt = __builtin_amdgcn_raw_buffer_load_b64(rs, vo + 384, 0, 0);
+                    const u32x2 dt = __builtin_amdgcn_raw_buffer_load_b64(rs, vo[k] + 384, 0, 0);
                     const float wk = rec.w[k];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        acc[mt][2 * c][0] = fma_mix_lo(acc[mt][2 * c][0], d[c][0], wk);
-                        acc[mt][2 * c][1] = fma_mix_hi(acc[mt][2 * c][1], d[c][0], wk);
-                        acc[mt][2 * c][2] = fma_mix_lo(acc[mt][2 * c][2], d[c][1], wk);
-                        acc[mt][2 * c][3] = fma_mix_hi(acc[mt][2 * c][3], d[c][1], wk);
-                        acc[mt][2 * c + 1][0] = fma_mix_lo(acc[mt][2 * c + 1][0], d[c][2], wk);
-                        acc[mt][2 * c + 1][1] = fma_mix_hi(acc[mt][2 * c + 1][1], d[c][2], wk);
-                        acc[mt][2 * c + 1][2] = fma_mix_lo(acc[mt][2 * c + 1][2], d[c][3], wk);
-                        acc[mt][2 * c + 1][3] = fma_mix_hi(acc[mt][2 * c + 1][3], d[c][3], wk);
-                    }
                     acc[mt][12][0] = fma_mix_lo(acc[mt][12][0], dt[0], wk);
                     acc[mt][12][1] = fma_mix_hi(acc[mt][12][1], dt[0], wk);
                     acc[mt][12][2] = fma_mix_lo(acc[mt][12][2], dt[1], wk);
@@ -270,9 +312,8 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
                 }
             }
             // ---- ReLU, fp16, store (natural channel order, 16-byte pieces, 64 contiguous bytes per row and k)
-            const unsigned grow = lrow0 + mt;
-            if (grow < nrows) {
-                __half* orow = hid + (size_t)grow * 832 + n * SLICE_CH;
+            if (lid.live && (!(CPN_ENCODE_ABLATE & 2) || acc[mt][0][0] == 123.456f)) {
+                __half* orow = hid + (lrow0 + mt) * 832 + n * SLICE_CH;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     half8 o;
@@ -289,7 +330,10 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
                 *reinterpret_cast<half4*>(orow + 192 + g * 4) = o4;
             }
         }
-        if (n + 1 < NSLICE) __syncthreads();    // (drains vmcnt) the next slice's fragments are in LDS
+        // The next slice's fragments are in LDS: this wave's DMA pieces were issued BEFORE its tap loads, loads
+        // retire in order and every tap load has been consumed above, so only the barrier is needed — no vmcnt(0)
+        // that would also wait for the hid stores just issued
+        if (n + 1 < NSLICE) __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -371,9 +415,13 @@ extern "C" int cpn_encode_hidden(const uint16_t* tab0, const uint16_t* tab1, con
                     ((uintptr_t)map3 % 16) == 0 && ((uintptr_t)wfrag % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
                     ((uintptr_t)hid % 16) == 0, CPN_E_ARG, "cpn_encode_hidden: pointers must be 16-byte aligned");
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-    hipLaunchKernelGGL(encode_hidden_kernel, dim3(cpn_cdiv(nrows, TILE_ROWS)), dim3(256), 0, (hipStream_t)stream,
+    const int nblk = (int)cpn_cdiv(S, TSB);
+    const long long tiles = (long long)cpn_cdiv(nrays, TG) * V * nblk;
+    CPN_REQUIRE(tiles < (1LL << 31), CPN_E_SHAPE, "cpn_encode_hidden: %lld tiles exceed the grid limit", tiles);
+    hipLaunchKernelGGL(encode_hidden_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
                        (const __half*)tab0, (const __half*)tab1, (const __half*)tab2, t0, t1, t2, (const __half*)map3, H, W,
-                       pixel_val, sec_grid, pe6, (const half8*)wfrag, bias, V, R, S, ray0, (unsigned)nrows, (__half*)hid);
+                       pixel_val, sec_grid, pe6, (const half8*)wfrag, bias, V, R, S, ray0, (unsigned)nrays, nblk,
+                       (__half*)hid);
     CPN_LAUNCH_CHECK("cpn_encode_hidden");
     return 0;
 }

@@ -1,0 +1,91 @@
+"""Phase ablation of cpn_encode_hidden (timing only — ablated results are wrong): builds variants of csrc/encode.hip with
+-DCPN_ENCODE_ABLATE=k into tools/_build/ (run `python tools/encode_ablate.py --build` where hipcc is, e.g. in the
+build container: the .so files travel to the GPU box) and times each on one 16 384-ray chunk of configs[1]."""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+BUILD = os.path.join(ROOT, "tools", "_build")
+VARIANTS = {0: "full", 1: "no table taps", 2: "no hid stores", 3: "no taps, no stores (MFMA + setup)", 4: "no MFMA",
+            8: "level-0 taps only", 16: "all taps -> texel 0 (L1-hot)", 18: "texel-0 taps, no stores"}
+
+
+def build():
+    os.makedirs(BUILD, exist_ok=True)
+    src = os.path.join(ROOT, "coponerf_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    err_o = os.path.join(BUILD, "error.o")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
+                           os.path.join(src, "error.cpp"), "-o", err_o])
+    for k in VARIANTS:
+        obj, out = os.path.join(BUILD, f"encode_abl{k}.o"), os.path.join(BUILD, f"libencode_abl{k}.so")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_ENCODE_ABLATE={k}", "-x", "hip",
+               "-c", os.path.join(src, "encode.hip"), "-o", obj]
+        print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, err_o, "-o", out])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    if a.build:
+        build()
+        return
+    import torch
+    from coponerf_amd import CoPoNeRF, synthetic as syn
+    dev = torch.device("cuda:0")
+    H, S, B, V, n = 256, 64, 1, 2, 16384
+    model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+    model.load_state_dict(syn.make_render_weights(), strict=False)
+    model = model.to(dev).eval()
+    eng = model._engine
+    inp = syn.make_inputs(B, H, H, 0, seed=100, full_image=True)
+    z, rel, flow = syn.make_latents(B, H, H, seed=200)
+    mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (
+        o.to(dev) if torch.is_tensor(o) else type(o)(mv(v) for v in o))
+    inp, z, rel = mv(inp), mv(z), rel.to(dev)
+    w = eng._weights(model._render_params())
+    maps, tabs = eng._feature_maps(z, w)
+    ctx, qry = inp["context"], inp["query"]
+    g = eng._geometry(ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], rel, True, S, H, H)
+    R = qry["uv"].shape[2]
+    hid = torch.empty(n * V * S * 2, 832, dtype=torch.float16, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    P, I = ctypes.c_void_p, ctypes.c_int
+    res = {}
+    for k, what in VARIANTS.items():
+        path = os.path.join(BUILD, f"libencode_abl{k}.so")
+        if not os.path.exists(path):
+            continue
+        fn = ctypes.CDLL(path).cpn_encode_hidden
+        fn.argtypes = [P, P, P, P, I, I, P, P, P, P, P, I, I, I, I, I, I, P, P]
+        fn.restype = I
+
+        def run():
+            rc = fn(tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), maps[3].data_ptr(), H, H,
+                    g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(), w["enc.frag"].data_ptr(),
+                    w["query_encode_latent.b"].data_ptr(), B, V, R, S, 16384, n, hid.data_ptr(), s)
+            assert rc == 0, rc
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        res[f"{k}: {what}"] = round(e0.elapsed_time(e1) / a.iters, 3)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
