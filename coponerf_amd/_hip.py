@@ -23,8 +23,9 @@ SIGNATURES: Dict[str, List] = {
     "cpn_nchw_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
     "cpn_pack_weight_f16": [_P, _I, _I, _P, _I, _P],
     "cpn_gather_rows": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "cpn_pack_encode_weights": [_P, _I, _P, _P, _P, _P, _P],
-    "cpn_encode_hidden": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_pack_encode_weights": [_P, _I, _P, _P, _P],
+    "cpn_node_features": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "cpn_encode_hidden": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
@@ -93,6 +94,8 @@ def lib() -> ctypes.CDLL:
         fn.restype = ctypes.c_int
     handle.cpn_abi_version.argtypes = []
     handle.cpn_abi_version.restype = ctypes.c_int
+    handle.cpn_encode_table_nodes.argtypes = [_I, _I]
+    handle.cpn_encode_table_nodes.restype = ctypes.c_longlong
     handle.cpn_gather_bwd_chunks.argtypes = [_I, _I]
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
     handle.cpn_conv4d_scratch.argtypes = [_I] * 7

@@ -195,8 +195,8 @@ class RenderEngine:
         #      full-resolution / point-encoding columns and the table projection weights of the three coarse levels
         W1 = f32("query_encode_latent.weight").reshape(832, 835)
         w["enc.frag"] = torch.empty(4 * 3 * 13 * 64 * 8, dtype=torch.float16, device=dev)
-        w["enc.wtab"] = [torch.empty(_hip.TAB_LD, 256, dtype=torch.float16, device=dev) for _ in range(3)]
-        call("cpn_pack_encode_weights", W1.data_ptr(), 835, w["enc.frag"].data_ptr(), *(t.data_ptr() for t in w["enc.wtab"]), s)
+        w["enc.wtab"] = torch.empty(_hip.TAB_LD, 768, dtype=torch.float16, device=dev)
+        call("cpn_pack_encode_weights", W1.data_ptr(), 835, w["enc.frag"].data_ptr(), w["enc.wtab"].data_ptr(), s)
         w["enc.zero_bias"] = torch.zeros(_hip.TAB_LD, dtype=torch.float32, device=dev)
         self._w, self._wkey = w, key
         self._wgen += 1
@@ -218,13 +218,17 @@ class RenderEngine:
             call("cpn_nchw_to_nhwc_f16", src.data_ptr(), dst.data_ptr(), n, c, h, w_, s)
             maps.append(dst)
         if self.tables:
-            for lvl in range(3):
-                m = maps[lvl]
-                texels = m.shape[0] * m.shape[1] * m.shape[2]
-                tab = torch.empty(texels, _hip.TAB_LD, dtype=torch.float16, device=m.device)
-                call("cpn_gemm_f16", m.data_ptr(), 256, w["enc.wtab"][lvl].data_ptr(), 256, w["enc.zero_bias"].data_ptr(),
-                     tab.data_ptr(), _hip.TAB_LD, texels, _hip.TAB_LD, 256, 0, 0, s)
-                tabs.append(tab)
+            # node tables of the three coarse levels (csrc/encode.hip): sample the levels at every node of the common
+            # grid, then project the (nodes, 768) features through the first layer's column blocks in ONE GEMM
+            nimg, Hf, Wf = maps[3].shape[0], maps[3].shape[1], maps[3].shape[2]
+            nodes = nimg * int(_hip.lib().cpn_encode_table_nodes(Hf, Wf))
+            feat = torch.empty(nodes, 768, dtype=torch.float16, device=maps[0].device)
+            call("cpn_node_features", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), Hf, Wf, nimg,
+                 feat.data_ptr(), s)
+            tab = torch.empty(nodes, _hip.TAB_LD, dtype=torch.float16, device=feat.device)
+            call("cpn_gemm_f16", feat.data_ptr(), 768, w["enc.wtab"].data_ptr(), 768, w["enc.zero_bias"].data_ptr(),
+                 tab.data_ptr(), _hip.TAB_LD, nodes, _hip.TAB_LD, 768, 0, 0, s)
+            tabs.append(tab)
         self._maps, self._tabs, self._mkey, self._mrefs = maps, tabs, key, tuple(z)
         return maps, tabs
 
@@ -425,7 +429,7 @@ class RenderEngine:
                 if prof is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                call("cpn_encode_hidden", tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), maps[3].data_ptr(),
+                call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(),
                      H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
                      w["query_encode_latent.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), s)
                 if prof is not None:

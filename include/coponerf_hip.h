@@ -118,25 +118,33 @@ int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int 
 /* ---- K2+K3a: first encoder layer straight from the feature maps ("project, then interpolate") -------------------
  * hid = ReLU(query_encode_latent([primary/secondary gather (832) | tanh(pt/5) (3)])) without the gathered rows ever
  * reaching HBM; replaces F.grid_sample x 8, torch.cat and the 835 -> 832 1x1 convolution (CoPoNeRF.py:312, 370,
- * 384-397 with the layer of :71).  A 1x1 convolution commutes with bilinear interpolation, so the three 256-channel
- * levels are projected once per stereo pair into tables
- *     tab_l (N, H_l, W_l, CPN_TAB_LD) fp16 = NHWC map_l (texels, 256) . wtab_l^T      (one cpn_gemm_f16 per level,
- *                                                                                      N = CPN_TAB_LD, K = 256, bias 0)
- * and a row becomes 12 weighted table taps + a K = 96 MFMA product over [level-3 gather (64) | pt (3) | 0] + bias.
- * Table layout: 4 slices of CPN_TAB_SLICE halves; slice n holds channels n*208 .. n*208+191 in order, then the last
+ * 384-397 with the layer of :71).  A 1x1 convolution commutes with bilinear interpolation, and the texel centres of the
+ * three 256-channel levels (H/16, H/8, H/4; align_corners=False) all lie on the nodes of one grid of spacing 2/W, on
+ * whose cells every level's interpolant is bilinear — so the projected sum of the three levels is tabulated once per
+ * stereo pair on that grid and interpolated from 4 nodes (exact in real arithmetic; csrc/encode.hip):
+ *   per image  T_border (H/2+1, W/2+1, CPN_TAB_LD) fp16   nodes 0..M         own image, 'border' padding
+ *              T_zeros  (H/2+9, W/2+9, CPN_TAB_LD) fp16   nodes -4..M+4      other image, 'zeros' padding
+ *   laid out image by image, border table first: cpn_encode_table_nodes(H, W) nodes (rows) per image.
+ *   Built as  cpn_node_features (the three levels sampled at every node -> (nodes, 768) fp16)
+ *             -> cpn_gemm_f16(A = node features, W = wtab, N = CPN_TAB_LD, K = 768, bias 0, fp16 out).
+ * A row is then 4 weighted table taps + a K = 96 MFMA product over [level-3 gather (64) | pt (3) | 0] + bias.
+ * Table row layout: 4 slices of CPN_TAB_SLICE halves; slice n holds channels n*208 .. n*208+191 in order, then the last
  * 16 channels as 4 groups of {4 channels, 4 zero halves} (64-byte aligned 64-byte reads for the 4 lanes of a row).
  *   cpn_pack_encode_weights: W (832, ldw >= 835) fp32 query_encode_latent.weight ->
- *       wfrag  (4*3*13*64*8 halves) MFMA A-operand fragments of W[:, 768:835] (K padded to 96)
- *       wtab_l (CPN_TAB_LD, 256) fp16 table projection weights of level l = 0,1,2 (row order = table column order)
- *   cpn_encode_hidden: hid (rays*V*S*2, 832) fp16 in the row order of this header; bias (832) fp32                  */
+ *       wfrag (4*3*13*64*8 halves) MFMA A-operand fragments of W[:, 768:835] (K padded to 96)
+ *       wtab  (CPN_TAB_LD, 768) fp16 table projection weights (row order = table column order)
+ *   cpn_encode_hidden: hid (rays*V*S*2, 832) fp16 in the row order of this header; bias (832) fp32; map3 the
+ *       full-resolution NHWC fp16 map (N, H, W, 64)                                                               */
 #define CPN_TAB_SLICE 224
 #define CPN_TAB_LD    896
-int cpn_pack_encode_weights(const float* W, int ldw, uint16_t* wfrag, uint16_t* wtab0, uint16_t* wtab1,
-                            uint16_t* wtab2, void* stream);
-int cpn_encode_hidden(const uint16_t* tab0, const uint16_t* tab1, const uint16_t* tab2, const uint16_t* map3,
-                      int H, int W, const float* pixel_val, const float* sec_grid, const float* pe6,
-                      const uint16_t* wfrag, const float* bias, int B, int V, int R, int S, int ray0, int nrays,
-                      uint16_t* hid, void* stream);
+#define CPN_NODE_PAD  4
+long long cpn_encode_table_nodes(int H, int W);
+int cpn_pack_encode_weights(const float* W, int ldw, uint16_t* wfrag, uint16_t* wtab, void* stream);
+int cpn_node_features(const uint16_t* map0, const uint16_t* map1, const uint16_t* map2, int H, int W, int nimg,
+                      uint16_t* out, void* stream);
+int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                      const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
+                      int B, int V, int R, int S, int ray0, int nrays, uint16_t* hid, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).

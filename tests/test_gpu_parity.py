@@ -273,9 +273,9 @@ def test_missing_library_is_loud(monkeypatch):
 # round 2: the projected-table form of the first encoder layer (csrc/encode.hip) and the parity holes of round 1
 # ------------------------------------------------------------------------------------------------------------------
 def test_encode_hidden_against_torch(dev):
-    """cpn_encode_hidden (tables + K=96 MFMA) vs grid_sample + fp32 linear layer on the same fp16-rounded maps, and vs
-    the gather + GEMM form (cpn_gather_rows + cpn_gemm_f16); border + zeros padding, huge / on-texel coordinates,
-    a row count that is not a multiple of the 128-row tile."""
+    """cpn_encode_hidden (node tables + K=96 MFMA) vs grid_sample + fp32 linear layer on the same fp16-rounded maps, and
+    vs the gather + GEMM form (cpn_gather_rows + cpn_gemm_f16); border + zeros padding, huge / on-texel / rim
+    coordinates, ray and sample counts that do not fill the 4-ray x 16-sample tiles."""
     from coponerf_amd import _hip
     from coponerf_amd._hip import call
     from oracle.render_ref import gather_levels
@@ -290,6 +290,10 @@ def test_encode_hidden_against_torch(dev):
     sg[0, 0, 0] = torch.tensor([1e10, -1e10])
     sg[1, 0, 1] = torch.tensor([-1.0, 1.0])
     pv[0, 1, 2] = torch.tensor([-1.0 + 1.0 / H, 1.0 - 1.0 / H])      # exactly on texel centres of the finest level
+    pv[0, 1, 3] = torch.tensor([-1.0, 1.0])                          # image corners: inside the per-level border clamps
+    pv[1, 2, 0] = torch.tensor([1.0 - 4.0 / H, -1.0 + 2.0 / H])      # on the clamp nodes of levels 1 / 2
+    for k, t in enumerate((-4, -3.5, -2, -1, -0.25, 0, 0.5)):        # the zero rim of the secondary gather, node by node
+        sg[0, 3, k] = torch.tensor([2.0 * t / (H // 2) - 1.0, 2.0 * (H // 2 - t) / (H // 2) - 1.0])
     pe = torch.rand(N, R, S, 6) * 2 - 1
     W1 = ((torch.rand(832, 835) * 2 - 1) / 835 ** 0.5)
     b1 = (torch.rand(832) * 2 - 1) * 0.05
@@ -303,23 +307,21 @@ def test_encode_hidden_against_torch(dev):
         maps.append(d)
     W1d, b1d = W1.to(dev).contiguous(), b1.to(dev).contiguous()
     frag = torch.empty(4 * 3 * 13 * 64 * 8, dtype=torch.float16, device=dev)
-    wtab = [torch.empty(_hip.TAB_LD, 256, dtype=torch.float16, device=dev) for _ in range(3)]
-    call("cpn_pack_encode_weights", W1d.data_ptr(), 835, frag.data_ptr(), *(t.data_ptr() for t in wtab), s)
+    wtab = torch.empty(_hip.TAB_LD, 768, dtype=torch.float16, device=dev)
+    call("cpn_pack_encode_weights", W1d.data_ptr(), 835, frag.data_ptr(), wtab.data_ptr(), s)
     zero_bias = torch.zeros(_hip.TAB_LD, device=dev)
-    tabs = []
-    for lvl in range(3):
-        m = maps[lvl]
-        texels = m.shape[0] * m.shape[1] * m.shape[2]
-        tab = torch.empty(texels, _hip.TAB_LD, dtype=torch.float16, device=dev)
-        call("cpn_gemm_f16", m.data_ptr(), 256, wtab[lvl].data_ptr(), 256, zero_bias.data_ptr(), tab.data_ptr(),
-             _hip.TAB_LD, texels, _hip.TAB_LD, 256, 0, 0, s)
-        tabs.append(tab)
+    nodes = N * int(_hip.lib().cpn_encode_table_nodes(H, H))
+    assert nodes == N * ((H // 2 + 1) ** 2 + (H // 2 + 9) ** 2)
+    feat = torch.empty(nodes, 768, dtype=torch.float16, device=dev)
+    call("cpn_node_features", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), H, H, N, feat.data_ptr(), s)
+    tab = torch.empty(nodes, _hip.TAB_LD, dtype=torch.float16, device=dev)
+    call("cpn_gemm_f16", feat.data_ptr(), 768, wtab.data_ptr(), 768, zero_bias.data_ptr(), tab.data_ptr(), _hip.TAB_LD,
+         nodes, _hip.TAB_LD, 768, 0, 0, s)
     pvd, sgd, ped = pv.to(dev), sg.to(dev), pe.to(dev)
     rows = B * R * V * S * 2
     hid = torch.full((rows, 832), float("nan"), dtype=torch.float16, device=dev)
-    call("cpn_encode_hidden", tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), maps[3].data_ptr(), H, H,
-         pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(), frag.data_ptr(), b1d.data_ptr(), B, V, R, S, 0, B * R,
-         hid.data_ptr(), s)
+    call("cpn_encode_hidden", tab.data_ptr(), maps[3].data_ptr(), H, H, pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(),
+         frag.data_ptr(), b1d.data_ptr(), B, V, R, S, 0, B * R, hid.data_ptr(), s)
     # ---- the gather + GEMM form on the same inputs
     xin = torch.zeros(rows, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
     call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, H,
@@ -454,10 +456,10 @@ def test_aux_outputs_values_on_device(name, model, dev, weights):
     for k in ("T_to_C1_pts", "T_to_C2_pts"):            # pixels (unbounded: points far outside the frame reach 1e4 px)
         want_k = ref[k]
         e = (out[k].cpu() - want_k).abs() / (1.0 + want_k.abs())
-        assert float(e.max()) <= 1e-3, (k, float(e.max()))            # the depth enters through fp16-weighted sums
+        assert float(e.max()) <= 3e-3, (k, float(e.max()))            # the depth enters through fp16-weighted sums
         if k in gold:
             gk = torch.from_numpy(gold[k])
-            assert float(((out[k].cpu() - gk).abs() / (1.0 + gk.abs())).max()) <= 2e-3
+            assert float(((out[k].cpu() - gk).abs() / (1.0 + gk.abs())).max()) <= 4e-3
     # C2_pts_to_C1 = integer pixel + flow looked up there: equal unless the reprojected pixel moved across a pixel edge
     c = (out["C2_pts_to_C1"].cpu() - ref["C2_pts_to_C1"]).abs().amax(-1)
     assert (c > 1e-3).float().mean() <= 2e-2

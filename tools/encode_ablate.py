@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tools", "_build")
 VARIANTS = {0: "full", 1: "no table taps", 2: "no hid stores", 3: "no taps, no stores (MFMA + setup)", 4: "no MFMA",
-            8: "level-0 taps only", 16: "all taps -> texel 0 (L1-hot)", 18: "texel-0 taps, no stores"}
+            16: "all taps -> node 0 (L1-hot)", 18: "node-0 taps, no stores"}
 
 
 def build():
@@ -66,11 +66,11 @@ def main():
         if not os.path.exists(path):
             continue
         fn = ctypes.CDLL(path).cpn_encode_hidden
-        fn.argtypes = [P, P, P, P, I, I, P, P, P, P, P, I, I, I, I, I, I, P, P]
+        fn.argtypes = [P, P, I, I, P, P, P, P, P, I, I, I, I, I, I, P, P]
         fn.restype = I
 
         def run():
-            rc = fn(tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), maps[3].data_ptr(), H, H,
+            rc = fn(tabs[0].data_ptr(), maps[3].data_ptr(), H, H,
                     g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(), w["enc.frag"].data_ptr(),
                     w["query_encode_latent.b"].data_ptr(), B, V, R, S, 16384, n, hid.data_ptr(), s)
             assert rc == 0, rc

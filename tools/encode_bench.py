@@ -56,7 +56,7 @@ def main():
 
     if a.only in ("both", "tables"):
         def enc():
-            call("cpn_encode_hidden", tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), maps[3].data_ptr(), H, H,
+            call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(), H, H,
                  g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(), w["enc.frag"].data_ptr(),
                  w["query_encode_latent.b"].data_ptr(), B, V, R, S, 16384, n, hid.data_ptr(), s)
         ms = timeit(enc)
