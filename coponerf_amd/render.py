@@ -102,6 +102,9 @@ class RenderEngine:
         # tables=True: first encoder layer from pre-projected feature tables (cpn_encode_hidden, csrc/encode.hip);
         # False: gather the 835-channel rows and run the 835 -> 832 GEMM on them (the form the training pass uses)
         self.tables = bool(tables)
+        # training: every fp16 activation gradient carries a power-of-two scale chosen per backward pass so that the
+        # largest entry of the first fp32 -> fp16 gradient lands near this value (train_fns.GradScale)
+        self.grad_scale_target = 256.0
         # ray chunks are independent: `lanes` HIP streams, each with its own workspace, take the chunks round-robin so
         # that the HBM-bound stages of one chunk (gather, hidden sums) run under the MFMA-bound GEMMs of another
         self.lanes = max(1, int(lanes))
@@ -266,7 +269,7 @@ class RenderEngine:
                      z: Sequence[torch.Tensor], rel_pose, val: bool, S: int, H: int, W: int) -> Dict[str, torch.Tensor]:
         """Same forward kernels as render(), wrapped in autograd Functions (coponerf_amd/train_fns.py); all rays of
         the call form one chunk (training uses <= 4096 rays per pair, /root/reference train.py:87)."""
-        from .train_fns import GemmFn, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn
+        from .train_fns import GemmFn, GradScale, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn
         dev = uv.device
         if dev.type != "cuda":
             raise RuntimeError("coponerf_amd renders on a HIP device only (got uv on %s)" % dev)
@@ -275,11 +278,12 @@ class RenderEngine:
             raise ValueError("render_train keeps all activations of the call: at most 32768 rays per call")
         g = self._geometry(ctx_c2w, ctx_K, qry_c2w, qry_K, uv, rel_pose, val, S, H, W)
         dims = (B, V, R, S)
+        gs = GradScale(self.grad_scale_target)      # one scale for all fp16 activation gradients of this pass
         P = params
         mat = lambda n, rows: P[n + ".weight"].reshape(rows, -1)
         bias = lambda n: P[n + ".bias"]
-        xin = GatherFn.apply(z[0], z[1], z[2], z[3], g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W))
-        hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False)
+        xin = GatherFn.apply(z[0], z[1], z[2], z[3], g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs)
+        hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False, gs)
         hid2 = hid.view(-1, 1664)
         W2, b2 = mat("query_encode_latent_2", 416), bias("query_encode_latent_2")
 
@@ -290,19 +294,19 @@ class RenderEngine:
 
         Wkf, ckf = fold("key_map", 128)
         Wvf, cvf = fold("latent_value", 416)
-        kh = GemmFn.apply(hid2, Wkf, ckf, True, False)
-        key2 = GemmFn.apply(kh, mat("key_map_2", 128), bias("key_map_2"), False, False)
-        hq = LocalHiddenFn.apply(g["loc8"], g["coords9"], mat("query_embed", 128), bias("query_embed"), None, dims)
-        ce = GemmFn.apply(hq, mat("query_embed_2", 128), bias("query_embed_2"), False, False)
-        hbar1, w1 = AttendHiddenFn.apply(key2, ce, hid2, dims)
-        z1 = GemmFn.apply(hbar1, Wvf, cvf, False, True)
+        kh = GemmFn.apply(hid2, Wkf, ckf, True, False, gs)
+        key2 = GemmFn.apply(kh, mat("key_map_2", 128), bias("key_map_2"), False, False, gs)
+        hq = LocalHiddenFn.apply(g["loc8"], g["coords9"], mat("query_embed", 128), bias("query_embed"), None, dims, gs)
+        ce = GemmFn.apply(hq, mat("query_embed_2", 128), bias("query_embed_2"), False, False, gs)
+        hbar1, w1 = AttendHiddenFn.apply(key2, ce, hid2, dims, gs)
+        z1 = GemmFn.apply(hbar1, Wvf, cvf, False, True, gs)
         ze = LinearF32Fn.apply(z1, mat("encode_latent", 128), bias("encode_latent"), None, False, False)
         Wr = mat("query_repeat_embed", 128)
         aq = LinearF32Fn.apply(ze, Wr[:, :128].contiguous(), None, None, False, False)
-        q2h = LocalHiddenFn.apply(g["loc8"], g["coords9"], Wr[:, 128:].contiguous(), bias("query_repeat_embed"), aq, dims)
-        q2 = GemmFn.apply(q2h, mat("query_repeat_embed_2", 128), bias("query_repeat_embed_2"), False, False)
-        hbar2, _ = AttendHiddenFn.apply(q2, ce, hid2, dims)
-        zs = GemmFn.apply(hbar2, Wvf, cvf, False, True)
+        q2h = LocalHiddenFn.apply(g["loc8"], g["coords9"], Wr[:, 128:].contiguous(), bias("query_repeat_embed"), aq, dims, gs)
+        q2 = GemmFn.apply(q2h, mat("query_repeat_embed_2", 128), bias("query_repeat_embed_2"), False, False, gs)
+        hbar2, _ = AttendHiddenFn.apply(q2, ce, hid2, dims, gs)
+        zs = GemmFn.apply(hbar2, Wvf, cvf, False, True, gs)
         zl = zs + float(V) * z1                                  # CoPoNeRF.py:481-485
         nray = B * R
         c18 = torch.zeros(nray, 32, dtype=torch.float32, device=dev)

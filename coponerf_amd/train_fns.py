@@ -21,6 +21,33 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class GradScale:
+    """Power-of-two scale carried by every fp16 activation gradient of ONE backward pass.
+
+    The reference trains in fp32 (no GradScaler, /root/reference wrapper.py:107-151) and its loss is an L1 `.mean()`
+    over B*R*3 ~ 5e4 elements, so dL/drgb ~ 2e-5 — already below fp16's smallest normal (6.1e-5) — and the gradient of
+    the per-sample hidden activations (softmax weight ~1/128 times that) would flush to zero if stored as plain
+    fp16.  Convention on this path: a gradient tensor of dtype fp16 holds `s * true gradient`, one of dtype fp32 holds
+    the true gradient.  `s` is fixed by the first backward function that turns an fp32 gradient into an fp16 one
+    (2^k such that its largest entry lands near `target`), lives on the device (no host sync), and is divided out
+    wherever an fp16 gradient is reduced into an fp32 one (weight / bias / feature-map gradients).  An overflow shows
+    up as a non-finite parameter gradient and makes the step's guard skip the update, like a lost AMP step."""
+
+    def __init__(self, target: float = 256.0):
+        self.target = float(target)
+        self.s = None
+
+    def ensure(self, d32: torch.Tensor) -> torch.Tensor:
+        if self.s is None:
+            amax = d32.detach().abs().amax().float().clamp_min(1e-30)
+            self.s = torch.exp2(torch.floor(torch.log2(self.target / amax))).clamp(2.0 ** -24, 2.0 ** 60)
+        return self.s
+
+    def scaled16(self, d: torch.Tensor) -> torch.Tensor:
+        """Incoming gradient -> the scaled representation (fp16 tensors already carry the scale)."""
+        return d if d.dtype == torch.float16 else d * self.ensure(d)
+
+
 def _mm_f32(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
     """(P,M) fp16 @ (M,Q) fp16 -> fp32 with fp32 accumulation AND fp32 output (hipBLASLt): M is millions of rows, an
     fp16 result would overflow / lose the tail of the sum."""
@@ -31,7 +58,7 @@ class GemmFn(Function):
     """C = act(A . W^T + b) through cpn_gemm_f16.  A (M, lda) fp16 (row stride lda >= K), W (N, K) fp32, b (N)."""
 
     @staticmethod
-    def forward(ctx, A16, W, b, relu: bool, out_f32: bool):
+    def forward(ctx, A16, W, b, relu: bool, out_f32: bool, gs: GradScale):
         M, lda = A16.shape
         N, K = W.shape
         Kp = ((K + 31) // 32) * 32
@@ -44,20 +71,21 @@ class GemmFn(Function):
         call("cpn_gemm_f16", A16.data_ptr(), lda, W16.data_ptr(), lda, bc.data_ptr(), C.data_ptr(), N, M, N, Kp,
              int(relu), int(out_f32), _stream())
         ctx.save_for_backward(A16, W16, C if relu else None)
-        ctx.relu, ctx.K = relu, K
+        ctx.relu, ctx.K, ctx.gs = relu, K, gs
         return C
 
     @staticmethod
     def backward(ctx, dC):
         A16, W16, C = ctx.saved_tensors
-        d = dC
+        d = ctx.gs.scaled16(dC.contiguous())                                 # s * dC (GradScale convention)
+        inv = 1.0 / ctx.gs.s
         if ctx.relu:
-            d = torch.ops.aten.threshold_backward(dC.contiguous(), C, 0)     # one pass: dC where C > 0
+            d = torch.ops.aten.threshold_backward(d, C.to(d.dtype) if C.dtype != d.dtype else C, 0)   # d where C > 0
         d16 = d.to(torch.float16)
-        dA = torch.matmul(d16, W16) if ctx.needs_input_grad[0] else None            # (M, lda): pad columns get 0
-        dW = _mm_f32(d16.t(), A16)[:, :ctx.K] if ctx.needs_input_grad[1] else None
-        db = d.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-        return dA, dW, db, None, None
+        dA = torch.matmul(d16, W16) if ctx.needs_input_grad[0] else None            # (M, lda) fp16, scaled; pad columns get 0
+        dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
+        db = d.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[2] else None
+        return dA, dW, db, None, None, None
 
 
 class LinearF32Fn(Function):
@@ -102,7 +130,7 @@ class LocalHiddenFn(Function):
     """out = fp16(relu(W . L(row) + b + add[ray])) through cpn_local_hidden."""
 
     @staticmethod
-    def forward(ctx, loc8, coords9, W, b, add, dims):
+    def forward(ctx, loc8, coords9, W, b, add, dims, gs: GradScale):
         B, V, R, S = dims
         nrays = B * R
         Wc, bc = W.detach().contiguous().float(), b.detach().contiguous().float()
@@ -111,25 +139,26 @@ class LocalHiddenFn(Function):
         call("cpn_local_hidden", loc8.data_ptr(), coords9.data_ptr(), Wc.data_ptr(), Wc.shape[1], bc.data_ptr(),
              0 if ac is None else ac.data_ptr(), B, V, R, S, 0, nrays, out.data_ptr(), _stream())
         ctx.save_for_backward(loc8, coords9, out)
-        ctx.dims, ctx.has_add = dims, add is not None
+        ctx.dims, ctx.has_add, ctx.gs = dims, add is not None, gs
         return out
 
     @staticmethod
     def backward(ctx, dout):
         loc8, coords9, out = ctx.saved_tensors
         B, V, R, S = ctx.dims
-        d = torch.ops.aten.threshold_backward(dout.contiguous(), out, 0).float()
+        ds = ctx.gs.scaled16(dout.contiguous()).to(torch.float16)
+        d = torch.ops.aten.threshold_backward(ds, out, 0).float() * (1.0 / ctx.gs.s)      # fp32, true scale from here on
         L = build_local_coords(loc8, coords9, B, V, R, S)
         dW = d.t() @ L
         dadd = d.view(B * R, V * S, 128).sum(1) if ctx.has_add else None
-        return None, None, dW, d.sum(0), dadd, None
+        return None, None, dW, d.sum(0), dadd, None, None
 
 
 class AttendHiddenFn(Function):
     """(hbar fp16 (rays,1664), w fp32 (N,R,S)) = cpn_attend_hidden(qa, qb, hid)."""
 
     @staticmethod
-    def forward(ctx, qa, qb, hid2, dims):
+    def forward(ctx, qa, qb, hid2, dims, gs: GradScale):
         B, V, R, S = dims
         nrays = B * R
         hbar = torch.empty(nrays, 1664, dtype=torch.float16, device=qa.device)
@@ -137,7 +166,7 @@ class AttendHiddenFn(Function):
         call("cpn_attend_hidden", qa.data_ptr(), qb.data_ptr(), 0, hid2.data_ptr(), B, V, R, S, 0, nrays, hbar.data_ptr(),
              w.data_ptr(), _stream())
         ctx.save_for_backward(qa, qb, hid2, w)
-        ctx.dims = dims
+        ctx.dims, ctx.gs = dims, gs
         return hbar, w
 
     @staticmethod
@@ -145,20 +174,26 @@ class AttendHiddenFn(Function):
         qa, qb, hid2, w = ctx.saved_tensors
         B, V, R, S = ctx.dims
         nrays = B * R
+        gs = ctx.gs
+        # the kernel is linear in (dhbar, dw): feed both in the scaled representation, get scaled fp16 gradients back.
+        # dhbar (fp16) already carries the scale its producer fixed; if only the softmax weights received a gradient
+        # (dhbar is the materialised zero tensor) the scale is fixed here from dw
+        if gs.s is None:
+            gs.ensure(dw)
         dh = dhbar.float().contiguous()
-        dwc = None if dw is None else dw.float().contiguous()
+        dwc = None if dw is None else (dw.float() * gs.s).contiguous()
         dqa, dqb, dhid = torch.empty_like(qa), torch.empty_like(qb), torch.empty_like(hid2)
         call("cpn_attend_hidden_bwd", qa.data_ptr(), qb.data_ptr(), hid2.data_ptr(), w.data_ptr(), dh.data_ptr(),
              0 if dwc is None else dwc.data_ptr(), B, V, R, S, 0, nrays, dqa.data_ptr(), dqb.data_ptr(),
              dhid.data_ptr(), _stream())
-        return dqa, dqb, dhid, None
+        return dqa, dqb, dhid, None, None
 
 
 class GatherFn(Function):
     """xin fp16 (rows2, 896) = cpn_gather_rows(NHWC fp16 copies of z0..z3); backward scatters into the maps."""
 
     @staticmethod
-    def forward(ctx, z0, z1, z2, z3, pixel_val, sec_grid, pe6, dims, HW):
+    def forward(ctx, z0, z1, z2, z3, pixel_val, sec_grid, pe6, dims, HW, gs: GradScale):
         B, V, R, S = dims
         H, W = HW
         s = _stream()
@@ -174,7 +209,7 @@ class GatherFn(Function):
         call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, W,
              pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, 0, nrays, xin.data_ptr(), s)
         ctx.save_for_backward(pixel_val, sec_grid)
-        ctx.dims, ctx.HW = dims, HW
+        ctx.dims, ctx.HW, ctx.gs = dims, HW, gs
         ctx.shapes = [tuple(t.shape) for t in (z0, z1, z2, z3)]
         return xin
 
@@ -183,11 +218,12 @@ class GatherFn(Function):
         pixel_val, sec_grid = ctx.saved_tensors
         B, V, R, S = ctx.dims
         H, W = ctx.HW
-        d = dxin.contiguous()
+        d = ctx.gs.scaled16(dxin.contiguous()).to(torch.float16)
+        inv = 1.0 / ctx.gs.s
         dmaps = [torch.zeros(n, h, w_, c, dtype=torch.float32, device=d.device) for (n, c, h, w_) in ctx.shapes]
         boxes = torch.empty(B * V * _hip.lib().cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=d.device)
         call("cpn_gather_rows_bwd", d.data_ptr(), d.shape[1], H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V, R, S,
              0, B * R, dmaps[0].data_ptr(), dmaps[1].data_ptr(), dmaps[2].data_ptr(), dmaps[3].data_ptr(),
              boxes.data_ptr(), _stream())
-        g = [m.permute(0, 3, 1, 2).contiguous() for m in dmaps]
-        return g[0], g[1], g[2], g[3], None, None, None, None, None
+        g = [m.mul_(inv).permute(0, 3, 1, 2).contiguous() for m in dmaps]         # fp32 accumulators back to true scale
+        return g[0], g[1], g[2], g[3], None, None, None, None, None, None

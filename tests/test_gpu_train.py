@@ -198,3 +198,79 @@ def test_conv_weight_gradient_kernels(dev):
         grads.append((xs.grad, ws.grad, bs.grad))
     for g_ref, g_hip in zip(*grads):
         assert (g_ref - g_hip).abs().max() <= 2e-4 * (1 + g_ref.abs().max())
+
+
+def test_mean_loss_gradients_survive_fp16(dev):
+    """the reference's loss is an L1 `.mean()` over B*R*3 ~ 5e4 values, so dL/drgb ~ 2e-5 and the
+    per-sample activation gradients (~1e-8) underflow plain fp16.  With the per-pass power-of-two scale of
+    train_fns.GradScale every gradient must match fp32 autograd through the oracle at THAT magnitude (the loss below
+    is the small case's L1 sum divided by 4*4096*3, i.e. the configs[2] normalisation)."""
+    from coponerf_amd import CoPoNeRF
+    from oracle import render_ref as orc
+    B, H, R, S = 2, 64, 80, 32
+    denom = 4 * 4096 * 3
+    weights = syn.make_render_weights(seed=17)
+    inp = syn.make_inputs(B, H, H, R, seed=51)
+    z, rel, flow = syn.make_latents(B, H, H, seed=52)
+    gt = inp["query"]["rgb"]
+    w_ref = {k: v.clone().requires_grad_(True) for k, v in weights.items()}
+    z_ref = [t.clone().requires_grad_(True) for t in z]
+    ((orc.forward(inp, z_ref, rel, flow, False, w_ref, npoints=S)["rgb"] - gt).abs().sum() / denom).backward()
+    model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+    model.load_state_dict(weights, strict=False)
+    model = model.to(dev).train()
+    z_hip = [t.to(dev).requires_grad_(True) for t in z]
+    out = model(to_device(inp, dev), z=z_hip, rel_pose=rel.to(dev), val=False, flow=to_device(flow, dev))
+    ((out["rgb"] - gt.to(dev)).abs().sum() / denom).backward()
+    params = dict(model.named_parameters())
+    bad, seen_small = [], False
+    for name, ref in list(w_ref.items()) + [(f"z{i}", t) for i, t in enumerate(z_ref)]:
+        got = (z_hip[int(name[1:])] if name[0] == "z" and name[1:].isdigit() else params[name]).grad
+        if ref.grad is None or float(ref.grad.norm()) == 0.0:
+            continue
+        assert got is not None and torch.isfinite(got).all(), name
+        seen_small |= float(ref.grad.abs().max()) < 6.1e-5               # below fp16's smallest normal
+        rel_err = float((got.cpu() - ref.grad).norm() / ref.grad.norm())
+        if rel_err > (0.12 if name.startswith("phi.") else 4e-2):
+            bad.append((name, rel_err, float(ref.grad.abs().max())))
+    assert seen_small, "the case does not exercise sub-fp16-normal gradients"
+    assert not bad, bad
+
+
+def test_config3_size_training_step(dev):
+    """BASELINE configs[2] at its real per-GPU size (batch 4 pairs x 4096 rays x 64 samples, 256x256): one full step
+    (get_z + render + L1 mean loss + backward) is finite, and because stereo pairs are independent work units the
+    batched render gradient equals the sum of the four per-pair gradients."""
+    from coponerf_amd import CoPoNeRF
+    B, H, R, S = 4, 256, 4096, 64
+    weights = syn.make_render_weights(seed=17)
+    model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+    model.load_state_dict(weights, strict=False)
+    model = model.to(dev).train()
+    inp = to_device(syn.make_inputs(B, H, H, R, seed=61), dev)
+    z, rel, flow = syn.make_latents(B, H, H, seed=62)
+    z, rel, flow = to_device(z, dev), rel.to(dev), to_device(flow, dev)
+    gt = inp["query"]["rgb"]
+    names = ("query_encode_latent.weight", "key_map.weight", "latent_value.weight", "phi.lin_out.weight",
+             "query_embed.weight", "query_repeat_embed_2.bias")
+    P = dict(model.named_parameters())
+
+    def grads(sel):
+        model.zero_grad(set_to_none=True)
+        sub = {"context": {k: v[sel] for k, v in inp["context"].items()}, "query": {k: v[sel] for k, v in inp["query"].items()}}
+        zz = [t.view(B, 2, *t.shape[1:])[sel].reshape(-1, *t.shape[1:]) for t in z]
+        out = model(sub, z=zz, rel_pose=rel[sel], val=False, flow=[f[sel] for f in flow])
+        loss = (out["rgb"] - gt[sel]).abs().sum() / (B * R * 3)
+        loss.backward()
+        return float(loss.detach()), {n: P[n].grad.detach().clone() for n in names}
+
+    loss_all, g_all = grads(slice(0, B))
+    assert torch.isfinite(torch.tensor(loss_all))
+    parts = [grads(slice(b, b + 1)) for b in range(B)]
+    assert abs(sum(p[0] for p in parts) - loss_all) <= 1e-5 * max(1.0, abs(loss_all))
+    for n in names:
+        want = sum(p[1][n] for p in parts)
+        assert torch.isfinite(g_all[n]).all() and float(g_all[n].abs().max()) > 0, n
+        rel_err = float((g_all[n] - want).norm() / (want.norm() + 1e-20))
+        # the batched and the per-pair passes pick their fp16 gradient scale separately: equal up to fp16 rounding
+        assert rel_err <= 2e-2, (n, rel_err)
