@@ -54,7 +54,7 @@ SIGNATURES: Dict[str, List] = {
 CAM_STRIDE = 96
 CAM_TQ, CAM_M, CAM_AOWN, CAM_AOTH, CAM_KQ, CAM_KC, CAM_KO, CAM_KN = 0, 16, 32, 48, 64, 68, 72, 76
 XIN_K, XIN_STRIDE = 864, 896
-TAB_LD, TAB_SLICE = 896, 224
+TAB_LD = 832
 ABI_VERSION = 1
 
 

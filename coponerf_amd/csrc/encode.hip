@@ -55,16 +55,15 @@
 namespace {
 
 constexpr int TILE_ROWS = 128;
-constexpr int NSLICE = 4;                 // 832 = 4 x 208 output channels
-constexpr int SLICE_CH = 208;
-constexpr int NT = 13;                    // 16-channel MFMA tiles per slice
+constexpr int NSLICE = 13;                // 832 = 13 x 64 output channels
+constexpr int SLICE_CH = 64;
+constexpr int NT = 4;                     // 16-channel MFMA tiles per slice
 constexpr int KSTEPS = 3;                 // K = 96 = 64 level-3 channels + 3 point encodings + zeros
 constexpr int PAD = CPN_NODE_PAD;         // zero rim of the 'zeros' table, in nodes (= level-0 texel pitch / 2)
-constexpr int TAB_SLICE_BYTES = CPN_TAB_SLICE * 2;             // 448: 384 main + 64 tail (4 x {8 B used, 8 B pad})
-constexpr int TAB_ROW_BYTES = CPN_TAB_LD * 2;                  // 1792 per node
+constexpr int TAB_SLICE_BYTES = SLICE_CH * 2;                  // 128: one cache line per node and slice
+constexpr int TAB_ROW_BYTES = CPN_TAB_LD * 2;                  // 1664 per node, channels in natural order
 constexpr int AIMG_BYTES = 2 * 4 * 2 * 1024 + 4 * 2 * 256;     // [k < 2][wave][mt][lane] half8 + [wave][mt][r] half8 (k = 2, g = 0)
 constexpr int AIMG2_OFF = 2 * 4 * 2 * 1024;                    // third K step: only lane group 0 holds data (pt enc)
-constexpr int WIMG_BYTES = KSTEPS * NT * 1024;                 // [k][nt][lane] half8
 constexpr int TG = 4;                     // rays per tile
 constexpr int TSB = 16;                   // samples per tile
 
@@ -143,13 +142,10 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
     const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, const float* __restrict__ pe6,
     const half8* __restrict__ wfrag, const float* __restrict__ bias, int V, int R, int S, int ray0, int nrays,
     int nblk, int groups_per_b, long long group0, __half* __restrict__ hid) {
-    // separate LDS objects (not one dynamic array): the compiler then knows that reads of the tap records do not
-    // alias the in-flight buffer_load ... lds of the weight image and does not drain vmcnt in front of them
     __shared__ __attribute__((aligned(16))) TapRec taps[TILE_ROWS];          // table taps
     __shared__ __attribute__((aligned(16))) TapRec taps3[TILE_ROWS];         // full-resolution level
     __shared__ __attribute__((aligned(16))) char aimg[AIMG_BYTES];
-    __shared__ __attribute__((aligned(16))) char wimg[WIMG_BYTES];
-    __shared__ __attribute__((aligned(16))) float bias_s[832];     // keeps the slice loop free of global loads up to the taps
+    __shared__ __attribute__((aligned(16))) float bias_s[832];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -165,19 +161,6 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
     const long long gq = group0 + tile / (unsigned)(nblk * V);
     const int b = (int)(gq / groups_per_b), rgroup = (int)(gq % groups_per_b);
     const NodeGrid ng{W >> 1, H >> 1};
-
-    // weight fragments of slice n -> LDS (lane-linear 1 KiB pieces, wave w moves pieces w, w+4, ...)
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)wfrag, 0, NSLICE * WIMG_BYTES, 0x00020000);
-    auto stage_w = [&](int n) {
-#pragma unroll
-        for (int i = 0; i < (KSTEPS * NT + 3) / 4; ++i) {
-            const int piece = wave + 4 * i;
-            if (piece < KSTEPS * NT)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(wimg + piece * 1024), 16, lane * 16,
-                                                         n * WIMG_BYTES + piece * 1024, 0, 0);
-        }
-    };
 
     // ---- phase A: tap records, thread = (row, {table, full-resolution level}) ---------------------------------
     for (int i = tid; i < 832 / 4; i += 256)
@@ -205,7 +188,6 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
         (half == 0 ? taps : taps3)[row] = rec;
     }
     __syncthreads();
-    stage_w(0);               // lands under phase B
 
     // image of the own (j = 0, border table) and of the other (j = 1, zeros table) view of this tile
     const int img_own = b * V + v, img_oth = b * V + (V - 1 - v);
@@ -253,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
             *reinterpret_cast<half8*>(aimg + AIMG2_OFF + ((w_ * 2 + mt) * 16 + rs) * 16) = p8;
         }
     }
-    __syncthreads();          // (drains vmcnt: slice 0 of the weights has landed too)
+    __syncthreads();          // last workgroup-wide barrier: from here on the four waves run independently
 
     half8 xa[KSTEPS][2];
 #pragma unroll
@@ -288,34 +270,73 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
         (void*)(tbase + img_bytes * img_oth + (size_t)ng.border_nodes() * TAB_ROW_BYTES), 0,
         (int)(ng.zeros_nodes() * TAB_ROW_BYTES), 0x00020000);
 
-    for (int n = 0; n < NSLICE; ++n) {
-        f32x4 acc[2][NT];
-        // bias of the lane's 52 channels (natural channel order)
-        {
-            const float* bp = bias_s + n * SLICE_CH;
+    // tap records of the lane's two rows (they do not change from slice to slice)
+    TapRec rec[2];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                acc[0][2 * k] = *reinterpret_cast<const f32x4*>(bp + k * 32 + g * 8);
-                acc[0][2 * k + 1] = *reinterpret_cast<const f32x4*>(bp + k * 32 + g * 8 + 4);
+    for (int mt = 0; mt < 2; ++mt) rec[mt] = taps[wave * 32 + 2 * rl + mt];
+    int vo[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo[mt][k] = ((CPN_ENCODE_ABLATE & 16) ? 0 : rec[mt].off[k]) + pl * 16;
+
+    // Slice loop, software-pipelined by one slice on the store side:
+    //     issue ALL loads of slice n (weight fragments, taps)  ->  issue the stores of slice n-1  ->  compute slice n.
+    // gfx9 has ONE counter for loads and stores (vmcnt) and they retire out of order against each other, so waiting
+    // for any load that was issued AFTER a store also waits for that store to reach memory.  With the order above every
+    // load a wave ever waits for is OLDER than the stores in flight: the 7 GB hid stream never stalls the wave that
+    // issued it, only the end of the kernel does.  No workgroup barrier, no LDS traffic except bias + bpermute.
+    half8 res[2][2];                                        // fp16 results of the previous slice, waiting to be stored
+    const __half* const hrow = hid + lrow0 * 832 + pl * 8;
+    auto store_slice = [&](int n) {
+        if (lid.live && (!(CPN_ENCODE_ABLATE & 2) || res[0][0][0] == (_Float16)123.0f)) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                __half* o = const_cast<__half*>(hrow) + mt * 832 + n * SLICE_CH;
+                *reinterpret_cast<half8*>(o) = res[mt][0];
+                *reinterpret_cast<half8*>(o + 32) = res[mt][1];
             }
-            acc[0][12] = *reinterpret_cast<const f32x4*>(bp + 192 + g * 4);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[1][nt] = acc[0][nt];
         }
-        // ---- K = 96 contraction of the full-resolution level + point encoding
+    };
+    for (int n = 0; n < NSLICE; ++n) {
+        // ---- loads of this slice: 12 weight fragments (coalesced 1 KiB each, L2-resident) + 16 tap pieces
+        half8 wf[KSTEPS][NT];
+#pragma unroll
+        for (int k = 0; k < KSTEPS; ++k)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[k][nt] = wfrag[((n * KSTEPS + k) * NT + nt) * 64 + lane];
+        u32x4 td[2][4][2];
+        if (!(CPN_ENCODE_ABLATE & 1)) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const __amdgpu_buffer_rsrc_t rs = mt == 0 ? trs_b : trs_z;
+                    td[mt][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[mt][k], n * TAB_SLICE_BYTES, 0);
+                    td[mt][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[mt][k] + 64, n * TAB_SLICE_BYTES, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n > 0) store_slice(n - 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- K = 96 contraction of the full-resolution level + point encoding, on top of the bias
+        f32x4 acc[2][NT];
+        {
+            const float* bp = bias_s + n * SLICE_CH + g * 8;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[0][nt] = *reinterpret_cast<const f32x4*>(bp + (nt >> 1) * 32 + (nt & 1) * 4);
+                acc[1][nt] = acc[0][nt];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < ((CPN_ENCODE_ABLATE & 4) ? 0 : KSTEPS); ++k)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const half8 wb = *reinterpret_cast<const half8*>(wimg + ((k * NT + nt) * 64 + lane) * 16);
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xa[k][0], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, xa[k][1], acc[1][nt], 0, 0, 0);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k][nt], xa[k][0], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k][nt], xa[k][1], acc[1][nt], 0, 0, 0);
             }
-        // every wave has read this slice's fragments.  Raw s_barrier, not __syncthreads(): the fence of the latter
-        // drains vmcnt to 0, i.e. it would wait here for the previous slice's hid stores to reach memory
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (n + 1 < NSLICE) stage_w(n + 1);     // the next slice lands under the table taps below
         // MFMA layout -> load layout
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -327,73 +348,34 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
                     acc[mt][nt][i] = __int_as_float(         //  reads element 0 for every i with this compiler)
                         __builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(t)));
                 }
-
-        // ---- 4 table taps per row, accumulated in fp32 on top of the MFMA result.  Order: 128-byte line (two
-        //      16-byte pieces per lane) outermost, the four taps inside: the taps of neighbouring rows that fall on
-        //      the same node request the same cache line back to back
-        const int col_off = n * TAB_SLICE_BYTES + pl * 16;
+        // ---- 4 table taps per row in fp32 on top of it, then ReLU and the fp16 rounding
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int trow = wave * 32 + 2 * rl + mt;
             if (!(CPN_ENCODE_ABLATE & 1)) {
-                const TapRec rec = taps[trow];
-                const __amdgpu_buffer_rsrc_t rs = mt == 0 ? trs_b : trs_z;
-                int vo[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) vo[k] = ((CPN_ENCODE_ABLATE & 16) ? 0 : rec.off[k]) + col_off;
-#pragma unroll
-                for (int cp = 0; cp < 3; ++cp) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const u32x4 d0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k] + cp * 128, 0, 0);
-                        const u32x4 d1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k] + cp * 128 + 64, 0, 0);
-                        const float wk = rec.w[k];
-                        f32x4* a4 = &acc[mt][4 * cp];
-                        a4[0][0] = fma_mix_lo(a4[0][0], d0[0], wk); a4[0][1] = fma_mix_hi(a4[0][1], d0[0], wk);
-                        a4[0][2] = fma_mix_lo(a4[0][2], d0[1], wk); a4[0][3] = fma_mix_hi(a4[0][3], d0[1], wk);
-                        a4[1][0] = fma_mix_lo(a4[1][0], d0[2], wk); a4[1][1] = fma_mix_hi(a4[1][1], d0[2], wk);
-                        a4[1][2] = fma_mix_lo(a4[1][2], d0[3], wk); a4[1][3] = fma_mix_hi(a4[1][3], d0[3], wk);
-                        a4[2][0] = fma_mix_lo(a4[2][0], d1[0], wk); a4[2][1] = fma_mix_hi(a4[2][1], d1[0], wk);
-                        a4[2][2] = fma_mix_lo(a4[2][2], d1[1], wk); a4[2][3] = fma_mix_hi(a4[2][3], d1[1], wk);
-                        a4[3][0] = fma_mix_lo(a4[3][0], d1[2], wk); a4[3][1] = fma_mix_hi(a4[3][1], d1[2], wk);
-                        a4[3][2] = fma_mix_lo(a4[3][2], d1[3], wk); a4[3][3] = fma_mix_hi(a4[3][3], d1[3], wk);
-                    }
-                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const u32x2 dt = __builtin_amdgcn_raw_buffer_load_b64(rs, vo[k] + 384, 0, 0);
-                    const float wk = rec.w[k];
-                    acc[mt][12][0] = fma_mix_lo(acc[mt][12][0], dt[0], wk);
-                    acc[mt][12][1] = fma_mix_hi(acc[mt][12][1], dt[0], wk);
-                    acc[mt][12][2] = fma_mix_lo(acc[mt][12][2], dt[1], wk);
-                    acc[mt][12][3] = fma_mix_hi(acc[mt][12][3], dt[1], wk);
-                }
-            }
-            // ---- ReLU, fp16, store (natural channel order; 4 adjacent lanes write 64 contiguous bytes of a row).
-            //      Plain stores: `nt` ones were measured to defeat the write combining in L2 (WRITE_SIZE 10.7 vs 7.3 GB)
-            if (lid.live && (!(CPN_ENCODE_ABLATE & 2) || acc[mt][0][0] == 123.456f)) {
-                __half* orow = hid + (lrow0 + mt) * 832 + n * SLICE_CH;
+                    const float wk = rec[mt].w[k];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    half8 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        o[i] = (_Float16)fmaxf(acc[mt][2 * c][i], 0.0f);
-                        o[4 + i] = (_Float16)fmaxf(acc[mt][2 * c + 1][i], 0.0f);
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x4 d = td[mt][k][h];
+                        f32x4* a2 = &acc[mt][2 * h];
+                        a2[0][0] = fma_mix_lo(a2[0][0], d[0], wk); a2[0][1] = fma_mix_hi(a2[0][1], d[0], wk);
+                        a2[0][2] = fma_mix_lo(a2[0][2], d[1], wk); a2[0][3] = fma_mix_hi(a2[0][3], d[1], wk);
+                        a2[1][0] = fma_mix_lo(a2[1][0], d[2], wk); a2[1][1] = fma_mix_hi(a2[1][1], d[2], wk);
+                        a2[1][2] = fma_mix_lo(a2[1][2], d[3], wk); a2[1][3] = fma_mix_hi(a2[1][3], d[3], wk);
                     }
-                    *reinterpret_cast<half8*>(orow + c * 32 + pl * 8) = o;
                 }
-                half4 o4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o4[i] = (_Float16)fmaxf(acc[mt][12][i], 0.0f);
-                *reinterpret_cast<half4*>(orow + 192 + pl * 4) = o4;
             }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    res[mt][h][i] = (_Float16)fmaxf(acc[mt][2 * h][i], 0.0f);
+                    res[mt][h][4 + i] = (_Float16)fmaxf(acc[mt][2 * h + 1][i], 0.0f);
+                }
         }
-        // The next slice's fragments are in LDS: this wave's DMA pieces were issued BEFORE its tap loads, loads
-        // retire in order and every tap load has been consumed above, so only the barrier is needed — no vmcnt(0)
-        // that would also wait for the hid stores just issued
-        if (n + 1 < NSLICE) __builtin_amdgcn_s_barrier();
     }
+    store_slice(NSLICE - 1);
 }
 
 // ---- node features: the three coarse levels sampled (grid_sample semantics of the mode) at every table node -------
@@ -439,7 +421,7 @@ __global__ void node_features_kernel(const __half* __restrict__ map0, const __ha
 // ---- weight images ------------------------------------------------------------------------------------------------
 // channel of a slice that MFMA tile nt, A-operand row a computes (lane (r, g) of the result then holds a = g*4 + i)
 __host__ __device__ inline int slice_channel(int nt, int a) {
-    return nt < 12 ? (nt >> 1) * 32 + (a >> 2) * 8 + (nt & 1) * 4 + (a & 3) : 192 + a;
+    return (nt >> 1) * 32 + (a >> 2) * 8 + (nt & 1) * 4 + (a & 3);
 }
 
 // W (832, 835) fp32 -> wfrag [slice][k][nt][lane] half8 over columns 768..834 (K padded to 96)
@@ -461,21 +443,12 @@ __global__ void pack_encode_frag_kernel(const float* __restrict__ W, int ldw, ha
     out[idx] = o;
 }
 
-// W (832, 835) fp32 -> the table projection (CPN_TAB_LD, 768) fp16 over the three coarse levels, table column c' -> channel
-//   slice n = c' / 224, q = c' % 224:  q < 192 -> n*208 + q ;  else u = q - 192: (u & 7) < 4 -> n*208 + 192 + (u>>3)*4 + (u&7)
-//   (the 4 lanes of a row read 8 bytes each at 16-byte pitch), else a zero row
+// W (832, 835) fp32 -> the table projection (832, 768) fp16 over the three coarse levels (natural channel order)
 __global__ void pack_table_weight_kernel(const float* __restrict__ W, int ldw, __half* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= CPN_TAB_LD * 768) return;
-    const int kc = idx % 768, cp = idx / 768;
-    const int n = cp / CPN_TAB_SLICE, qq = cp % CPN_TAB_SLICE;
-    int ch = -1;
-    if (qq < 192) ch = n * SLICE_CH + qq;
-    else {
-        const int u = qq - 192;
-        if ((u & 7) < 4) ch = n * SLICE_CH + 192 + (u >> 3) * 4 + (u & 7);
-    }
-    out[idx] = __float2half(ch >= 0 ? W[(size_t)ch * ldw + kc] : 0.0f);
+    const int kc = idx % 768, ch = idx / 768;
+    out[idx] = __float2half(W[(size_t)ch * ldw + kc]);
 }
 
 }  // namespace
@@ -528,7 +501,7 @@ extern "C" int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int 
     CPN_REQUIRE(((uintptr_t)tab % 16) == 0 && ((uintptr_t)map3 % 16) == 0 && ((uintptr_t)wfrag % 16) == 0 &&
                     ((uintptr_t)bias % 16) == 0 && ((uintptr_t)hid % 16) == 0, CPN_E_ARG,
                 "cpn_encode_hidden: pointers must be 16-byte aligned");
-    static_assert(2 * (2 * TILE_ROWS * 32 + AIMG_BYTES + WIMG_BYTES + 832 * 4) <= 160 * 1024, "two workgroups per CU");
+    static_assert(2 * (2 * TILE_ROWS * 32 + AIMG_BYTES + 832 * 4) <= 160 * 1024, "at least two workgroups per CU");
     // ray groups: TG consecutive rays of ONE batch element (r aligned to TG), so a tile's images are uniform
     const int groups_per_b = (int)cpn_cdiv(R, TG);
     const int b_lo = ray0 / R, b_hi = (ray0 + nrays - 1) / R;

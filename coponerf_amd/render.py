@@ -197,7 +197,7 @@ class RenderEngine:
         # ---- "project, then interpolate" form of the first layer (csrc/encode.hip): MFMA fragments of the
         #      full-resolution / point-encoding columns and the table projection weights of the three coarse levels
         W1 = f32("query_encode_latent.weight").reshape(832, 835)
-        w["enc.frag"] = torch.empty(4 * 3 * 13 * 64 * 8, dtype=torch.float16, device=dev)
+        w["enc.frag"] = torch.empty(13 * 3 * 4 * 64 * 8, dtype=torch.float16, device=dev)
         w["enc.wtab"] = torch.empty(_hip.TAB_LD, 768, dtype=torch.float16, device=dev)
         call("cpn_pack_encode_weights", W1.data_ptr(), 835, w["enc.frag"].data_ptr(), w["enc.wtab"].data_ptr(), s)
         w["enc.zero_bias"] = torch.zeros(_hip.TAB_LD, dtype=torch.float32, device=dev)

@@ -128,15 +128,13 @@ int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int 
  *   Built as  cpn_node_features (the three levels sampled at every node -> (nodes, 768) fp16)
  *             -> cpn_gemm_f16(A = node features, W = wtab, N = CPN_TAB_LD, K = 768, bias 0, fp16 out).
  * A row is then 4 weighted table taps + a K = 96 MFMA product over [level-3 gather (64) | pt (3) | 0] + bias.
- * Table row layout: 4 slices of CPN_TAB_SLICE halves; slice n holds channels n*208 .. n*208+191 in order, then the last
- * 16 channels as 4 groups of {4 channels, 4 zero halves} (64-byte aligned 64-byte reads for the 4 lanes of a row).
+ * Table rows hold the 832 channels in natural order (1664 B, 13 cache lines; the kernel walks 13 slices of 64 channels).
  *   cpn_pack_encode_weights: W (832, ldw >= 835) fp32 query_encode_latent.weight ->
- *       wfrag (4*3*13*64*8 halves) MFMA A-operand fragments of W[:, 768:835] (K padded to 96)
- *       wtab  (CPN_TAB_LD, 768) fp16 table projection weights (row order = table column order)
+ *       wfrag (13*3*4*64*8 halves) MFMA A-operand fragments of W[:, 768:835] (K padded to 96)
+ *       wtab  (832, 768) fp16 table projection weights W[:, 0:768]
  *   cpn_encode_hidden: hid (rays*V*S*2, 832) fp16 in the row order of this header; bias (832) fp32; map3 the
  *       full-resolution NHWC fp16 map (N, H, W, 64)                                                               */
-#define CPN_TAB_SLICE 224
-#define CPN_TAB_LD    896
+#define CPN_TAB_LD    832
 #define CPN_NODE_PAD  4
 long long cpn_encode_table_nodes(int H, int W);
 int cpn_pack_encode_weights(const float* W, int ldw, uint16_t* wfrag, uint16_t* wtab, void* stream);

@@ -306,7 +306,7 @@ def test_encode_hidden_against_torch(dev):
         call("cpn_nchw_to_nhwc_f16", src.data_ptr(), d.data_ptr(), n, c, h, w, s)
         maps.append(d)
     W1d, b1d = W1.to(dev).contiguous(), b1.to(dev).contiguous()
-    frag = torch.empty(4 * 3 * 13 * 64 * 8, dtype=torch.float16, device=dev)
+    frag = torch.empty(13 * 3 * 4 * 64 * 8, dtype=torch.float16, device=dev)
     wtab = torch.empty(_hip.TAB_LD, 768, dtype=torch.float16, device=dev)
     call("cpn_pack_encode_weights", W1d.data_ptr(), 835, frag.data_ptr(), wtab.data_ptr(), s)
     zero_bias = torch.zeros(_hip.TAB_LD, device=dev)
