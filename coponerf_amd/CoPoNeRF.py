@@ -97,7 +97,18 @@ class CoPoNeRF(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _render_params(self) -> Dict[str, torch.Tensor]:
-        return {k: v for k, v in self.named_parameters() if k.split(".")[0] in RENDER_PARAM_PREFIXES}
+        # the Parameter OBJECTS are stable across .to()/.cuda()/load_state_dict (those rewrite .data in place), so the
+        # walk over the 636 parameters of the module tree is done once, not on every ray chunk of a full-image render
+        rp = self.__dict__.get("_rp_cache")
+        if rp is None or any(self._parameters_changed(rp)):
+            rp = {k: v for k, v in self.named_parameters() if k.split(".")[0] in RENDER_PARAM_PREFIXES}
+            self.__dict__["_rp_cache"] = rp
+        return rp
+
+    def _parameters_changed(self, rp):
+        # a replaced Parameter (e.g. `model.phi.lin_out.weight = nn.Parameter(...)`) shows up as a different object
+        yield self.query_encode_latent.weight is not rp["query_encode_latent.weight"]
+        yield self.phi.lin_out.weight is not rp["phi.lin_out.weight"]
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         out = super().load_state_dict(state_dict, strict=strict, assign=assign)

@@ -48,6 +48,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "cpn_soft_argmax_pair": [_P, _I, _I, _F, _P, _P, _P],
     "cpn_soft_argmax_pair_bwd": [_P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
+    "cpn_linear_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
+    "cpn_cross_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
 }
 
@@ -96,6 +98,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_abi_version.restype = ctypes.c_int
     handle.cpn_encode_table_nodes.argtypes = [_I, _I]
     handle.cpn_encode_table_nodes.restype = ctypes.c_longlong
+    handle.cpn_linear_attention_scratch.argtypes = [_I, _I, _I, _I]
+    handle.cpn_linear_attention_scratch.restype = ctypes.c_longlong
     handle.cpn_gather_bwd_chunks.argtypes = [_I, _I]
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
     handle.cpn_conv4d_scratch.argtypes = [_I] * 7

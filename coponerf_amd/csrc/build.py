@@ -23,6 +23,7 @@ UNITS = [
     ("attend.hip", []),
     ("linear_f32.hip", []),
     ("ufc.hip", []),
+    ("ufc_attn.hip", []),
     ("backward.hip", []),
 ]
 

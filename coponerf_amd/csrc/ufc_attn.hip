@@ -1,0 +1,216 @@
+// K9 / K10 — the two attention forms of UFCLayer on gfx950 (get_z path).
+//
+//   cpn_linear_attention   aggregation.LinearAttention.forward (/root/reference models/aggregation.py:84-117):
+//                          phi = ELU + 1;  KV = sum_s phi(K)_s (x) V_s / L;  out = phi(Q).KV * L / (phi(Q).sum_s phi(K)_s + eps)
+//   cpn_cross_attention    the cost-volume cross attention of UFCLayer.forward_cross (aggregation.py:327-328):
+//                          src_attn = softmax_t(corr) . trg_v ,  trg_attn = softmax_s(corr)^T . src_v
+//
+// Both are tiny in FLOPs (<= 0.6 GFLOP per call) and were ~15 ATen launches each (elu, add, div, three einsums with
+// their permute copies / two strided softmaxes and two einsums): HBM/launch-bound glue.  Here each is two launches
+// that read every operand once in its native layout.  fp32 throughout.
+#include "common.h"
+
+namespace {
+
+constexpr int LA_D = 32;                    // head dimension of q / k
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x + 1.0f : expf(x); }        // elu(x) + 1, alpha = 1
+
+// value addressing: token-major (B, L, H, Dv) [the feature branch] or channel-major (B, H, Dv, L) [the cost-volume
+// branch: (B, H*Ht*Wt, fs, fs) maps are exactly that, so neither the operand nor the result needs a permute copy]
+__device__ __forceinline__ size_t v_index(bool cm, int b, int l, int h, int dv, int L, int H, int Dv) {
+    return cm ? (((size_t)b * H + h) * Dv + dv) * L + l : (((size_t)b * L + l) * H + h) * Dv + dv;
+}
+
+// ---- phase 1: per (b, h, 32-wide dv tile, l split): partial KV (32 x 32) and partial Ksum (32) ---------------------
+// thread = (d, 4 dv columns); K and V rows of a 32-token tile are staged in LDS
+__global__ __launch_bounds__(256) void linear_attention_reduce_kernel(
+    const float* __restrict__ k, const float* __restrict__ v, int B, int L, int H, int Dv, int cm, int nsplit,
+    float* __restrict__ kv_part, float* __restrict__ ks_part) {
+    __shared__ float ks[32][LA_D + 1];
+    __shared__ float vs[32][33];
+    const int tid = threadIdx.x;
+    const int dvt = blockIdx.x, h = blockIdx.y % H, b = blockIdx.y / H, sp = blockIdx.z;
+    const int d = tid >> 3, c4 = (tid & 7) * 4;
+    const int lper = (L + nsplit - 1) / nsplit;
+    const int l0 = sp * lper, l1 = min(L, l0 + lper);
+    const float invL = 1.0f / (float)L;
+    float acc[4] = {0, 0, 0, 0}, ksum = 0.0f;
+    for (int lt = l0; lt < l1; lt += 32) {
+        // stage 32 tokens: K (32 x 32, token-major always) and V (32 x 32 slice)
+        for (int i = tid; i < 32 * 32; i += 256) {
+            const int tl = i >> 5, e = i & 31;
+            const int l = lt + tl;
+            ks[tl][e] = l < l1 ? elu1(k[(((size_t)b * L + l) * H + h) * LA_D + e]) : 0.0f;
+        }
+        for (int i = tid; i < 32 * 32; i += 256) {
+            // channel-major: consecutive threads walk l (contiguous); token-major: consecutive threads walk dv
+            const int tl = cm ? (i & 31) : (i >> 5), e = cm ? (i >> 5) : (i & 31);
+            const int l = lt + tl, dv = dvt * 32 + e;
+            vs[tl][e] = (l < l1 && dv < Dv) ? v[v_index(cm, b, l, h, dv, L, H, Dv)] * invL : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int tl = 0; tl < 32; ++tl) {
+            const float kd = ks[tl][d];
+            ksum += kd;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += kd * vs[tl][c4 + j];
+        }
+        __syncthreads();
+    }
+    const size_t pb = ((size_t)(b * H + h) * nsplit + sp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dv = dvt * 32 + c4 + j;
+        if (dv < Dv) kv_part[(pb * LA_D + d) * Dv + dv] = acc[j];
+    }
+    if (dvt == 0 && (tid & 7) == 0) ks_part[pb * LA_D + d] = ksum;
+}
+
+// ---- phase 2: out[l, h, dv] = L * (Q_l . KV[:, dv]) / (Q_l . Ksum + eps) ---------------------------------------------
+// block = (b, h, 64-token tile, 64-wide dv tile); the split partials are summed in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void linear_attention_apply_kernel(
+    const float* __restrict__ q, const float* __restrict__ kv_part, const float* __restrict__ ks_part, int B, int L,
+    int H, int Dv, int cm, int nsplit, float eps, float* __restrict__ out) {
+    __shared__ float kvs[LA_D][65];
+    __shared__ float kss[LA_D];
+    __shared__ float qs[64][LA_D + 1];
+    __shared__ float zs[64];
+    const int tid = threadIdx.x;
+    const int lt = blockIdx.x * 64, dv0 = blockIdx.y * 64;
+    const int h = blockIdx.z % H, b = blockIdx.z / H;
+    const size_t pb = (size_t)(b * H + h) * nsplit;
+    for (int i = tid; i < LA_D * 64; i += 256) {
+        const int d = i >> 6, e = i & 63;
+        float s = 0.0f;
+        if (dv0 + e < Dv)
+            for (int sp = 0; sp < nsplit; ++sp) s += kv_part[((pb + sp) * LA_D + d) * Dv + dv0 + e];
+        kvs[d][e] = s;
+    }
+    if (tid < LA_D) {
+        float s = 0.0f;
+        for (int sp = 0; sp < nsplit; ++sp) s += ks_part[(pb + sp) * LA_D + tid];
+        kss[tid] = s;
+    }
+    for (int i = tid; i < 64 * LA_D; i += 256) {
+        const int tl = i >> 5, d = i & 31;
+        const int l = lt + tl;
+        qs[tl][d] = l < L ? elu1(q[(((size_t)b * L + l) * H + h) * LA_D + d]) : 0.0f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < LA_D; ++d) s += qs[tid][d] * kss[d];
+        zs[tid] = 1.0f / (s + eps);
+    }
+    __syncthreads();
+    const float fL = (float)L;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        // channel-major output: consecutive threads walk l; token-major: consecutive threads walk dv
+        const int tl = cm ? (i & 63) : (i >> 6), e = cm ? (i >> 6) : (i & 63);
+        const int l = lt + tl, dv = dv0 + e;
+        if (l >= L || dv >= Dv) continue;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < LA_D; ++d) s += qs[tl][d] * kvs[d][e];
+        out[v_index(cm, b, l, h, dv, L, H, Dv)] = s * zs[tl] * fL;
+    }
+}
+
+// ---- cross attention, row direction: src_attn[b, s, h, :] = sum_t softmax_t(c[b,h,s,:])_t trg_v[b, t, h, :] ------------
+// one wave per row s; the row's probabilities go through LDS, lanes 0-31 then own one output channel each
+template <int C>
+__global__ __launch_bounds__(256) void cross_rows_kernel(const float* __restrict__ c, const float* __restrict__ tv,
+                                                         int B, int H, int S, int T, float* __restrict__ out) {
+    extern __shared__ float prob[];                                   // 4 waves x T
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wave, h = blockIdx.y % H, b = blockIdx.y / H;
+    if (s >= S) return;
+    const float* row = c + (((size_t)b * H + h) * S + s) * T;
+    float* p = prob + wave * T;
+    float m = -INFINITY;
+    for (int t = lane; t < T; t += 64) { const float x = row[t]; p[t] = x; m = fmaxf(m, x); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float z = 0.0f;
+    for (int t = lane; t < T; t += 64) { const float e = expf(p[t] - m); p[t] = e; z += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // lanes 0..C-1 own a channel; lanes C..2C-1 take the second half of the t range (C = 32: the whole wave works)
+    const int ch = lane % C, part = lane / C, nparts = 64 / C;
+    float acc = 0.0f;
+    for (int t = part; t < T; t += nparts) acc += p[t] * tv[(((size_t)b * T + t) * H + h) * C + ch];
+    for (int o = C; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+    if (part == 0) out[(((size_t)b * S + s) * H + h) * C + ch] = acc / z;
+}
+
+// ---- cross attention, column direction: trg_attn[b, t, h, :] = sum_s softmax_s(c[b,h,:,t])_s src_v[b, s, h, :] --------
+// thread = column t (coalesced reads down the rows), two passes: online (max, sum) then the weighted sum
+template <int C>
+__global__ __launch_bounds__(64) void cross_cols_kernel(const float* __restrict__ c, const float* __restrict__ sv,
+                                                        int B, int H, int S, int T, float* __restrict__ out) {
+    extern __shared__ float svs[];                                    // S x C values of this (b, h)
+    const int t = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y % H, b = blockIdx.y / H;
+    for (int i = threadIdx.x; i < S * C; i += 64) svs[i] = sv[(((size_t)b * S + i / C) * H + h) * C + i % C];
+    __syncthreads();
+    if (t >= T) return;
+    const float* col = c + ((size_t)b * H + h) * S * T + t;
+    float m = -INFINITY, z = 0.0f;
+    for (int s = 0; s < S; ++s) {
+        const float x = col[(size_t)s * T];
+        const float mn = fmaxf(m, x);
+        z = z * expf(m - mn) + expf(x - mn);
+        m = mn;
+    }
+    float acc[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) acc[i] = 0.0f;
+    for (int s = 0; s < S; ++s) {
+        const float p = expf(col[(size_t)s * T] - m);
+#pragma unroll
+        for (int i = 0; i < C; ++i) acc[i] += p * svs[s * C + i];
+    }
+    const float iz = 1.0f / z;
+    float* o = out + (((size_t)b * T + t) * H + h) * C;
+#pragma unroll
+    for (int i = 0; i < C; ++i) o[i] = acc[i] * iz;
+}
+
+}  // namespace
+
+extern "C" long long cpn_linear_attention_scratch(int B, int H, int Dv, int nsplit) {
+    return (long long)B * H * nsplit * LA_D * (Dv + 1);
+}
+
+extern "C" int cpn_linear_attention(const float* q, const float* k, const float* v, int B, int L, int H, int Dv,
+                                    int channel_major, float eps, int nsplit, float* scratch, float* out, void* stream) {
+    CPN_REQUIRE(q && k && v && scratch && out, CPN_E_ARG, "cpn_linear_attention: null pointer");
+    CPN_REQUIRE(B > 0 && L > 0 && H > 0 && Dv > 0 && nsplit > 0 && nsplit <= 64 && (long long)B * H < 65536, CPN_E_SHAPE,
+                "cpn_linear_attention: bad shape");
+    const hipStream_t s = (hipStream_t)stream;
+    float* kv_part = scratch;
+    float* ks_part = scratch + (size_t)B * H * nsplit * LA_D * Dv;
+    hipLaunchKernelGGL(linear_attention_reduce_kernel, dim3(cpn_cdiv(Dv, 32), B * H, nsplit), dim3(256), 0, s, k, v, B, L, H,
+                       Dv, channel_major, nsplit, kv_part, ks_part);
+    hipLaunchKernelGGL(linear_attention_apply_kernel, dim3(cpn_cdiv(L, 64), cpn_cdiv(Dv, 64), B * H), dim3(256), 0, s, q,
+                       kv_part, ks_part, B, L, H, Dv, channel_major, nsplit, eps, out);
+    CPN_LAUNCH_CHECK("cpn_linear_attention");
+    return 0;
+}
+
+extern "C" int cpn_cross_attention(const float* corr, const float* src_v, const float* trg_v, int B, int H, int S, int T,
+                                   int C, float* src_attn, float* trg_attn, void* stream) {
+    CPN_REQUIRE(corr && src_v && trg_v && src_attn && trg_attn, CPN_E_ARG, "cpn_cross_attention: null pointer");
+    CPN_REQUIRE(B > 0 && H > 0 && S > 0 && T > 0 && C == 32 && (long long)B * H < 65536 && S * C * 4 <= 64 * 1024 &&
+                    T * 16 <= 64 * 1024, CPN_E_SHAPE, "cpn_cross_attention: need C == 32, S, T <= 512 (got C=%d S=%d T=%d)", C, S, T);
+    const hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cross_rows_kernel<32>, dim3(cpn_cdiv(S, 4), B * H), dim3(256), (size_t)4 * T * sizeof(float), s, corr,
+                       trg_v, B, H, S, T, src_attn);
+    hipLaunchKernelGGL(cross_cols_kernel<32>, dim3(cpn_cdiv(T, 64), B * H), dim3(64), (size_t)S * 32 * sizeof(float), s, corr,
+                       src_v, B, H, S, T, trg_attn);
+    CPN_LAUNCH_CHECK("cpn_cross_attention");
+    return 0;
+}

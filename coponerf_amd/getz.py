@@ -136,16 +136,6 @@ def _map_to_tokens(x):
     return x.flatten(2).transpose(1, 2)
 
 
-def _linear_attention(q, k, v, eps=1e-6):
-    """aggregation.LinearAttention (aggregation.py:84-117): phi = ELU + 1."""
-    Q, K = F.elu(q) + 1, F.elu(k) + 1
-    L = v.shape[1]
-    v = v / L
-    KV = torch.einsum("nshd,nshv->nhdv", K, v)
-    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
-    return (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * L).contiguous()
-
-
 def _corr_to_maps(corr):
     """(B,H,Hs,Ws,Ht,Wt) -> (B, H*Ht*Wt, Hs, Ws)."""
     B, H, Hs, Ws, Ht, Wt = corr.shape
@@ -185,12 +175,11 @@ class UFCLayer(nn.Module):
         q = self.q_proj(cf).view(B, -1, self.nhead, self.dim) + self.pos_embed
         k = self.k_proj(cf).view(B, -1, self.nhead, self.dim) + self.pos_embed
         vf = self.v_proj(feat).view(B, -1, self.nhead, self.dim)
-        vc = ops.resize_bilinear(_corr_to_maps(self.v_proj_corr(corr, ops)), fs)
-        vc = vc.reshape(B, H, Ht * Wt, fs * fs).permute(0, 3, 1, 2)                  # (B, L, H, Ht*Wt)
-        msg_feat = _linear_attention(q, k, vf).view(B, -1, self.nhead * self.dim)
-        msg_corr = _linear_attention(q, k, vc)                                       # (B, L, H, Ht*Wt)
-        msg_corr = msg_corr.permute(0, 2, 3, 1).reshape(B, H * Ht * Wt, fs, fs)
-        msg_corr = ops.resize_bilinear(msg_corr, Hs)
+        vc = ops.resize_bilinear(_corr_to_maps(self.v_proj_corr(corr, ops)), fs)      # (B, H*Ht*Wt, fs, fs)
+        msg_feat = ops.linear_attention(q, k, vf).view(B, -1, self.nhead * self.dim)
+        # the cost-volume values stay channel-major (B, H, Ht*Wt, L): that IS the map layout, no permute copies
+        msg_corr = ops.linear_attention(q, k, vc.reshape(B, H, Ht * Wt, fs * fs), channel_major=True)
+        msg_corr = ops.resize_bilinear(msg_corr.reshape(B, H * Ht * Wt, fs, fs), Hs)
         msg_corr = msg_corr.reshape(B, H, Ht, Wt, Hs, Ws).permute(0, 1, 4, 5, 2, 3)
         msg_feat = feat_r + msg_feat
         msg_corr = corr + msg_corr
@@ -198,15 +187,16 @@ class UFCLayer(nn.Module):
         msg_corr = msg_corr + self.mlp_corr(msg_corr, ops)
         return msg_corr, msg_feat
 
-    def _cross(self, corr, src, trg):                   # aggregation.py:312-340
+    def _cross(self, corr, src, trg, ops):              # aggregation.py:312-340
         B, H, Hs, Ws, Ht, Wt = corr.shape
         fs = self.fs
         c = corr.reshape(B, H, Hs * Ws, Ht * Wt)
         pool = lambda t, hh: _map_to_tokens(F.avg_pool2d(_tokens_to_map(t, fs), fs // hh))
         trg_v = self.v_cross(self.norm_cross1(pool(trg, Ht))).view(B, -1, self.nhead, self.dim)
         src_v = self.v_cross(self.norm_cross1(pool(src, Hs))).view(B, -1, self.nhead, self.dim)
-        src_attn = torch.einsum("bhst,bthc->bshc", c.softmax(-1), trg_v).reshape(B, -1, self.nhead * self.dim)
-        trg_attn = torch.einsum("bhst,bshc->bthc", c.softmax(-2), src_v).reshape(B, -1, self.nhead * self.dim)
+        src_attn, trg_attn = ops.cross_attention(c, src_v, trg_v)
+        src_attn = src_attn.reshape(B, -1, self.nhead * self.dim)
+        trg_attn = trg_attn.reshape(B, -1, self.nhead * self.dim)
         up = lambda t, hh: _map_to_tokens(_tokens_to_map(t, hh).repeat_interleave(fs // hh, 2)
                                           .repeat_interleave(fs // hh, 3))
         src = src + up(src_attn, Hs)
@@ -222,7 +212,7 @@ class UFCLayer(nn.Module):
         corr_r = corr_src + t4(corr_trg)
         corr_r = corr_r + self.feat_to_corr1(ops.correlation_tokens(src_r, trg_r, self.fs), ops)
         corr_r = corr_r + self.mlp_refine_corr(corr_r, ops)
-        src_r, trg_r = self._cross(corr_r, src_r, trg_r)
+        src_r, trg_r = self._cross(corr_r, src_r, trg_r, ops)
         corr_r = corr_r + self.feat_to_corr2(ops.correlation_tokens(src_r, trg_r, self.fs), ops)
         corr_r = corr_r + self.mlp_refine_corr2(corr_r, ops)
         return corr_r, src_r, trg_r

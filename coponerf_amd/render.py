@@ -26,6 +26,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _to_host(*mats: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:
+    """float32 CPU copies of a few small device tensors with ONE device->host transfer (each .cpu() is a host sync)."""
+    live = [m for m in mats if m is not None]
+    if not live or all(m.device.type == "cpu" for m in live):
+        return [None if m is None else m.detach().float() for m in mats]
+    dev = next(m.device for m in live if m.device.type != "cpu")
+    flat = torch.cat([m.detach().float().to(dev).reshape(-1) for m in live]).cpu()
+    out, off = [], 0
+    for m in mats:
+        if m is None:
+            out.append(None)
+            continue
+        out.append(flat[off:off + m.numel()].view(m.shape).clone())
+        off += m.numel()
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # (a1) pose algebra on the host — O(B) 4x4 matrices, float32, LAPACK: deterministic and identical to
 # what the CPU oracle computes, so everything downstream can be compared bit for bit.
@@ -242,9 +259,7 @@ class RenderEngine:
         B, _, R, _ = uv.shape
         N = B * V
         s = _stream()
-        cam_cpu, Tq_cpu = build_camera_block(ctx_c2w.detach().float().cpu(), ctx_K.detach().float().cpu(),
-                                             qry_c2w.detach().float().cpu(), qry_K.detach().float().cpu(),
-                                             None if rel_pose is None else rel_pose.detach().float().cpu(), val, H)
+        cam_cpu, Tq_cpu = build_camera_block(*_to_host(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose), val, H)
         cam = cam_cpu.to(dev)
         ikey = (S, str(dev))
         if ikey not in self._interval:
@@ -343,9 +358,7 @@ class RenderEngine:
         w = self._weights(params)
         maps, tabs = self._feature_maps(z, w)
 
-        cam_cpu, Tq_cpu = build_camera_block(ctx_c2w.detach().float().cpu(), ctx_K.detach().float().cpu(),
-                                             qry_c2w.detach().float().cpu(), qry_K.detach().float().cpu(),
-                                             None if rel_pose is None else rel_pose.detach().float().cpu(), val, H)
+        cam_cpu, Tq_cpu = build_camera_block(*_to_host(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose), val, H)
         cam = cam_cpu.to(dev)
         ikey = (S, str(dev))
         if ikey not in self._interval:

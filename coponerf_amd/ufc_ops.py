@@ -236,6 +236,22 @@ class _ResizeFn(Function):
                                                                  list(ctx.in_shape), True, None, None), None
 
 
+def _linear_attention_lib(q, k, v, channel_major, eps=1e-6):
+    """Library-op statement of cpn_linear_attention (only its VJP is ever used: training backward)."""
+    if channel_major:
+        v = v.permute(0, 3, 1, 2)
+    Q, K = F.elu(q) + 1, F.elu(k) + 1
+    L = v.shape[1]
+    KV = torch.einsum("nshd,nshv->nhdv", K, v / L)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
+    out = torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * L
+    return out.permute(0, 2, 3, 1) if channel_major else out
+
+
+def _cross_attention_lib(c, src_v, trg_v):
+    return (torch.einsum("bhst,bthc->bshc", c.softmax(-1), trg_v), torch.einsum("bhst,bshc->bthc", c.softmax(-2), src_v))
+
+
 def _correlation_lib(src, trg, fs):
     n = lambda t: t / (t.norm(dim=-1, p=2, keepdim=True) + 1e-5)
     return torch.einsum("bsc,btc->bst", n(src), n(trg)).reshape(src.shape[0], 1, fs, fs, fs, fs)
@@ -243,7 +259,8 @@ def _correlation_lib(src, trg, fs):
 
 
 class HipOps:
-    """conv4d + GroupNorm + ReLU, cosine correlation and soft-argmax on gfx950 (csrc/ufc.hip)."""
+    """conv4d + GroupNorm + ReLU, cosine correlation, soft-argmax (csrc/ufc.hip) and the two attention forms of
+    UFCLayer (csrc/ufc_attn.hip) on gfx950."""
 
     @staticmethod
     def _need_gpu(t):
@@ -295,6 +312,40 @@ class HipOps:
         call("cpn_correlation", s_.data_ptr(), t_.data_ptr(), B, L, C, 1e-5, sn.data_ptr(), tn.data_ptr(),
              out.data_ptr(), _stream())
         return out
+
+    def linear_attention(self, q, k, v, channel_major=False, eps=1e-6):
+        """aggregation.LinearAttention (models/aggregation.py:84-117) on cpn_linear_attention.
+        q, k (B,L,H,32); v / result (B,L,H,Dv) or, channel_major, (B,H,Dv,L)."""
+        self._need_gpu(q)
+        if _wants_grad(q, k, v):
+            return _HipForwardVjp.apply(lambda a, b, c: self.linear_attention(a, b, c, channel_major, eps),
+                                        lambda a, b, c: _linear_attention_lib(a, b, c, channel_major, eps),
+                                        q.float(), k.float(), v.float())
+        from . import _hip
+        q_, k_, v_ = q.contiguous().float(), k.contiguous().float(), v.contiguous().float()
+        B, L, H, D = q_.shape
+        if D != 32:
+            raise ValueError("cpn_linear_attention is built for head dimension 32 (got %d)" % D)
+        Dv = v_.shape[2] if channel_major else v_.shape[3]
+        nsplit = max(1, min(16, L // 256))
+        scr = torch.empty(_hip.lib().cpn_linear_attention_scratch(B, H, Dv, nsplit), dtype=torch.float32, device=q.device)
+        out = torch.empty_like(v_)
+        call("cpn_linear_attention", q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), B, L, H, Dv, int(channel_major), float(eps),
+             nsplit, scr.data_ptr(), out.data_ptr(), _stream())
+        return out
+
+    def cross_attention(self, c, src_v, trg_v):
+        """UFCLayer.forward_cross's two softmax-weighted sums (models/aggregation.py:327-328) on cpn_cross_attention.
+        c (B,H,S,T), src_v (B,S,H,32), trg_v (B,T,H,32) -> (B,S,H,32), (B,T,H,32)."""
+        self._need_gpu(c)
+        if _wants_grad(c, src_v, trg_v):
+            return _HipForwardVjp.apply(self.cross_attention, _cross_attention_lib, c.float(), src_v.float(), trg_v.float())
+        c_, s_, t_ = c.contiguous().float(), src_v.contiguous().float(), trg_v.contiguous().float()
+        B, H, S, T = c_.shape
+        src_attn, trg_attn = torch.empty_like(s_), torch.empty_like(t_)
+        call("cpn_cross_attention", c_.data_ptr(), s_.data_ptr(), t_.data_ptr(), B, H, S, T, s_.shape[-1],
+             src_attn.data_ptr(), trg_attn.data_ptr(), _stream())
+        return src_attn, trg_attn
 
     def soft_argmax_pair(self, c):
         self._need_gpu(c)

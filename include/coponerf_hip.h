@@ -260,6 +260,22 @@ int cpn_soft_argmax_pair(const float* c, int B, int h, float beta, float* t_to_s
 int cpn_soft_argmax_pair_bwd(const float* c, int B, int h, float beta, const float* t_to_s, const float* s_to_t,
                              const float* g_t_to_s, const float* g_s_to_t, float* dc, void* stream);
 
+/* ---- K9: linear attention of UFCLayer.forward_attention (models/aggregation.py:84-117) ------------------------------
+ * phi = ELU + 1;  out = phi(Q) . (sum_s phi(K)_s (x) V_s / L) * L / (phi(Q) . sum_s phi(K)_s + eps)
+ *   q, k (B, L, H, 32) fp32;  v and out: channel_major = 0 -> (B, L, H, Dv) (feature branch),
+ *   channel_major = 1 -> (B, H, Dv, L) (cost-volume branch: (B, H*Ht*Wt, fs, fs) maps as stored, no permute copies)
+ *   scratch: cpn_linear_attention_scratch(B, H, Dv, nsplit) floats; nsplit = number of token ranges reduced in
+ *   parallel (partials are summed in a fixed order: deterministic)                                             */
+long long cpn_linear_attention_scratch(int B, int H, int Dv, int nsplit);
+int cpn_linear_attention(const float* q, const float* k, const float* v, int B, int L, int H, int Dv,
+                         int channel_major, float eps, int nsplit, float* scratch, float* out, void* stream);
+
+/* ---- K10: cost-volume cross attention of UFCLayer.forward_cross (models/aggregation.py:327-328) -------------------
+ * corr (B, H, S, T) fp32; src_v (B, S, H, C), trg_v (B, T, H, C), C == 32
+ *   src_attn (B, S, H, C) = softmax over t of corr . trg_v ;  trg_attn (B, T, H, C) = softmax over s of corr, transposed . src_v */
+int cpn_cross_attention(const float* corr, const float* src_v, const float* trg_v, int B, int H, int S, int T, int C,
+                        float* src_attn, float* trg_attn, void* stream);
+
 /* ---- bilinear resize, align_corners=True, of `planes` independent (h,w) fp32 images -> (H,W) ----------
  * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /
  * interpolate2d_token (models/aggregation.py:49-63, 285, 293, 299).                                           */

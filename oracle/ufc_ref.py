@@ -72,6 +72,26 @@ class TorchOps:
         return c.reshape(B, 1, fs, fs, fs, fs)
 
     @staticmethod
+    def linear_attention(q, k, v, channel_major=False, eps=1e-6):
+        """aggregation.LinearAttention.forward (models/aggregation.py:84-117), phi = ELU + 1.
+        q, k (B,L,H,D); v / result (B,L,H,Dv), or (B,H,Dv,L) when channel_major."""
+        if channel_major:
+            v = v.permute(0, 3, 1, 2)
+        Q, K = F.elu(q) + 1, F.elu(k) + 1
+        L = v.shape[1]
+        KV = torch.einsum("nshd,nshv->nhdv", K, v / L)
+        Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
+        out = torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * L
+        return out.permute(0, 2, 3, 1).contiguous() if channel_major else out.contiguous()
+
+    @staticmethod
+    def cross_attention(c, src_v, trg_v):
+        """UFCLayer.forward_cross, models/aggregation.py:327-328: c (B,H,S,T), src_v (B,S,H,C), trg_v (B,T,H,C)."""
+        src_attn = torch.einsum("bhst,bthc->bshc", c.softmax(-1), trg_v)
+        trg_attn = torch.einsum("bhst,bshc->bthc", c.softmax(-2), src_v)
+        return src_attn.contiguous(), trg_attn.contiguous()
+
+    @staticmethod
     def _soft_argmax(corr, beta=0.02):
         b, _, h, w = corr.shape
         m, _ = corr.max(dim=1, keepdim=True)

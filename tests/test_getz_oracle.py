@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from coponerf_amd import CoPoNeRF, synthetic as syn
-from coponerf_amd.getz import Encoder4D, _linear_attention, positional_encodings
+from coponerf_amd.getz import Encoder4D, positional_encodings
 from oracle.ufc_ref import TorchOps
 from tests.helpers import GOLDEN
 
@@ -33,7 +33,10 @@ def test_oracle_ufc_operators_match_reference(ops_gold):
     assert (t2s - torch.from_numpy(ops_gold["t_to_s"])).abs().max() <= 1e-5
     assert (s2t - torch.from_numpy(ops_gold["s_to_t"])).abs().max() <= 1e-5
     q, k_, v = syn.normal((2, 30, 4, 8), 93), syn.normal((2, 30, 4, 8), 94), syn.normal((2, 30, 4, 12), 95)
-    assert (_linear_attention(q, k_, v) - torch.from_numpy(ops_gold["linear_attention"])).abs().max() <= 1e-5
+    want = torch.from_numpy(ops_gold["linear_attention"])                        # upstream LinearAttention.forward
+    assert (TorchOps.linear_attention(q, k_, v) - want).abs().max() <= 1e-5
+    cm = TorchOps.linear_attention(q, k_, v.permute(0, 2, 3, 1).contiguous(), channel_major=True)   # (B,H,Dv,L) layout
+    assert (cm.permute(0, 3, 1, 2) - want).abs().max() <= 1e-5
 
 
 def test_positional_encodings_closed_form():

@@ -84,3 +84,30 @@ def test_get_z_and_render_end_to_end(dev):
         out2 = model(inp, val=True) if False else None
     assert out["rgb"].shape == (1, 1, 64, 3) and torch.isfinite(out["rgb"]).all()
     assert out["pixel_val"].shape == (2, 64, 64, 2)
+
+
+def test_attention_kernels_against_oracle(dev):
+    """cpn_linear_attention (both value layouts, the three token counts of UFC, Dv = 32 / 256) and cpn_cross_attention
+    against the oracle operators (oracle/ufc_ref.py, pinned to the upstream LinearAttention fixture on the CPU)."""
+    from coponerf_amd.ufc_ops import HipOps
+    from oracle.ufc_ref import TorchOps
+    hip = HipOps()
+    for (B, L, Dv, cm) in ((1, 256, 32, False), (2, 1024, 32, False), (1, 4096, 256, True), (2, 256, 256, True), (1, 100, 40, True)):
+        q, k = syn.normal((B, L, 8, 32), seed=101) * 0.7, syn.normal((B, L, 8, 32), seed=102) * 0.7
+        v = syn.normal((B, 8, Dv, L) if cm else (B, L, 8, Dv), seed=103)
+        want = TorchOps.linear_attention(q, k, v, channel_major=cm)
+        got = hip.linear_attention(q.to(dev), k.to(dev), v.to(dev), channel_major=cm).cpu()
+        assert got.shape == want.shape
+        assert (got - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max())), (B, L, Dv, cm)
+    for (B, S, T) in ((1, 256, 256), (2, 256, 256), (1, 64, 100)):
+        c = syn.normal((B, 8, S, T), seed=104) * 3.0
+        sv, tv = syn.normal((B, S, 8, 32), seed=105), syn.normal((B, T, 8, 32), seed=106)
+        ws, wt = TorchOps.cross_attention(c, sv, tv)
+        gs, gt = hip.cross_attention(c.to(dev), sv.to(dev), tv.to(dev))
+        assert (gs.cpu() - ws).abs().max() <= 2e-5 and (gt.cpu() - wt).abs().max() <= 2e-5, (B, S, T)
+    # training: forward on the kernels, backward = VJP of the library statement
+    q = (syn.normal((1, 256, 8, 32), seed=107) * 0.5).to(dev).requires_grad_(True)
+    v = syn.normal((1, 8, 256, 256), seed=108).to(dev).requires_grad_(True)
+    out = hip.linear_attention(q, q.detach() * 0.9, v, channel_major=True)
+    out.square().mean().backward()
+    assert torch.isfinite(q.grad).all() and torch.isfinite(v.grad).all() and float(v.grad.abs().max()) > 0

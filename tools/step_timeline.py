@@ -29,9 +29,9 @@ R.build_camera_block = build
 orig_call = R.call
 seen = set()
 def call(name, *a):
-    if name in ("cpn_sample_geometry", "cpn_mask_rgb") or (name == "cpn_gather_rows" and "g" not in seen):
+    if name in ("cpn_sample_geometry", "cpn_mask_rgb") or (name in ("cpn_gather_rows", "cpn_encode_hidden") and "g" not in seen):
         tick("before " + name)
-        seen.add("g") if name == "cpn_gather_rows" else None
+        seen.add("g") if name in ("cpn_gather_rows", "cpn_encode_hidden") else None
     if name == "cpn_linear_f32" and a[10] == 32 and "phi" not in seen:   # K = 32: phi.lin_in
         tick("chunks done"); seen.add("phi")
     return orig_call(name, *a)
