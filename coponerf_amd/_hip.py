@@ -50,6 +50,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_soft_argmax_pair_bwd": [_P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "cpn_linear_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
     "cpn_cross_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_conv_map7x7": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "cpn_prepare_input": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
 }
 

@@ -24,6 +24,8 @@ UNITS = [
     ("linear_f32.hip", []),
     ("ufc.hip", []),
     ("ufc_attn.hip", []),
+    ("encoder.hip", []),
+    ("input.hip", []),
     ("backward.hip", []),
 ]
 

@@ -4,7 +4,7 @@ Restates `CoPoNeRF.get_z` (/root/reference models/CoPoNeRF.py:159-206) with the 
 (checkpoint contract):
 
   encoder.*                   ResNet-34 trunk, no first max-pool (models/backbone.py:10-102)          stock ops
-  conv_map                    7x7 conv on the normalised image (CoPoNeRF.py:69,187)                    stock op
+  conv_map                    7x7 conv on the normalised image (CoPoNeRF.py:69,187)                    HIP (cpn_conv_map7x7)
   feature_cost_aggregation.*  UFC (models/aggregation.py:146-562, models/conv4d.py:57-163)            in scope (§8 a22-a29)
   cross_attention.*           CrossBlock / "fundamental-matrix" attention (models/backbone.py:280-428) stock ops
   pose/rotation/translation_regressor                                                               stock ops
@@ -391,7 +391,12 @@ def get_z(model, input, ops):
     model.H, model.W = H, W
     x = imagenet_normalise((rgb.flatten(0, 1).permute(0, 3, 1, 2) + 1) / 2.)
     z = model.encoder(x)[:3]
-    z_conv = model.conv_map(x)
+    # conv_map straight from the (N,H,W,3) image (normalisation fused); on the inference path the kernel also emits the
+    # NHWC fp16 copy of this level, which the render engine adopts instead of re-laying the map out
+    infer = not torch.is_grad_enabled()
+    z_conv, z_conv_nhwc16 = ops.conv_map(rgb.flatten(0, 1), model.conv_map.weight, model.conv_map.bias, want_nhwc16=infer)
+    if z_conv_nhwc16 is not None and hasattr(model, "_engine"):
+        model._engine.adopt_level3(z_conv, z_conv_nhwc16)
     feats, flows, c = model.feature_cost_aggregation(z, model.n_view, ops)
     Kn = input["context"]["intrinsics"].clone()
     Kn[:, :, :2, :] = Kn[:, :, :2, :] / H

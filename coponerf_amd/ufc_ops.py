@@ -252,6 +252,14 @@ def _cross_attention_lib(c, src_v, trg_v):
     return (torch.einsum("bhst,bthc->bshc", c.softmax(-1), trg_v), torch.einsum("bhst,bshc->bthc", c.softmax(-2), src_v))
 
 
+def _conv_map_lib(rgb, w, b):
+    """Library-op statement of cpn_conv_map7x7 (only its VJP is used): CoPoNeRF.py:182-187."""
+    x = (rgb.permute(0, 3, 1, 2) + 1) / 2.
+    mean = torch.tensor((0.485, 0.456, 0.406), device=x.device).view(1, 3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225), device=x.device).view(1, 3, 1, 1)
+    return F.conv2d((x - mean) / std, w, b, stride=1, padding=3)
+
+
 def _correlation_lib(src, trg, fs):
     n = lambda t: t / (t.norm(dim=-1, p=2, keepdim=True) + 1e-5)
     return torch.einsum("bsc,btc->bst", n(src), n(trg)).reshape(src.shape[0], 1, fs, fs, fs, fs)
@@ -312,6 +320,21 @@ class HipOps:
         call("cpn_correlation", s_.data_ptr(), t_.data_ptr(), B, L, C, 1e-5, sn.data_ptr(), tn.data_ptr(),
              out.data_ptr(), _stream())
         return out
+
+    def conv_map(self, rgb, w, b, want_nhwc16=False):
+        """conv_map of get_z (CoPoNeRF.py:69, 182-187) on cpn_conv_map7x7: rgb (N,H,W,3) in [-1,1] as the input dict
+        holds it -> (N,64,H,W) fp32 [, (N,H,W,64) fp16 for the render path's gather]."""
+        self._need_gpu(rgb)
+        if _wants_grad(rgb, w, b):
+            return _HipForwardVjp.apply(lambda r, ww, bb: self.conv_map(r, ww, bb)[0], _conv_map_lib,
+                                        rgb.float(), w, b), None
+        r_, w_, b_ = rgb.contiguous().float(), w.detach().contiguous().float(), b.detach().contiguous().float()
+        N, H, W, _ = r_.shape
+        out = torch.empty(N, 64, H, W, dtype=torch.float32, device=rgb.device)
+        nhwc = torch.empty(N, H, W, 64, dtype=torch.float16, device=rgb.device) if want_nhwc16 else None
+        call("cpn_conv_map7x7", r_.data_ptr(), w_.data_ptr(), b_.data_ptr(), N, H, W, out.data_ptr(),
+             0 if nhwc is None else nhwc.data_ptr(), _stream())
+        return out, nhwc
 
     def linear_attention(self, q, k, v, channel_major=False, eps=1e-6):
         """aggregation.LinearAttention (models/aggregation.py:84-117) on cpn_linear_attention.

@@ -276,10 +276,26 @@ int cpn_linear_attention(const float* q, const float* k, const float* v, int B, 
 int cpn_cross_attention(const float* corr, const float* src_v, const float* trg_v, int B, int H, int S, int T, int C,
                         float* src_attn, float* trg_attn, void* stream);
 
+/* ---- f3: conv_map, the 7x7 3 -> 64 convolution behind the full-resolution feature level (CoPoNeRF.py:69, 182-187) -----
+ * rgb (N, H, W, 3) fp32 in [-1, 1] exactly as the input dict holds it; fused (rgb+1)/2, ImageNet normalisation
+ * (utils_training/utils.py:247-257), zero-padded 7x7 convolution and bias.  w (64, 3, 7, 7), bias (64).
+ * out_nchw (N, 64, H, W) fp32 = z[3] of get_z; out_nhwc_f16 (N, H, W, 64) fp16 or NULL: the layout the render path gathers from */
+int cpn_conv_map7x7(const float* rgb, const float* w, const float* bias, int N, int H, int W, float* out_nchw,
+                    uint16_t* out_nhwc_f16, void* stream);
+
 /* ---- bilinear resize, align_corners=True, of `planes` independent (h,w) fp32 images -> (H,W) ----------
  * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /
  * interpolate2d_token (models/aggregation.py:49-63, 285, 293, 299).                                           */
 int cpn_resize_bilinear_ac(const float* src, float* dst, long long planes, int h, int w, int H, int W, void* stream);
+
+/* ==== input pipeline: uint8 frames -> the float tensors of the input dict ========================
+ * replaces the host-side square crop + `rgb.astype(np.float32) / 127.5 - 1` + query-pixel selection of
+ * data/realestate10k_dataio.py:333-441 (utils_training/data_util.py:116-121).
+ *   frames_u8 (B, 3, Hs, Ws, 3) uint8: context view 0, context view 1, query frame of every sample
+ *   crop window rows [y0, y0+H), columns [x0, x0+W);  ray_pix (B, R) int32 = y*W + x in the cropped query frame
+ *   ctx_rgb (B, 2, H, W, 3) fp32, qry_rgb (B, 1, R, 3) fp32: u8 / 127.5 - 1, bit-identical to the reference's numpy  */
+int cpn_prepare_input(const uint8_t* frames_u8, int B, int Hs, int Ws, int y0, int x0, int H, int W, int R,
+                      const int32_t* ray_pix, float* ctx_rgb, float* qry_rgb, void* stream);
 
 #ifdef __cplusplus
 }

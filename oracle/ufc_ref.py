@@ -72,6 +72,14 @@ class TorchOps:
         return c.reshape(B, 1, fs, fs, fs, fs)
 
     @staticmethod
+    def conv_map(rgb, w, b, want_nhwc16=False):
+        """models/CoPoNeRF.py:182-187: (rgb+1)/2, ImageNet normalisation, 7x7 convolution.  rgb (N,H,W,3)."""
+        x = (rgb.permute(0, 3, 1, 2) + 1) / 2.
+        mean = torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1)
+        std = torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1)
+        return F.conv2d((x - mean) / std, w, b, stride=1, padding=3), None
+
+    @staticmethod
     def linear_attention(q, k, v, channel_major=False, eps=1e-6):
         """aggregation.LinearAttention.forward (models/aggregation.py:84-117), phi = ELU + 1.
         q, k (B,L,H,D); v / result (B,L,H,Dv), or (B,H,Dv,L) when channel_major."""

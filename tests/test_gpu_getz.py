@@ -111,3 +111,17 @@ def test_attention_kernels_against_oracle(dev):
     out = hip.linear_attention(q, q.detach() * 0.9, v, channel_major=True)
     out.square().mean().backward()
     assert torch.isfinite(q.grad).all() and torch.isfinite(v.grad).all() and float(v.grad.abs().max()) > 0
+
+
+def test_conv_map_kernel_against_oracle(dev):
+    """cpn_conv_map7x7 (normalisation fused, reads the (N,H,W,3) image) against the stock statement; the NHWC fp16 copy
+    it emits is the layout pass of the render path applied to the same values."""
+    from coponerf_amd.ufc_ops import HipOps
+    from oracle.ufc_ref import TorchOps
+    for (N, H, W) in ((2, 256, 256), (3, 40, 72)):
+        rgb = syn.uniform((N, H, W, 3), 111, -1.0, 1.0)
+        w, b = syn.normal((64, 3, 7, 7), seed=112) * 0.1, syn.normal((64,), seed=113) * 0.1
+        want, _ = TorchOps.conv_map(rgb, w, b)
+        got, nhwc = HipOps().conv_map(rgb.to(dev), w.to(dev), b.to(dev), want_nhwc16=True)
+        assert (got.cpu() - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max()))
+        assert torch.equal(nhwc.float().cpu(), got.cpu().permute(0, 2, 3, 1).half().float())
