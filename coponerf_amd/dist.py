@@ -46,6 +46,29 @@ def grads_finite(params: Iterable[torch.nn.Parameter], group=None) -> bool:
     return bool(ok.item() > 0)
 
 
+def guard_and_clip(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, group=None):
+    """The reference's invalid-gradient guard (wrapper.py:44-58) and `clip_grad_norm_` (wrapper.py:142-146) from ONE
+    pass over the gradients: per-tensor 2-norms (`torch._foreach_norm`, a handful of launches for the 570 tensors),
+    combined in float64.  NaN / Inf entries make their tensor's norm non-finite, so `finite` is exactly "no gradient
+    holds a NaN or an Inf" without squaring anything in fp32 (a sum of squares would overflow for large-but-finite
+    gradients).  The flag is MIN-all-reduced: every rank takes the same branch.  Clipping (per rank, BEFORE the
+    exchange, like the reference) scales the gradients in place by min(1, max_norm / (norm + 1e-6)).
+    Returns (finite: bool, total_norm: float64 tensor)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return True, torch.zeros((), dtype=torch.float64)
+    norms = torch.stack(torch._foreach_norm(grads)).double()
+    total = norms.square().sum().sqrt()
+    ok = torch.isfinite(total).float()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    finite = bool(ok.item() > 0)
+    if finite and max_norm and max_norm > 0:
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0).float()
+        torch._foreach_mul_(grads, coef)
+    return finite, total
+
+
 def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None) -> int:
     """In-place gradient averaging across ranks; returns the number of data collectives issued.
 

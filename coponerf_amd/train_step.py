@@ -42,11 +42,10 @@ class TrainStep:
         e1 = self._ev() if timed else None
         loss.backward()
         e2 = self._ev() if timed else None
-        stepped = cdist.grads_finite(self.params, group=self.group)      # same answer on every rank
+        # guard + clip in one pass over the gradients; the flag is the same on every rank
+        stepped, _ = cdist.guard_and_clip(self.params, float(self.clip_grad or 0.0), group=self.group)
         ncoll, nbytes = 0, 0
         if stepped:
-            if self.clip_grad:
-                torch.nn.utils.clip_grad_norm_(self.params, max_norm=float(self.clip_grad))
             e3 = self._ev() if timed else None
             ncoll = cdist.average_gradients(self.params, bucket_bytes=self.bucket_bytes, group=self.group)
             if ncoll:

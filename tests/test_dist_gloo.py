@@ -49,11 +49,24 @@ def _worker(rank, world, port, q):
     uneven_ok = (model[3].weight.grad is None) if rank == 0 else bool(torch.allclose(model[3].weight.grad, local / world))
     model[0].weight.grad.fill_(1e30)                   # squares overflow fp32; the values themselves are finite
     big_finite = cd.grads_finite(model.parameters())
+    # guard + clip in one pass: equals clip_grad_norm_ on finite gradients, reports the NaN on both ranks
+    model.zero_grad(set_to_none=True)
+    model[:3](x).sum().backward()
+    ref = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    ref_norm = torch.sqrt(sum(g.double().pow(2).sum() for g in ref))            # what clip_grad_norm_ computes
+    fin, tot = cd.guard_and_clip(model.parameters(), max_norm=0.5)
+    got = [p.grad for p in model.parameters() if p.grad is not None]
+    scale = min(1.0, 0.5 / (float(ref_norm) + 1e-6))
+    clip_ok = fin and abs(float(tot) - float(ref_norm)) <= 1e-4 * float(ref_norm) and all(
+        torch.allclose(g, r * scale, rtol=1e-5, atol=1e-7) for g, r in zip(got, ref))
+    if rank == 0:
+        got[0].view(-1)[0] = float("inf")
+    clip_nan, _ = cd.guard_and_clip(model.parameters(), max_norm=0.5)
     w0 = model[0].weight.detach().clone()
     gathered = [torch.zeros_like(w0) for _ in range(world)]
     dist.all_gather(gathered, w0)
     q.put((rank, ok, ncoll, nb, finite_all, finite_after_nan, bool(torch.equal(gathered[0], gathered[1])),
-           uneven_ok, big_finite, list(cd.shard_pairs(5, rank, world))))
+           uneven_ok, big_finite, clip_ok, clip_nan, list(cd.shard_pairs(5, rank, world))))
     dist.destroy_process_group()
 
 
@@ -68,8 +81,8 @@ def test_bucketed_allreduce_and_finite_flag_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, ncoll, nb, finite_all, finite_after_nan, synced, uneven_ok, big_finite, shard in res:
-        assert ok and synced and uneven_ok and big_finite
+    for rank, ok, ncoll, nb, finite_all, finite_after_nan, synced, uneven_ok, big_finite, clip_ok, clip_nan, shard in res:
+        assert ok and synced and uneven_ok and big_finite and clip_ok and clip_nan is False
         assert 1 <= ncoll < 6 and nb >= 1            # fewer collectives than the 6 gradient tensors
         assert finite_all is True and finite_after_nan is False
     assert res[0][-1] == [0, 2, 4] and res[1][-1] == [1, 3]
