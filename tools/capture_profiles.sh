@@ -1,0 +1,27 @@
+#!/bin/bash
+# Capture the round's evidence on the GPU box into gpurun_out/<tag>/ (copy what should be judged into profiles/):
+#   bench json (render + train block), rocprofv3 kernel stats of the render bench, PMC passes of the dominant kernel,
+#   steady-state kernel lists of one get_z call and of one training step.
+#   tools/capture_profiles.sh <tag>
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp PYTHONPATH=$ROOT
+cd "$ROOT"
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python bench.py --no-tables --cpu-rays 0 --train-steps 0 > "$OUT/bench_gather_gemm_form.json" 2>> "$OUT/bench.err"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render_prof" -o r -- python "$ROOT/bench.py" --cpu-rays 0 --train-steps 0 --steps 5 ) > "$OUT/render_prof.log" 2>&1
+python tools/summarize_pmc.py "$(find "$OUT/render_prof" -name '*kernel_stats.csv' | head -1)" "$OUT/render_kernel_stats.summary.csv" 40
+tools/pmc_passes.sh "$OUT/pmc_encode" encode_hidden -- python "$ROOT/tools/encode_bench.py" --only tables --iters 3 > "$OUT/pmc_encode.log" 2>&1
+python tools/make_traffic_json.py "$OUT/pmc_encode/summary.json" 4194304 "$OUT/traffic.json" >> "$OUT/pmc_encode.log" 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/getz_prof" -o g -- python "$ROOT/tools/getz_time.py" ) > "$OUT/getz_prof.log" 2>&1
+python tools/trace_step.py "$(find "$OUT/getz_prof" -name '*kernel_trace.csv' | head -1)" soft_argmax_cols 45 > "$OUT/getz_step_kernels.txt" 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/train_prof" -o t -- python "$ROOT/tools/train_time.py" --steps 3 ) > "$OUT/train_prof.log" 2>&1
+python tools/trace_step.py "$(find "$OUT/train_prof" -name '*kernel_trace.csv' | head -1)" project_rays 60 > "$OUT/train_step_kernels.txt" 2>&1
+grep -h train_ms_per_step "$OUT/train_prof.log" > "$OUT/train_step.json"
+python tools/encode_ablate.py > "$OUT/encode_ablation.json" 2>/dev/null
+find "$OUT" -name "*kernel_trace.csv" -delete
+find "$OUT" -name "*.csv" -size +2M -delete
+ls "$OUT"

@@ -1,38 +1,51 @@
 #!/usr/bin/env python
-"""Condense rocprofv3 counter_collection / kernel_stats CSVs to our own kernels (short names) for profiles/."""
-import csv, re, sys, collections
+"""Condense a rocprofv3 kernel_stats CSV (or a counter_collection CSV) into the small summaries kept under profiles/.
+Usage: summarize_pmc.py <csv> <out.csv> [top N]"""
+import collections
+import csv
+import re
+import sys
+
 
 def short(name):
-    m = re.search(r"(gemm_f16_w4_kernel|gemm_f16_p8_kernel|gemm_f16_p4_kernel|gemm_f16_ring_kernel|gemm_f16_kernel|gather_rows_kernel|attend_kernel|attend_hidden_kernel|attend_hidden_bwd_kernel|gather_rows_bwd_kernel|gather_bbox_kernel|local_hidden_kernel|local_mlp_kernel|row_stats_kernel|col_stats_kernel|dual_softmax_apply_kernel|dual_softmax_bwd_apply_kernel|conv_wgrad_planes_kernel|conv_wgrad_reduce_kernel|dwconv3x3_wgrad_kernel|gn_relu_bwd_reduce_kernel|gn_relu_bwd_apply_kernel|conv4d_k3s1_kernel|resize_bilinear_ac_kernel|"
-                  r"linear_f32_kernel|conv4d_kernel|gn_relu_kernel|gemm_nt_f32_kernel|l2norm_rows_kernel|soft_argmax_rows_kernel|soft_argmax_cols_kernel|sample_geometry_kernel|project_rays_kernel|nchw_to_nhwc_f16_kernel|"
-                  r"mask_rgb_kernel|pack_weight_f16_kernel|ray_mlp_kernel|fused_\w+)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else None
+    n = re.sub(r"\(anonymous namespace\)::", "", name)
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)                 # drop the argument list
+    if n.startswith("at::native::"):
+        n = "aten:" + re.sub(r"<.*", "", n[len("at::native::"):])
+    if n.startswith("Cijk_"):
+        n = "hipBLASLt:" + n[:40]
+    return n[:90]
 
-def main(path, out):
+
+def main(path, out, top=60):
     rows = list(csv.DictReader(open(path)))
     if rows and "Counter_Name" in rows[0]:
         agg = collections.OrderedDict()
         for r in rows:
-            k = short(r["Kernel_Name"])
-            if k:
-                agg.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+            agg.setdefault((short(r["Kernel_Name"]), r["Counter_Name"]), []).append(float(r["Counter_Value"]))
         with open(out, "w") as f:
             f.write("kernel,counter,mean_per_dispatch,dispatches\n")
             for (k, c), v in agg.items():
                 f.write(f'"{k}",{c},{sum(v)/len(v):.3f},{len(v)}\n')
-    else:
-        tot = sum(int(r["TotalDurationNs"]) for r in rows)
-        with open(out, "w") as f:
-            f.write("kernel,calls,total_ms,avg_us,pct_of_all_gpu_time\n")
-            other = 0
-            for r in rows:
-                k = short(r["Name"])
-                if k:
-                    f.write(f'"{k}",{r["Calls"]},{int(r["TotalDurationNs"])/1e6:.3f},{float(r["AverageNs"])/1e3:.2f},'
-                            f'{100.0*int(r["TotalDurationNs"])/tot:.2f}\n')
-                else:
-                    other += int(r["TotalDurationNs"])
-            f.write(f'"(torch plumbing: aux outputs, copies, 4x4 algebra)",,{other/1e6:.3f},,{100.0*other/tot:.2f}\n')
+        return
+    tot = sum(int(r["TotalDurationNs"]) for r in rows)
+    agg = collections.OrderedDict()
+    for r in rows:
+        k = short(r["Name"])
+        a = agg.setdefault(k, [0, 0])
+        a[0] += int(r["Calls"])
+        a[1] += int(r["TotalDurationNs"])
+    items = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    with open(out, "w") as f:
+        f.write("kernel,calls,total_ms,avg_us,pct_of_all_gpu_time\n")
+        for k, (calls, ns) in items[:top]:
+            f.write(f'"{k}",{calls},{ns/1e6:.3f},{ns/1e3/calls:.2f},{100.0*ns/tot:.2f}\n')
+        rest = items[top:]
+        if rest:
+            ns = sum(v[1] for _, v in rest)
+            f.write(f'"({len(rest)} more kernels)",{sum(v[0] for _, v in rest)},{ns/1e6:.3f},,{100.0*ns/tot:.2f}\n')
+
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 60)
