@@ -4,7 +4,8 @@
   getz.npz     CoPoNeRF.get_z on one 256x256 synthetic pair with deterministic weights for all 744 state_dict entries:
                rel_pose, the 4 flows, strided samples + statistics of the 4 latent maps.
   ufc_ops.npz  Encoder4D (Conv4d + GroupNorm + ReLU) for the three (kernel, stride, padding) variants UFC uses,
-               aggregation.correlation, aggregation.soft_argmax (both directions), LinearAttention — on small inputs.
+               aggregation.correlation, aggregation.soft_argmax (both directions), LinearAttention — on small inputs;
+               plus the upstream gradients of the three Encoder4D cases (input and every parameter).
 """
 import os
 import sys
@@ -61,6 +62,13 @@ def main():
         with torch.no_grad():
             y = enc(x)
         ops[f"enc4d_{tag}"] = y.numpy()
+        # the upstream module's OWN gradients (autograd through Conv4d / MaxPool4d / GroupNorm / ReLU) for the same case
+        xg = x.clone().requires_grad_(True)
+        yg = enc(xg)
+        (yg * syn.normal(tuple(yg.shape), seed=85 + s)).sum().backward()
+        ops[f"enc4d_{tag}_dx"] = xg.grad.numpy()
+        for name, prm in enc.named_parameters():
+            ops[f"enc4d_{tag}_d.{name}"] = prm.grad.numpy()
     a = syn.normal((2, 36, 24), seed=90)
     b = syn.normal((2, 36, 24), seed=91)
     to_map = lambda t: t.transpose(1, 2).reshape(2, 24, 6, 6)

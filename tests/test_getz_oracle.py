@@ -76,3 +76,30 @@ def test_get_z_glue_matches_reference():
         assert f.shape == g.shape == (1, 2, 64, 64)
         assert (f - g).abs().max() <= (5e-2 if i < 2 else 2e-3), i          # pixel units / normalised units
     assert (rel_pose - torch.from_numpy(gold["rel_pose"])).abs().max() <= 2e-3
+
+
+def _enc4d_grads(tag, cin, mid, k, s, p, n, ops, dev="cpu"):
+    """Input / parameter gradients of coponerf_amd.getz.Encoder4D on the fixture case `tag` with operator set `ops`."""
+    enc = Encoder4D((cin, mid), k, s, p)
+    shp = {kk: tuple(v.shape) for kk, v in enc.state_dict().items()}
+    enc.load_state_dict(syn.make_full_weights(shp, seed=70 + s))
+    enc = enc.to(dev)
+    x = syn.normal((2, cin, n, n, n, n), seed=80 + s).to(dev).requires_grad_(True)
+    y = enc(x, ops)
+    (y * syn.normal(tuple(y.shape), seed=85 + s).to(dev)).sum().backward()
+    out = {"dx": x.grad.cpu()}
+    out.update({"d." + name: prm.grad.cpu() for name, prm in enc.named_parameters()})
+    return out
+
+
+ENC4D_CASES = {"k3s1": (3, 5, 3, 1, 1, 6), "k3s2": (1, 8, 3, 2, 1, 10), "k5s4": (1, 8, 5, 4, 2, 16)}
+
+
+def test_oracle_encoder4d_gradients_match_upstream(ops_gold):
+    """Autograd through the oracle's Conv4d / pooling / GroupNorm / ReLU restatement == the upstream module's own
+    gradients (tests/golden/ufc_ops.npz: input and every parameter, all three (kernel, stride, padding) variants)."""
+    for tag, cfg in ENC4D_CASES.items():
+        got = _enc4d_grads(tag, *cfg, ops=TorchOps)
+        for name, g in got.items():
+            want = torch.from_numpy(ops_gold[f"enc4d_{tag}_{name}"])
+            assert (g - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max())), (tag, name)

@@ -10,6 +10,9 @@ from tests.helpers import GOLDEN, to_device
 
 pytestmark = pytest.mark.gpu
 
+# flows 0/1 are in pixels of the 64x64 grid (|flow| up to ~60), flows 2/3 normalised to [-1, 1]; measured 1.1e-5 px / 3.6e-7
+FLOW_TOL_PX, FLOW_TOL_NORM = 5e-4, 2e-5
+
 
 @pytest.fixture(scope="module")
 def dev():
@@ -76,8 +79,10 @@ def test_get_z_and_render_end_to_end(dev):
         cs, ss = strides[i]
         g = torch.from_numpy(gold[f"z{i}_sample"])
         assert (t[:, ::cs, ::ss, ::ss].cpu() - g).abs().max() <= 5e-3 * max(1.0, float(g.abs().max())), i
-    for i, f in enumerate(flows):
-        assert (f.cpu() - torch.from_numpy(gold[f"flow{i}"])).abs().max() <= (1e-1 if i < 2 else 4e-3), i
+    ferr = [float((f.cpu() - torch.from_numpy(gold[f"flow{i}"])).abs().max()) for i, f in enumerate(flows)]
+    print("get_z flow max-abs errors vs upstream:", ferr)
+    for i, e in enumerate(ferr):
+        assert e <= (FLOW_TOL_PX if i < 2 else FLOW_TOL_NORM), (i, ferr)
     assert (rel_pose.cpu() - torch.from_numpy(gold["rel_pose"])).abs().max() <= 5e-3
     with torch.no_grad():
         out = model(inp, z=z, rel_pose=rel_pose, val=True, flow=flows)
@@ -125,3 +130,18 @@ def test_conv_map_kernel_against_oracle(dev):
         got, nhwc = HipOps().conv_map(rgb.to(dev), w.to(dev), b.to(dev), want_nhwc16=True)
         assert (got.cpu() - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max()))
         assert torch.equal(nhwc.float().cpu(), got.cpu().permute(0, 2, 3, 1).half().float())
+
+
+def test_encoder4d_gradients_match_upstream_fixture(dev):
+    """Verdict r1: the strided-Conv4d gradient test compared the library VJP with the oracle — the same formula twice.
+    Here the gradients of the HIP operator path (forward on cpn_conv4d + cpn_gn_relu, backward on cpn_gn_relu_bwd, the
+    HIP data-gradient conv / cpn_conv_wgrad_planes for stride 1 and the library VJP for the strided layers) are
+    compared with the UPSTREAM module's own gradients (tests/golden/ufc_ops.npz), input and every parameter."""
+    from coponerf_amd.ufc_ops import HipOps
+    from tests.test_getz_oracle import ENC4D_CASES, _enc4d_grads
+    gold = dict(np.load(os.path.join(GOLDEN, "ufc_ops.npz")))
+    for tag, cfg in ENC4D_CASES.items():
+        got = _enc4d_grads(tag, *cfg, ops=HipOps(), dev=dev)
+        for name, g in got.items():
+            want = torch.from_numpy(gold[f"enc4d_{tag}_{name}"])
+            assert (g - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max())), (tag, name, float((g - want).abs().max()))
