@@ -92,8 +92,9 @@ __global__ __launch_bounds__(256) void attend_hidden_bwd_kernel(
         *reinterpret_cast<half8*>(dqa + (row0 + row) * 128 + g * 8) = oa;
         *reinterpret_cast<half8*>(dqb + (row0 + row) * 128 + g * 8) = ob;
     }
-    // dhid = w[row] * dhbar : thread = 8 channels, rows streamed
-    if (tid < HC / 8) {
+    // dhid = w[row] * dhbar : thread = 8 channels, rows streamed (skipped when the caller combines the hidden-activation
+    // gradients of all consumers in cpn_hid_grad_combine instead of materialising one 7 GB tensor per consumer)
+    if (dhid && tid < HC / 8) {
         float d8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) d8[e] = dh[tid * 8 + e];
@@ -105,6 +106,56 @@ __global__ __launch_bounds__(256) void attend_hidden_bwd_kernel(
             *reinterpret_cast<half8*>(dhid + (row0 + row) * HC + tid * 8) = o;
         }
     }
+}
+
+// d(pre-activation of the first encoder layer) from ALL consumers of `hid` in one pass:
+//     out[row, c] = hid[row, c] > 0 ? dkey[row, c] + w1[row] * dh1[ray, j*832 + c] + w2[row] * dh2[ray, j*832 + c] : 0
+// hid feeds the key path (a GEMM, gradient dkey) and the two attention-weighted hidden sums (gradients w_i (x) dhbar_i,
+// rank one per ray).  Autograd used to materialise the three 7 GB tensors, add them twice and mask the sum (84 GB of
+// traffic per step at 4 x 4096 rays); this kernel reads hid and dkey once and writes the masked sum once (21 GB).
+// thread = (row, 8-channel chunk); all gradient operands carry the pass's power-of-two scale (train_fns.GradScale).
+__global__ __launch_bounds__(256) void hid_grad_combine_kernel(
+    const __half* __restrict__ dkey, const __half* __restrict__ hid, const float* __restrict__ w1,
+    const float* __restrict__ dh1, const float* __restrict__ w2, const float* __restrict__ dh2, int V, int R, int S,
+    int ray0, long long nchunks, __half* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nchunks) return;
+    const int c8 = (int)(idx % 104);
+    long long row = idx / 104;
+    const int j = (int)(row & 1);
+    long long t = row >> 1;
+    const int s = (int)(t % S); t /= S;
+    const int v = (int)(t % V); t /= V;                             // t = ray inside this launch
+    const long long ray = ray0 + t;
+    const int b = (int)(ray / R), r = (int)(ray % R);
+    const size_t widx = (((size_t)(b * V + v)) * R + r) * S + s;
+    const half8 h = *reinterpret_cast<const half8*>(hid + (size_t)row * 832 + c8 * 8);
+    float acc[8];
+    if (dkey) {
+        const half8 d = *reinterpret_cast<const half8*>(dkey + (size_t)row * 832 + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = (float)d[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    }
+    const size_t hoff = (size_t)t * HC + j * 832 + c8 * 8;
+    if (w1) {
+        const float w = w1[widx];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(dh1 + hoff), bq = *reinterpret_cast<const f32x4*>(dh1 + hoff + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += w * a[e]; acc[4 + e] += w * bq[e]; }
+    }
+    if (w2) {
+        const float w = w2[widx];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(dh2 + hoff), bq = *reinterpret_cast<const f32x4*>(dh2 + hoff + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += w * a[e]; acc[4 + e] += w * bq[e]; }
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)h[e] > 0.0f ? (_Float16)acc[e] : (_Float16)0.0f;
+    *reinterpret_cast<half8*>(out + (size_t)row * 832 + c8 * 8) = o;
 }
 
 // Scatter-add of the gather gradient without atomic contention.
@@ -333,7 +384,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
 extern "C" int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, const float* at_wt,
                                      const float* dhbar, const float* dw_ext, int B, int V, int R, int S, int ray0,
                                      int nrays, uint16_t* dqa, uint16_t* dqb, uint16_t* dhid, void* stream) {
-    CPN_REQUIRE(qa && qb && hid && at_wt && dhbar && dqa && dqb && dhid, CPN_E_ARG, "cpn_attend_hidden_bwd: null pointer");
+    CPN_REQUIRE(qa && qb && hid && at_wt && dhbar && dqa && dqb, CPN_E_ARG, "cpn_attend_hidden_bwd: null pointer");
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && V * S <= 2048, CPN_E_SHAPE, "cpn_attend_hidden_bwd: bad shape");
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_attend_hidden_bwd: ray range outside B*R");
@@ -342,6 +393,21 @@ extern "C" int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, con
                        (const __half*)qa, (const __half*)qb, (const __half*)hid, at_wt, dhbar, dw_ext, V, R, S, ray0,
                        (__half*)dqa, (__half*)dqb, (__half*)dhid);
     CPN_LAUNCH_CHECK("cpn_attend_hidden_bwd");
+    return 0;
+}
+
+extern "C" int cpn_hid_grad_combine(const uint16_t* dkey, const uint16_t* hid, const float* w1, const float* dh1,
+                                    const float* w2, const float* dh2, int B, int V, int R, int S, int ray0, int nrays,
+                                    uint16_t* out, void* stream) {
+    CPN_REQUIRE(hid && out && (!w1 || dh1) && (!w2 || dh2), CPN_E_ARG, "cpn_hid_grad_combine: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0, CPN_E_SHAPE, "cpn_hid_grad_combine: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_hid_grad_combine: ray range outside B*R");
+    const long long nchunks = (long long)nrays * V * S * 2 * 104;
+    CPN_REQUIRE(nchunks / 256 < (1LL << 31), CPN_E_SHAPE, "cpn_hid_grad_combine: chunk too large");
+    hipLaunchKernelGGL(hid_grad_combine_kernel, dim3((unsigned)cpn_cdiv(nchunks, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __half*)dkey, (const __half*)hid, w1, dh1, w2, dh2, V, R, S, ray0, nchunks, (__half*)out);
+    CPN_LAUNCH_CHECK("cpn_hid_grad_combine");
     return 0;
 }
 

@@ -295,7 +295,7 @@ class RenderEngine:
                      z: Sequence[torch.Tensor], rel_pose, val: bool, S: int, H: int, W: int) -> Dict[str, torch.Tensor]:
         """Same forward kernels as render(), wrapped in autograd Functions (coponerf_amd/train_fns.py); all rays of
         the call form one chunk (training uses <= 4096 rays per pair, /root/reference train.py:87)."""
-        from .train_fns import GemmFn, GradScale, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn
+        from .train_fns import GemmFn, GradScale, HidGradParts, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn
         dev = uv.device
         if dev.type != "cuda":
             raise RuntimeError("coponerf_amd renders on a HIP device only (got uv on %s)" % dev)
@@ -305,11 +305,12 @@ class RenderEngine:
         g = self._geometry(ctx_c2w, ctx_K, qry_c2w, qry_K, uv, rel_pose, val, S, H, W)
         dims = (B, V, R, S)
         gs = GradScale(self.grad_scale_target)      # one scale for all fp16 activation gradients of this pass
+        hp = HidGradParts()                         # rank-one gradients of hid, combined in its producer's backward
         P = params
         mat = lambda n, rows: P[n + ".weight"].reshape(rows, -1)
         bias = lambda n: P[n + ".bias"]
         xin = GatherFn.apply(z[0], z[1], z[2], z[3], g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs)
-        hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False, gs)
+        hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False, gs, hp, dims)
         hid2 = hid.view(-1, 1664)
         W2, b2 = mat("query_encode_latent_2", 416), bias("query_encode_latent_2")
 
@@ -324,14 +325,14 @@ class RenderEngine:
         key2 = GemmFn.apply(kh, mat("key_map_2", 128), bias("key_map_2"), False, False, gs)
         hq = LocalHiddenFn.apply(g["loc8"], g["coords9"], mat("query_embed", 128), bias("query_embed"), None, dims, gs)
         ce = GemmFn.apply(hq, mat("query_embed_2", 128), bias("query_embed_2"), False, False, gs)
-        hbar1, w1 = AttendHiddenFn.apply(key2, ce, hid2, dims, gs)
+        hbar1, w1 = AttendHiddenFn.apply(key2, ce, hid2, dims, gs, hp)
         z1 = GemmFn.apply(hbar1, Wvf, cvf, False, True, gs)
         ze = LinearF32Fn.apply(z1, mat("encode_latent", 128), bias("encode_latent"), None, False, False)
         Wr = mat("query_repeat_embed", 128)
         aq = LinearF32Fn.apply(ze, Wr[:, :128].contiguous(), None, None, False, False)
         q2h = LocalHiddenFn.apply(g["loc8"], g["coords9"], Wr[:, 128:].contiguous(), bias("query_repeat_embed"), aq, dims, gs)
         q2 = GemmFn.apply(q2h, mat("query_repeat_embed_2", 128), bias("query_repeat_embed_2"), False, False, gs)
-        hbar2, _ = AttendHiddenFn.apply(q2, ce, hid2, dims, gs)
+        hbar2, _ = AttendHiddenFn.apply(q2, ce, hid2, dims, gs, hp)
         zs = GemmFn.apply(hbar2, Wvf, cvf, False, True, gs)
         zl = zs + float(V) * z1                                  # CoPoNeRF.py:481-485
         nray = B * R

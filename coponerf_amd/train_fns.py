@@ -48,6 +48,16 @@ class GradScale:
         return d if d.dtype == torch.float16 else d * self.ensure(d)
 
 
+class HidGradParts:
+    """Gradient contributions to the hidden activations `hid` that are rank one per ray (w (x) dhbar, from the two
+    attention-weighted hidden sums).  Their backward functions park them here instead of materialising a 7 GB tensor
+    each; the backward of the layer that PRODUCED hid (autograd runs it after all of hid's consumers) combines them with
+    the key path's gradient and the ReLU mask in one kernel (cpn_hid_grad_combine)."""
+
+    def __init__(self):
+        self.parts = []                     # (w (N,R,S) fp32, dhbar (rays,1664) fp32 scaled)
+
+
 def _mm_f32(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
     """(P,M) fp16 @ (M,Q) fp16 -> fp32 with fp32 accumulation AND fp32 output (hipBLASLt): M is millions of rows, an
     fp16 result would overflow / lose the tail of the sum."""
@@ -58,7 +68,7 @@ class GemmFn(Function):
     """C = act(A . W^T + b) through cpn_gemm_f16.  A (M, lda) fp16 (row stride lda >= K), W (N, K) fp32, b (N)."""
 
     @staticmethod
-    def forward(ctx, A16, W, b, relu: bool, out_f32: bool, gs: GradScale):
+    def forward(ctx, A16, W, b, relu: bool, out_f32: bool, gs: GradScale, hid_parts=None, dims=None):
         M, lda = A16.shape
         N, K = W.shape
         Kp = ((K + 31) // 32) * 32
@@ -72,20 +82,35 @@ class GemmFn(Function):
              int(relu), int(out_f32), _stream())
         ctx.save_for_backward(A16, W16, C if relu else None)
         ctx.relu, ctx.K, ctx.gs = relu, K, gs
+        ctx.hid_parts, ctx.dims = hid_parts, dims
         return C
 
     @staticmethod
     def backward(ctx, dC):
         A16, W16, C = ctx.saved_tensors
-        d = ctx.gs.scaled16(dC.contiguous())                                 # s * dC (GradScale convention)
-        inv = 1.0 / ctx.gs.s
-        if ctx.relu:
-            d = torch.ops.aten.threshold_backward(d, C.to(d.dtype) if C.dtype != d.dtype else C, 0)   # d where C > 0
-        d16 = d.to(torch.float16)
+        if ctx.hid_parts is not None and ctx.hid_parts.parts:
+            # C = hid: key-path gradient (dC) + the parked rank-one contributions + ReLU mask in ONE pass
+            B, V, R, S = ctx.dims
+            d = ctx.gs.scaled16(dC.contiguous()).to(torch.float16)
+            parts = ctx.hid_parts.parts
+            (w1, dh1), (w2, dh2) = parts[0], (parts[1] if len(parts) > 1 else (None, None))
+            d16 = torch.empty_like(C)
+            call("cpn_hid_grad_combine", d.data_ptr(), C.data_ptr(), w1.data_ptr(), dh1.data_ptr(),
+                 0 if w2 is None else w2.data_ptr(), 0 if dh2 is None else dh2.data_ptr(), B, V, R, S, 0, B * R,
+                 d16.data_ptr(), _stream())
+            ctx.hid_parts.parts = []
+            d = d16
+            inv = 1.0 / ctx.gs.s
+        else:
+            d = ctx.gs.scaled16(dC.contiguous())                                 # s * dC (GradScale convention)
+            inv = 1.0 / ctx.gs.s
+            if ctx.relu:
+                d = torch.ops.aten.threshold_backward(d, C.to(d.dtype) if C.dtype != d.dtype else C, 0)   # d where C > 0
+            d16 = d.to(torch.float16)
         dA = torch.matmul(d16, W16) if ctx.needs_input_grad[0] else None            # (M, lda) fp16, scaled; pad columns get 0
         dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
         db = d.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[2] else None
-        return dA, dW, db, None, None, None
+        return dA, dW, db, None, None, None, None, None
 
 
 class LinearF32Fn(Function):
@@ -158,7 +183,7 @@ class AttendHiddenFn(Function):
     """(hbar fp16 (rays,1664), w fp32 (N,R,S)) = cpn_attend_hidden(qa, qb, hid)."""
 
     @staticmethod
-    def forward(ctx, qa, qb, hid2, dims, gs: GradScale):
+    def forward(ctx, qa, qb, hid2, dims, gs: GradScale, hid_parts=None):
         B, V, R, S = dims
         nrays = B * R
         hbar = torch.empty(nrays, 1664, dtype=torch.float16, device=qa.device)
@@ -166,7 +191,7 @@ class AttendHiddenFn(Function):
         call("cpn_attend_hidden", qa.data_ptr(), qb.data_ptr(), 0, hid2.data_ptr(), B, V, R, S, 0, nrays, hbar.data_ptr(),
              w.data_ptr(), _stream())
         ctx.save_for_backward(qa, qb, hid2, w)
-        ctx.dims, ctx.gs = dims, gs
+        ctx.dims, ctx.gs, ctx.hid_parts = dims, gs, hid_parts
         return hbar, w
 
     @staticmethod
@@ -182,11 +207,15 @@ class AttendHiddenFn(Function):
             gs.ensure(dw)
         dh = dhbar.float().contiguous()
         dwc = None if dw is None else (dw.float() * gs.s).contiguous()
-        dqa, dqb, dhid = torch.empty_like(qa), torch.empty_like(qb), torch.empty_like(hid2)
+        dqa, dqb = torch.empty_like(qa), torch.empty_like(qb)
+        park = ctx.hid_parts is not None
+        dhid = None if park else torch.empty_like(hid2)
         call("cpn_attend_hidden_bwd", qa.data_ptr(), qb.data_ptr(), hid2.data_ptr(), w.data_ptr(), dh.data_ptr(),
              0 if dwc is None else dwc.data_ptr(), B, V, R, S, 0, nrays, dqa.data_ptr(), dqb.data_ptr(),
-             dhid.data_ptr(), _stream())
-        return dqa, dqb, dhid, None, None
+             0 if park else dhid.data_ptr(), _stream())
+        if park:                            # dhid = w (x) dhbar is formed by the producer of hid (cpn_hid_grad_combine)
+            ctx.hid_parts.parts.append((w, dh))
+        return dqa, dqb, dhid, None, None, None
 
 
 class GatherFn(Function):

@@ -181,10 +181,18 @@ int cpn_mask_rgb(const float* rgb_raw, int ld, const uint8_t* overlaps, int B, i
 /* ==== training: backward of the two non-GEMM stages (plain GEMM gradients use hipBLASLt via torch.matmul) ==== */
 
 /* gradient of cpn_attend_hidden: dhbar (rays,1664) fp32, dw_ext (N,R,S) fp32 or NULL (external gradient on the
- * softmax weights), at_wt (N,R,S) the forward weights -> dqa, dqb (rays*V*S,128) fp16, dhid (rays*V*S,1664) fp16   */
+ * softmax weights), at_wt (N,R,S) the forward weights -> dqa, dqb (rays*V*S,128) fp16, dhid (rays*V*S,1664) fp16 or
+ * NULL (the caller then forms the hidden-activation gradient of all consumers with cpn_hid_grad_combine)        */
 int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, const float* at_wt,
                           const float* dhbar, const float* dw_ext, int B, int V, int R, int S, int ray0, int nrays,
                           uint16_t* dqa, uint16_t* dqb, uint16_t* dhid, void* stream);
+
+/* gradient w.r.t. the pre-activation of the first encoder layer from ALL consumers of hid, in one pass:
+ *   out[row,c] = hid[row,c] > 0 ? dkey[row,c] + w1[n,r,s]*dh1[ray, j*832+c] + w2[n,r,s]*dh2[ray, j*832+c] : 0
+ * dkey (rows, 832) fp16 or NULL = gradient through the key path; (w_i (N,R,S) fp32, dh_i (rays,1664) fp32) or NULL =
+ * the attention-weighted hidden sums (w_i: forward softmax weights, dh_i: gradient of the summed vector).            */
+int cpn_hid_grad_combine(const uint16_t* dkey, const uint16_t* hid, const float* w1, const float* dh1, const float* w2,
+                         const float* dh2, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out, void* stream);
 
 /* gradient of cpn_gather_rows w.r.t. the feature maps: dxin (rows, ldx) fp16 -> accumulated into dmap0..3
  * (N,h,w,C) fp32 NHWC, which the caller zeroes first.  No coordinate gradient (CoPoNeRF.py:380-381).
