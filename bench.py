@@ -244,6 +244,23 @@ def run(args):
         line["get_z_ms"] = getz_ms
         line["image_rays_per_s"] = rays_per_step / (getz_ms * 1e-3 + elapsed / args.steps)
         del zz
+        # the same pipeline with get_z of pair i+1 on a second HIP stream under the render of pair i
+        # (coponerf_amd/pipeline.py; pairs are independent, results identical to the serial order)
+        if B == 1:
+            from coponerf_amd.pipeline import render_images
+            pairs = [inp] + [_to(syn.make_inputs(1, H, H, 0, seed=300 + rank * 16 + i, full_image=True), dev) for i in range(3)]
+            with torch.no_grad():
+                for _ in render_images(model, pairs[:2]):
+                    pass
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                nimg = 0
+                for _ in render_images(model, pairs + pairs):
+                    nimg += 1
+                torch.cuda.synchronize()
+                pdt = time.perf_counter() - p0
+            line["image_rays_per_s_pipelined"] = nimg * R / pdt
+            line["image_ms_pipelined"] = 1e3 * pdt / nimg
 
     if rank == 0:
         line.update(roofline_block(prof, args, tables))

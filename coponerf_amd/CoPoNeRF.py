@@ -139,16 +139,16 @@ class CoPoNeRF(nn.Module):
         out = {"flow": flow, "uv": qry["uv"], "coords": core["coords"]}
         out["pixel_val"] = core["pixel_val_cpu"]                  # models/CoPoNeRF.py:490 (callers expect a CPU tensor)
         out["at_wts"] = [core["at_wt"]]
-        out.update(aux_outputs(input, flow, core["at_wt"], core["pt"], core["Tq"]))
+        host = core["host"]                                       # O(B) inverses done with the host pose algebra
+        out.update(aux_outputs(input, flow, core["at_wt"], core["pt"], core["Tq"], host["inv_Kq"], host["inv_qc2w"]))
         out["at_wt"] = core["at_wt"]
         out["valid_mask"] = core["valid_mask"]
         out["rgb"] = core["rgb"]
         out["z"] = z
         out["rel_pose_flip"] = _rigid_inverse(rel_pose)
         out["rel_pose"] = rel_pose
-        c2w = ctx["cam2world"]
-        out["gt_rel_pose"] = torch.inverse(c2w[:, 0]) @ c2w[:, 1]
-        out["gt_rel_pose_flip"] = torch.inverse(torch.inverse(c2w[:, -1]) @ c2w[:, 0])
+        out["gt_rel_pose"] = host["gt_rel_pose"]                  # models/CoPoNeRF.py:570-574
+        out["gt_rel_pose_flip"] = host["gt_rel_pose_flip"]
         if debug:
             out["_core"] = core
         return out

@@ -42,9 +42,9 @@ def cycle_masks(flow: Sequence[torch.Tensor], width: int):
     return m1, m2
 
 
-def _reproject(kp, depth, Ki, Kj, T):
+def _reproject(kp, depth, Ki_inv, Kj, T):
     ones = kp.new_ones(kp.shape[:-1] + (1,))
-    p = torch.cat([kp, ones], -1) @ torch.inverse(Ki).transpose(-1, -2)
+    p = torch.cat([kp, ones], -1) @ Ki_inv.transpose(-1, -2)
     p = p * depth[..., None]
     q = torch.cat([p, ones], -1) @ T.transpose(-1, -2)
     q = q[..., :-1] / (q[..., -1:] + 1e-6)
@@ -72,7 +72,9 @@ def _flow_products(flow: Sequence[torch.Tensor], width: int):
 
 
 def aux_outputs(inp: Dict, flow: Sequence[torch.Tensor], at_wt: torch.Tensor, pt: torch.Tensor,
-                Tq: torch.Tensor) -> Dict[str, torch.Tensor]:
+                Tq: torch.Tensor, inv_Kq: torch.Tensor = None, inv_qc2w: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+    """inv_Kq (B,3,3) / inv_qc2w (B,4,4): inverses of the query intrinsics / pose computed with the host pose algebra
+    (a GPU torch.inverse is a host synchronisation); computed here if not given."""
     ctx, qry = inp["context"], inp["query"]
     B, V = ctx["rgb"].shape[:2]
     R = qry["uv"].shape[2]
@@ -81,11 +83,14 @@ def aux_outputs(inp: Dict, flow: Sequence[torch.Tensor], at_wt: torch.Tensor, pt
     at_max = at_wt.argmax(dim=-1)[..., None]
     expected = (at_wt[..., None] * torch.clamp(pt, -100, 100)).sum(dim=-2).view(B, V, R, 3).sum(dim=1)
     hom = torch.cat((expected, torch.ones(B, R, 1, device=dev)), dim=2).permute(0, 2, 1)
-    depth_ray = torch.inverse(qry["cam2world"][:, 0]).bmm(hom).permute(0, 2, 1)[..., 2]
+    if inv_qc2w is None:
+        inv_qc2w = torch.inverse(qry["cam2world"][:, 0])
+    if inv_Kq is None:
+        inv_Kq = torch.inverse(qry["intrinsics"][:, 0, :3, :3])
+    depth_ray = inv_qc2w.bmm(hom).permute(0, 2, 1)[..., 2]
     uvq = qry["uv"].squeeze(1)
-    Kq = qry["intrinsics"][:, 0, :3, :3]
-    t1 = _reproject(uvq, depth_ray, Kq, ctx["intrinsics"][:, 0, :3, :3], Tq[:, 0])
-    t2 = _reproject(uvq, depth_ray, Kq, ctx["intrinsics"][:, 1, :3, :3], Tq[:, 1])
+    t1 = _reproject(uvq, depth_ray, inv_Kq, ctx["intrinsics"][:, 0, :3, :3], Tq[:, 0])
+    t2 = _reproject(uvq, depth_ray, inv_Kq, ctx["intrinsics"][:, 1, :3, :3], Tq[:, 1])
     tl = t2.long()
     kp = torch.clamp(tl.transpose(1, 2), 0, 255)                          # (B,2,R): x row 0, y row 1
     bidx = torch.arange(B, device=dev)[:, None]

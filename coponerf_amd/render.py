@@ -47,6 +47,32 @@ def _to_host(*mats: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:
 # (a1) pose algebra on the host — O(B) 4x4 matrices, float32, LAPACK: deterministic and identical to
 # what the CPU oracle computes, so everything downstream can be compared bit for bit.
 # ----------------------------------------------------------------------------------------------
+def _upload(host: Dict[str, torch.Tensor], dev) -> Dict[str, torch.Tensor]:
+    """Small CPU float32 tensors -> device views of ONE pinned staging buffer, one asynchronous H2D copy."""
+    total = sum(t.numel() for t in host.values())
+    stage = torch.empty(total, dtype=torch.float32, pin_memory=(dev.type == "cuda"))
+    off = 0
+    for t in host.values():
+        stage[off:off + t.numel()] = t.reshape(-1)
+        off += t.numel()
+    flat = stage.to(dev, non_blocking=True)
+    out, off = {}, 0
+    for k, t in host.items():
+        out[k] = flat[off:off + t.numel()].view(t.shape)
+        off += t.numel()
+    return out
+
+
+def host_pose_products(ctx_c2w: torch.Tensor, qry_c2w: torch.Tensor, qry_K: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """O(B) 4x4 / 3x3 inverses the outputs need (CoPoNeRF.py:568-574 gt_rel_pose*, utils.py:140-170 and
+    geometry.py:395-406 for the auxiliary reprojections), on the HOST next to the rest of the pose algebra: a GPU
+    `torch.inverse` checks its LAPACK status on the host, i.e. every one of them is a full stream synchronisation at the
+    END of a render pass (5 per call in round 1: the host could not run ahead of the GPU at all)."""
+    return {"gt_rel_pose": torch.inverse(ctx_c2w[:, 0]) @ ctx_c2w[:, 1],
+            "gt_rel_pose_flip": torch.inverse(torch.inverse(ctx_c2w[:, -1]) @ ctx_c2w[:, 0]),
+            "inv_Kq": torch.inverse(qry_K[:, 0, :3, :3]), "inv_qc2w": torch.inverse(qry_c2w[:, 0])}
+
+
 def _rigid_inverse(m: torch.Tensor) -> torch.Tensor:
     out = torch.zeros_like(m)
     rt = m[..., :3, :3].transpose(-1, -2)
@@ -270,8 +296,10 @@ class RenderEngine:
         B, _, R, _ = uv.shape
         N = B * V
         s = _stream()
-        cam_cpu, Tq_cpu = build_camera_block(*_to_host(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose), val, H)
-        cam = cam_cpu.to(dev)
+        hc2w, hK, hqc2w, hqK, hrel = _to_host(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
+        cam_cpu, Tq_cpu = build_camera_block(hc2w, hK, hqc2w, hqK, hrel, val, H)
+        up = _upload(dict(host_pose_products(hc2w, hqc2w, hqK), cam=cam_cpu, Tq=Tq_cpu), dev)
+        cam = up["cam"]
         ikey = (S, str(dev))
         if ikey not in self._interval:
             self._interval[ikey] = torch.linspace(0, 1, S).to(dev)
@@ -282,7 +310,7 @@ class RenderEngine:
              "overlaps": torch.empty(N, R, dtype=torch.uint8, device=dev),
              "pixel_val": torch.empty(N, R, S, 2, dtype=f32, device=dev), "pt": torch.empty(N, R, S, 3, dtype=f32, device=dev),
              "sec_grid": torch.empty(N, R, S, 2, dtype=f32, device=dev), "pe6": torch.empty(N, R, S, 6, dtype=f32, device=dev),
-             "loc8": torch.empty(N, R, S, 8, dtype=f32, device=dev), "Tq": Tq_cpu.to(dev)}
+             "loc8": torch.empty(N, R, S, 8, dtype=f32, device=dev), "Tq": up["Tq"], "host": up}
         call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), B, V, R, g["coords9"].data_ptr(), g["seg"].data_ptr(),
              g["overlaps"].data_ptr(), s)
         call("cpn_sample_geometry", cam.data_ptr(), g["coords9"].data_ptr(), g["seg"].data_ptr(), interval.data_ptr(),
@@ -350,7 +378,7 @@ class RenderEngine:
         rgb = raw.view(B, R, 3) * valid[..., None] + (1 - valid[..., None])
         return {"rgb": rgb.view(B, 1, R, 3), "valid_mask": valid[..., None], "pixel_val": g["pixel_val"],
                 "pixel_val_cpu": g["pixel_val"].cpu(), "pt": g["pt"], "at_wt": w1, "coords": g["coords9"],
-                "z_local": zl, "Tq": g["Tq"], "sec_grid": g["sec_grid"], "rgb_raw": raw}
+                "z_local": zl, "Tq": g["Tq"], "sec_grid": g["sec_grid"], "rgb_raw": raw, "host": g["host"]}
 
     # ---- the render pass -------------------------------------------------------------------------
     @torch.no_grad()
@@ -370,8 +398,10 @@ class RenderEngine:
         w = self._weights(params)
         maps, tabs = self._feature_maps(z, w)
 
-        cam_cpu, Tq_cpu = build_camera_block(*_to_host(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose), val, H)
-        cam = cam_cpu.to(dev)
+        hc2w, hK, hqc2w, hqK, hrel = _to_host(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
+        cam_cpu, Tq_cpu = build_camera_block(hc2w, hK, hqc2w, hqK, hrel, val, H)
+        up = _upload(dict(host_pose_products(hc2w, hqc2w, hqK), cam=cam_cpu, Tq=Tq_cpu), dev)
+        cam = up["cam"]
         ikey = (S, str(dev))
         if ikey not in self._interval:
             self._interval[ikey] = torch.linspace(0, 1, S).to(dev)       # CPU linspace, as the oracle's
@@ -563,5 +593,5 @@ class RenderEngine:
         copy_done.synchronize()
         return {"rgb": rgb, "valid_mask": valid, "pixel_val": pixel_val, "pixel_val_cpu": pixel_val_cpu, "pt": pt,
                 "at_wt": at_wt,
-                "coords": coords9, "z_local": zl, "Tq": Tq_cpu.to(dev), "sec_grid": sec_grid.clone(),
+                "coords": coords9, "z_local": zl, "Tq": up["Tq"], "host": up, "sec_grid": sec_grid.clone(),
                 "rgb_raw": rgb_raw[:, :3].clone()}

@@ -145,3 +145,31 @@ def test_encoder4d_gradients_match_upstream_fixture(dev):
         for name, g in got.items():
             want = torch.from_numpy(gold[f"enc4d_{tag}_{name}"])
             assert (g - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max())), (tag, name, float((g - want).abs().max()))
+
+
+def test_pipelined_images_equal_serial(dev):
+    """coponerf_amd.pipeline.render_images (get_z of pair i+1 on a second stream under the render of pair i) returns
+    what the serial get_z -> forward order returns, pair by pair."""
+    from coponerf_amd import CoPoNeRF
+    from coponerf_amd.pipeline import render_images
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev).eval()
+    pairs = [to_device(syn.make_inputs(1, 256, 256, 2048, seed=500 + i), dev) for i in range(3)]
+
+    def serial_rgb(p):
+        z, rel, flow = model.get_z(p)
+        return model(p, z=z, rel_pose=rel, val=True, flow=flow)["rgb"].clone()
+
+    with torch.no_grad():
+        serial = [serial_rgb(p) for p in pairs]
+        piped = [out["rgb"].clone() for _, out in render_images(model, pairs)]
+        again = serial_rgb(pairs[0])
+    torch.cuda.synchronize()
+    # get_z accumulates its GroupNorm statistics with atomics: two runs of the SAME pair agree to rounding only
+    noise = float((again - serial[0]).abs().max())
+    assert len(piped) == 3
+    for a, b in zip(serial, piped):
+        assert float((a - b).abs().max()) <= max(10 * noise, 1e-6), (float((a - b).abs().max()), noise)
+    assert float((serial[0] - serial[1]).abs().max()) > 1e-3
