@@ -58,7 +58,7 @@ constexpr int TILE_ROWS = 128;
 constexpr int NSLICE = 13;                // 832 = 13 x 64 output channels
 constexpr int SLICE_CH = 64;
 constexpr int NT = 4;                     // 16-channel MFMA tiles per slice
-constexpr int KSTEPS = 3;                 // K = 96 = 64 level-3 channels + 3 point encodings + zeros
+constexpr int KSTEPS = 3;                 // K = 80 = 2 x 32 level-3 channels + a 16-wide tail (3 point encodings + zeros)
 constexpr int PAD = CPN_NODE_PAD;         // zero rim of the 'zeros' table, in nodes (= level-0 texel pitch / 2)
 constexpr int TAB_SLICE_BYTES = SLICE_CH * 2;                  // 128: one cache line per node and slice
 constexpr int TAB_ROW_BYTES = CPN_TAB_LD * 2;                  // 1664 per node, channels in natural order
@@ -237,19 +237,6 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
     }
     __syncthreads();          // last workgroup-wide barrier: from here on the four waves run independently
 
-    half8 xa[KSTEPS][2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-            xa[k][mt] = *reinterpret_cast<const half8*>(aimg + (((k * 4 + wave) * 2 + mt) * 64 + lane) * 16);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const half8 p8 = *reinterpret_cast<const half8*>(aimg + AIMG2_OFF + ((wave * 2 + mt) * 16 + r) * 16);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xa[2][mt][e] = (g == 0) ? p8[e] : (_Float16)0.0f;
-    }
-
     // Tap / store phase lane roles ("load layout"): lane = 4*rl + pl -> row rl, 16-byte piece pl, so that 4 ADJACENT lanes
     // read / write 64 contiguous bytes of one node / row.  The texture addresser walks a wave 4 lanes per cycle and
     // the vector L1 does one tag lookup per distinct line of such a quad: in the MFMA layout (lane = r + 16 g) a quad
@@ -280,8 +267,8 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) vo[mt][k] = ((CPN_ENCODE_ABLATE & 16) ? 0 : rec[mt].off[k]) + pl * 16;
 
-    // Slice loop, software-pipelined by one slice on the store side:
-    //     issue ALL loads of slice n (weight fragments, taps)  ->  issue the stores of slice n-1  ->  compute slice n.
+    // Slice loop, software-pipelined by one slice on both sides:
+    //     issue ALL loads of the iteration (weights of slice n+1, taps of slice n)  ->  the stores of slice n-1  ->  compute slice n.
     // gfx9 has ONE counter for loads and stores (vmcnt) and they retire out of order against each other, so waiting
     // for any load that was issued AFTER a store also waits for that store to reach memory.  With the order above every
     // load a wave ever waits for is OLDER than the stores in flight: the 7 GB hid stream never stalls the wave that
@@ -298,13 +285,22 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
             }
         }
     };
-    for (int n = 0; n < NSLICE; ++n) {
-        // ---- loads of this slice: 12 weight fragments (coalesced 1 KiB each, L2-resident) + 16 tap pieces
-        half8 wf[KSTEPS][NT];
+    // weight fragments: [slice][k < 2][tile][lane] half8 for the 64 full-resolution channels, then
+    // [slice][tile][lane] half4 for the K tail (3 point-encoding columns + zero), consumed by a 16x16x16 MFMA
+    const half4* const wtail = reinterpret_cast<const half4*>(wfrag + NSLICE * 2 * NT * 64);
+    auto load_w = [&](int n, half8 (&w)[2][NT]) {
 #pragma unroll
-        for (int k = 0; k < KSTEPS; ++k)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[k][nt] = wfrag[((n * KSTEPS + k) * NT + nt) * 64 + lane];
+            for (int nt = 0; nt < NT; ++nt) w[k][nt] = wfrag[((n * 2 + k) * NT + nt) * 64 + lane];
+    };
+    // one slice: `wc` holds this slice's main fragments (fetched during the previous slice), `wn` receives the next one's
+    auto slice = [&](int n, half8 (&wc)[2][NT], half8 (&wn)[2][NT]) {
+        // ---- every load of this iteration first: next slice's weights, this slice's K tail and its 16 tap pieces
+        if (n + 1 < NSLICE) load_w(n + 1, wn);
+        half4 wt[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wt[nt] = wtail[(n * NT + nt) * 64 + lane];
         u32x4 td[2][4][2];
         if (!(CPN_ENCODE_ABLATE & 1)) {
 #pragma unroll
@@ -320,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
         if (n > 0) store_slice(n - 1);
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- K = 96 contraction of the full-resolution level + point encoding, on top of the bias
+        // ---- K = 80 contraction of the full-resolution level + point encoding, on top of the bias.  The B operands
+        //      (this wave's rows) come back from LDS every slice: 24 registers that the prefetched weights need
         f32x4 acc[2][NT];
         {
             const float* bp = bias_s + n * SLICE_CH + g * 8;
@@ -330,13 +327,33 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
                 acc[1][nt] = acc[0][nt];
             }
         }
+        if (!(CPN_ENCODE_ABLATE & 4)) {
+            half8 xa[2][2];
 #pragma unroll
-        for (int k = 0; k < ((CPN_ENCODE_ABLATE & 4) ? 0 : KSTEPS); ++k)
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    xa[k][mt] = *reinterpret_cast<const half8*>(aimg + (((k * 4 + wave) * 2 + mt) * 64 + lane) * 16);
+            half4 xt[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const half4 p4 = *reinterpret_cast<const half4*>(aimg + AIMG2_OFF + ((wave * 2 + mt) * 16 + r) * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xt[mt][e] = (g == 0) ? p4[e] : (_Float16)0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[k][nt], xa[k][0], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[k][nt], xa[k][1], acc[1][nt], 0, 0, 0);
+                }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k][nt], xa[k][0], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k][nt], xa[k][1], acc[1][nt], 0, 0, 0);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wt[nt], xt[0], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wt[nt], xt[1], acc[1][nt], 0, 0, 0);
             }
+        }
         // MFMA layout -> load layout
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -374,7 +391,14 @@ __global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
                     res[mt][h][4 + i] = (_Float16)fmaxf(acc[mt][2 * h + 1][i], 0.0f);
                 }
         }
+    };
+    half8 wA[2][NT], wB[2][NT];
+    load_w(0, wA);
+    for (int n = 0; n + 1 < NSLICE; n += 2) {               // ping-pong: no register copies between slices
+        slice(n, wA, wB);
+        slice(n + 1, wB, wA);
     }
+    slice(NSLICE - 1, wA, wB);
     store_slice(NSLICE - 1);
 }
 
@@ -424,23 +448,36 @@ __host__ __device__ inline int slice_channel(int nt, int a) {
     return (nt >> 1) * 32 + (a >> 2) * 8 + (nt & 1) * 4 + (a & 3);
 }
 
-// W (832, 835) fp32 -> wfrag [slice][k][nt][lane] half8 over columns 768..834 (K padded to 96)
+// W (832, 835) fp32 -> wfrag: [slice][k < 2][nt][lane] half8 over columns 768..831 (the full-resolution level), followed
+// by [slice][nt][lane] half4 over columns 832..834 + one zero (the K tail, v_mfma_f32_16x16x16_f16: lane group 0 only)
 __global__ void pack_encode_frag_kernel(const float* __restrict__ W, int ldw, half8* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NSLICE * KSTEPS * NT * 64) return;
-    const int lane = idx & 63;
-    int t = idx >> 6;
-    const int nt = t % NT; t /= NT;
-    const int k = t % KSTEPS;
-    const int n = t / KSTEPS;
-    const int ch = n * SLICE_CH + slice_channel(nt, lane & 15);
-    half8 o;
+    const int nmain = NSLICE * 2 * NT * 64;
+    if (idx < nmain) {
+        const int lane = idx & 63;
+        int t = idx >> 6;
+        const int nt = t % NT; t /= NT;
+        const int k = t % 2;
+        const int n = t / 2;
+        const int ch = n * SLICE_CH + slice_channel(nt, lane & 15);
+        half8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int kk = k * 32 + (lane >> 4) * 8 + e;
-        o[e] = (_Float16)(kk < 67 ? W[(size_t)ch * ldw + 768 + kk] : 0.0f);
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)W[(size_t)ch * ldw + 768 + k * 32 + (lane >> 4) * 8 + e];
+        out[idx] = o;
+        return;
     }
-    out[idx] = o;
+    const int j = idx - nmain;
+    if (j >= NSLICE * NT * 64) return;
+    const int lane = j & 63;
+    const int nt = (j >> 6) % NT, n = (j >> 6) / NT;
+    const int ch = n * SLICE_CH + slice_channel(nt, lane & 15);
+    half4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int kk = (lane >> 4) * 4 + e;                         // K index inside the 16-wide tail
+        o[e] = (_Float16)(kk < 3 ? W[(size_t)ch * ldw + 832 + kk] : 0.0f);
+    }
+    reinterpret_cast<half4*>(out + nmain)[j] = o;
 }
 
 // W (832, 835) fp32 -> the table projection (832, 768) fp16 over the three coarse levels (natural channel order)
@@ -463,7 +500,7 @@ extern "C" int cpn_pack_encode_weights(const float* W, int ldw, uint16_t* wfrag,
     CPN_REQUIRE(W && wfrag && wtab, CPN_E_ARG, "cpn_pack_encode_weights: null pointer");
     CPN_REQUIRE(ldw >= 835, CPN_E_SHAPE, "cpn_pack_encode_weights: ldw=%d < 835", ldw);
     const hipStream_t s = (hipStream_t)stream;
-    const int nf = NSLICE * KSTEPS * NT * 64;
+    const int nf = NSLICE * 2 * NT * 64 + NSLICE * NT * 64;           // main half8 fragments + half4 tail fragments
     hipLaunchKernelGGL(pack_encode_frag_kernel, dim3(cpn_cdiv(nf, 256)), dim3(256), 0, s, W, ldw, (half8*)wfrag);
     hipLaunchKernelGGL(pack_table_weight_kernel, dim3(cpn_cdiv(CPN_TAB_LD * 768, 256)), dim3(256), 0, s, W, ldw,
                        (__half*)wtab);

@@ -163,6 +163,7 @@ class RenderEngine:
         self._tabs: List[torch.Tensor] = []
         self._wgen = 0                  # bumped whenever the packed weights are rebuilt (the tables depend on them)
         self._l3_hint = None            # (z[3] tensor, its version, NHWC fp16 copy) handed over by get_z's conv_map kernel
+        self._hostc = None              # (input tensors, their versions, host copies) of the last call's 4x4 inputs
         self._ws: Dict[str, torch.Tensor] = {}
         self._interval: Dict[Tuple[int, str], torch.Tensor] = {}
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops)
@@ -187,6 +188,19 @@ class RenderEngine:
         self._mrefs = ()
         self._maps, self._tabs = [], []
         self._l3_hint = None
+        self._hostc = None
+
+    def _host_inputs(self, *mats):
+        """Host copies of the call's 4x4 inputs.  The device->host read is a stream synchronisation, and a full-image
+        render calls forward() once per ray chunk with the SAME camera tensors (/root/reference test.py:176-190,
+        wrapper.py:180-188): the copies are cached on tensor identity + version (the entry holds the tensors)."""
+        c = self._hostc
+        if c is not None and len(c[0]) == len(mats) and all(
+                (a is b) and (a is None or a._version == v) for a, b, v in zip(c[0], mats, c[1])):
+            return c[2]
+        host = _to_host(*mats)
+        self._hostc = (mats, tuple(None if m is None else m._version for m in mats), host)
+        return host
 
     def adopt_level3(self, z3: torch.Tensor, nhwc16: torch.Tensor) -> None:
         """get_z's conv_map kernel already wrote the full-resolution level as NHWC fp16: use it for THIS z3 tensor
@@ -296,7 +310,7 @@ class RenderEngine:
         B, _, R, _ = uv.shape
         N = B * V
         s = _stream()
-        hc2w, hK, hqc2w, hqK, hrel = _to_host(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
+        hc2w, hK, hqc2w, hqK, hrel = self._host_inputs(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
         cam_cpu, Tq_cpu = build_camera_block(hc2w, hK, hqc2w, hqK, hrel, val, H)
         up = _upload(dict(host_pose_products(hc2w, hqc2w, hqK), cam=cam_cpu, Tq=Tq_cpu), dev)
         cam = up["cam"]
@@ -398,7 +412,7 @@ class RenderEngine:
         w = self._weights(params)
         maps, tabs = self._feature_maps(z, w)
 
-        hc2w, hK, hqc2w, hqK, hrel = _to_host(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
+        hc2w, hK, hqc2w, hqK, hrel = self._host_inputs(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
         cam_cpu, Tq_cpu = build_camera_block(hc2w, hK, hqc2w, hqK, hrel, val, H)
         up = _upload(dict(host_pose_products(hc2w, hqc2w, hqK), cam=cam_cpu, Tq=Tq_cpu), dev)
         cam = up["cam"]
