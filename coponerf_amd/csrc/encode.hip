@@ -54,19 +54,13 @@
 
 namespace {
 
-constexpr int TILE_ROWS = 128;
 constexpr int NSLICE = 13;                // 832 = 13 x 64 output channels
 constexpr int SLICE_CH = 64;
 constexpr int NT = 4;                     // 16-channel MFMA tiles per slice
-constexpr int KSTEPS = 3;                 // K = 80 = 2 x 32 level-3 channels + a 16-wide tail (3 point encodings + zeros)
+// K = 80 = 2 x 32 full-resolution channels (v_mfma_f32_16x16x32_f16) + a 16-wide tail (3 point encodings + zeros, 16x16x16)
 constexpr int PAD = CPN_NODE_PAD;         // zero rim of the 'zeros' table, in nodes (= level-0 texel pitch / 2)
 constexpr int TAB_SLICE_BYTES = SLICE_CH * 2;                  // 128: one cache line per node and slice
 constexpr int TAB_ROW_BYTES = CPN_TAB_LD * 2;                  // 1664 per node, channels in natural order
-constexpr int AIMG_BYTES = 2 * 4 * 2 * 1024 + 4 * 2 * 256;     // [k < 2][wave][mt][lane] half8 + [wave][mt][r] half8 (k = 2, g = 0)
-constexpr int AIMG2_OFF = 2 * 4 * 2 * 1024;                    // third K step: only lane group 0 holds data (pt enc)
-constexpr int TG = 4;                     // rays per tile
-constexpr int TSB = 16;                   // samples per tile
-
 typedef __attribute__((address_space(3))) void lds_void;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -120,286 +114,266 @@ __device__ __forceinline__ TapRec node_taps(float gx, float gy, const NodeGrid n
     return t;
 }
 
-// Which (ray, sample) a tile row is.  A tile = TG adjacent rays (same batch element) x TSB consecutive samples x
-// {own, other image} of one view; wave w takes samples 4w..4w+3 of the block, MFMA column r = (sample & 3)*4 + (ray & 3).
+// Which (ray, sample) a row of a wave tile is.  A wave tile = 4 adjacent rays (same batch element) x 4 consecutive
+// samples x {own, other image} of one view = 32 rows; MFMA column / load-layout row index c = (sample & 3)*4 + (ray & 3),
+// so ONE load instruction covers a 4 x 4 patch of (sample, ray) whose taps fall on a handful of nodes.
+constexpr int TG = 4;                     // rays per wave tile
+constexpr int TSW = 4;                    // samples per wave tile
+
 struct RowId {
     bool live;
-    int j, s, r;                          // r = ray index inside its batch element
+    int s, r;                             // sample, ray index inside its batch element
 };
-__device__ __forceinline__ RowId tile_row(int row, int rgroup, int blk, int S, int R, int b, int ray0, int nrays) {
-    const int w = row >> 5, rl = row & 31, rs = rl >> 1;
+__device__ __forceinline__ RowId tile_row(int c, int rgroup, int sblk, int S, int R, int b, int ray0, int nrays) {
     RowId o;
-    o.j = rl & 1;
-    o.s = blk * TSB + w * 4 + (rs >> 2);
-    o.r = rgroup * TG + (rs & 3);
+    o.s = sblk * TSW + (c >> 2);
+    o.r = rgroup * TG + (c & 3);
     const long long ray = (long long)b * R + o.r;
     o.live = (o.s < S) && (o.r < R) && ray >= ray0 && ray < (long long)ray0 + nrays;
     return o;
 }
 
-__global__ __launch_bounds__(256, 2) void encode_hidden_kernel(
+constexpr int WMAIN_HALF8 = NSLICE * 2 * NT * 64;              // [slice][k < 2][tile][lane] half8: 104 KiB
+constexpr int WTAIL_HALF4 = NSLICE * NT * 16;                  // [slice][tile][A-operand row] half4 (lane group 0 only): 6.5 KiB
+constexpr int ENC_WAVES = 8;
+
+// Persistent kernel: one 8-wave workgroup per CU keeps ALL weight fragments of the K = 80 contraction in LDS for the
+// whole launch (111 KiB: they are the same for every row; as per-wave L2 loads they were 35 % of the bytes through the
+// texture path, which rocprofv3 showed 82 % busy), and every wave walks its own sequence of 32-row wave tiles with no
+// workgroup barrier after the prologue.  Nothing else lives in LDS: the per-row tap records and the K = 80 operand
+// (full-resolution gather + point encoding) are produced in registers, in the load layout, and moved to the MFMA
+// layout with ds_bpermute.
+__global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
     const __half* __restrict__ tab, const __half* __restrict__ map3, int H, int W,
     const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, const float* __restrict__ pe6,
     const half8* __restrict__ wfrag, const float* __restrict__ bias, int V, int R, int S, int ray0, int nrays,
-    int nblk, int groups_per_b, long long group0, __half* __restrict__ hid) {
-    __shared__ __attribute__((aligned(16))) TapRec taps[TILE_ROWS];          // table taps
-    __shared__ __attribute__((aligned(16))) TapRec taps3[TILE_ROWS];         // full-resolution level
-    __shared__ __attribute__((aligned(16))) char aimg[AIMG_BYTES];
+    int nsblk, int groups_per_b, long long group0, long long nwtiles, __half* __restrict__ hid) {
+    __shared__ __attribute__((aligned(16))) half8 wmain[WMAIN_HALF8];
+    __shared__ __attribute__((aligned(16))) half4 wtail_s[WTAIL_HALF4];
     __shared__ __attribute__((aligned(16))) float bias_s[832];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-
-    // XCD-aware order: blocks go round-robin over the 8 XCDs; each XCD takes a contiguous range of tiles
-    // (= neighbouring rays = overlapping node footprints), so its private L2 works on 1/8 of the tables
-    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, rem = nb & 7;
-    const unsigned tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
-    const int blk = (int)(tile % (unsigned)nblk);
-    const int v = (int)((tile / (unsigned)nblk) % (unsigned)V);
-    const long long gq = group0 + tile / (unsigned)(nblk * V);
-    const int b = (int)(gq / groups_per_b), rgroup = (int)(gq % groups_per_b);
-    const NodeGrid ng{W >> 1, H >> 1};
-
-    // ---- phase A: tap records, thread = (row, {table, full-resolution level}) ---------------------------------
-    for (int i = tid; i < 832 / 4; i += 256)
+    for (int i = tid; i < WMAIN_HALF8; i += 64 * ENC_WAVES) wmain[i] = wfrag[i];
+    {
+        const half4* tsrc = reinterpret_cast<const half4*>(wfrag + WMAIN_HALF8);      // [slice][tile][lane] half4 in memory
+        for (int i = tid; i < WTAIL_HALF4; i += 64 * ENC_WAVES) wtail_s[i] = tsrc[(i >> 4) * 64 + (i & 15)];
+    }
+    for (int i = tid; i < 832 / 4; i += 64 * ENC_WAVES)
         *reinterpret_cast<f32x4*>(bias_s + i * 4) = *reinterpret_cast<const f32x4*>(bias + i * 4);
-    {
-        const int row = tid >> 1, half = tid & 1;
-        const RowId id = tile_row(row, rgroup, blk, S, R, b, ray0, nrays);
-        const size_t sidx = (((size_t)(b * V + v)) * R + min(id.r, R - 1)) * S + min(id.s, S - 1);
-        const float2 gc = *reinterpret_cast<const float2*>((id.j == 0 ? pixel_val : sec_grid) + sidx * 2);
-        TapRec rec;
-        if (half == 0) {
-            rec = node_taps(gc.x, gc.y, ng, id.j == 0);
-        } else {
-            const Taps tp = make_taps(gc.x, gc.y, W, H, id.j == 0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                rec.off[k] = tp.off[k] * 128;                           // 64 fp16 channels per texel
-                rec.w[k] = tp.w[k];
-            }
-        }
-        if (!id.live) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { rec.off[k] = 0; rec.w[k] = 0.0f; }
-        }
-        (half == 0 ? taps : taps3)[row] = rec;
-    }
-    __syncthreads();
+    __syncthreads();          // the only workgroup-wide barrier: from here on the eight waves run independently
 
-    // image of the own (j = 0, border table) and of the other (j = 1, zeros table) view of this tile
-    const int img_own = b * V + v, img_oth = b * V + (V - 1 - v);
-    // ---- phase B: the K = 96 operand image: level-3 gather (64 ch) ‖ tanh(pt/5) (3) ‖ zeros --------------------
-    // B-operand order: fragment (k, wave, mt) is 1 KiB, lane (r, g) reads its 16 bytes at lane*16
-    {
-        const int row = tid >> 1, half = tid & 1;
-        const int w_ = row >> 5, rl = row & 31, rs = rl >> 1, mt = rl & 1;
-        const TapRec rec = taps3[row];
-        const char* m3 = reinterpret_cast<const char*>(map3) + (size_t)(mt == 0 ? img_own : img_oth) * H * W * 128 + half * 64;
-        half8 tv[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) tv[c][k] = *reinterpret_cast<const half8*>(m3 + (size_t)(unsigned)rec.off[k] + c * 16);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const u32x4 tq = __builtin_bit_cast(u32x4, tv[c][k]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[2 * i] = fma_mix_lo(acc[2 * i], tq[i], rec.w[k]);
-                    acc[2 * i + 1] = fma_mix_hi(acc[2 * i + 1], tq[i], rec.w[k]);
-                }
-            }
-            half8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[e];
-            // chunk = half*4 + c: K step `half`, lane group g = c
-            *reinterpret_cast<half8*>(aimg + (((half * 4 + w_) * 2 + mt) * 64 + c * 16 + rs) * 16) = o;
-        }
-        // third K step: halves 64..66 = point encoding of this row, the rest zero: only lane group g = 0 has data
-        if (half == 0) {
-            const RowId id = tile_row(row, rgroup, blk, S, R, b, ray0, nrays);
-            half8 p8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) p8[e] = (_Float16)0.0f;
-            if (id.live) {
-                const size_t sidx = (((size_t)(b * V + v)) * R + id.r) * S + id.s;
-                const float* pe = pe6 + sidx * 6 + id.j * 3;
-                p8[0] = (_Float16)pe[0]; p8[1] = (_Float16)pe[1]; p8[2] = (_Float16)pe[2];
-            }
-            *reinterpret_cast<half8*>(aimg + AIMG2_OFF + ((w_ * 2 + mt) * 16 + rs) * 16) = p8;
-        }
-    }
-    __syncthreads();          // last workgroup-wide barrier: from here on the four waves run independently
-
-    // Tap / store phase lane roles ("load layout"): lane = 4*rl + pl -> row rl, 16-byte piece pl, so that 4 ADJACENT lanes
-    // read / write 64 contiguous bytes of one node / row.  The texture addresser walks a wave 4 lanes per cycle and
-    // the vector L1 does one tag lookup per distinct line of such a quad: in the MFMA layout (lane = r + 16 g) a quad
-    // is 4 different rows = up to 4 lookups for 64 bytes (rocprofv3: 40 L1 accesses per load instruction, TA 73 %
-    // busy); here it is one.  Register contents are the same in both layouts (lane (r, g) and lane (rl = r, pl = g)
-    // own the same 52 channels), so switching is one ds_bpermute per accumulator register after the MFMA phase.
-    const int rl = lane >> 2, pl = lane & 3;
-    const int perm_addr = (rl + 16 * pl) * 4;                // this lane takes the accumulators of MFMA lane (r = rl, g = pl)
-    // rows of this lane in that phase: tile rows 32*wave + 2*rl + mt, mt = 0 (own image), 1 (other image)
-    const RowId lid = tile_row(wave * 32 + 2 * rl, rgroup, blk, S, R, b, ray0, nrays);
-    const size_t lrow0 = ((((size_t)b * R + lid.r - ray0) * V + v) * S + lid.s) * 2;          // + mt (only used when live)
-    // (image, mode) tables: border table of the own image for mt = 0, zeros table of the other image for mt = 1
+    const int r = lane & 15, g = lane >> 4;                   // MFMA layout: column (row of the tile) r, K / channel group g
+    const int rl = lane >> 2, pl = lane & 3;                  // load layout: row rl, 16-byte piece pl (see below)
+    const int to_ll = (rl + 16 * pl) * 4;                     // ds_bpermute address: this lane takes MFMA lane (r = rl, g = pl)
+    const int to_mfma = (4 * r + g) * 4;                      //                      this lane takes load-layout lane (rl = r, pl = g)
+    const NodeGrid ng{W >> 1, H >> 1};
     const size_t img_bytes = (size_t)ng.nodes_per_image() * TAB_ROW_BYTES;
-    const char* tbase = reinterpret_cast<const char*>(tab);
-    const __amdgpu_buffer_rsrc_t trs_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(tbase + img_bytes * img_own), 0, (int)(ng.border_nodes() * TAB_ROW_BYTES), 0x00020000);
-    const __amdgpu_buffer_rsrc_t trs_z = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(tbase + img_bytes * img_oth + (size_t)ng.border_nodes() * TAB_ROW_BYTES), 0,
-        (int)(ng.zeros_nodes() * TAB_ROW_BYTES), 0x00020000);
+    const char* const tbase = reinterpret_cast<const char*>(tab);
+    const char* const m3base = reinterpret_cast<const char*>(map3);
 
-    // tap records of the lane's two rows (they do not change from slice to slice)
-    TapRec rec[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) rec[mt] = taps[wave * 32 + 2 * rl + mt];
-    int vo[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) vo[mt][k] = ((CPN_ENCODE_ABLATE & 16) ? 0 : rec[mt].off[k]) + pl * 16;
+    // XCD-aware, CU-local order: blocks go round-robin over the 8 XCDs; XCD x owns a contiguous range of wave tiles and
+    // its workgroups take them in lock step, the 8 waves of a workgroup 8 consecutive ones (= neighbouring samples of
+    // the same 4 rays, then the next rays): one CU's L1 and one XCD's L2 see overlapping node footprints
+    const unsigned nbk = gridDim.x, nx = nbk < 8 ? nbk : 8;        // tile ranges: one per XCD that received a block
+    const unsigned xcd = blockIdx.x % nx, wgx = blockIdx.x / nx;
+    const unsigned wg_on_xcd = nbk / nx + (xcd < nbk % nx ? 1 : 0);
+    const long long q = nwtiles / nx, rem = nwtiles % nx;
+    const long long x_begin = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    const long long x_end = x_begin + q + (xcd < rem ? 1 : 0);
 
-    // Slice loop, software-pipelined by one slice on both sides:
-    //     issue ALL loads of the iteration (weights of slice n+1, taps of slice n)  ->  the stores of slice n-1  ->  compute slice n.
-    // gfx9 has ONE counter for loads and stores (vmcnt) and they retire out of order against each other, so waiting
-    // for any load that was issued AFTER a store also waits for that store to reach memory.  With the order above every
-    // load a wave ever waits for is OLDER than the stores in flight: the 7 GB hid stream never stalls the wave that
-    // issued it, only the end of the kernel does.  No workgroup barrier, no LDS traffic except bias + bpermute.
-    half8 res[2][2];                                        // fp16 results of the previous slice, waiting to be stored
-    const __half* const hrow = hid + lrow0 * 832 + pl * 8;
-    auto store_slice = [&](int n) {
-        if (lid.live && (!(CPN_ENCODE_ABLATE & 2) || res[0][0][0] == (_Float16)123.0f)) {
+    for (long long wt = x_begin + (long long)wgx * ENC_WAVES + wave; wt < x_end; wt += (long long)wg_on_xcd * ENC_WAVES) {
+        // ---- decode the wave tile: (ray group, view, block of 4 samples)
+        const int sblk = (int)(wt % nsblk);
+        const int v = (int)((wt / nsblk) % V);
+        const long long gq = group0 + wt / ((long long)nsblk * V);
+        const int b = (int)(gq / groups_per_b), rgroup = (int)(gq % groups_per_b);
+        const int img_own = b * V + v, img_oth = b * V + (V - 1 - v);
+
+        // ---- per-row records in the LOAD layout (lane = 4*rl + pl: 4 adjacent lanes = 64 contiguous bytes of one row;
+        //      the texture addresser walks a wave 4 lanes per cycle and the L1 does one tag lookup per distinct line of
+        //      such a quad).  mt = 0: own image (border padding, pixel_val), mt = 1: other image (zeros, sec_grid).
+        const RowId lid = tile_row(rl, rgroup, sblk, S, R, b, ray0, nrays);
+        const size_t sidx_l = (((size_t)(b * V + v)) * R + min(lid.r, R - 1)) * S + min(lid.s, S - 1);
+        TapRec rec[2];
+        half8 xl[2][2];                                       // K = 64 operand pieces of this lane's row, load layout
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                __half* o = const_cast<__half*>(hrow) + mt * 832 + n * SLICE_CH;
-                *reinterpret_cast<half8*>(o) = res[mt][0];
-                *reinterpret_cast<half8*>(o + 32) = res[mt][1];
+        for (int mt = 0; mt < 2; ++mt) {
+            const float2 gc = *reinterpret_cast<const float2*>((mt == 0 ? pixel_val : sec_grid) + sidx_l * 2);
+            rec[mt] = node_taps(gc.x, gc.y, ng, mt == 0);
+            const Taps t3 = make_taps(gc.x, gc.y, W, H, mt == 0);
+            const char* m3 = m3base + (size_t)(mt == 0 ? img_own : img_oth) * H * W * 128 + pl * 16;
+            u32x4 tv[2][4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    tv[k][t] = *reinterpret_cast<const u32x4*>(m3 + (size_t)(unsigned)t3.off[t] * 128 + k * 64);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a8[2 * i] = fma_mix_lo(a8[2 * i], tv[k][t][i], t3.w[t]);
+                        a8[2 * i + 1] = fma_mix_hi(a8[2 * i + 1], tv[k][t][i], t3.w[t]);
+                    }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xl[k][mt][e] = lid.live ? (_Float16)a8[e] : (_Float16)0.0f;
+            }
+            if (!lid.live) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { rec[mt].off[t] = 0; rec[mt].w[t] = 0.0f; }
             }
         }
-    };
-    // weight fragments: [slice][k < 2][tile][lane] half8 for the 64 full-resolution channels, then
-    // [slice][tile][lane] half4 for the K tail (3 point-encoding columns + zero), consumed by a 16x16x16 MFMA
-    const half4* const wtail = reinterpret_cast<const half4*>(wfrag + NSLICE * 2 * NT * 64);
-    auto load_w = [&](int n, half8 (&w)[2][NT]) {
+        // ---- the same operand in the MFMA layout (B operand: lane (r, g) holds K = g*8 .. g*8+7 of row r)
+        half8 xa[2][2];
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w[k][nt] = wfrag[((n * 2 + k) * NT + nt) * 64 + lane];
-    };
-    // one slice: `wc` holds this slice's main fragments (fetched during the previous slice), `wn` receives the next one's
-    auto slice = [&](int n, half8 (&wc)[2][NT], half8 (&wn)[2][NT]) {
-        // ---- every load of this iteration first: next slice's weights, this slice's K tail and its 16 tap pieces
-        if (n + 1 < NSLICE) load_w(n + 1, wn);
-        half4 wt[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wt[nt] = wtail[(n * NT + nt) * 64 + lane];
-        u32x4 td[2][4][2];
-        if (!(CPN_ENCODE_ABLATE & 1)) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const __amdgpu_buffer_rsrc_t rs = mt == 0 ? trs_b : trs_z;
-                    td[mt][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[mt][k], n * TAB_SLICE_BYTES, 0);
-                    td[mt][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[mt][k] + 64, n * TAB_SLICE_BYTES, 0);
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (n > 0) store_slice(n - 1);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- K = 80 contraction of the full-resolution level + point encoding, on top of the bias.  The B operands
-        //      (this wave's rows) come back from LDS every slice: 24 registers that the prefetched weights need
-        f32x4 acc[2][NT];
-        {
-            const float* bp = bias_s + n * SLICE_CH + g * 8;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[0][nt] = *reinterpret_cast<const f32x4*>(bp + (nt >> 1) * 32 + (nt & 1) * 4);
-                acc[1][nt] = acc[0][nt];
-            }
-        }
-        if (!(CPN_ENCODE_ABLATE & 4)) {
-            half8 xa[2][2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    xa[k][mt] = *reinterpret_cast<const half8*>(aimg + (((k * 4 + wave) * 2 + mt) * 64 + lane) * 16);
-            half4 xt[2];
-#pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const half4 p4 = *reinterpret_cast<const half4*>(aimg + AIMG2_OFF + ((wave * 2 + mt) * 16 + r) * 16);
+                const u32x4 src = __builtin_bit_cast(u32x4, xl[k][mt]);
+                u32x4 dst;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xt[mt][e] = (g == 0) ? p4[e] : (_Float16)0.0f;
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[k][nt], xa[k][0], acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[k][nt], xa[k][1], acc[1][nt], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned sv = src[i];
+                    dst[i] = (unsigned)__builtin_amdgcn_ds_bpermute(to_mfma, (int)sv);
                 }
+                xa[k][mt] = __builtin_bit_cast(half8, dst);
+            }
+        // K tail: tanh(pt/5) of the row (3 values), lane group 0 only
+        const RowId mid = tile_row(r, rgroup, sblk, S, R, b, ray0, nrays);
+        half4 xt[2];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wt[nt], xt[0], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wt[nt], xt[1], acc[1][nt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[mt][e] = (_Float16)0.0f;
+            if (g == 0 && mid.live) {
+                const float* pe = pe6 + ((((size_t)(b * V + v)) * R + mid.r) * S + mid.s) * 6 + mt * 3;
+                xt[mt][0] = (_Float16)pe[0]; xt[mt][1] = (_Float16)pe[1]; xt[mt][2] = (_Float16)pe[2];
             }
         }
-        // MFMA layout -> load layout
+
+        int vo[2][4];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int k = 0; k < 4; ++k) vo[mt][k] = ((CPN_ENCODE_ABLATE & 16) ? 0 : rec[mt].off[k]) + pl * 16;
+        // (image, mode) tables: border table of the own image for mt = 0, zeros table of the other image for mt = 1
+        const __amdgpu_buffer_rsrc_t trs_b = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(tbase + img_bytes * img_own), 0, (int)(ng.border_nodes() * TAB_ROW_BYTES), 0x00020000);
+        const __amdgpu_buffer_rsrc_t trs_z = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(tbase + img_bytes * img_oth + (size_t)ng.border_nodes() * TAB_ROW_BYTES), 0,
+            (int)(ng.zeros_nodes() * TAB_ROW_BYTES), 0x00020000);
+        // output rows of this lane (load layout): ((ray, view, sample), j = mt)
+        const size_t lrow0 = ((((size_t)b * R + lid.r - ray0) * V + v) * S + lid.s) * 2;      // + mt (only used when live)
+        __half* const hrow = hid + lrow0 * 832 + pl * 8;
+
+        // Slice loop, software-pipelined by one slice on the store side:
+        //     issue the 16 tap loads of slice n  ->  issue the stores of slice n-1  ->  compute slice n.
+        // gfx9 has ONE counter for loads and stores (vmcnt) and they retire out of order against each other, so waiting
+        // for any load that was issued AFTER a store also waits for that store to reach memory.  With this order every
+        // load a wave waits for is OLDER than the stores in flight: the 7 GB hid stream never stalls the wave that
+        // issued it.
+        half8 res[2][2];                                      // fp16 results of the previous slice, waiting to be stored
+        auto store_slice = [&](int n) {
+            if (lid.live && (!(CPN_ENCODE_ABLATE & 2) || res[0][0][0] == (_Float16)123.0f)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float t = acc[mt][nt][i];          // (a bit_cast applied to the vector-element lvalue itself
-                    acc[mt][nt][i] = __int_as_float(         //  reads element 0 for every i with this compiler)
-                        __builtin_amdgcn_ds_bpermute(perm_addr, __float_as_int(t)));
-                }
-        // ---- 4 table taps per row in fp32 on top of it, then ReLU and the fp16 rounding
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            if (!(CPN_ENCODE_ABLATE & 1)) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float wk = rec[mt].w[k];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const u32x4 d = td[mt][k][h];
-                        f32x4* a2 = &acc[mt][2 * h];
-                        a2[0][0] = fma_mix_lo(a2[0][0], d[0], wk); a2[0][1] = fma_mix_hi(a2[0][1], d[0], wk);
-                        a2[0][2] = fma_mix_lo(a2[0][2], d[1], wk); a2[0][3] = fma_mix_hi(a2[0][3], d[1], wk);
-                        a2[1][0] = fma_mix_lo(a2[1][0], d[2], wk); a2[1][1] = fma_mix_hi(a2[1][1], d[2], wk);
-                        a2[1][2] = fma_mix_lo(a2[1][2], d[3], wk); a2[1][3] = fma_mix_hi(a2[1][3], d[3], wk);
-                    }
+                for (int mt = 0; mt < 2; ++mt) {
+                    __half* o = hrow + mt * 832 + n * SLICE_CH;
+                    *reinterpret_cast<half8*>(o) = res[mt][0];
+                    *reinterpret_cast<half8*>(o + 32) = res[mt][1];
                 }
             }
+        };
+        for (int n = 0; n < NSLICE; ++n) {
+            u32x4 td[2][4][2];
+            if (!(CPN_ENCODE_ABLATE & 1)) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    res[mt][h][i] = (_Float16)fmaxf(acc[mt][2 * h][i], 0.0f);
-                    res[mt][h][4 + i] = (_Float16)fmaxf(acc[mt][2 * h + 1][i], 0.0f);
+                    for (int k = 0; k < 4; ++k) {
+                        const __amdgpu_buffer_rsrc_t rs = mt == 0 ? trs_b : trs_z;
+                        td[mt][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[mt][k], n * TAB_SLICE_BYTES, 0);
+                        td[mt][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[mt][k] + 64, n * TAB_SLICE_BYTES, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (n > 0) store_slice(n - 1);
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- K = 80 contraction of the full-resolution level + point encoding, on top of the bias; weights from LDS
+            f32x4 acc[2][NT];
+            {
+                const float* bp = bias_s + n * SLICE_CH + g * 8;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][nt] = *reinterpret_cast<const f32x4*>(bp + (nt >> 1) * 32 + (nt & 1) * 4);
+                    acc[1][nt] = acc[0][nt];
                 }
+            }
+            if (!(CPN_ENCODE_ABLATE & 4)) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const half8 wf = wmain[((n * 2 + k) * NT + nt) * 64 + lane];
+                        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xa[k][0], acc[0][nt], 0, 0, 0);
+                        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xa[k][1], acc[1][nt], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    half4 wq = wtail_s[(n * NT + nt) * 16 + r];
+                    if (g != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) wq[e] = (_Float16)0.0f;
+                    }
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wq, xt[0], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wq, xt[1], acc[1][nt], 0, 0, 0);
+                }
+            }
+            // MFMA layout -> load layout
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = acc[mt][nt][i];      // (a bit_cast applied to the vector-element lvalue itself
+                        acc[mt][nt][i] = __int_as_float(     //  reads element 0 for every i with this compiler)
+                            __builtin_amdgcn_ds_bpermute(to_ll, __float_as_int(t)));
+                    }
+            // ---- 4 table taps per row in fp32 on top of it, then ReLU and the fp16 rounding
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                if (!(CPN_ENCODE_ABLATE & 1)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float wk = rec[mt].w[k];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const u32x4 d = td[mt][k][h];
+                            f32x4* a2 = &acc[mt][2 * h];
+                            a2[0][0] = fma_mix_lo(a2[0][0], d[0], wk); a2[0][1] = fma_mix_hi(a2[0][1], d[0], wk);
+                            a2[0][2] = fma_mix_lo(a2[0][2], d[1], wk); a2[0][3] = fma_mix_hi(a2[0][3], d[1], wk);
+                            a2[1][0] = fma_mix_lo(a2[1][0], d[2], wk); a2[1][1] = fma_mix_hi(a2[1][1], d[2], wk);
+                            a2[1][2] = fma_mix_lo(a2[1][2], d[3], wk); a2[1][3] = fma_mix_hi(a2[1][3], d[3], wk);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        res[mt][h][i] = (_Float16)fmaxf(acc[mt][2 * h][i], 0.0f);
+                        res[mt][h][4 + i] = (_Float16)fmaxf(acc[mt][2 * h + 1][i], 0.0f);
+                    }
+            }
         }
-    };
-    half8 wA[2][NT], wB[2][NT];
-    load_w(0, wA);
-    for (int n = 0; n + 1 < NSLICE; n += 2) {               // ping-pong: no register copies between slices
-        slice(n, wA, wB);
-        slice(n + 1, wB, wA);
+        store_slice(NSLICE - 1);
     }
-    slice(NSLICE - 1, wA, wB);
-    store_slice(NSLICE - 1);
 }
 
 // ---- node features: the three coarse levels sampled (grid_sample semantics of the mode) at every table node -------
@@ -538,18 +512,25 @@ extern "C" int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int 
     CPN_REQUIRE(((uintptr_t)tab % 16) == 0 && ((uintptr_t)map3 % 16) == 0 && ((uintptr_t)wfrag % 16) == 0 &&
                     ((uintptr_t)bias % 16) == 0 && ((uintptr_t)hid % 16) == 0, CPN_E_ARG,
                 "cpn_encode_hidden: pointers must be 16-byte aligned");
-    static_assert(2 * (2 * TILE_ROWS * 32 + AIMG_BYTES + 832 * 4) <= 160 * 1024, "at least two workgroups per CU");
-    // ray groups: TG consecutive rays of ONE batch element (r aligned to TG), so a tile's images are uniform
+    // ray groups: TG consecutive rays of ONE batch element (r aligned to TG), so a wave tile's images are uniform
     const int groups_per_b = (int)cpn_cdiv(R, TG);
     const int b_lo = ray0 / R, b_hi = (ray0 + nrays - 1) / R;
     const long long group0 = (long long)b_lo * groups_per_b + (ray0 - b_lo * R) / TG;
     const long long group1 = (long long)b_hi * groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
-    const int nblk = (int)cpn_cdiv(S, TSB);
-    const long long tiles = (group1 - group0 + 1) * V * nblk;
-    CPN_REQUIRE(tiles < (1LL << 31), CPN_E_SHAPE, "cpn_encode_hidden: %lld tiles exceed the grid limit", tiles);
-    hipLaunchKernelGGL(encode_hidden_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
+    const int nsblk = (int)cpn_cdiv(S, TSW);
+    const long long nwtiles = (group1 - group0 + 1) * V * nsblk;
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        num_cu = n;
+    }
+    const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nwtiles, ENC_WAVES));      // persistent: one workgroup per CU
+    hipLaunchKernelGGL(encode_hidden_kernel, dim3(grid), dim3(64 * ENC_WAVES), 0, (hipStream_t)stream,
                        (const __half*)tab, (const __half*)map3, H, W, pixel_val, sec_grid, pe6, (const half8*)wfrag,
-                       bias, V, R, S, ray0, nrays, nblk, groups_per_b, group0, (__half*)hid);
+                       bias, V, R, S, ray0, nrays, nsblk, groups_per_b, group0, nwtiles, (__half*)hid);
     CPN_LAUNCH_CHECK("cpn_encode_hidden");
     return 0;
 }
