@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
         const __half* hp = hid + row0 * HC + tid * 8;
 #pragma unroll 4
         for (int row = 0; row < T; ++row) {
-            const half8 h = *reinterpret_cast<const half8*>(hp + (size_t)row * HC);
+            const half8 h = __builtin_nontemporal_load(reinterpret_cast<const half8*>(hp + (size_t)row * HC));
             const float w = wts[row];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += w * (float)h[e];

@@ -24,32 +24,43 @@
 // would be 13x the map (218 MB per pair) and is kept as a contraction.  Numerically the node features are rounded to
 // fp16 like the gathered rows of the GEMM form were, the table entry once more, the 4-tap sum runs in fp32.
 //
-// gfx950 design
-//   * workgroup = 128 rows = 4 adjacent rays x 16 consecutive samples x {own image, other image} of one view, 4 waves,
-//     two workgroups per CU; wave w walks the four 208-channel slices of the output with 2 x 13 accumulator tiles of
-//     v_mfma_f32_16x16x32_f16 (weights as the A operand: a lane holds 4 consecutive channels of one row per tile).
-//   * MFMA tile mt <-> j (own / other image); column r = (sample & 3)*4 + (ray & 3): ONE load instruction covers a
-//     4 x 4 patch of (sample, ray) whose taps fall on a handful of nodes -> most 64-byte requests hit lines a
-//     neighbouring lane just brought into the vector L1.
-//   * the channel -> (tile, register) assignment is chosen so that a lane's 52 channels of a slice are 6 x 8
-//     consecutive ones (k*32 + g*8 .. +8) + 4 (192 + g*4 ..): a table tap is 6 16-byte loads + 1 8-byte load per
-//     lane, the 4 lanes of a row reading 64 contiguous, 64-byte aligned bytes (tables are stored with each
-//     208-channel slice padded to 224 halves for that), and the fp16 row leaves as 16-byte stores.
-//   * per-row tap offsets / weights are computed once per row (not per lane) into LDS; the full-resolution level and
-//     the point encoding are gathered once per row into an LDS image in MFMA B-operand order; the bias sits in LDS.
-//   * weight fragments of a slice (39 KiB) stream through LDS by buffer_load ... lds under the previous slice's taps;
-//     the slice loop uses raw s_barriers (no vmcnt(0)): a wave never waits for its own hid stores there.
-// Bound (rocprofv3 PMC, profiles/r02_*): the texture-address / vector-L1 path (64 B/clk/CU) for the taps and the
-// 7 GB hid write stream per 16 384 rays; algorithmic FLOPs of the layer it replaces 2*835*832 per row.
+// gfx950 design (v6; the counter trail of v1..v6 is DESIGN.md §4.1)
+//   * persistent workgroups, one per CU, 16 waves (4 per SIMD, <= 128 VGPRs).  All K = 80 weight fragments of the layer
+//     (13 slices x [2 x half8 + a half4 tail] per lane and tile = 123 KiB; the bias rides in the tail as an fp16
+//     (hi, lo) pair against two constant-one operand entries) are loaded into LDS ONCE per workgroup; one
+//     __syncthreads() after that and none in the tile loop.
+//   * unit of work = a 16-row WAVE tile: 4 adjacent rays x 4 consecutive samples of one (view, image).  The wave-tile
+//     range is split over the XCDs that received a workgroup (blockIdx % 8), each XCD's workgroups walk their range in
+//     lock step, so the 4 x 4 (sample, ray) patches a private L2 sees at one time are neighbours on the epipolar lines.
+//   * two register layouts of the same 16 x 64 tile: the "load layout" (lane = 4*row + piece: the 4 lanes of a quad
+//     read 64 contiguous, 64-byte aligned bytes of one row - the texture addresser takes a wave 4 lanes per cycle, so
+//     a quad = one tag lookup) for table taps and level-3 gather, and the MFMA layout (lane = row + 16*group) for the
+//     contraction; ds_bpermute switches between them (operands once per tile, accumulators once per slice).
+//   * per tile: tap offsets / weights (node_taps), the 64 full-resolution channels (4 texels, fp32 blend) and
+//     tanh(pt/5) are computed in registers; then 13 slices of 64 channels: 8 tap loads of slice n are issued, THEN
+//     the stores of slice n-1 (gfx9 has one vmcnt: a wait on a load younger than a store waits for the store), then
+//     3 MFMAs per 16-channel tile on the LDS-resident weights (v_mfma_f32_16x16x32_f16 x 2 + v_mfma_f32_16x16x16f16
+//     for the tail; C = inline 0) run while the taps are in flight, then the 4-tap fp32 blend (v_fma_mix_f32 takes
+//     the fp16 table entry directly), v_cvt_pk_f16_f32 + v_pk_max_f16 (ReLU).
+//   * hid leaves as NON-TEMPORAL stores of WHOLE 128-byte lines: neighbouring quads swap one 64-byte half with two
+//     DPP row shifts so that 8 consecutive lanes cover one line.  Write-back stores let the 7 GB stream evict the
+//     tables from L2 (2.7 ms), nt stores of 64-byte pieces run at 3.6 TB/s, whole lines at 6.2 TB/s (tools/write_bw.py).
+// Bound (rocprofv3 PMC, profiles/r02_*): the 7 GB hid write stream per 16 384 rays (1.1 ms at the 6.2 TB/s the part
+// sustains for this pattern) behind VALU (4-tap blend) + MFMA + LDS issue; algorithmic FLOPs of the layer it
+// replaces: 2*835*832 per row.
 #include <algorithm>
 
 #include "common.h"
 #include "taps.h"
 
 // timing-only ablations for tools/encode_ablate.py (results are wrong when non-zero; the product builds with 0):
-// 1 = no table taps, 2 = no hid stores, 4 = no MFMA phase, 16 = every tap reads node 0
+// 1 = no table taps, 2 = no hid stores, 4 = no MFMA phase, 16 = every tap reads node 0, 32 = stores wrap into a 1.7 MB window
 #ifndef CPN_ENCODE_ABLATE
 #define CPN_ENCODE_ABLATE 0
+#endif
+// images (own / other) per wave tile: 2 = 32-row wave tiles, 8 waves per CU; 1 = 16-row wave tiles, 16 waves per CU
+#ifndef CPN_ENCODE_MT
+#define CPN_ENCODE_MT 1
 #endif
 
 namespace {
@@ -63,6 +74,8 @@ constexpr int TAB_SLICE_BYTES = SLICE_CH * 2;                  // 128: one cache
 constexpr int TAB_ROW_BYTES = CPN_TAB_LD * 2;                  // 1664 per node, channels in natural order
 typedef __attribute__((address_space(3))) void lds_void;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 struct TapRec {
     int off[4];                           // byte offsets of the 4 nodes / texels inside the (image, mode) table / map
@@ -77,6 +90,26 @@ __device__ __forceinline__ float fma_mix_lo(float acc, unsigned packed, float w)
 __device__ __forceinline__ float fma_mix_hi(float acc, unsigned packed, float w) {
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
     return acc;
+}
+
+// 16-byte hid store; CPN_ENCODE_STORE selects the cache policy bits (experiment; 0 = default write-back)
+#ifndef CPN_ENCODE_STORE
+#define CPN_ENCODE_STORE 1
+#endif
+__device__ __forceinline__ void store16(__half* p, half8 v) {
+#if CPN_ENCODE_STORE == 0
+    *reinterpret_cast<half8*>(p) = v;
+#elif CPN_ENCODE_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#elif CPN_ENCODE_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif CPN_ENCODE_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif CPN_ENCODE_STORE == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+#elif CPN_ENCODE_STORE == 5
+    asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+#endif
 }
 
 // node-grid geometry of one image: border table first, zeros table behind it
@@ -133,13 +166,28 @@ __device__ __forceinline__ RowId tile_row(int c, int rgroup, int sblk, int S, in
     return o;
 }
 
-constexpr int WMAIN_HALF8 = NSLICE * 2 * NT * 64;              // [slice][k < 2][tile][lane] half8: 104 KiB
-constexpr int WTAIL_HALF4 = NSLICE * NT * 16;                  // [slice][tile][A-operand row] half4 (lane group 0 only): 6.5 KiB
-constexpr int ENC_WAVES = 8;
+// channel of a slice that MFMA tile nt, A-operand row a computes (lane (r, g) of the result then holds a = g*4 + i)
+__host__ __device__ inline int slice_channel(int nt, int a) {
+    return (nt >> 1) * 32 + (a >> 2) * 8 + (nt & 1) * 4 + (a & 3);
+}
 
-// Persistent kernel: one 8-wave workgroup per CU keeps ALL weight fragments of the K = 80 contraction in LDS for the
-// whole launch (111 KiB: they are the same for every row; as per-wave L2 loads they were 35 % of the bytes through the
-// texture path, which rocprofv3 showed 82 % busy), and every wave walks its own sequence of 32-row wave tiles with no
+constexpr int WMAIN_HALF8 = NSLICE * 2 * NT * 64;              // [slice][k < 2][tile][lane] half8: 104 KiB
+constexpr int WTAIL_HALF4 = NSLICE * NT * 48;                  // [slice][tile][K group < 3][A-operand row] half4: 19.5 KiB
+constexpr int MTN = CPN_ENCODE_MT;
+#ifndef CPN_ENCODE_WAVES
+#define CPN_ENCODE_WAVES (16 / CPN_ENCODE_MT)
+#endif
+#ifndef CPN_ENCODE_DB
+#define CPN_ENCODE_DB 0
+#endif
+#ifndef CPN_ENCODE_ORDER
+#define CPN_ENCODE_ORDER 0
+#endif
+constexpr int ENC_WAVES = CPN_ENCODE_WAVES;
+
+// Persistent kernel: one workgroup per CU keeps ALL weight fragments of the K = 80 contraction in LDS for the whole
+// launch (123 KiB: they are the same for every row; as per-wave L2 loads they were 35 % of the bytes through the
+// texture path, which rocprofv3 showed 82 % busy), and every wave walks its own sequence of wave tiles with no
 // workgroup barrier after the prologue.  Nothing else lives in LDS: the per-row tap records and the K = 80 operand
 // (full-resolution gather + point encoding) are produced in registers, in the load layout, and moved to the MFMA
 // layout with ds_bpermute.
@@ -150,22 +198,34 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
     int nsblk, int groups_per_b, long long group0, long long nwtiles, __half* __restrict__ hid) {
     __shared__ __attribute__((aligned(16))) half8 wmain[WMAIN_HALF8];
     __shared__ __attribute__((aligned(16))) half4 wtail_s[WTAIL_HALF4];
-    __shared__ __attribute__((aligned(16))) float bias_s[832];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < WMAIN_HALF8; i += 64 * ENC_WAVES) wmain[i] = wfrag[i];
     {
-        const half4* tsrc = reinterpret_cast<const half4*>(wfrag + WMAIN_HALF8);      // [slice][tile][lane] half4 in memory
-        for (int i = tid; i < WTAIL_HALF4; i += 64 * ENC_WAVES) wtail_s[i] = tsrc[(i >> 4) * 64 + (i & 15)];
+        // K tail (16 wide): k = 0..2 the point encoding, k = 3 and 4 the bias as an fp16 (hi, lo) pair against two
+        // constant 1.0 entries of the operand (fp32-accurate; the accumulators then start from the inline constant 0),
+        // k >= 8 zero.  In memory [slice][tile][lane] half4 with only the weights filled in; lane groups 2, 3 share one
+        // zero image in LDS.
+        const half4* tsrc = reinterpret_cast<const half4*>(wfrag + WMAIN_HALF8);
+        for (int i = tid; i < WTAIL_HALF4; i += 64 * ENC_WAVES) {
+            const int f = i / 48, l = i - f * 48;
+            half4 t = tsrc[f * 64 + l];
+            if (l < 32) {
+                const float bv = bias[(f / NT) * SLICE_CH + slice_channel(f % NT, l & 15)];
+                const _Float16 hi = (_Float16)bv;
+                if (l < 16) t[3] = hi;
+                else t[0] = (_Float16)(bv - (float)hi);
+            }
+            wtail_s[i] = t;
+        }
     }
-    for (int i = tid; i < 832 / 4; i += 64 * ENC_WAVES)
-        *reinterpret_cast<f32x4*>(bias_s + i * 4) = *reinterpret_cast<const f32x4*>(bias + i * 4);
     __syncthreads();          // the only workgroup-wide barrier: from here on the eight waves run independently
 
     const int r = lane & 15, g = lane >> 4;                   // MFMA layout: column (row of the tile) r, K / channel group g
     const int rl = lane >> 2, pl = lane & 3;                  // load layout: row rl, 16-byte piece pl (see below)
+    const int tail_lane = min(g, 2) * 16 + r;                 // K-tail fragment: groups 2 and 3 read the shared zero image
     const int to_ll = (rl + 16 * pl) * 4;                     // ds_bpermute address: this lane takes MFMA lane (r = rl, g = pl)
     const int to_mfma = (4 * r + g) * 4;                      //                      this lane takes load-layout lane (rl = r, pl = g)
     const NodeGrid ng{W >> 1, H >> 1};
@@ -185,9 +245,22 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
 
     for (long long wt = x_begin + (long long)wgx * ENC_WAVES + wave; wt < x_end; wt += (long long)wg_on_xcd * ENC_WAVES) {
         // ---- decode the wave tile: (ray group, view, block of 4 samples)
-        const int sblk = (int)(wt % nsblk);
-        const int v = (int)((wt / nsblk) % V);
-        const long long gq = group0 + wt / ((long long)nsblk * V);
+#if CPN_ENCODE_ORDER == 0
+        const long long wu = MTN == 2 ? wt : (wt >> 1);
+        const int j0 = MTN == 2 ? 0 : (int)(wt & 1);          // image of tile row block 0 (wave-uniform)
+        const int sblk = (int)(wu % nsblk);
+        const int v = (int)((wu / nsblk) % V);
+        const long long gq = group0 + wu / ((long long)nsblk * V);
+#else
+        // (view, image) outermost: with 8 XCDs each private L2 serves ONE of the four (image, padding mode) tables
+        const long long per_vj = nwtiles / (V * (2 / MTN));                  // ray groups x sample blocks
+        const int vj = (int)(wt / per_vj);
+        const long long wu = wt - (long long)vj * per_vj;
+        const int v = MTN == 2 ? vj : (vj >> 1);
+        const int j0 = MTN == 2 ? 0 : (vj & 1);
+        const int sblk = (int)(wu % nsblk);
+        const long long gq = group0 + wu / nsblk;
+#endif
         const int b = (int)(gq / groups_per_b), rgroup = (int)(gq % groups_per_b);
         const int img_own = b * V + v, img_oth = b * V + (V - 1 - v);
 
@@ -196,14 +269,15 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
         //      such a quad).  mt = 0: own image (border padding, pixel_val), mt = 1: other image (zeros, sec_grid).
         const RowId lid = tile_row(rl, rgroup, sblk, S, R, b, ray0, nrays);
         const size_t sidx_l = (((size_t)(b * V + v)) * R + min(lid.r, R - 1)) * S + min(lid.s, S - 1);
-        TapRec rec[2];
-        half8 xl[2][2];                                       // K = 64 operand pieces of this lane's row, load layout
+        TapRec rec[MTN];
+        half8 xl[2][MTN];                                     // K = 64 operand pieces of this lane's row, load layout
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const float2 gc = *reinterpret_cast<const float2*>((mt == 0 ? pixel_val : sec_grid) + sidx_l * 2);
-            rec[mt] = node_taps(gc.x, gc.y, ng, mt == 0);
-            const Taps t3 = make_taps(gc.x, gc.y, W, H, mt == 0);
-            const char* m3 = m3base + (size_t)(mt == 0 ? img_own : img_oth) * H * W * 128 + pl * 16;
+        for (int mt = 0; mt < MTN; ++mt) {
+            const bool own = (j0 + mt) == 0;
+            const float2 gc = *reinterpret_cast<const float2*>((own ? pixel_val : sec_grid) + sidx_l * 2);
+            rec[mt] = node_taps(gc.x, gc.y, ng, own);
+            const Taps t3 = make_taps(gc.x, gc.y, W, H, own);
+            const char* m3 = m3base + (size_t)(own ? img_own : img_oth) * H * W * 128 + pl * 16;
             u32x4 tv[2][4];
 #pragma unroll
             for (int k = 0; k < 2; ++k)
@@ -229,11 +303,11 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
             }
         }
         // ---- the same operand in the MFMA layout (B operand: lane (r, g) holds K = g*8 .. g*8+7 of row r)
-        half8 xa[2][2];
+        half8 xa[2][MTN];
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MTN; ++mt) {
                 const u32x4 src = __builtin_bit_cast(u32x4, xl[k][mt]);
                 u32x4 dst;
 #pragma unroll
@@ -245,31 +319,49 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
             }
         // K tail: tanh(pt/5) of the row (3 values), lane group 0 only
         const RowId mid = tile_row(r, rgroup, sblk, S, R, b, ray0, nrays);
-        half4 xt[2];
+        half4 xt[MTN];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MTN; ++mt) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) xt[mt][e] = (_Float16)0.0f;
             if (g == 0 && mid.live) {
-                const float* pe = pe6 + ((((size_t)(b * V + v)) * R + mid.r) * S + mid.s) * 6 + mt * 3;
+                const float* pe = pe6 + ((((size_t)(b * V + v)) * R + mid.r) * S + mid.s) * 6 + (j0 + mt) * 3;
                 xt[mt][0] = (_Float16)pe[0]; xt[mt][1] = (_Float16)pe[1]; xt[mt][2] = (_Float16)pe[2];
+                xt[mt][3] = (_Float16)1.0f;                   // x bias (hi)
             }
+            if (g == 1 && mid.live) xt[mt][0] = (_Float16)1.0f;   // x bias (lo)
         }
 
-        int vo[2][4];
+        int vo[MTN][4];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
             for (int k = 0; k < 4; ++k) vo[mt][k] = ((CPN_ENCODE_ABLATE & 16) ? 0 : rec[mt].off[k]) + pl * 16;
-        // (image, mode) tables: border table of the own image for mt = 0, zeros table of the other image for mt = 1
-        const __amdgpu_buffer_rsrc_t trs_b = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(tbase + img_bytes * img_own), 0, (int)(ng.border_nodes() * TAB_ROW_BYTES), 0x00020000);
-        const __amdgpu_buffer_rsrc_t trs_z = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(tbase + img_bytes * img_oth + (size_t)ng.border_nodes() * TAB_ROW_BYTES), 0,
-            (int)(ng.zeros_nodes() * TAB_ROW_BYTES), 0x00020000);
+        // (image, mode) tables: border table of the own image for j = 0, zeros table of the other image for j = 1
+        __amdgpu_buffer_rsrc_t trs[MTN];
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt) {
+            const bool own = (j0 + mt) == 0;
+            const char* tb = own ? tbase + img_bytes * img_own
+                                 : tbase + img_bytes * img_oth + (size_t)ng.border_nodes() * TAB_ROW_BYTES;
+            trs[mt] = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)tb, 0, (int)((own ? ng.border_nodes() : ng.zeros_nodes()) * TAB_ROW_BYTES), 0x00020000);
+        }
         // output rows of this lane (load layout): ((ray, view, sample), j = mt)
-        const size_t lrow0 = ((((size_t)b * R + lid.r - ray0) * V + v) * S + lid.s) * 2;      // + mt (only used when live)
-        __half* const hrow = hid + lrow0 * 832 + pl * 8;
+        // Stores: the 4 lanes of a quad hold 64 contiguous bytes of a row (pieces pl of each half), but a non-temporal
+        // store stream only runs at the full rate when an instruction writes WHOLE 128-byte lines (tools/write_bw.py:
+        // 6.2 TB/s against 3.6 TB/s for 64-byte pieces).  The even quad 2m (row c = 2m) and the odd quad 2m+1
+        // (row c + 1 = the neighbouring ray of the same sample) therefore swap one half each with two DPP row shifts:
+        // instruction A writes row 2m (even quad: its half 0, odd quad: half 1 of row 2m), instruction B row 2m+1.
+        const int qodd = (lane >> 2) & 1;
+        const RowId lidA = tile_row(rl & ~1, rgroup, sblk, S, R, b, ray0, nrays);
+        const RowId lidB = tile_row(rl | 1, rgroup, sblk, S, R, b, ray0, nrays);
+        auto out_row = [&](const RowId& id) {
+            const size_t row = ((((size_t)b * R + id.r - ray0) * V + v) * S + id.s) * 2;       // + j (only used when live)
+            return hid + ((CPN_ENCODE_ABLATE & 32) ? (row & 1023) : row) * 832 + (pl + 4 * qodd) * 8;  // 32: L2-resident window
+        };
+        __half* const hrowA = out_row(lidA);
+        __half* const hrowB = out_row(lidB);
 
         // Slice loop, software-pipelined by one slice on the store side:
         //     issue the 16 tap loads of slice n  ->  issue the stores of slice n-1  ->  compute slice n.
@@ -277,66 +369,68 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
         // for any load that was issued AFTER a store also waits for that store to reach memory.  With this order every
         // load a wave waits for is OLDER than the stores in flight: the 7 GB hid stream never stalls the wave that
         // issued it.
-        half8 res[2][2];                                      // fp16 results of the previous slice, waiting to be stored
+        half8 res[MTN][2];                                    // fp16 results of the previous slice, waiting to be stored
         auto store_slice = [&](int n) {
-            if (lid.live && (!(CPN_ENCODE_ABLATE & 2) || res[0][0][0] == (_Float16)123.0f)) {
+            if (!(CPN_ENCODE_ABLATE & 2) || res[0][0][0] == (_Float16)123.0f) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    __half* o = hrow + mt * 832 + n * SLICE_CH;
-                    *reinterpret_cast<half8*>(o) = res[mt][0];
-                    *reinterpret_cast<half8*>(o + 32) = res[mt][1];
+                for (int mt = 0; mt < MTN; ++mt) {
+                    const u32x4 h0 = __builtin_bit_cast(u32x4, res[mt][0]), h1 = __builtin_bit_cast(u32x4, res[mt][1]);
+                    u32x4 sa, sb;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned a0 = h0[i], a1 = h1[i];
+                        // even quads (banks 0, 2) take half 0 of lane + 4 into B; odd quads (banks 1, 3) half 1 of lane - 4 into A
+                        sb[i] = (unsigned)__builtin_amdgcn_update_dpp((int)a1, (int)a0, 0x104, 0xF, 0x5, false);
+                        sa[i] = (unsigned)__builtin_amdgcn_update_dpp((int)a0, (int)a1, 0x114, 0xF, 0xA, false);
+                    }
+                    const int co = (j0 + mt) * 832 + n * SLICE_CH;
+                    if (lidA.live) store16(hrowA + co, __builtin_bit_cast(half8, sa));
+                    if (lidB.live) store16(hrowB + co, __builtin_bit_cast(half8, sb));
                 }
             }
         };
-        for (int n = 0; n < NSLICE; ++n) {
-            u32x4 td[2][4][2];
+        typedef u32x4 TapData[MTN][4][2];
+        auto issue_taps = [&](int n, TapData& td) {
             if (!(CPN_ENCODE_ABLATE & 1)) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const __amdgpu_buffer_rsrc_t rs = mt == 0 ? trs_b : trs_z;
+                        const __amdgpu_buffer_rsrc_t rs = trs[mt];
                         td[mt][k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[mt][k], n * TAB_SLICE_BYTES, 0);
                         td[mt][k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[mt][k] + 64, n * TAB_SLICE_BYTES, 0);
                     }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (n > 0) store_slice(n - 1);
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto compute_slice = [&](int n, TapData& td) {
 
             // ---- K = 80 contraction of the full-resolution level + point encoding, on top of the bias; weights from LDS
-            f32x4 acc[2][NT];
-            {
-                const float* bp = bias_s + n * SLICE_CH + g * 8;
+            f32x4 acc[MTN][NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[0][nt] = *reinterpret_cast<const f32x4*>(bp + (nt >> 1) * 32 + (nt & 1) * 4);
-                    acc[1][nt] = acc[0][nt];
-                }
-            }
+            for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (!(CPN_ENCODE_ABLATE & 4)) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const half8 wf = wmain[((n * 2 + k) * NT + nt) * 64 + lane];
-                        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xa[k][0], acc[0][nt], 0, 0, 0);
-                        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xa[k][1], acc[1][nt], 0, 0, 0);
+#pragma unroll
+                        for (int mt = 0; mt < MTN; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xa[k][mt], acc[mt][nt], 0, 0, 0);
                     }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    half4 wq = wtail_s[(n * NT + nt) * 16 + r];
-                    if (g != 0) {
+                    const half4 wq = wtail_s[(n * NT + nt) * 48 + tail_lane];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) wq[e] = (_Float16)0.0f;
-                    }
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wq, xt[0], acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wq, xt[1], acc[1][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MTN; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wq, xt[mt], acc[mt][nt], 0, 0, 0);
                 }
             }
             // MFMA layout -> load layout
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -347,7 +441,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
                     }
             // ---- 4 table taps per row in fp32 on top of it, then ReLU and the fp16 rounding
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MTN; ++mt) {
                 if (!(CPN_ENCODE_ABLATE & 1)) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -363,15 +457,52 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
                         }
                     }
                 }
+                // fp16 rounding two at a time (v_cvt_pk_f16_f32), ReLU on the packed pair (v_pk_max_f16): rounding is
+                // monotonic and keeps the sign, so this equals max(x, 0) followed by the rounding
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 pk;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        res[mt][h][i] = (_Float16)fmaxf(acc[mt][2 * h][i], 0.0f);
-                        res[mt][h][4 + i] = (_Float16)fmaxf(acc[mt][2 * h + 1][i], 0.0f);
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4& src = acc[mt][2 * h + (q >> 1)];
+                        const f32x2v two = {src[2 * (q & 1)], src[2 * (q & 1) + 1]};
+                        half2v hv = __builtin_convertvector(two, half2v);
+                        hv = __builtin_elementwise_max(hv, (half2v){(_Float16)0.0f, (_Float16)0.0f});
+                        pk[q] = __builtin_bit_cast(unsigned, hv);
                     }
+                    res[mt][h] = __builtin_bit_cast(half8, pk);
+                }
             }
+        };
+#if CPN_ENCODE_DB
+        // taps double-buffered: the loads of slice n+1 are in flight during the whole of slice n
+        TapData tda, tdb;
+        issue_taps(0, tda);
+        for (int n = 0; n < NSLICE - 1; n += 2) {
+            issue_taps(n + 1, tdb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n > 0) store_slice(n - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_slice(n, tda);
+            issue_taps(n + 2, tda);
+            __builtin_amdgcn_sched_barrier(0);
+            store_slice(n);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_slice(n + 1, tdb);
         }
+        store_slice(NSLICE - 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_slice(NSLICE - 1, tda);
+#else
+        for (int n = 0; n < NSLICE; ++n) {
+            TapData td;
+            issue_taps(n, td);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n > 0) store_slice(n - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_slice(n, td);
+        }
+#endif
         store_slice(NSLICE - 1);
     }
 }
@@ -417,10 +548,6 @@ __global__ void node_features_kernel(const __half* __restrict__ map0, const __ha
 }
 
 // ---- weight images ------------------------------------------------------------------------------------------------
-// channel of a slice that MFMA tile nt, A-operand row a computes (lane (r, g) of the result then holds a = g*4 + i)
-__host__ __device__ inline int slice_channel(int nt, int a) {
-    return (nt >> 1) * 32 + (a >> 2) * 8 + (nt & 1) * 4 + (a & 3);
-}
 
 // W (832, 835) fp32 -> wfrag: [slice][k < 2][nt][lane] half8 over columns 768..831 (the full-resolution level), followed
 // by [slice][nt][lane] half4 over columns 832..834 + one zero (the K tail, v_mfma_f32_16x16x16_f16: lane group 0 only)
@@ -518,7 +645,7 @@ extern "C" int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int 
     const long long group0 = (long long)b_lo * groups_per_b + (ray0 - b_lo * R) / TG;
     const long long group1 = (long long)b_hi * groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
     const int nsblk = (int)cpn_cdiv(S, TSW);
-    const long long nwtiles = (group1 - group0 + 1) * V * nsblk;
+    const long long nwtiles = (group1 - group0 + 1) * V * nsblk * (2 / MTN);
     static int num_cu = 0;
     if (num_cu == 0) {
         int dev = 0, n = 0;

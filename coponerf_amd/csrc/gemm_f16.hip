@@ -96,6 +96,9 @@ __device__ __forceinline__ TileWalk tile_walk(int total) {
 // Q (key_map -> ReLU -> key_map_2 -> logit in one kernel).  The accumulator layout of the first layer (lane = row,
 // columns nt*16 + fk*4 + 0..3) serves directly as the MFMA B operand of K block p = tile pair (2p, 2p+1); the W2
 // fragments are laid out in LDS for exactly that k order (k = 32p + fk*4 + e, 32p + 16 + fk*4 + e).
+#ifndef CPN_HID_READ_NT
+#define CPN_HID_READ_NT 1
+#endif
 template <int NT, bool OUT_F32, bool RELU, int DOT = 0>
 __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict__ A, int lda,
                                                              const __half* __restrict__ W, int ldw,
@@ -105,6 +108,9 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
                                                              int ldq = 0, const __half* __restrict__ W2 = nullptr,
                                                              int ldw2 = 0, const float* __restrict__ bias2 = nullptr) {
     using C_ = Cfg<NT>;
+    // the chained key kernel streams hid (7 GB per chunk, read once per pass): non-temporal, so that the node tables
+    // of encode_hidden stay in L2 / Infinity Cache across the chunk loop
+    constexpr int A_AUX = (DOT == 2 && CPN_HID_READ_NT) ? 2 : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
     // one DMA piece = one wave-wide 1 KiB buffer_load...lds
     auto piece_a = [&](const __amdgpu_buffer_rsrc_t& ra, int kt, int slot, int i) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(smem + slot * C_::A_BYTES + wave * 1024 + i * 8192),
-                                                 16, voff_a, kt * BK * 2 + i * 128 * lda, 0, 0);
+                                                 16, voff_a, kt * BK * 2 + i * 128 * lda, 0, A_AUX);
     };
     auto piece_b = [&](const __amdgpu_buffer_rsrc_t& rw, int kt, int slot, int i) {
         char* sbase = smem_b + slot * C_::B_BYTES + wave * 1024;

@@ -11,8 +11,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tools", "_build")
+# kernel configurations (CPN_ENCODE_MT images per wave tile, CPN_ENCODE_WAVES per workgroup, CPN_ENCODE_DB taps double-buffered)
+CONFIGS = ((2, 8, 0), (1, 16, 0), (1, 12, 1), (1, 8, 1))
+STORES = (0, 1)             # CPN_ENCODE_STORE cache-policy experiments on configuration (2, 8, 0)
+ORDERS = ((2, 8), (1, 16))  # CPN_ENCODE_ORDER=1 (tables outermost) on these (MT, waves)
+FULL_ABLATION = ((2, 8, 0),)          # the other configurations are only timed in full
 VARIANTS = {0: "full", 1: "no table taps", 2: "no hid stores", 3: "no taps, no stores (MFMA + setup)", 4: "no MFMA",
-            16: "all taps -> node 0 (L1-hot)", 18: "node-0 taps, no stores"}
+            16: "all taps -> node 0 (L1-hot)", 18: "node-0 taps, no stores",
+            32: "stores wrap into a 1.7 MB window (L2-resident)", 33: "no taps, stores into the window"}
 
 
 def build():
@@ -22,22 +28,60 @@ def build():
     err_o = os.path.join(BUILD, "error.o")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
                            os.path.join(src, "error.cpp"), "-o", err_o])
-    for k in VARIANTS:
-        obj, out = os.path.join(BUILD, f"encode_abl{k}.o"), os.path.join(BUILD, f"libencode_abl{k}.so")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_ENCODE_ABLATE={k}", "-x", "hip",
-               "-c", os.path.join(src, "encode.hip"), "-o", obj]
-        print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, err_o, "-o", out])
+    for cfg in CONFIGS:
+        mt, waves, db = cfg
+        for k in VARIANTS:
+            if k and cfg not in FULL_ABLATION:
+                continue
+            tag = f"{k}_mt{mt}w{waves}db{db}"
+            obj, out = os.path.join(BUILD, f"encode_abl{tag}.o"), os.path.join(BUILD, f"libencode_abl{tag}.so")
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_ENCODE_ABLATE={k}",
+                   f"-DCPN_ENCODE_MT={mt}", f"-DCPN_ENCODE_WAVES={waves}", f"-DCPN_ENCODE_DB={db}", "-x", "hip", "-c",
+                   os.path.join(src, "encode.hip"), "-o", obj]
+            print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, err_o, "-o", out])
+
+
+def build_store_variants():
+    src = os.path.join(ROOT, "coponerf_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    for st in STORES:
+        obj, out = os.path.join(BUILD, f"encode_store{st}.o"), os.path.join(BUILD, f"libencode_store{st}.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_ENCODE_STORE={st}",
+                               "-x", "hip", "-c", os.path.join(src, "encode.hip"), "-o", obj])
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, os.path.join(BUILD, "error.o"),
+                               "-o", out])
+
+
+def build_order_variants():
+    src = os.path.join(ROOT, "coponerf_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    for mt, waves in ORDERS:
+        obj, out = os.path.join(BUILD, f"encode_order_mt{mt}.o"), os.path.join(BUILD, f"libencode_order_mt{mt}.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCPN_ENCODE_ORDER=1",
+                               f"-DCPN_ENCODE_MT={mt}", f"-DCPN_ENCODE_WAVES={waves}", "-x", "hip", "-c",
+                               os.path.join(src, "encode.hip"), "-o", obj])
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, os.path.join(BUILD, "error.o"),
+                               "-o", out])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--ray0", type=int, default=16384, help="first ray of the timed chunk")
+    ap.add_argument("--flush", action="store_true", help="stream 8 GB through the caches between launches (as the "
+                    "key / attend kernels of the chunk loop do) and time each launch on its own")
+    ap.add_argument("--flush-mb", type=int, default=4096, help="size of the flush stream buffer (fp32 add_: 2x traffic)")
+    ap.add_argument("--warm", default="", choices=("", "tables", "geometry", "all"), help="with --flush: read the node "
+                    "tables + level-3 map / the per-sample geometry arrays once after the flush, before the timed launch")
+    ap.add_argument("--only", default="", help="substring filter on the variant label")
     a = ap.parse_args()
     if a.build:
         build()
+        build_store_variants()
+        build_order_variants()
         return
     import torch
     from coponerf_amd import CoPoNeRF, synthetic as syn
@@ -61,8 +105,15 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     P, I = ctypes.c_void_p, ctypes.c_int
     res = {}
-    for k, what in VARIANTS.items():
-        path = os.path.join(BUILD, f"libencode_abl{k}.so")
+    runs = [(f"mt{c[0]} w{c[1]} db{c[2]} {k}: {what}", f"libencode_abl{k}_mt{c[0]}w{c[1]}db{c[2]}.so")
+            for c in CONFIGS for k, what in VARIANTS.items()]
+    runs += [(f"store policy {st}", f"libencode_store{st}.so") for st in STORES]
+    runs += [(f"order: tables outermost, mt{mt} w{w}", f"libencode_order_mt{mt}.so") for mt, w in ORDERS]
+    flush_buf = torch.zeros(a.flush_mb << 18, dtype=torch.float32, device=dev) if a.flush else None
+    for label, so in runs:
+        if a.only and a.only not in label:
+            continue
+        path = os.path.join(BUILD, so)
         if not os.path.exists(path):
             continue
         fn = ctypes.CDLL(path).cpn_encode_hidden
@@ -72,18 +123,34 @@ def main():
         def run():
             rc = fn(tabs[0].data_ptr(), maps[3].data_ptr(), H, H,
                     g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(), w["enc.frag"].data_ptr(),
-                    w["query_encode_latent.b"].data_ptr(), B, V, R, S, 16384, n, hid.data_ptr(), s)
+                    w["query_encode_latent.b"].data_ptr(), B, V, R, S, a.ray0, n, hid.data_ptr(), s)
             assert rc == 0, rc
         for _ in range(3):
             run()
         torch.cuda.synchronize()
+        if a.flush:
+            tot = 0.0
+            for _ in range(a.iters):
+                flush_buf.add_(1)
+                if a.warm in ("tables", "all"):
+                    warm_sink = tabs[0].view(torch.int32).sum() + maps[3].view(torch.int32).sum()
+                if a.warm in ("geometry", "all"):
+                    warm_sink = g["pixel_val"].sum() + g["sec_grid"].sum() + g["pe6"].sum()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run()
+                e1.record()
+                torch.cuda.synchronize()
+                tot += e0.elapsed_time(e1)
+            res[label] = round(tot / a.iters, 3)
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
             run()
         e1.record()
         torch.cuda.synchronize()
-        res[f"{k}: {what}"] = round(e0.elapsed_time(e1) / a.iters, 3)
+        res[label] = round(e0.elapsed_time(e1) / a.iters, 3)
     print(json.dumps(res, indent=1))
 
 
