@@ -57,6 +57,7 @@ def parse_args(argv=None):
                          "and the per-kernel roofline timing is no longer clean)")
     ap.add_argument("--no-tables", action="store_true",
                     help="first encoder layer as gather + 835->832 GEMM instead of the projected-table form")
+    ap.add_argument("--no-image", action="store_true", help="skip the secondary image-pipeline figures (get_z + render)")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=3,
                     help="steps of the secondary training measurement in render mode (0 = skip)")
@@ -231,7 +232,7 @@ def run(args):
     }
 
     # ---- secondary figure: the whole image pipeline (get_z once per pair + the render pass), SURVEY.md §8(d)
-    if H == 256:
+    if H == 256 and not args.no_image:
         with torch.no_grad():
             for _ in range(2):
                 zz = model.get_z(inp)

@@ -177,12 +177,6 @@ constexpr int MTN = CPN_ENCODE_MT;
 #ifndef CPN_ENCODE_WAVES
 #define CPN_ENCODE_WAVES (16 / CPN_ENCODE_MT)
 #endif
-#ifndef CPN_ENCODE_DB
-#define CPN_ENCODE_DB 0
-#endif
-#ifndef CPN_ENCODE_ORDER
-#define CPN_ENCODE_ORDER 0
-#endif
 constexpr int ENC_WAVES = CPN_ENCODE_WAVES;
 
 // Persistent kernel: one workgroup per CU keeps ALL weight fragments of the K = 80 contraction in LDS for the whole
@@ -245,22 +239,11 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
 
     for (long long wt = x_begin + (long long)wgx * ENC_WAVES + wave; wt < x_end; wt += (long long)wg_on_xcd * ENC_WAVES) {
         // ---- decode the wave tile: (ray group, view, block of 4 samples)
-#if CPN_ENCODE_ORDER == 0
         const long long wu = MTN == 2 ? wt : (wt >> 1);
         const int j0 = MTN == 2 ? 0 : (int)(wt & 1);          // image of tile row block 0 (wave-uniform)
         const int sblk = (int)(wu % nsblk);
         const int v = (int)((wu / nsblk) % V);
         const long long gq = group0 + wu / ((long long)nsblk * V);
-#else
-        // (view, image) outermost: with 8 XCDs each private L2 serves ONE of the four (image, padding mode) tables
-        const long long per_vj = nwtiles / (V * (2 / MTN));                  // ray groups x sample blocks
-        const int vj = (int)(wt / per_vj);
-        const long long wu = wt - (long long)vj * per_vj;
-        const int v = MTN == 2 ? vj : (vj >> 1);
-        const int j0 = MTN == 2 ? 0 : (vj & 1);
-        const int sblk = (int)(wu % nsblk);
-        const long long gq = group0 + wu / nsblk;
-#endif
         const int b = (int)(gq / groups_per_b), rgroup = (int)(gq % groups_per_b);
         const int img_own = b * V + v, img_oth = b * V + (V - 1 - v);
 
@@ -474,26 +457,6 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
                 }
             }
         };
-#if CPN_ENCODE_DB
-        // taps double-buffered: the loads of slice n+1 are in flight during the whole of slice n
-        TapData tda, tdb;
-        issue_taps(0, tda);
-        for (int n = 0; n < NSLICE - 1; n += 2) {
-            issue_taps(n + 1, tdb);
-            __builtin_amdgcn_sched_barrier(0);
-            if (n > 0) store_slice(n - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_slice(n, tda);
-            issue_taps(n + 2, tda);
-            __builtin_amdgcn_sched_barrier(0);
-            store_slice(n);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_slice(n + 1, tdb);
-        }
-        store_slice(NSLICE - 2);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_slice(NSLICE - 1, tda);
-#else
         for (int n = 0; n < NSLICE; ++n) {
             TapData td;
             issue_taps(n, td);
@@ -502,7 +465,6 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
             __builtin_amdgcn_sched_barrier(0);
             compute_slice(n, td);
         }
-#endif
         store_slice(NSLICE - 1);
     }
 }

@@ -11,11 +11,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tools", "_build")
-# kernel configurations (CPN_ENCODE_MT images per wave tile, CPN_ENCODE_WAVES per workgroup, CPN_ENCODE_DB taps double-buffered)
-CONFIGS = ((2, 8, 0), (1, 16, 0), (1, 12, 1), (1, 8, 1))
-STORES = (0, 1)             # CPN_ENCODE_STORE cache-policy experiments on configuration (2, 8, 0)
-ORDERS = ((2, 8), (1, 16))  # CPN_ENCODE_ORDER=1 (tables outermost) on these (MT, waves)
-FULL_ABLATION = ((2, 8, 0),)          # the other configurations are only timed in full
+# kernel configurations (CPN_ENCODE_MT images per wave tile, CPN_ENCODE_WAVES per workgroup)
+CONFIGS = ((1, 16), (2, 8))
+STORES = (0, 1)             # CPN_ENCODE_STORE cache policy: 0 = write-back, 1 = non-temporal (the product)
+FULL_ABLATION = ((1, 16),)          # the other configurations are only timed in full
 VARIANTS = {0: "full", 1: "no table taps", 2: "no hid stores", 3: "no taps, no stores (MFMA + setup)", 4: "no MFMA",
             16: "all taps -> node 0 (L1-hot)", 18: "node-0 taps, no stores",
             32: "stores wrap into a 1.7 MB window (L2-resident)", 33: "no taps, stores into the window"}
@@ -29,14 +28,14 @@ def build():
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
                            os.path.join(src, "error.cpp"), "-o", err_o])
     for cfg in CONFIGS:
-        mt, waves, db = cfg
+        mt, waves = cfg
         for k in VARIANTS:
             if k and cfg not in FULL_ABLATION:
                 continue
-            tag = f"{k}_mt{mt}w{waves}db{db}"
+            tag = f"{k}_mt{mt}w{waves}"
             obj, out = os.path.join(BUILD, f"encode_abl{tag}.o"), os.path.join(BUILD, f"libencode_abl{tag}.so")
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_ENCODE_ABLATE={k}",
-                   f"-DCPN_ENCODE_MT={mt}", f"-DCPN_ENCODE_WAVES={waves}", f"-DCPN_ENCODE_DB={db}", "-x", "hip", "-c",
+                   f"-DCPN_ENCODE_MT={mt}", f"-DCPN_ENCODE_WAVES={waves}", "-x", "hip", "-c",
                    os.path.join(src, "encode.hip"), "-o", obj]
             print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -54,18 +53,6 @@ def build_store_variants():
                                "-o", out])
 
 
-def build_order_variants():
-    src = os.path.join(ROOT, "coponerf_amd", "csrc")
-    hipcc = "/opt/rocm/bin/hipcc"
-    for mt, waves in ORDERS:
-        obj, out = os.path.join(BUILD, f"encode_order_mt{mt}.o"), os.path.join(BUILD, f"libencode_order_mt{mt}.so")
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCPN_ENCODE_ORDER=1",
-                               f"-DCPN_ENCODE_MT={mt}", f"-DCPN_ENCODE_WAVES={waves}", "-x", "hip", "-c",
-                               os.path.join(src, "encode.hip"), "-o", obj])
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, os.path.join(BUILD, "error.o"),
-                               "-o", out])
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
@@ -76,12 +63,12 @@ def main():
     ap.add_argument("--flush-mb", type=int, default=4096, help="size of the flush stream buffer (fp32 add_: 2x traffic)")
     ap.add_argument("--warm", default="", choices=("", "tables", "geometry", "all"), help="with --flush: read the node "
                     "tables + level-3 map / the per-sample geometry arrays once after the flush, before the timed launch")
+    ap.add_argument("--alt-hid", action="store_true", help="hot loop writing two hid buffers alternately")
     ap.add_argument("--only", default="", help="substring filter on the variant label")
     a = ap.parse_args()
     if a.build:
         build()
         build_store_variants()
-        build_order_variants()
         return
     import torch
     from coponerf_amd import CoPoNeRF, synthetic as syn
@@ -102,13 +89,14 @@ def main():
     g = eng._geometry(ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], rel, True, S, H, H)
     R = qry["uv"].shape[2]
     hid = torch.empty(n * V * S * 2, 832, dtype=torch.float16, device=dev)
+    hids = [hid, torch.empty_like(hid)] if a.alt_hid else [hid]
+    it_no = [0]
     s = torch.cuda.current_stream().cuda_stream
     P, I = ctypes.c_void_p, ctypes.c_int
     res = {}
-    runs = [(f"mt{c[0]} w{c[1]} db{c[2]} {k}: {what}", f"libencode_abl{k}_mt{c[0]}w{c[1]}db{c[2]}.so")
+    runs = [(f"mt{c[0]} w{c[1]} {k}: {what}", f"libencode_abl{k}_mt{c[0]}w{c[1]}.so")
             for c in CONFIGS for k, what in VARIANTS.items()]
     runs += [(f"store policy {st}", f"libencode_store{st}.so") for st in STORES]
-    runs += [(f"order: tables outermost, mt{mt} w{w}", f"libencode_order_mt{mt}.so") for mt, w in ORDERS]
     flush_buf = torch.zeros(a.flush_mb << 18, dtype=torch.float32, device=dev) if a.flush else None
     for label, so in runs:
         if a.only and a.only not in label:
@@ -123,7 +111,8 @@ def main():
         def run():
             rc = fn(tabs[0].data_ptr(), maps[3].data_ptr(), H, H,
                     g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(), w["enc.frag"].data_ptr(),
-                    w["query_encode_latent.b"].data_ptr(), B, V, R, S, a.ray0, n, hid.data_ptr(), s)
+                    w["query_encode_latent.b"].data_ptr(), B, V, R, S, a.ray0, n, hids[it_no[0] % len(hids)].data_ptr(), s)
+            it_no[0] += 1
             assert rc == 0, rc
         for _ in range(3):
             run()

@@ -52,3 +52,23 @@ for grid in (1024, 4096, 16384):
 ms = timed(lambda: buf.zero_())
 res["torch zero_"] = {"ms": round(ms, 3), "TB/s": round(gb / ms, 3)}
 print(json.dumps(res, indent=1))
+
+# ---- does a read fill the Infinity Cache (MALL, 256 MB)?  128 MB buffer: hot loop / after a flush / after flush + one read
+small = torch.zeros(128 << 18, dtype=torch.float32, device=dev)      # 128 MB
+n16s = small.numel() // 4
+mall = {}
+ms = timed(lambda: lib.wb_read(small.data_ptr(), n16s, 1024, sink.data_ptr(), s), it=20)
+mall["128 MB read, hot loop"] = {"ms": round(ms, 4), "TB/s": round(0.134217728 / ms, 2)}
+def one(after_flush_read):
+    tot = 0.0
+    for _ in range(8):
+        flush_buf.add_(1)
+        if after_flush_read:
+            lib.wb_read(small.data_ptr(), n16s, 1024, sink.data_ptr(), s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); lib.wb_read(small.data_ptr(), n16s, 1024, sink.data_ptr(), s); e1.record(); torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / 8
+ms = one(False); mall["128 MB read after an 8 GB flush"] = {"ms": round(ms, 4), "TB/s": round(0.134217728 / ms, 2)}
+ms = one(True); mall["128 MB read after flush + one warming read"] = {"ms": round(ms, 4), "TB/s": round(0.134217728 / ms, 2)}
+print(json.dumps(mall, indent=1))
