@@ -220,58 +220,81 @@ __global__ __launch_bounds__(256) void local_hidden_kernel(
 // off the registers against W2 fragments held in LDS (lane-linear 16-byte slots, 32 KiB).  Output rows use the
 // same channel permutation: 16-byte stores, 64 contiguous bytes per row and tile pair.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void local_mlp_kernel(
+__global__ __launch_bounds__(512, 4) void local_mlp_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
     const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
     const float* __restrict__ b2, int V, int R, int S, int ray0, long long nrows, __half* __restrict__ out,
     const __half* __restrict__ dot_with, float* __restrict__ logits_out) {
+    // 8 waves share the W2 fragments; 2 workgroups per CU = 4 waves per SIMD (<= 128 VGPRs): the first layer's bias
+    // rides on the unused K = 3 input slot (x = 1, exact in the fp32 MFMA), the second layer's sits in LDS, and the
+    // inputs of the NEXT 16-row group are requested before the MFMAs of the current one.
     __shared__ __attribute__((aligned(16))) half8 w2l[8 * 4 * 64];        // [tile t][k block p][lane]
-    __shared__ __attribute__((aligned(16))) half8 ostage[4][16 * 17];
-    const int lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) half8 ostage[8][16 * 17];
+    __shared__ __attribute__((aligned(16))) float b2s[128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int a = lane & 15, fg = lane >> 4;
-    for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) {
+    for (int i = threadIdx.x; i < 8 * 4 * 64; i += 512) {
         const int l = i & 63, p = (i >> 6) & 3, t = i >> 8;
         const int ch = (t >> 1) * 32 + ((l & 15) >> 2) * 8 + (t & 1) * 4 + (l & 3);       // output channel of tile row
         w2l[i] = *reinterpret_cast<const half8*>(w2 + (size_t)ch * ldw2 + p * 32 + (l >> 4) * 8);
     }
-    f32x4 wv[8], bv[8], b2v[8];
+    if (threadIdx.x < 128) b2s[threadIdx.x] = b2[threadIdx.x];
+    f32x4 wv[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const int p = t >> 1, h = t & 1;
-        wv[t] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(p * 32 + (a >> 2) * 8 + h * 4 + (a & 3)) * ldw1 + fg * 4);
-        bv[t] = *reinterpret_cast<const f32x4*>(b1 + p * 32 + fg * 8 + h * 4);
-        b2v[t] = *reinterpret_cast<const f32x4*>(b2 + p * 32 + fg * 8 + h * 4);
+        const int ch = (t >> 1) * 32 + (a >> 2) * 8 + (t & 1) * 4 + (a & 3);
+        wv[t] = *reinterpret_cast<const f32x4*>(w1 + (size_t)ch * ldw1 + fg * 4);
+        if (fg == 0) wv[t][3] = b1[ch];                        // K slot 3 is unused by the inputs: bias x 1.0
     }
     __syncthreads();
     const unsigned ngroups = (unsigned)((nrows + 15) >> 4);
-    const unsigned wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    for (unsigned grp = wave_id; grp < ngroups; grp += nwaves) {
+    const unsigned wave_id = blockIdx.x * 8 + wave, nwaves = gridDim.x * 8;
+
+    struct RowIn {
+        f32x4 lv;          // this lane's 4 K entries of the 16-wide input
+        unsigned rayrel;   // ray - ray0 (row of `add`)
+    };
+    auto fetch = [&](unsigned grp) {
         const unsigned row = grp * 16 + a;
-        const bool live = row < (unsigned)nrows;
-        unsigned t_ = live ? row : (unsigned)nrows - 1;
+        unsigned t_ = row < (unsigned)nrows ? row : (unsigned)nrows - 1;
         const int s = (int)(t_ % (unsigned)S); t_ /= (unsigned)S;
         const int v = (int)(t_ % (unsigned)V); t_ /= (unsigned)V;
         const unsigned ray = (unsigned)ray0 + t_;
         const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
         const size_t nr = ((size_t)(b * V + v)) * R + r;
-        const f32x4 l0 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8);
-        const f32x4 l1 = *reinterpret_cast<const f32x4*>(loc8 + (nr * S + s) * 8 + 4);
+        const float* lp = loc8 + (nr * S + s) * 8;
         const float* c9 = coords9 + nr * 9;
-        f32x4 lv;
-        if (fg == 0) lv = f32x4{l0[0], l0[1], l0[2], 0.f};
-        else if (fg == 1) lv = f32x4{0.f, 0.f, c9[0], c9[1]};
-        else if (fg == 2) lv = f32x4{c9[2], l0[3], l1[0], l1[1]};
-        else lv = f32x4{l1[2], c9[6], c9[7], c9[8]};
+        RowIn o;
+        o.rayrel = t_;
+        if (fg == 0) { const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp); o.lv = f32x4{l0[0], l0[1], l0[2], 1.0f}; }
+        else if (fg == 1) o.lv = f32x4{0.f, 0.f, c9[0], c9[1]};
+        else if (fg == 2) o.lv = f32x4{c9[2], lp[3], lp[4], lp[5]};
+        else o.lv = f32x4{lp[6], c9[6], c9[7], c9[8]};
+        return o;
+    };
+
+    RowIn cur = fetch(wave_id < ngroups ? wave_id : 0);
+    for (unsigned grp = wave_id; grp < ngroups; grp += nwaves) {
+        const unsigned row = grp * 16 + a;
+        const bool live = row < (unsigned)nrows;
+        const RowIn nxt = fetch(grp + nwaves < ngroups ? grp + nwaves : grp);
+        half8 cv[4];
+        if (logits_out) {
+            const unsigned crow = live ? row : (unsigned)nrows - 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(dot_with + (size_t)crow * 128 + p * 32 + fg * 8));
+        }
         f32x4 acc[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            acc[t] = bv[t];
-            if (add) acc[t] += *reinterpret_cast<const f32x4*>(add + (size_t)t_ * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (add) acc[t] = *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], lv[e], acc[t], 0, 0, 0);
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], cur.lv[e], acc[t], 0, 0, 0);
         // hidden layer -> fp16 B operands: K block p = channels p*32 .. p*32+31, this lane holds fg*8 .. fg*8+7 of it
         half8 hb[4];
 #pragma unroll
@@ -284,33 +307,30 @@ __global__ __launch_bounds__(256) void local_mlp_kernel(
         f32x4 o2[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            o2[t] = b2v[t];
+            o2[t] = *reinterpret_cast<const f32x4*>(b2s + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 o2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[(t * 4 + p) * 64 + lane], hb[p], o2[t], 0, 0, 0);
         }
+        cur = nxt;
         if (logits_out) {
             // the consumer only needs <out[row], dot_with[row]>: form it here from the fp16-rounded outputs (the values
             // a stored row would have had) and write 4 bytes per row instead of 256
             float dsum = 0.0f;
-            if (live) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const half8 cv = *reinterpret_cast<const half8*>(dot_with + (size_t)row * 128 + p * 32 + fg * 8);
+            for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        dsum += (float)(_Float16)o2[2 * p][i] * (float)cv[i];
-                        dsum += (float)(_Float16)o2[2 * p + 1][i] * (float)cv[4 + i];
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    dsum += (float)(_Float16)o2[2 * p][i] * (float)cv[p][i];
+                    dsum += (float)(_Float16)o2[2 * p + 1][i] * (float)cv[p][4 + i];
                 }
-            }
             dsum += __shfl_xor(dsum, 16);
             dsum += __shfl_xor(dsum, 32);
             if (live && fg == 0) logits_out[row] = dsum;
             continue;
         }
         // stage the wave's 16 x 128 tile in LDS and write whole 256-byte rows (4 rows per store instruction)
-        half8* stg = ostage[threadIdx.x >> 6];
+        half8* stg = ostage[wave];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             half8 o;
@@ -408,8 +428,8 @@ extern "C" int cpn_local_mlp(const float* loc8, const float* coords9, const floa
     const long long nrows = (long long)nrays * V * S;
     CPN_REQUIRE(nrows * 16 < (1LL << 31), CPN_E_SHAPE, "cpn_local_mlp: chunk too large for 32-bit indexing");
     const long long groups = cpn_cdiv(nrows, 16);
-    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(groups, 4), 2048);
-    hipLaunchKernelGGL(local_mlp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(groups, 8), 1024);
+    hipLaunchKernelGGL(local_mlp_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
                        (const __half*)w2, ldw2, b2, V, R, S, ray0, nrows, (__half*)out, (const __half*)dot_with, logits_out);
     CPN_LAUNCH_CHECK("cpn_local_mlp");
     return 0;
