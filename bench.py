@@ -225,7 +225,7 @@ def run(args):
         "config": {"workload": f"configs[1]: {H}x{H} stereo pair, full-image render {R} rays x {S} samples, "
                                f"{B} pair(s) per GPU, render path only (z/rel_pose/flow given, val=True)",
                    "chunk_rays": args.chunk_rays, "lanes": args.lanes, "pairs_per_gpu": B,
-                   "first_layer": "projected tables + K=96 MFMA (cpn_encode_hidden)" if tables
+                   "first_layer": "projected tables + K=80 MFMA (cpn_encode_hidden)" if tables
                                   else "gather + 835->832 GEMM"},
         "path_tflops": value * f_ray(S) / 1e12,          # algorithmic FLOPs of the reference formulation
         "executed_tflops": value * exec_per_ray / 1e12,  # what the kernels execute after the restructurings
@@ -318,10 +318,11 @@ def roofline_block(prof, args, tables):
             traffic, tsrc = rec["hbm_bytes"], os.path.relpath(tpath, ROOT)
     if tables:
         # What bounds this kernel is its HBM stream: 832 fp16 written per row (the node tables and the full-resolution
-        # map it reads are L2 / Infinity-Cache resident: FETCH_SIZE ~ 0.3 GB per launch).  The canonical work of the
+        # map it reads are L2 / Infinity-Cache resident: FETCH_SIZE x 2 = 0.43 GB per launch).  The canonical work of the
         # layer it replaces (what the reference computes, 2*835*832 FLOP per row) is reported next to
-        # it against the MFMA peak; the kernel itself executes 4 table taps + a K = 96 MFMA product per row.
-        nimg_bytes = 2 * (129 * 129 + 137 * 137) * 1664.0 + 2 * 256 * 256 * 128.0          # tables + level-3 map of a pair
+        # it against the MFMA peak; the kernel itself executes 4 table taps + a K = 80 MFMA product per row.
+        hh = args.height                                                                  # tables + level-3 map of a pair
+        nimg_bytes = 2 * ((hh // 2 + 1) ** 2 + (hh // 2 + 9) ** 2) * 1664.0 + 2 * hh * hh * 128.0
         alg_bytes = rows * 832 * 2.0 + nimg_bytes
         gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
         out["roofline"] = {
@@ -332,8 +333,8 @@ def roofline_block(prof, args, tables):
             "canonical_mfma_view": {"bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": achieved / F16_MFMA_PEAK_TFLOPS, "flops_per_launch": flops,
                                     "note": "FLOPs of the layer as the reference formulates it / launch time; the kernel "
-                                            "executes 4 table taps + a K=96 MFMA product per row (DESIGN.md §4.1)"},
-            "executed_tflops": (2.0 * rows * 832 * (96 + 4)) / (avg_ms * 1e-3) / 1e12}
+                                            "executes 4 table taps + a K=80 MFMA product per row (DESIGN.md §4.1)"},
+            "executed_tflops": (2.0 * rows * 832 * (80 + 4)) / (avg_ms * 1e-3) / 1e12}
     else:
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel<13> (query_encode_latent 835->832)",
                            "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -127,7 +127,7 @@ int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int 
  *   laid out image by image, border table first: cpn_encode_table_nodes(H, W) nodes (rows) per image.
  *   Built as  cpn_node_features (the three levels sampled at every node -> (nodes, 768) fp16)
  *             -> cpn_gemm_f16(A = node features, W = wtab, N = CPN_TAB_LD, K = 768, bias 0, fp16 out).
- * A row is then 4 weighted table taps + a K = 96 MFMA product over [level-3 gather (64) | pt (3) | 0] + bias.
+ * A row is then 4 weighted table taps + a K = 80 MFMA product over [level-3 gather (64) | pt (3) | bias hi, lo | 0].
  * Table rows hold the 832 channels in natural order (1664 B, 13 cache lines; the kernel walks 13 slices of 64 channels).
  *   cpn_pack_encode_weights: W (832, ldw >= 835) fp32 query_encode_latent.weight ->
  *       wfrag (13*3*4*64*8 halves) MFMA A-operand fragments of W[:, 768:835] (K padded to 96)
