@@ -34,29 +34,67 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kb = 0; kb < K; kb += 16) {
-        f32x4 xv = *reinterpret_cast<const f32x4*>(xp + kb);
+    // operands of k block kb+16 are requested before the 4*NT MFMAs of block kb (L2 latency ~ the MFMA time of a block)
+    const float* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = t * 16 + fi;
+        wp[t] = W + (size_t)(n < N ? n : N - 1) * ldw + fg * 4;
+    }
+    auto load_w = [&](int kb, f32x4 (&wv)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            wv[t] = *reinterpret_cast<const f32x4*>(wp[t] + kb);
+            if (t * 16 + fi >= N) wv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto step = [&](f32x4 xv, const f32x4 (&wv)[NT]) {
         if (relu_in) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = fmaxf(xv[e], 0.0f);
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = t * 16 + fi;
-            f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (n < N) wv = *reinterpret_cast<const f32x4*>(W + (size_t)n * ldw + kb + fg * 4);
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], xv[e], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], xv[e], acc[t], 0, 0, 0);
+    };
+    f32x4 xa = *reinterpret_cast<const f32x4*>(xp), wa[NT], xb, wb[NT];
+    load_w(0, wa);
+    int kb = 0;
+    for (; kb + 32 <= K; kb += 32) {
+        xb = *reinterpret_cast<const f32x4*>(xp + kb + 16);
+        load_w(kb + 16, wb);
+        step(xa, wa);
+        if (kb + 32 < K) {
+            xa = *reinterpret_cast<const f32x4*>(xp + kb + 32);
+            load_w(kb + 32, wa);
         }
+        step(xb, wb);
     }
+    if (kb < K) step(xa, wa);                                   // K / 16 odd: the last block is already in (xa, wa)
     const int m = m0 + fi;
     if (m >= M) return;
+    const bool vec = ((N | ldy | ldr) & 3) == 0 &&               // 16-byte epilogue: a lane owns 4 consecutive columns
+                     (((uintptr_t)Y | (uintptr_t)bias | (uintptr_t)res) & 15) == 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        const int n0 = t * 16 + fg * 4;
+        if (vec) {
+            if (n0 >= N) continue;
+            f32x4 v = acc[t];
+            if (bias) v += *reinterpret_cast<const f32x4*>(bias + n0);
+            if (res) v += *reinterpret_cast<const f32x4*>(res + (size_t)m * ldr + n0);
+            if (relu_out) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+            }
+            *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + n0) = v;
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = t * 16 + fg * 4 + i;
+            const int n = n0 + i;
             if (n >= N) continue;
             float v = acc[t][i];
             if (bias) v += bias[n];
