@@ -262,6 +262,19 @@ def run(args):
                 pdt = time.perf_counter() - p0
             line["image_rays_per_s_pipelined"] = nimg * R / pdt
             line["image_ms_pipelined"] = 1e3 * pdt / nimg
+            # throughput form of the same loop: get_z batched over 4 consecutive pairs (one launch sequence for four)
+            with torch.no_grad():
+                for _ in render_images(model, pairs, getz_batch=4):
+                    pass
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                nimg = 0
+                for _ in render_images(model, pairs + pairs, getz_batch=4):
+                    nimg += 1
+                torch.cuda.synchronize()
+                pdt = time.perf_counter() - p0
+            line["image_rays_per_s_getz_batch4"] = nimg * R / pdt
+            line["image_ms_getz_batch4"] = 1e3 * pdt / nimg
 
     if rank == 0:
         line.update(roofline_block(prof, args, tables))

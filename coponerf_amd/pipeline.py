@@ -28,39 +28,87 @@ def _record(obj, stream) -> None:
             _record(o, stream)
 
 
-def render_images(model, inputs: Iterable[Dict]) -> Iterator[Tuple[Dict, Dict]]:
+def _collate(items):
+    """Batch a list of model_input dicts (each B = 1, or any B) along dim 0, leaf by leaf."""
+    first = items[0]
+    if torch.is_tensor(first):
+        return torch.cat(items, dim=0)
+    if isinstance(first, dict):
+        return {k: _collate([it[k] for it in items]) for k in first}
+    if isinstance(first, (list, tuple)):
+        return type(first)(_collate([it[i] for it in items]) for i in range(len(first)))
+    return first
+
+
+def _pair_slice(obj, lo: int, hi: int, per: int):
+    """Rows [lo*per, hi*per) of every tensor in a (nested) get_z result: per = 2 for the (2B, ...) feature maps."""
+    if torch.is_tensor(obj):
+        return obj[lo * per:hi * per]
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_pair_slice(o, lo, hi, per) for o in obj)
+    return obj
+
+
+def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1) -> Iterator[Tuple[Dict, Dict]]:
     """For every model_input dict (on the device) yield (model_input, forward(model_input, z, rel_pose, val=True, flow)),
-    with `get_z` of the next input overlapped with the render of the current one.  Call under torch.no_grad()."""
+    with `get_z` of the next inputs overlapped with the render of the current ones.  Call under torch.no_grad().
+
+    getz_batch > 1 runs `get_z` ONCE for that many consecutive inputs (batched along dim 0: its ~1 100 kernels are
+    launch / latency bound, 15.8 ms for one pair, ~10 ms per pair at four) and renders them one after the other from
+    slices of the batched features; per-pair results are those of the serial order up to the rounding noise of get_z's
+    atomically accumulated GroupNorm statistics (tests/test_gpu_getz.py)."""
     it = iter(inputs)
-    try:
-        cur = next(it)
-    except StopIteration:
+
+    def take():
+        grp = []
+        for x in it:
+            grp.append(x)
+            if len(grp) == max(1, getz_batch):
+                break
+        return grp
+
+    def features(grp):
+        feats = model.get_z(grp[0] if len(grp) == 1 else _collate(grp))
+        return feats, getattr(model._engine, "_l3_hint", None), [int(g["context"]["rgb"].shape[0]) for g in grp]
+
+    cur = take()
+    if not cur:
         return
     main = torch.cuda.current_stream()
     # high priority: the small kernels of get_z are dispatched ahead of the render's queued workgroups instead of
     # waiting behind each of the render's chip-filling launches
     side = torch.cuda.Stream(device=main.device, priority=-1)
-    feats = model.get_z(cur)                                   # first pair: nothing to hide it under
-    while cur is not None:
-        nxt = next(it, None)
-        z, rel_pose, flow = feats
+    state = features(cur)                                      # first group: nothing to hide it under
+    while cur:
+        nxt = take()
+        (z, rel_pose, flow), hint, sizes = state
         H, W = model.H, model.W
-        if nxt is not None:
-            side.wait_stream(main)          # BEFORE the render is enqueued: the side stream then only waits for what is
-                                            # already on the main stream (the previous image), not for this render
-        model.H, model.W = H, W
-        # 1. the render of the current pair: a few dozen launches, asynchronous except for two short host waits
-        out = model(cur, z=z, rel_pose=rel_pose, val=True, flow=flow)
-        nfeats = None
-        if nxt is not None:
-            # 2. the ~1 100 launches of the next pair's get_z on the side stream: the host issues them while the GPU
-            #    renders, the small kernels run in the gaps of / beside the HBM-bound render kernels
-            with torch.cuda.stream(side):
-                nfeats = model.get_z(nxt)
-                hint = getattr(model._engine, "_l3_hint", None)
-            main.wait_stream(side)          # the NEXT render (and whatever the caller enqueues) follows get_z(next)
-            _record(nfeats, main)
-            if hint is not None:
-                _record(hint[2], main)
-        yield cur, out
-        cur, feats = nxt, nfeats
+        if nxt:
+            side.wait_stream(main)          # BEFORE the renders are enqueued: the side stream then only waits for what
+                                            # is already on the main stream (the previous group), not for these renders
+        nstate = None
+        lo = 0
+        for i, inp in enumerate(cur):
+            hi = lo + sizes[i]
+            if len(cur) == 1:
+                zi, ri, fi = z, rel_pose, flow
+            else:
+                zi, ri, fi = _pair_slice(z, lo, hi, 2), rel_pose[lo:hi], _pair_slice(flow, lo, hi, 1)
+                if hint is not None and hint[0] is z[3]:
+                    model._engine.adopt_level3(zi[3], hint[2][2 * lo:2 * hi])
+            lo = hi
+            model.H, model.W = H, W
+            # 1. the render of this pair: a few dozen launches, asynchronous except for two short host waits
+            out = model(inp, z=zi, rel_pose=ri, val=True, flow=fi)
+            if i == 0 and nxt:
+                # 2. the ~1 100 launches of the next group's get_z on the side stream: the host issues them while the
+                #    GPU renders, the small kernels run in the gaps of / beside the HBM-bound render kernels
+                with torch.cuda.stream(side):
+                    nstate = features(nxt)
+            if i == len(cur) - 1 and nxt:
+                main.wait_stream(side)      # the NEXT renders (and whatever the caller enqueues) follow get_z(next)
+                _record(nstate[0], main)
+                if nstate[1] is not None:
+                    _record(nstate[1][2], main)
+            yield inp, out
+        cur, state = nxt, nstate

@@ -165,11 +165,15 @@ def test_pipelined_images_equal_serial(dev):
     with torch.no_grad():
         serial = [serial_rgb(p) for p in pairs]
         piped = [out["rgb"].clone() for _, out in render_images(model, pairs)]
+        batched = [out["rgb"].clone() for _, out in render_images(model, pairs, getz_batch=2)]   # groups of 2 + 1
         again = serial_rgb(pairs[0])
     torch.cuda.synchronize()
     # get_z accumulates its GroupNorm statistics with atomics: two runs of the SAME pair agree to rounding only
     noise = float((again - serial[0]).abs().max())
-    assert len(piped) == 3
+    assert len(piped) == 3 and len(batched) == 3
     for a, b in zip(serial, piped):
         assert float((a - b).abs().max()) <= max(10 * noise, 1e-6), (float((a - b).abs().max()), noise)
+    # get_z batched over two pairs (one launch sequence for both), rendered from slices of the batched features
+    for a, b in zip(serial, batched):
+        assert float((a - b).abs().max()) <= max(10 * noise, 2e-5), (float((a - b).abs().max()), noise)
     assert float((serial[0] - serial[1]).abs().max()) > 1e-3
