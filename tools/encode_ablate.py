@@ -60,8 +60,10 @@ def main():
     ap.add_argument("--ray0", type=int, default=16384, help="first ray of the timed chunk")
     ap.add_argument("--flush", action="store_true", help="stream 8 GB through the caches between launches (as the "
                     "key / attend kernels of the chunk loop do) and time each launch on its own")
+    ap.add_argument("--flush-kind", default="rw", choices=("rw", "read", "write"), help="foreign traffic of the flush: "
+                    "add_ (read + write), sum (read only) or zero_ (write only)")
     ap.add_argument("--flush-mb", type=int, default=4096, help="size of the flush stream buffer (fp32 add_: 2x traffic)")
-    ap.add_argument("--warm", default="", choices=("", "tables", "geometry", "all"), help="with --flush: read the node "
+    ap.add_argument("--warm", default="", choices=("", "tables", "geometry", "all", "pages"), help="with --flush: read the node "
                     "tables + level-3 map / the per-sample geometry arrays once after the flush, before the timed launch")
     ap.add_argument("--alt-hid", action="store_true", help="hot loop writing two hid buffers alternately")
     ap.add_argument("--only", default="", help="substring filter on the variant label")
@@ -120,9 +122,18 @@ def main():
         if a.flush:
             tot = 0.0
             for _ in range(a.iters):
-                flush_buf.add_(1)
+                if a.flush_kind == "rw":
+                    flush_buf.add_(1)
+                elif a.flush_kind == "read":
+                    flush_sink = flush_buf.sum()
+                else:
+                    flush_buf.zero_()
                 if a.warm in ("tables", "all"):
                     warm_sink = tabs[0].view(torch.int32).sum() + maps[3].view(torch.int32).sum()
+                if a.warm == "pages":          # one element per 4 KiB page of the output, tables and geometry arrays
+                    warm_sink = sum(t.view(-1).view(torch.int16 if t.element_size() == 2 else torch.int32)
+                                    [::4096 // t.element_size()].sum()
+                                    for t in (hids[it_no[0] % len(hids)], tabs[0], g["pixel_val"], g["sec_grid"], g["pe6"]))
                 if a.warm in ("geometry", "all"):
                     warm_sink = g["pixel_val"].sum() + g["sec_grid"].sum() + g["pe6"].sum()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
