@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--flush-kind", default="rw", choices=("rw", "read", "write"), help="foreign traffic of the flush: "
                     "add_ (read + write), sum (read only) or zero_ (write only)")
     ap.add_argument("--flush-mb", type=int, default=4096, help="size of the flush stream buffer (fp32 add_: 2x traffic)")
-    ap.add_argument("--warm", default="", choices=("", "tables", "geometry", "all", "pages"), help="with --flush: read the node "
+    ap.add_argument("--warm", default="", choices=("", "tables", "geometry", "all", "pages", "plain"), help="with --flush: read the node "
                     "tables + level-3 map / the per-sample geometry arrays once after the flush, before the timed launch")
     ap.add_argument("--alt-hid", action="store_true", help="hot loop writing two hid buffers alternately")
     ap.add_argument("--only", default="", help="substring filter on the variant label")
@@ -99,6 +99,11 @@ def main():
     runs = [(f"mt{c[0]} w{c[1]} {k}: {what}", f"libencode_abl{k}_mt{c[0]}w{c[1]}.so")
             for c in CONFIGS for k, what in VARIANTS.items()]
     runs += [(f"store policy {st}", f"libencode_store{st}.so") for st in STORES]
+    wlib = wsink = None
+    if a.warm == "plain":
+        wlib = ctypes.CDLL(os.path.join(BUILD, "libwrite_bw.so"))
+        wlib.wb_read.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        wsink = torch.zeros(1, dtype=torch.int32, device=dev)
     flush_buf = torch.zeros(a.flush_mb << 18, dtype=torch.float32, device=dev) if a.flush else None
     for label, so in runs:
         if a.only and a.only not in label:
@@ -130,6 +135,9 @@ def main():
                     flush_buf.zero_()
                 if a.warm in ("tables", "all"):
                     warm_sink = tabs[0].view(torch.int32).sum() + maps[3].view(torch.int32).sum()
+                if a.warm == "plain":          # tables, level-3 map and geometry arrays through plain (cached) loads
+                    for t in (tabs[0], maps[3], g["pixel_val"], g["sec_grid"], g["pe6"]):
+                        wlib.wb_read(t.data_ptr(), t.numel() * t.element_size() // 16, 1024, wsink.data_ptr(), s)
                 if a.warm == "pages":          # one element per 4 KiB page of the output, tables and geometry arrays
                     warm_sink = sum(t.view(-1).view(torch.int16 if t.element_size() == 2 else torch.int32)
                                     [::4096 // t.element_size()].sum()
