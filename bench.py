@@ -275,6 +275,19 @@ def run(args):
                 pdt = time.perf_counter() - p0
             line["image_rays_per_s_getz_batch4"] = nimg * R / pdt
             line["image_ms_getz_batch4"] = 1e3 * pdt / nimg
+            # get_z of each pair replayed as a captured HIP graph (coponerf_amd/graphs.py), one pair at a time
+            with torch.no_grad():
+                for _ in render_images(model, pairs[:2], graph=True):
+                    pass
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                nimg = 0
+                for _ in render_images(model, pairs + pairs, graph=True):
+                    nimg += 1
+                torch.cuda.synchronize()
+                pdt = time.perf_counter() - p0
+            line["image_rays_per_s_getz_graph"] = nimg * R / pdt
+            line["image_ms_getz_graph"] = 1e3 * pdt / nimg
 
     if rank == 0:
         line.update(roofline_block(prof, args, tables))

@@ -113,6 +113,7 @@ class CoPoNeRF(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         out = super().load_state_dict(state_dict, strict=strict, assign=assign)
         self._engine.invalidate()               # packed fp16 weights / tables are derived from the parameters
+        self._param_epoch = getattr(self, "_param_epoch", 0) + 1       # captured get_z graphs (graphs.py) are dropped
         return out
 
     def get_z(self, input, val: bool = False, ops=None):

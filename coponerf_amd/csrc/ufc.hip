@@ -193,19 +193,22 @@ __global__ __launch_bounds__(256) void conv4d_pooled_kernel(const float* __restr
     }
 }
 
-// stride-1 3x3x3x3 fast path (57 of the 63 Conv4d calls of a get_z): one thread computes ALL output channels of
-// its position, so every input value is read once per tap instead of once per (tap, output channel); the weights
-// are staged in LDS as [cin][tap][branch][cout] and read as wave-uniform (broadcast) 16-byte vectors.
+// stride-1 3x3x3x3 fast path (57 of the 63 Conv4d calls of a get_z): one thread computes COUT output channels of
+// its position (blockIdx.y = channel group), so every input value is read once per tap instead of once per (tap,
+// output channel); the weights are staged in LDS as [cin][tap][branch][cout] and read as wave-uniform (broadcast)
+// 16-byte vectors.  COUT = all channels when the volume alone fills the chip (training batches); at B = 1 a 16^4
+// volume is 1 024 waves = ONE per SIMD, so the channels are split over 4 (2) groups for latency hiding.
 template <int COUT>
 __global__ __launch_bounds__(256) void conv4d_k3s1_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                           const float* __restrict__ bq, const float* __restrict__ ws,
                                                           const float* __restrict__ bs, int Cin, int Hq, int Wq,
-                                                          int Hs, int Ws, float* __restrict__ y,
+                                                          int Hs, int Ws, int cout_total, float* __restrict__ y,
                                                           double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float wl[];        // Cin * 9 * 2 * COUT floats
     const int b = blockIdx.z;
+    const int o0 = blockIdx.y * COUT;
     for (int i = threadIdx.x; i < Cin * 9 * 2 * COUT; i += 256) {
-        const int o = i % COUT;
+        const int o = o0 + i % COUT;
         int t = i / COUT;
         const int br = t & 1; t >>= 1;
         const int tap = t % 9, c = t / 9;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void conv4d_k3s1_kernel(const float* __restric
         const int qy = (int)(t / Wq);
         float acc[COUT];
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) acc[o] = bq[o] + bs[o];
+        for (int o = 0; o < COUT; ++o) acc[o] = bq[o0 + o] + bs[o0 + o];
         const size_t cstride = (size_t)npos;
         const float* xb = x + (size_t)b * Cin * cstride;
         for (int c = 0; c < Cin; ++c) {
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void conv4d_k3s1_kernel(const float* __restric
         }
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
-            y[((size_t)b * COUT + o) * npos + pos] = acc[o];
+            y[((size_t)b * cout_total + o0 + o) * npos + pos] = acc[o];
             s1 += (double)acc[o];
             s2 += (double)acc[o] * acc[o];
         }
@@ -713,13 +716,19 @@ extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, cons
     dim3 grid(cpn_cdiv(npos, 256), Cout, B);
     const size_t wbytes = (size_t)Cin * 9 * 2 * Cout * sizeof(float);
     if (k == 3 && s == 1 && p == 1 && (Cout == 8 || Cout == 32) && wbytes <= 64 * 1024) {
-        dim3 g1(cpn_cdiv(npos, 256), 1, B);
-        if (Cout == 8)
-            hipLaunchKernelGGL(conv4d_k3s1_kernel<8>, g1, dim3(256), wbytes, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs,
-                               Ws, y, stats);
+        const bool small = (long long)B * npos <= 131072;        // <= 2 waves per SIMD with one thread per position
+        const int per = Cout == 8 ? (small ? 4 : 8) : (small ? 8 : 32);
+        dim3 g1(cpn_cdiv(npos, 256), Cout / per, B);
+        const size_t wb = wbytes / (Cout / per);
+        if (per == 4)
+            hipLaunchKernelGGL(conv4d_k3s1_kernel<4>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
+                               y, stats);
+        else if (per == 8)
+            hipLaunchKernelGGL(conv4d_k3s1_kernel<8>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
+                               y, stats);
         else
-            hipLaunchKernelGGL(conv4d_k3s1_kernel<32>, g1, dim3(256), wbytes, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs,
-                               Ws, y, stats);
+            hipLaunchKernelGGL(conv4d_k3s1_kernel<32>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
+                               y, stats);
     } else if (s > 1 && scratch) {
         float* psv = scratch;
         float* pqv = scratch + (size_t)B * Cin * Hq * Wq * Os * Ps_;

@@ -18,6 +18,7 @@ reference (UFC feat_size 16/32/64, learned pos_embed, pose head input size).
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Sequence, Tuple
 
 import torch
@@ -127,6 +128,17 @@ class _DWConv(nn.Module):
         return y.flatten(2).transpose(1, 2)
 
 
+TWO_STREAMS = os.environ.get("CPN_GETZ_TWO_STREAMS", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _tokens_to_map(x, h):
     B, L, C = x.shape
     return x.transpose(1, 2).reshape(B, C, h, L // h)
@@ -207,8 +219,24 @@ class UFCLayer(nn.Module):
 
     def forward(self, corr, src, trg, ops):             # aggregation.py:342-356
         t4 = lambda x: x.permute(0, 1, 4, 5, 2, 3)
-        corr_src, src_r = self._attention(corr, src, ops)
-        corr_trg, trg_r = self._attention(t4(corr).contiguous(), trg, ops)
+        if corr.is_cuda and TWO_STREAMS and torch.cuda.is_current_stream_capturing():
+            # Inside a HIP-graph capture (coponerf_amd/graphs.py) the source and target attention passes — independent,
+            # and made of kernels that each fill a fraction of the chip (16^4 volumes, a few hundred workgroups) — are
+            # forked onto a second stream: the replay runs them side by side (14.1 vs 15.1 ms per pair).  Not in eager
+            # mode: there the host launch rate is the limit anyway, and blocks that change streams make the caching
+            # allocator fall back to hipMalloc in the next call (a serial get_z -> render loop got 35 % slower).
+            cur = torch.cuda.current_stream()
+            side = _side_stream(corr.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                corr_trg, trg_r = self._attention(t4(corr).contiguous(), trg, ops)
+            corr_src, src_r = self._attention(corr, src, ops)
+            cur.wait_stream(side)
+            corr_trg.record_stream(cur)
+            trg_r.record_stream(cur)
+        else:
+            corr_src, src_r = self._attention(corr, src, ops)
+            corr_trg, trg_r = self._attention(t4(corr).contiguous(), trg, ops)
         corr_r = corr_src + t4(corr_trg)
         corr_r = corr_r + self.feat_to_corr1(ops.correlation_tokens(src_r, trg_r, self.fs), ops)
         corr_r = corr_r + self.mlp_refine_corr(corr_r, ops)

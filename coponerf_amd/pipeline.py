@@ -49,15 +49,24 @@ def _pair_slice(obj, lo: int, hi: int, per: int):
     return obj
 
 
-def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1) -> Iterator[Tuple[Dict, Dict]]:
+def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: bool = False) -> Iterator[Tuple[Dict, Dict]]:
     """For every model_input dict (on the device) yield (model_input, forward(model_input, z, rel_pose, val=True, flow)),
     with `get_z` of the next inputs overlapped with the render of the current ones.  Call under torch.no_grad().
 
     getz_batch > 1 runs `get_z` ONCE for that many consecutive inputs (batched along dim 0: its ~1 100 kernels are
     launch / latency bound, 15.8 ms for one pair, ~10 ms per pair at four) and renders them one after the other from
     slices of the batched features; per-pair results are those of the serial order up to the rounding noise of get_z's
-    atomically accumulated GroupNorm statistics (tests/test_gpu_getz.py)."""
+    atomically accumulated GroupNorm statistics (tests/test_gpu_getz.py).
+
+    graph=True replays `get_z` as a captured HIP graph (coponerf_amd/graphs.py: one hipGraphLaunch instead of ~1 100
+    eager launches; same kernels, same results)."""
     it = iter(inputs)
+    getz = model.get_z
+    if graph:
+        from .graphs import GraphedGetZ
+        getz = getattr(model, "_graphed_getz", None)
+        if getz is None:
+            getz = model._graphed_getz = GraphedGetZ(model)
 
     def take():
         grp = []
@@ -68,7 +77,7 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1) -> Iterato
         return grp
 
     def features(grp):
-        feats = model.get_z(grp[0] if len(grp) == 1 else _collate(grp))
+        feats = getz(grp[0] if len(grp) == 1 else _collate(grp))
         return feats, getattr(model._engine, "_l3_hint", None), [int(g["context"]["rgb"].shape[0]) for g in grp]
 
     cur = take()

@@ -166,6 +166,8 @@ def test_pipelined_images_equal_serial(dev):
         serial = [serial_rgb(p) for p in pairs]
         piped = [out["rgb"].clone() for _, out in render_images(model, pairs)]
         batched = [out["rgb"].clone() for _, out in render_images(model, pairs, getz_batch=2)]   # groups of 2 + 1
+        graphed = [out["rgb"].clone() for _, out in render_images(model, pairs, graph=True)]     # get_z as a HIP graph
+        graphed2 = [out["rgb"].clone() for _, out in render_images(model, pairs[::-1], graph=True)]   # replay only
         again = serial_rgb(pairs[0])
     torch.cuda.synchronize()
     # get_z accumulates its GroupNorm statistics with atomics: two runs of the SAME pair agree to rounding only
@@ -173,6 +175,13 @@ def test_pipelined_images_equal_serial(dev):
     assert len(piped) == 3 and len(batched) == 3
     for a, b in zip(serial, piped):
         assert float((a - b).abs().max()) <= max(10 * noise, 1e-6), (float((a - b).abs().max()), noise)
+    for a, b, c in zip(serial, graphed, graphed2[::-1]):
+        assert float((a - b).abs().max()) <= max(10 * noise, 2e-5), (float((a - b).abs().max()), noise)
+        assert float((a - c).abs().max()) <= max(10 * noise, 2e-5), (float((a - c).abs().max()), noise)
+    # a parameter reload drops the captured graph (CoPoNeRF._param_epoch)
+    epoch = model._param_epoch
+    model.load_state_dict(model.state_dict())
+    assert model._param_epoch == epoch + 1
     # get_z batched over two pairs (one launch sequence for both), rendered from slices of the batched features
     for a, b in zip(serial, batched):
         assert float((a - b).abs().max()) <= max(10 * noise, 2e-5), (float((a - b).abs().max()), noise)
