@@ -350,6 +350,72 @@ def test_encode_hidden_against_torch(dev):
     assert e_t <= 1.5 * e_g + 1e-5, (e_t, e_g)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,R,S,ray0,nrays", [
+    (1, 1, 1, 0, 1),            # one row pair
+    (1, 5, 3, 0, 5),            # neither a multiple of the 4-ray x 4-sample wave tile
+    (2, 7, 9, 3, 9),            # a ray range that starts mid-group and crosses the batch boundary
+    (3, 6, 33, 6, 12),          # all of batch element 1 and 2, none of 0
+    (2, 17, 64, 30, 4),         # the tail of the last element
+    (1, 130, 8, 1, 127),        # more than 8 workgroups' worth of wave tiles, odd ends
+])
+def test_encode_hidden_ragged_ranges(B, R, S, ray0, nrays, dev):
+    """cpn_encode_hidden on ray sub-ranges / shapes that leave wave tiles partly dead: rows inside the range equal the
+    gather + GEMM form (same fp16 inputs, two valid roundings apart), rows outside it are not written at all."""
+    from coponerf_amd import _hip
+    from coponerf_amd._hip import call
+    g = torch.Generator().manual_seed(1000 * B + 10 * R + S)
+    V, H = 2, 32
+    N = B * V
+    z = [torch.randn(N, 256, H // 16, H // 16, generator=g), torch.randn(N, 256, H // 8, H // 8, generator=g),
+         torch.randn(N, 256, H // 4, H // 4, generator=g), torch.randn(N, 64, H, H, generator=g)]
+    pv = torch.rand(N, R, S, 2, generator=g) * 2.4 - 1.2
+    sg = torch.rand(N, R, S, 2, generator=g) * 3 - 1.5
+    pe = torch.rand(N, R, S, 6, generator=g) * 2 - 1
+    W1 = (torch.rand(832, 835, generator=g) * 2 - 1) / 835 ** 0.5
+    b1 = (torch.rand(832, generator=g) * 2 - 1) * 0.05
+    s = torch.cuda.current_stream().cuda_stream
+    maps = []
+    for t in z:
+        n, c, h, w = t.shape
+        d = torch.empty(n, h, w, c, dtype=torch.float16, device=dev)
+        src = t.to(dev).contiguous()
+        call("cpn_nchw_to_nhwc_f16", src.data_ptr(), d.data_ptr(), n, c, h, w, s)
+        maps.append(d)
+    W1d, b1d = W1.to(dev).contiguous(), b1.to(dev).contiguous()
+    frag = torch.empty(13 * 3 * 4 * 64 * 8, dtype=torch.float16, device=dev)
+    wtab = torch.empty(_hip.TAB_LD, 768, dtype=torch.float16, device=dev)
+    call("cpn_pack_encode_weights", W1d.data_ptr(), 835, frag.data_ptr(), wtab.data_ptr(), s)
+    zero_bias = torch.zeros(_hip.TAB_LD, device=dev)
+    nodes = N * int(_hip.lib().cpn_encode_table_nodes(H, H))
+    feat = torch.empty(nodes, 768, dtype=torch.float16, device=dev)
+    call("cpn_node_features", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), H, H, N, feat.data_ptr(), s)
+    tab = torch.empty(nodes, _hip.TAB_LD, dtype=torch.float16, device=dev)
+    call("cpn_gemm_f16", feat.data_ptr(), 768, wtab.data_ptr(), 768, zero_bias.data_ptr(), tab.data_ptr(), _hip.TAB_LD,
+         nodes, _hip.TAB_LD, 768, 0, 0, s)
+    pvd, sgd, ped = pv.to(dev), sg.to(dev), pe.to(dev)
+    rows = nrays * V * S * 2                                   # the chunk's rows only (row 0 = ray0)
+    guard = 64                                                 # canary rows behind the chunk
+    hid = torch.full((rows + guard, 832), float("nan"), dtype=torch.float16, device=dev)
+    call("cpn_encode_hidden", tab.data_ptr(), maps[3].data_ptr(), H, H, pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(),
+         frag.data_ptr(), b1d.data_ptr(), B, V, R, S, ray0, nrays, hid.data_ptr(), s)
+    xin = torch.zeros(rows, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
+    call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, H,
+         pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(), B, V, R, S, ray0, nrays, xin.data_ptr(), s)
+    W16 = torch.empty(832, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
+    call("cpn_pack_weight_f16", W1d.data_ptr(), 832, 835, W16.data_ptr(), _hip.XIN_STRIDE, s)
+    hid_g = torch.empty(rows, 832, dtype=torch.float16, device=dev)
+    call("cpn_gemm_f16", xin.data_ptr(), _hip.XIN_STRIDE, W16.data_ptr(), _hip.XIN_STRIDE, b1d.data_ptr(),
+         hid_g.data_ptr(), 832, rows, 832, _hip.XIN_K, 1, 0, s)
+    torch.cuda.synchronize()
+    got, ref = hid[:rows].float().cpu(), hid_g.float().cpu()
+    assert torch.isfinite(got).all(), "rows of the chunk left unwritten"
+    assert torch.isnan(hid[rows:].float()).all(), "wrote past the chunk"
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= 6e-3 * scale, float((got - ref).abs().max())
+    assert float((got - ref).pow(2).mean().sqrt()) <= 4e-4 * scale
+
+
 def test_table_mode_matches_gather_mode(model, dev, weights):
     """RenderEngine(tables=False) materialises the gathered 835-channel rows and runs the 835 -> 832 GEMM on them
     (round-1 form, still what the training pass differentiates); the default projected-table form must agree with it
