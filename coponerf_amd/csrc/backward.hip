@@ -13,6 +13,163 @@
 #include "common.h"
 #include "taps.h"
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradients of the 128-wide per-sample layers: dW (128, K) = dY^T (128, M) . X (M, K) with M = millions of rows
+// and K = 128 (fp16 operands) or 16 (fp32 operands).  69 / 8.6 GFLOP over 1.07 GB of operands: pure streaming work,
+// but the library's GEMM heuristics pick split-K kernels that run these at 24 TFLOP/s (2.9 ms and 2.2 ms per call,
+// 13 ms per training step).  Here a workgroup streams 64-row tiles of both operands through LDS (coalesced 16-byte
+// loads), the contraction index (the row) is put on the MFMA K axis by reading the fragments column-wise from the
+// row-major LDS image (2-byte LDS reads: slow per element, irrelevant at 0.27 FLOP per byte), partial sums leave with
+// one atomic pass per workgroup.  db[n] = sum_m dY[m][n] falls out of the same loads.
+// ---------------------------------------------------------------------------------------------
+constexpr int WS_ROWS = 64;                 // rows per tile
+constexpr int WS_LD = 128 + 2;              // padded row stride (halves): the 4 K groups of a fragment hit different banks
+
+__global__ __launch_bounds__(256) void wgrad_skinny_f16_kernel(const __half* __restrict__ dY, const __half* __restrict__ X,
+                                                               int ldx, long long M, float* __restrict__ dW,
+                                                               float* __restrict__ db) {
+    __shared__ __attribute__((aligned(16))) __half sy[WS_ROWS * WS_LD];
+    __shared__ __attribute__((aligned(16))) __half sx[WS_ROWS * WS_LD];
+    __shared__ float sdb[16][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int lr = tid >> 4, lc = (tid & 15) * 8;            // loader: row lr (+16 per pass), 8 columns from lc
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long ntiles = (M + WS_ROWS - 1) / WS_ROWS;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long m0 = t * WS_ROWS;
+        half8 vy[4], vx[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long long m = m0 + lr + 16 * p;
+            if (m < M) {
+                vy[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(dY + m * 128 + lc));
+                vx[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(X + m * ldx + lc));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { vy[p][e] = (_Float16)0.0f; vx[p][e] = (_Float16)0.0f; }
+            }
+        }
+        __syncthreads();                                      // previous tile's fragments are read
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // rows are 260 bytes apart: 4-byte stores
+            unsigned* py = reinterpret_cast<unsigned*>(sy + (lr + 16 * p) * WS_LD + lc);
+            unsigned* px = reinterpret_cast<unsigned*>(sx + (lr + 16 * p) * WS_LD + lc);
+            const u32x4 uy = __builtin_bit_cast(u32x4, vy[p]), ux = __builtin_bit_cast(u32x4, vx[p]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { py[e] = uy[e]; px[e] = ux[e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += (float)vy[p][e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < WS_ROWS / 32; ++ks) {
+            // fragment element e of lane (fi, fg): row ks*32 + fg*8 + e, column tile*16 + fi
+            half8 fa[2], fb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int row = ks * 32 + fg * 8 + e;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fa[a][e] = sy[row * WS_LD + (wave * 2 + a) * 16 + fi];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) fb[b][e] = sx[row * WS_LD + b * 16 + fi];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // D tile (a, b): lane (fi, fg) holds rows n = (wave*2+a)*16 + fg*4 + i, column k = b*16 + fi
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                atomicAdd(dW + ((wave * 2 + a) * 16 + fg * 4 + i) * 128 + b * 16 + fi, acc[a][b][i]);
+    if (db) {
+        // threads with the same (tid & 15) own the same 8 columns: reduce the 16 row groups through LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = bsum[e];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            bsum[e] = v;
+        }
+        __syncthreads();
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdb[lane][e] = 0.0f;
+        }
+        __syncthreads();
+        if (fg == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&sdb[fi][e], bsum[e]);
+        }
+        __syncthreads();
+        if (tid < 128) atomicAdd(db + tid, sdb[tid >> 3][tid & 7]);
+    }
+}
+
+// dW (128, 16) = d^T (128, M) . L (M, 16), fp32: thread = (output row n, half of the 16 columns), rows streamed
+__global__ __launch_bounds__(256) void wgrad_small_f32_kernel(const float* __restrict__ d, const float* __restrict__ L,
+                                                              long long M, long long rows_per_block,
+                                                              float* __restrict__ dW) {
+    const int n = threadIdx.x & 127, kh = threadIdx.x >> 7;
+    const long long m0 = (long long)blockIdx.x * rows_per_block;
+    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long m = m0; m < m1; ++m) {
+        const float dv = d[m * 128 + n];
+        const f32x4 l0 = *reinterpret_cast<const f32x4*>(L + m * 16 + kh * 8);
+        const f32x4 l1 = *reinterpret_cast<const f32x4*>(L + m * 16 + kh * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] += dv * l0[e];
+            acc[4 + e] += dv * l1[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(dW + n * 16 + kh * 8 + e, acc[e]);
+}
+
+}  // namespace
+
+extern "C" int cpn_wgrad_skinny_f16(const uint16_t* dY, const uint16_t* X, int ldx, long long M, float* dW, float* db,
+                                    void* stream) {
+    CPN_REQUIRE(dY && X && dW, CPN_E_ARG, "cpn_wgrad_skinny_f16: null pointer");
+    CPN_REQUIRE(M > 0 && ldx >= 128 && (ldx % 8) == 0, CPN_E_SHAPE, "cpn_wgrad_skinny_f16: bad shape (ldx=%d)", ldx);
+    CPN_REQUIRE(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0, CPN_E_ARG,
+                "cpn_wgrad_skinny_f16: operands must be 16-byte aligned");
+    const long long ntiles = (M + WS_ROWS - 1) / WS_ROWS;
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, 1024);
+    hipLaunchKernelGGL(wgrad_skinny_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __half*)dY,
+                       (const __half*)X, ldx, M, dW, db);
+    CPN_LAUNCH_CHECK("cpn_wgrad_skinny_f16");
+    return 0;
+}
+
+extern "C" int cpn_wgrad_small_f32(const float* d, const float* L, long long M, float* dW, void* stream) {
+    CPN_REQUIRE(d && L && dW, CPN_E_ARG, "cpn_wgrad_small_f32: null pointer");
+    CPN_REQUIRE(M > 0, CPN_E_SHAPE, "cpn_wgrad_small_f32: M must be positive");
+    CPN_REQUIRE(((uintptr_t)L % 16) == 0, CPN_E_ARG, "cpn_wgrad_small_f32: L must be 16-byte aligned");
+    const long long rpb = std::max<long long>(64, (M + 4095) / 4096);
+    const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
+    hipLaunchKernelGGL(wgrad_small_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d, L, M, rpb, dW);
+    CPN_LAUNCH_CHECK("cpn_wgrad_small_f32");
+    return 0;
+}
+
 extern "C" long long cpn_gather_bwd_chunks(int R, int S);
 
 namespace {

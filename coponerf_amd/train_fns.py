@@ -124,6 +124,13 @@ class GemmFn(Function):
                 d = torch.ops.aten.threshold_backward(d, C.to(d.dtype) if C.dtype != d.dtype else C, 0)   # d where C > 0
             d16 = d.to(torch.float16)
         dA = _data_grad(d16, W16) if ctx.needs_input_grad[0] else None               # (M, lda) fp16, scaled; pad columns get 0
+        if d16.shape[1] == 128 and A16.shape[1] == 128 and d16.is_contiguous() and ctx.needs_input_grad[1]:
+            # 128 x 128 outputs over millions of rows: a streaming reduction, not a GEMM the library handles well
+            dW = torch.zeros(128, 128, dtype=torch.float32, device=d16.device)
+            db = torch.zeros(128, dtype=torch.float32, device=d16.device)
+            call("cpn_wgrad_skinny_f16", d16.data_ptr(), A16.data_ptr(), 128, d16.shape[0], dW.data_ptr(), db.data_ptr(),
+                 _stream())
+            return dA, dW[:, :ctx.K] * inv, (db * inv if ctx.needs_input_grad[2] else None), None, None, None, None, None
         dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
         db = d.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[2] else None
         return dA, dW, db, None, None, None, None, None
@@ -189,8 +196,9 @@ class LocalHiddenFn(Function):
         B, V, R, S = ctx.dims
         ds = ctx.gs.scaled16(dout.contiguous()).to(torch.float16)
         d = torch.ops.aten.threshold_backward(ds, out, 0).float() * (1.0 / ctx.gs.s)      # fp32, true scale from here on
-        L = build_local_coords(loc8, coords9, B, V, R, S)
-        dW = d.t() @ L
+        L = build_local_coords(loc8, coords9, B, V, R, S).contiguous()
+        dW = torch.zeros(128, 16, dtype=torch.float32, device=d.device)
+        call("cpn_wgrad_small_f32", d.data_ptr(), L.data_ptr(), d.shape[0], dW.data_ptr(), _stream())
         dadd = d.view(B * R, V * S, 128).sum(1) if ctx.has_add else None
         return None, None, dW, d.sum(0), dadd, None, None
 

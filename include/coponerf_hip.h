@@ -194,6 +194,14 @@ int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, const uint16_t
 int cpn_hid_grad_combine(const uint16_t* dkey, const uint16_t* hid, const float* w1, const float* dh1, const float* w2,
                          const float* dh2, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out, void* stream);
 
+/* weight gradients of the 128-wide per-sample layers (torch.mm(dY.t(), X) in the reference's autograd, i.e. the
+ * Conv2d(128->128,1x1) / Conv2d(16->128,1x1) layers of models/CoPoNeRF.py:82,85-86,95-96 under wrapper.py:138):
+ *   dW (128,128) fp32 += dY^T . X,  db (128) fp32 += column sums of dY (or NULL);  dY (M,128) fp16, X (M,ldx) fp16 of
+ *   which the first 128 columns are used.  Both outputs are accumulated: the caller zeroes them.                      */
+int cpn_wgrad_skinny_f16(const uint16_t* dY, const uint16_t* X, int ldx, long long M, float* dW, float* db, void* stream);
+/*   dW (128,16) fp32 += d^T . L,  d (M,128) fp32, L (M,16) fp32                                                     */
+int cpn_wgrad_small_f32(const float* d, const float* L, long long M, float* dW, void* stream);
+
 /* gradient of cpn_gather_rows w.r.t. the feature maps: dxin (rows, ldx) fp16 -> accumulated into dmap0..3
  * (N,h,w,C) fp32 NHWC, which the caller zeroes first.  No coordinate gradient (CoPoNeRF.py:380-381).
  * chunk_boxes: scratch of B*V*cpn_gather_bwd_chunks(R,S)*16 int32.                                                */

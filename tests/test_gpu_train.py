@@ -274,3 +274,31 @@ def test_config3_size_training_step(dev):
         rel_err = float((g_all[n] - want).norm() / (want.norm() + 1e-20))
         # the batched and the per-pair passes pick their fp16 gradient scale separately: equal up to fp16 rounding
         assert rel_err <= 2e-2, (n, rel_err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 63, 64, 4099, 70000])
+def test_skinny_weight_gradient_kernels(M):
+    """cpn_wgrad_skinny_f16 / cpn_wgrad_small_f32 (dW = dY^T . X over M rows for the 128-wide layers) against float64."""
+    from coponerf_amd._hip import call
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M)
+    dY = (torch.randn(M, 128, generator=g) * 0.5).half()
+    X = torch.randn(M, 160, generator=g).half()                     # row stride 160 > 128: only the first 128 columns count
+    s = torch.cuda.current_stream().cuda_stream
+    dYd, Xd = dY.to(dev), X.to(dev)
+    dW = torch.zeros(128, 128, device=dev)
+    db = torch.zeros(128, device=dev)
+    call("cpn_wgrad_skinny_f16", dYd.data_ptr(), Xd.data_ptr(), 160, M, dW.data_ptr(), db.data_ptr(), s)
+    want = dY.double().t() @ X[:, :128].double()
+    wantb = dY.double().sum(0)
+    tol = 2e-4 * max(1.0, float(want.abs().max()))
+    assert float((dW.cpu().double() - want).abs().max()) <= tol, float((dW.cpu().double() - want).abs().max())
+    assert float((db.cpu().double() - wantb).abs().max()) <= 2e-4 * max(1.0, float(wantb.abs().max()))
+    d32 = torch.randn(M, 128, generator=g)
+    L = torch.randn(M, 16, generator=g)
+    dW2 = torch.zeros(128, 16, device=dev)
+    d32d, Ld = d32.to(dev), L.to(dev)
+    call("cpn_wgrad_small_f32", d32d.data_ptr(), Ld.data_ptr(), M, dW2.data_ptr(), s)
+    want2 = d32.double().t() @ L.double()
+    assert float((dW2.cpu().double() - want2).abs().max()) <= 2e-5 * max(1.0, float(want2.abs().max()))
