@@ -46,6 +46,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_gn_relu_bwd": [_P, _P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "cpn_conv_wgrad_planes": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_dwconv3x3_wgrad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_dwconv3x3_tokens": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_dwconv3x3_tokens_wgrad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "cpn_dual_softmax": [_P, _I, _I, _I, _P, _P, _P, _P],
     "cpn_dual_softmax_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],

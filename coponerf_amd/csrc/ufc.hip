@@ -516,6 +516,70 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same depthwise convolution directly on the TOKEN layout (B, L = H*W, C) the feed-forward blocks work in
+// (aggregation.py:18-28 transposes to (B,C,H,W), runs the grouped Conv2d and transposes back).  With the channel
+// innermost a thread = (position, 4 channels) reads nine coalesced float4 rows: no transposed copies on either side,
+// and the library's depthwise kernel (0.76 ms for 4 x 1024 x 64 x 64, 12x the streaming time) is not needed.
+//   flip = 0: y = b + sum_ij w[c][i][j] * x[p + (i-1, j-1)]        (forward)
+//   flip = 1: y =     sum_ij w[c][2-i][2-j] * x[p + (i-1, j-1)]    (data gradient: correlation with the flipped taps)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv3x3_tokens_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, int H, int W, int C4,
+                                                               long long total, int flip, float* __restrict__ y) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % C4);
+    const long long pos = idx / C4;                           // b * H*W + yy * W + xx
+    const int xx = (int)(pos % W);
+    const int yy = (int)((pos / W) % H);
+    const int C = C4 * 4;
+    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float wr[4][9];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[e][t] = w[(c4 * 4 + e) * 9 + (flip ? 8 - t : t)];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int Y = yy + i - 1, X = xx + j - 1;
+            if (Y < 0 || Y >= H || X < 0 || X >= W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (pos + (long long)(i - 1) * W + (j - 1)) * C + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += wr[e][i * 3 + j] * v[e];
+        }
+    *reinterpret_cast<f32x4*>(y + pos * C + c4 * 4) = acc;
+}
+
+// weight / bias gradient in the token layout: block = (slab of positions) x (256 consecutive channels), thread = channel
+__global__ __launch_bounds__(256) void dwconv3x3_tokens_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     int H, int W, int C, long long npos, int slab,
+                                                                     float* __restrict__ dw, float* __restrict__ db) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long long p0 = (long long)blockIdx.x * slab;
+    const long long p1 = p0 + slab < npos ? p0 + slab : npos;
+    float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long pos = p0; pos < p1; ++pos) {
+        const int xx = (int)(pos % W);
+        const int yy = (int)((pos / W) % H);
+        const float g = dy[pos * C + c];
+        a[9] += g;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int Y = yy + i - 1, X = xx + j - 1;
+                if (Y >= 0 && Y < H && X >= 0 && X < W) a[i * 3 + j] += g * x[(pos + (long long)(i - 1) * W + (j - 1)) * C + c];
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(dw + c * 9 + t, a[t]);
+    if (db) atomicAdd(db + c, a[9]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // correlation: tokens (B, L, C) -> x / (||x|| + eps), then C[b] = S_n[b] . T_n[b]^T with the exact-f32 MFMA
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -1008,6 +1072,33 @@ extern "C" int cpn_dwconv3x3_wgrad(const float* x, const float* dy, int N, int C
                 "cpn_dwconv3x3_wgrad: bad shape");
     hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, dy, N, C, H, W, dw, db);
     CPN_LAUNCH_CHECK("cpn_dwconv3x3_wgrad");
+    return 0;
+}
+
+extern "C" int cpn_dwconv3x3_tokens(const float* x, const float* w, const float* bias, int B, int H, int W, int C,
+                                    int flip, float* y, void* stream) {
+    CPN_REQUIRE(x && w && y, CPN_E_ARG, "cpn_dwconv3x3_tokens: null pointer");
+    CPN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, CPN_E_SHAPE, "cpn_dwconv3x3_tokens: need C %% 4 == 0");
+    CPN_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0, CPN_E_ARG,
+                "cpn_dwconv3x3_tokens: pointers must be 16-byte aligned");
+    const long long total = (long long)B * H * W * (C / 4);
+    CPN_REQUIRE(total / 256 < (1LL << 31), CPN_E_SHAPE, "cpn_dwconv3x3_tokens: too large");
+    hipLaunchKernelGGL(dwconv3x3_tokens_kernel, dim3((unsigned)cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, H, W, C / 4, total, flip, y);
+    CPN_LAUNCH_CHECK("cpn_dwconv3x3_tokens");
+    return 0;
+}
+
+extern "C" int cpn_dwconv3x3_tokens_wgrad(const float* x, const float* dy, int B, int H, int W, int C, float* dw, float* db,
+                                          void* stream) {
+    CPN_REQUIRE(x && dy && dw, CPN_E_ARG, "cpn_dwconv3x3_tokens_wgrad: null pointer");
+    CPN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, CPN_E_SHAPE, "cpn_dwconv3x3_tokens_wgrad: bad shape");
+    const long long npos = (long long)B * H * W;
+    const int slab = (int)std::max<long long>(16, cpn_cdiv(npos, 512));
+    dim3 grid((unsigned)cpn_cdiv(npos, slab), (unsigned)cpn_cdiv(C, 256));
+    hipLaunchKernelGGL(dwconv3x3_tokens_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, dy, H, W, C, npos, slab, dw,
+                       db);
+    CPN_LAUNCH_CHECK("cpn_dwconv3x3_tokens_wgrad");
     return 0;
 }
 

@@ -119,12 +119,11 @@ class _DWConv(nn.Module):
 
     def forward(self, x):                       # (B, L, C) tokens
         B, L, C = x.shape
+        if x.is_cuda and x.dtype == torch.float32 and C % 4 == 0:
+            from .ufc_ops import DwConvTokensFn            # the convolution on the token layout itself (csrc/ufc.hip)
+            return DwConvTokensFn.apply(x, self.dwconv.weight, self.dwconv.bias, self.size)
         xm = x.transpose(1, 2).reshape(B, C, self.size, self.size)
-        if xm.is_cuda and torch.is_grad_enabled() and (xm.requires_grad or self.dwconv.weight.requires_grad):
-            from .ufc_ops import DwConv3x3Fn               # training on the GPU: HIP weight-gradient kernel
-            y = DwConv3x3Fn.apply(xm, self.dwconv.weight, self.dwconv.bias)
-        else:
-            y = self.dwconv(xm)
+        y = self.dwconv(xm)
         return y.flatten(2).transpose(1, 2)
 
 

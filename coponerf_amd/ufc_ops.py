@@ -222,6 +222,41 @@ class DwConv3x3Fn(Function):
         return dx, dw, db
 
 
+class DwConvTokensFn(Function):
+    """The DWConv of the UFC feed-forward blocks on the token layout (B, L = size*size, C) itself: forward, data
+    gradient and weight gradient on cpn_dwconv3x3_tokens / _wgrad — no (B,C,H,W) transposes on either side."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, size: int):
+        B, L, C = x.shape
+        xc = x.detach().contiguous().float()
+        wc = w.detach().reshape(C, 9).contiguous().float()
+        bc = None if b is None else b.detach().contiguous().float()
+        y = torch.empty_like(xc)
+        call("cpn_dwconv3x3_tokens", xc.data_ptr(), wc.data_ptr(), 0 if bc is None else bc.data_ptr(), B, size, size, C, 0,
+             y.data_ptr(), _stream())
+        ctx.save_for_backward(xc, wc)
+        ctx.size, ctx.has_b, ctx.wshape = size, b is not None, tuple(w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        B, L, C = xc.shape
+        dyc = dy.contiguous().float()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xc)
+            call("cpn_dwconv3x3_tokens", dyc.data_ptr(), wc.data_ptr(), 0, B, ctx.size, ctx.size, C, 1, dx.data_ptr(), _stream())
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = torch.zeros(C, 9, dtype=torch.float32, device=xc.device)
+            db = torch.zeros(C, dtype=torch.float32, device=xc.device) if ctx.has_b else None
+            call("cpn_dwconv3x3_tokens_wgrad", xc.data_ptr(), dyc.data_ptr(), B, ctx.size, ctx.size, C, dw.data_ptr(),
+                 0 if db is None else db.data_ptr(), _stream())
+            dw = dw.view(ctx.wshape)
+        return dx, dw, db, None
+
+
 class _ResizeFn(Function):
     """forward: cpn_resize_bilinear_ac.  backward: the adjoint of the (linear) interpolation, no forward re-run."""
 

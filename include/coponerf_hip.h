@@ -253,6 +253,15 @@ int cpn_conv_wgrad_planes(const float* x, const float* dy, int B, int Cin, int C
 int cpn_dwconv3x3_wgrad(const float* x, const float* dy, int N, int C, int H, int W, float* dw, float* db,
                         void* stream);
 
+/* the same DWConv directly on the token layout x (B, H*W, C) fp32 the feed-forward blocks work in (the reference
+ * transposes to (B,C,H,W) around a grouped Conv2d, aggregation.py:18-28): y = bias + w (*) x (flip = 0, forward) or the
+ * data gradient w_flipped (*) dy (flip = 1, bias NULL).  w (C,9).  C % 4 == 0.                                        */
+int cpn_dwconv3x3_tokens(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int flip, float* y,
+                         void* stream);
+/* its weight / bias gradient: dw (C,9), db (C, may be NULL) are ACCUMULATED into (the caller zeroes them)             */
+int cpn_dwconv3x3_tokens_wgrad(const float* x, const float* dy, int B, int H, int W, int C, float* dw, float* db,
+                               void* stream);
+
 /* dual softmax of the pose branch's cross attention (models/backbone.py:296-330), a (B,L,M) fp32:
  * f = softmax(a, dim=-1) * softmax(a, dim=-2); rstat (B,L,2) / cstat (B,M,2) receive (max, sum exp) per row / column
  * and feed the backward: da from df with srow (B,L), scol (B,M) scratch.                                            */

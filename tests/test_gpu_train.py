@@ -198,6 +198,30 @@ def test_conv_weight_gradient_kernels(dev):
         grads.append((xs.grad, ws.grad, bs.grad))
     for g_ref, g_hip in zip(*grads):
         assert (g_ref - g_hip).abs().max() <= 2e-4 * (1 + g_ref.abs().max())
+    # the token-layout form (B, H*W, C) used by the feed-forward blocks: value and all three gradients against the
+    # reference's transpose -> grouped Conv2d -> transpose (models/aggregation.py:18-28); non-square check via H != W is
+    # not needed (size x size maps only), but an odd size and C = 44 (not a multiple of 8) are
+    from coponerf_amd.ufc_ops import DwConvTokensFn
+    for (Bq, size, C) in ((2, 7, 44), (3, 16, 256)):
+        xt = syn.normal((Bq, size * size, C), seed=76 + C).to(dev)
+        wt = (syn.normal((C, 1, 3, 3), seed=77 + C) * 0.3).to(dev)
+        bt = (syn.normal((C,), seed=78 + C) * 0.1).to(dev)
+        ct = syn.normal((Bq, size * size, C), seed=79 + C).to(dev)
+
+        def ref(a, w_, b_):
+            m = a.transpose(1, 2).reshape(Bq, C, size, size)
+            return F.conv2d(m, w_, b_, 1, 1, 1, C).flatten(2).transpose(1, 2)
+        outs, grads = [], []
+        for fn in (ref, lambda a, w_, b_: DwConvTokensFn.apply(a, w_, b_, size)):
+            xs, ws, bs = (t.clone().requires_grad_(True) for t in (xt, wt, bt))
+            y = fn(xs, ws, bs)
+            (y * ct).sum().backward()
+            outs.append(y.detach())
+            grads.append((xs.grad, ws.grad, bs.grad))
+        assert (outs[0] - outs[1]).abs().max() <= 1e-5 * (1 + outs[0].abs().max())
+        for g_ref, g_hip in zip(*grads):
+            assert g_ref.shape == g_hip.shape
+            assert (g_ref - g_hip).abs().max() <= 2e-4 * (1 + g_ref.abs().max())
 
 
 def test_mean_loss_gradients_survive_fp16(dev):
