@@ -15,18 +15,24 @@ from coponerf_amd import CoPoNeRF, synthetic as syn      # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--top", type=int, default=60)
 ap.add_argument("--all", action="store_true")
+ap.add_argument("--getz", type=int, default=0, metavar="B", help="profile one inference get_z at batch B instead of a training step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 model = CoPoNeRF.CoPoNeRF(n_view=2)
 shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
 model.load_state_dict(syn.make_full_weights(shapes), strict=True)
-model = model.to(dev).train()
+model = model.to(dev)
+model.eval() if a.getz else model.train()
 mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (o.to(dev) if torch.is_tensor(o) else o)
-inp = mv(syn.make_inputs(4, 256, 256, 4096, seed=61))
+inp = mv(syn.make_inputs(a.getz or 4, 256, 256, 4096, seed=61))
 opt = torch.optim.Adam(model.parameters(), lr=1e-5)
 
 
 def step():
+    if a.getz:
+        with torch.no_grad():
+            model.get_z(inp)
+        return
     opt.zero_grad(set_to_none=True)
     out = model(inp, val=False)
     (out["rgb"] - inp["query"]["rgb"]).abs().mean().backward()
