@@ -121,26 +121,45 @@ __global__ __launch_bounds__(256) void wgrad_skinny_f16_kernel(const __half* __r
     }
 }
 
-// dW (128, 16) = d^T (128, M) . L (M, 16), fp32: thread = (output row n, half of the 16 columns), rows streamed
+// dW (128, 16) = d^T (128, M) . L (M, 16), fp32.  thread = 4 consecutive output rows n (one 16-byte load of d per row
+// of the slab) x all 16 columns; 8 row lanes per block; four rows in flight per thread; the row of L is wave-uniform.
+// The 8 row lanes meet in LDS, one global atomic pass per block (global atomics from every thread cost 3x the kernel).
 __global__ __launch_bounds__(256) void wgrad_small_f32_kernel(const float* __restrict__ d, const float* __restrict__ L,
                                                               long long M, long long rows_per_block,
                                                               float* __restrict__ dW) {
-    const int n = threadIdx.x & 127, kh = threadIdx.x >> 7;
+    __shared__ float red[128 * 16];
+    const int n4 = threadIdx.x & 31, rl = threadIdx.x >> 5;                // 32 threads cover a 512-byte row of d
+    for (int i = threadIdx.x; i < 128 * 16; i += 256) red[i] = 0.0f;
+    __syncthreads();
     const long long m0 = (long long)blockIdx.x * rows_per_block;
     const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long m = m0; m < m1; ++m) {
-        const float dv = d[m * 128 + n];
-        const f32x4 l0 = *reinterpret_cast<const f32x4*>(L + m * 16 + kh * 8);
-        const f32x4 l1 = *reinterpret_cast<const f32x4*>(L + m * 16 + kh * 8 + 4);
+    f32x4 acc[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[e] += dv * l0[e];
-            acc[4 + e] += dv * l1[e];
+    for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    for (long long m = m0 + rl * U; m < m1; m += 8 * U) {
+        f32x4 dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            dv[u] = m + u < m1 ? *reinterpret_cast<const f32x4*>(d + (m + u) * 128 + n4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (m + u >= m1) break;
+            const float* lp = L + (m + u) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lp + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q * 4 + e] += dv[u] * l4[e];
+            }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(dW + n * 16 + kh * 8 + e, acc[e]);
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&red[(n4 * 4 + i) * 16 + k], acc[k][i]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 128 * 16; i += 256) atomicAdd(dW + i, red[i]);
 }
 
 }  // namespace
@@ -163,7 +182,7 @@ extern "C" int cpn_wgrad_small_f32(const float* d, const float* L, long long M, 
     CPN_REQUIRE(d && L && dW, CPN_E_ARG, "cpn_wgrad_small_f32: null pointer");
     CPN_REQUIRE(M > 0, CPN_E_SHAPE, "cpn_wgrad_small_f32: M must be positive");
     CPN_REQUIRE(((uintptr_t)L % 16) == 0, CPN_E_ARG, "cpn_wgrad_small_f32: L must be 16-byte aligned");
-    const long long rpb = std::max<long long>(64, (M + 4095) / 4096);
+    const long long rpb = std::max<long long>(64, (M + 1023) / 1024);
     const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
     hipLaunchKernelGGL(wgrad_small_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d, L, M, rpb, dW);
     CPN_LAUNCH_CHECK("cpn_wgrad_small_f32");

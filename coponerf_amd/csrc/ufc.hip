@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_tokens_wgrad_kernel(const float
     const long long p0 = (long long)blockIdx.x * slab;
     const long long p1 = p0 + slab < npos ? p0 + slab : npos;
     float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (long long pos = p0; pos < p1; ++pos) {
         const int xx = (int)(pos % W);
         const int yy = (int)((pos / W) % H);
@@ -1094,7 +1095,7 @@ extern "C" int cpn_dwconv3x3_tokens_wgrad(const float* x, const float* dy, int B
     CPN_REQUIRE(x && dy && dw, CPN_E_ARG, "cpn_dwconv3x3_tokens_wgrad: null pointer");
     CPN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, CPN_E_SHAPE, "cpn_dwconv3x3_tokens_wgrad: bad shape");
     const long long npos = (long long)B * H * W;
-    const int slab = (int)std::max<long long>(16, cpn_cdiv(npos, 512));
+    const int slab = (int)std::max<long long>(16, cpn_cdiv(npos, 192));
     dim3 grid((unsigned)cpn_cdiv(npos, slab), (unsigned)cpn_cdiv(C, 256));
     hipLaunchKernelGGL(dwconv3x3_tokens_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, dy, H, W, C, npos, slab, dw,
                        db);
