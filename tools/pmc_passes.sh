@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 counter passes (one --pmc group per run: SQ 8 / TCC 4 slots; never combined with tracing) for one command.
-#   tools/pmc_passes.sh <out_dir> <kernel_substring> -- <command...>
+#   tools/pmc_passes.sh <out_dir> <kernel_substring[,substring...]> -- <command...>
 # Writes <out_dir>/pass<i>/ (raw CSVs) and <out_dir>/summary.json (mean counter value per dispatch of the kernel).
 set -u
 OUT=$(realpath -m "$1"); KSUB="$2"; shift 3
@@ -24,16 +24,19 @@ for g in "${PMC_GROUPS[@]}"; do
   i=$((i+1))
 done
 python3 - "$OUT" "$KSUB" <<'PY'
-import csv, glob, json, os, sys, collections
-out, ksub = sys.argv[1], sys.argv[2]
-agg = collections.OrderedDict()
+import csv, glob, json, os, re, sys, collections
+out, ksubs = sys.argv[1], sys.argv[2].split(",")          # several kernels: comma-separated substrings
+aggs = [collections.OrderedDict() for _ in ksubs]
 for f in sorted(glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
-        if ksub in r["Kernel_Name"]:
-            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-res = {k: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for k, v in agg.items()}
-json.dump({"kernel": ksub, "counters": res}, open(os.path.join(out, "summary.json"), "w"), indent=1)
-print(json.dumps({k: round(v["mean_per_dispatch"], 1) for k, v in res.items()}, indent=1))
+        for ksub, agg in zip(ksubs, aggs):
+            if ksub in r["Kernel_Name"]:
+                agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+for i, (ksub, agg) in enumerate(zip(ksubs, aggs)):
+    res = {k: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for k, v in agg.items()}
+    name = "summary.json" if i == 0 else "summary_" + re.sub(r"[^A-Za-z0-9]+", "_", ksub).strip("_") + ".json"
+    json.dump({"kernel": ksub, "counters": res}, open(os.path.join(out, name), "w"), indent=1)
+    print(ksub, json.dumps({k: round(v["mean_per_dispatch"], 1) for k, v in res.items()}))
 PY
 # keep only the summaries and logs (raw CSVs are large)
 find "$OUT" -name "*.csv" -size +2M -delete
