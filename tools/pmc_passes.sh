@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 counter passes (one --pmc group per run: SQ 8 / TCC 4 slots; never combined with tracing) for one command.
-#   tools/pmc_passes.sh <out_dir> <kernel_substring[,substring...]> -- <command...>
+#   tools/pmc_passes.sh <out_dir> <kernel_substring[;substring...]> -- <command...>
 # Writes <out_dir>/pass<i>/ (raw CSVs) and <out_dir>/summary.json (mean counter value per dispatch of the kernel).
 set -u
 OUT=$(realpath -m "$1"); KSUB="$2"; shift 3
@@ -25,7 +25,7 @@ for g in "${PMC_GROUPS[@]}"; do
 done
 python3 - "$OUT" "$KSUB" <<'PY'
 import csv, glob, json, os, re, sys, collections
-out, ksubs = sys.argv[1], sys.argv[2].split(",")          # several kernels: comma-separated substrings
+out, ksubs = sys.argv[1], sys.argv[2].split(";")          # several kernels: ";"-separated substrings (kernel names contain commas)
 aggs = [collections.OrderedDict() for _ in ksubs]
 for f in sorted(glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
