@@ -216,7 +216,7 @@ def run(args):
     if tables:
         exec_per_ray -= S * 4 * 2.0 * 832 * (768 - 12)
     line = {
-        "metric": "rendered rays/sec (RealEstate10K-shaped 256x256 stereo pair, full-image render, 64 samples/ray)",
+        "metric": f"rendered rays/sec (RealEstate10K-shaped {H}x{H} stereo pair, full-image render, {S} samples/ray)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
