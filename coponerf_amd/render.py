@@ -337,7 +337,7 @@ class RenderEngine:
                      z: Sequence[torch.Tensor], rel_pose, val: bool, S: int, H: int, W: int) -> Dict[str, torch.Tensor]:
         """Same forward kernels as render(), wrapped in autograd Functions (coponerf_amd/train_fns.py); all rays of
         the call form one chunk (training uses <= 4096 rays per pair, /root/reference train.py:87)."""
-        from .train_fns import GemmFn, GradScale, HidGradParts, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn
+        from .train_fns import GemmFn, GradScale, HidGradParts, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn, EncodeFn
         dev = uv.device
         if dev.type != "cuda":
             raise RuntimeError("coponerf_amd renders on a HIP device only (got uv on %s)" % dev)
@@ -351,8 +351,13 @@ class RenderEngine:
         P = params
         mat = lambda n, rows: P[n + ".weight"].reshape(rows, -1)
         bias = lambda n: P[n + ".bias"]
-        xin = GatherFn.apply(z[0], z[1], z[2], z[3], g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs)
-        hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False, gs, hp, dims)
+        if self.tables:
+            # the first layer on the node tables, as in inference: no gathered input in the forward pass
+            hid = EncodeFn.apply(z[0], z[1], z[2], z[3], mat("query_encode_latent", 832), bias("query_encode_latent"),
+                                 g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs, hp)
+        else:
+            xin = GatherFn.apply(z[0], z[1], z[2], z[3], g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs)
+            hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False, gs, hp, dims)
         hid2 = hid.view(-1, 1664)
         W2, b2 = mat("query_encode_latent_2", 416), bias("query_encode_latent_2")
 

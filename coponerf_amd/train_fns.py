@@ -242,6 +242,87 @@ class AttendHiddenFn(Function):
         return dqa, dqb, dhid, None, None, None
 
 
+class EncodeFn(Function):
+    """hid fp16 (rows2, 832) = relu(query_encode_latent([gather | tanh(pt/5)])) through cpn_encode_hidden (node tables +
+    K = 80 MFMA: the inference kernel) — the gathered 835-channel input is NOT materialised in the forward
+    pass.  The backward is that of GatherFn + GemmFn: it re-gathers the input rows once (cpn_gather_rows, 2.8 ms) for the
+    weight gradient, forms the data gradient on cpn_gemm_f16 and scatters it into the maps (cpn_gather_rows_bwd)."""
+
+    @staticmethod
+    def forward(ctx, z0, z1, z2, z3, W, b, pixel_val, sec_grid, pe6, dims, HW, gs: GradScale, hid_parts):
+        B, V, R, S = dims
+        H, Wd = HW
+        s = _stream()
+        dev = z0.device
+        maps = []
+        for t in (z0, z1, z2, z3):
+            src = t.detach().float().contiguous()
+            n, c, h, w_ = src.shape
+            dst = torch.empty(n, h, w_, c, dtype=torch.float16, device=dev)
+            call("cpn_nchw_to_nhwc_f16", src.data_ptr(), dst.data_ptr(), n, c, h, w_, s)
+            maps.append(dst)
+        Wc = W.detach().contiguous().float()
+        bc = b.detach().contiguous().float()
+        frag = torch.empty(13 * 3 * 4 * 64 * 8, dtype=torch.float16, device=dev)
+        wtab = torch.empty(_hip.TAB_LD, 768, dtype=torch.float16, device=dev)
+        call("cpn_pack_encode_weights", Wc.data_ptr(), Wc.shape[1], frag.data_ptr(), wtab.data_ptr(), s)
+        nimg = z0.shape[0]
+        nodes = nimg * int(_hip.lib().cpn_encode_table_nodes(H, Wd))
+        feat = torch.empty(nodes, 768, dtype=torch.float16, device=dev)
+        call("cpn_node_features", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), H, Wd, nimg, feat.data_ptr(), s)
+        tab = torch.empty(nodes, _hip.TAB_LD, dtype=torch.float16, device=dev)
+        zero = torch.zeros(_hip.TAB_LD, dtype=torch.float32, device=dev)
+        call("cpn_gemm_f16", feat.data_ptr(), 768, wtab.data_ptr(), 768, zero.data_ptr(), tab.data_ptr(), _hip.TAB_LD, nodes,
+             _hip.TAB_LD, 768, 0, 0, s)
+        nrays = B * R
+        hid = torch.empty(nrays * V * S * 2, 832, dtype=torch.float16, device=dev)
+        call("cpn_encode_hidden", tab.data_ptr(), maps[3].data_ptr(), H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
+             pe6.data_ptr(), frag.data_ptr(), bc.data_ptr(), B, V, R, S, 0, nrays, hid.data_ptr(), s)
+        W16 = torch.zeros(832, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
+        call("cpn_pack_weight_f16", Wc.data_ptr(), 832, Wc.shape[1], W16.data_ptr(), _hip.XIN_STRIDE, s)
+        ctx.save_for_backward(maps[0], maps[1], maps[2], maps[3], pixel_val, sec_grid, pe6, W16, hid)
+        ctx.dims, ctx.HW, ctx.gs, ctx.hid_parts, ctx.K = dims, HW, gs, hid_parts, Wc.shape[1]
+        ctx.shapes = [tuple(t.shape) for t in (z0, z1, z2, z3)]
+        return hid
+
+    @staticmethod
+    def backward(ctx, dC):
+        m0, m1, m2, m3, pixel_val, sec_grid, pe6, W16, hid = ctx.saved_tensors
+        B, V, R, S = ctx.dims
+        H, Wd = ctx.HW
+        s = _stream()
+        d = ctx.gs.scaled16(dC.contiguous()).to(torch.float16)
+        parts = ctx.hid_parts.parts if ctx.hid_parts is not None else []
+        (w1, dh1) = parts[0] if len(parts) > 0 else (None, None)
+        (w2, dh2) = parts[1] if len(parts) > 1 else (None, None)
+        d16 = torch.empty_like(hid)                          # relu mask (.) (key-path gradient + parked rank-one parts)
+        call("cpn_hid_grad_combine", d.data_ptr(), hid.data_ptr(), 0 if w1 is None else w1.data_ptr(),
+             0 if dh1 is None else dh1.data_ptr(), 0 if w2 is None else w2.data_ptr(), 0 if dh2 is None else dh2.data_ptr(),
+             B, V, R, S, 0, B * R, d16.data_ptr(), s)
+        if ctx.hid_parts is not None:
+            ctx.hid_parts.parts = []
+        del d
+        inv = 1.0 / ctx.gs.s
+        rows = hid.shape[0]
+        xin = torch.empty(rows, _hip.XIN_STRIDE, dtype=torch.float16, device=hid.device)
+        call("cpn_gather_rows", m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), m3.data_ptr(), H, Wd, pixel_val.data_ptr(),
+             sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, 0, B * R, xin.data_ptr(), s)
+        dW = _mm_f32(d16.t(), xin)[:, :ctx.K] * inv if ctx.needs_input_grad[4] else None
+        del xin
+        db = d16.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[5] else None
+        g = [None] * 4
+        if any(ctx.needs_input_grad[:4]):
+            dA = _data_grad(d16, W16)                            # (rows, 896) fp16, scaled
+            del d16
+            dmaps = [torch.zeros(n, h, w_, c, dtype=torch.float32, device=dA.device) for (n, c, h, w_) in ctx.shapes]
+            boxes = torch.empty(B * V * _hip.lib().cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=dA.device)
+            call("cpn_gather_rows_bwd", dA.data_ptr(), dA.shape[1], H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V,
+                 R, S, 0, B * R, dmaps[0].data_ptr(), dmaps[1].data_ptr(), dmaps[2].data_ptr(), dmaps[3].data_ptr(),
+                 boxes.data_ptr(), s)
+            g = [m.mul_(inv).permute(0, 3, 1, 2).contiguous() for m in dmaps]
+        return g[0], g[1], g[2], g[3], dW, db, None, None, None, None, None, None, None
+
+
 class GatherFn(Function):
     """xin fp16 (rows2, 896) = cpn_gather_rows(NHWC fp16 copies of z0..z3); backward scatters into the maps."""
 

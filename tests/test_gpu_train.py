@@ -326,3 +326,34 @@ def test_skinny_weight_gradient_kernels(M):
     call("cpn_wgrad_small_f32", d32d.data_ptr(), Ld.data_ptr(), M, dW2.data_ptr(), s)
     want2 = d32.double().t() @ L.double()
     assert float((dW2.cpu().double() - want2).abs().max()) <= 2e-5 * max(1.0, float(want2.abs().max()))
+
+
+def test_table_form_training_matches_gather_form(dev):
+    """render_train with the first layer on the node tables (EncodeFn: no gathered input in the forward pass, re-gathered
+    once in the backward) gives the gradients of the gather + GEMM form (GatherFn + GemmFn): same formulation of the
+    backward, forward values two fp16 roundings apart."""
+    from coponerf_amd import CoPoNeRF
+    B, H, R, S = 2, 64, 50, 24
+    weights = syn.make_render_weights(seed=27)
+    inp = to_device(syn.make_inputs(B, H, H, R, seed=55), dev)
+    z, rel, flow = syn.make_latents(B, H, H, seed=56)
+    coef = syn.normal((B, 1, R, 3), seed=57).to(dev)
+    res = []
+    for tables in (True, False):
+        model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+        model.load_state_dict(weights, strict=False)
+        model = model.to(dev).train()
+        model._engine.tables = tables
+        zz = [t.to(dev).requires_grad_(True) for t in z]
+        out = model(inp, z=zz, rel_pose=rel.to(dev), val=False, flow=to_device(flow, dev))
+        (out["rgb"] * coef).sum().backward()
+        grads = {"z%d" % i: t.grad for i, t in enumerate(zz)}
+        grads.update({k: p.grad for k, p in model.named_parameters() if p.grad is not None and
+                      k.startswith(("query_encode_latent.", "key_map.", "phi.lin_out."))})
+        res.append((out["rgb"].detach(), grads))
+    (rgb_t, g_t), (rgb_g, g_g) = res
+    assert float((rgb_t - rgb_g).abs().max()) <= 5e-4
+    assert set(g_t) == set(g_g) and "query_encode_latent.weight" in g_t
+    for k in g_t:
+        rel_err = float((g_t[k] - g_g[k]).norm() / (g_g[k].norm() + 1e-20))
+        assert rel_err <= 2e-2, (k, rel_err)
