@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void conv4d_pooled_kernel(const float* __restr
 // 16-byte vectors.  COUT = all channels when the volume alone fills the chip (training batches); at B = 1 a 16^4
 // volume is 1 024 waves = ONE per SIMD, so the channels are split over 4 (2) groups for latency hiding.
 template <int COUT>
-__global__ __launch_bounds__(256) void conv4d_k3s1_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+__global__ __launch_bounds__(256, 4) void conv4d_k3s1_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                           const float* __restrict__ bq, const float* __restrict__ ws,
                                                           const float* __restrict__ bs, int Cin, int Hq, int Wq,
                                                           int Hs, int Ws, int cout_total, float* __restrict__ y,
@@ -228,27 +228,42 @@ __global__ __launch_bounds__(256) void conv4d_k3s1_kernel(const float* __restric
         float acc[COUT];
 #pragma unroll
         for (int o = 0; o < COUT; ++o) acc[o] = bq[o0 + o] + bs[o0 + o];
-        const size_t cstride = (size_t)npos;
-        const float* xb = x + (size_t)b * Cin * cstride;
+        // The 18 taps of this position as 32-bit byte offsets into the batch element's (Cin, npos) block, read with
+        // buffer loads (scalar base + per-lane offset; an out-of-range offset returns 0 = the zero padding).  Registers
+        // are what limits this kernel: with 64-bit per-lane addresses it needed 512 VGPRs = one wave per SIMD.
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(x + (size_t)b * Cin * (size_t)npos), 0, (int)((size_t)Cin * npos * 4), 0x00020000);
+        int off[18];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int t = i * 3 + j;
+                const int Y = qy + i - 1, X = qx + j - 1, U = sy + i - 1, Vv = sx + j - 1;
+                const bool okq = Y >= 0 && Y < Hq && X >= 0 && X < Wq, oks = U >= 0 && U < Hs && Vv >= 0 && Vv < Ws;
+                off[2 * t] = okq ? (((Y * Wq + X) * Hs + sy) * Ws + sx) * 4 : 0x7ffffff0;
+                off[2 * t + 1] = oks ? (((qy * Wq + qx) * Hs + U) * Ws + Vv) * 4 : 0x7ffffff0;
+            }
+#pragma unroll 1
         for (int c = 0; c < Cin; ++c) {
-            const float* xc = xb + c * cstride;
+            const int cbase = c * (int)npos * 4;              // scalar offset of the channel
+            float xv[18];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int t = 0; t < 18; ++t)
+                xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off[t], cbase, 0));
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int Y = qy + i - 1, X = qx + j - 1, U = sy + i - 1, Vv = sx + j - 1;
-                    const float vq = (Y >= 0 && Y < Hq && X >= 0 && X < Wq)
-                                         ? xc[(((size_t)Y * Wq + X) * Hs + sy) * Ws + sx] : 0.0f;
-                    const float vs = (U >= 0 && U < Hs && Vv >= 0 && Vv < Ws)
-                                         ? xc[(((size_t)qy * Wq + qx) * Hs + U) * Ws + Vv] : 0.0f;
-                    const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ((c * 9 + i * 3 + j) * 2) * COUT);
+            for (int t = 0; t < 9; ++t) {
+                const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ((c * 9 + t) * 2) * COUT);
+                const float vq = xv[2 * t], vs = xv[2 * t + 1];
 #pragma unroll
-                    for (int o4 = 0; o4 < COUT / 4; ++o4) {
-                        const f32x4 a = w4[o4], bb = w4[COUT / 4 + o4];
+                for (int o4 = 0; o4 < COUT / 4; ++o4) {
+                    const f32x4 a = w4[o4], bb = w4[COUT / 4 + o4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[o4 * 4 + e] += a[e] * vq + bb[e] * vs;
-                    }
+                    for (int e = 0; e < 4; ++e)              // two chained FMAs per output (v_pk_fma_f32 pairs)
+                        acc[o4 * 4 + e] = __builtin_fmaf(bb[e], vs, __builtin_fmaf(a[e], vq, acc[o4 * 4 + e]));
+                    if ((o4 & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // <= 4 weight vectors in flight
                 }
+            }
         }
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
@@ -780,9 +795,14 @@ extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, cons
     const hipStream_t st = (hipStream_t)stream;
     dim3 grid(cpn_cdiv(npos, 256), Cout, B);
     const size_t wbytes = (size_t)Cin * 9 * 2 * Cout * sizeof(float);
-    if (k == 3 && s == 1 && p == 1 && (Cout == 8 || Cout == 32) && wbytes <= 64 * 1024) {
-        const bool small = (long long)B * npos <= 131072;        // <= 2 waves per SIMD with one thread per position
-        const int per = Cout == 8 ? (small ? 4 : 8) : (small ? 8 : 32);
+    if (k == 3 && s == 1 && p == 1 && (Cout == 8 || Cout == 32) && wbytes <= 64 * 1024 &&
+        (long long)Cin * npos * 4 < 0x7ffffff0LL) {
+        // channels per thread: 8 (4 when one thread per position would leave <= 2 waves per SIMD).  All 32 channels in one
+        // thread read every input once instead of four times, but the compiler cannot hold 32 accumulators + a tap's
+        // weights + 18 taps under 128 VGPRs (512 VGPRs = one wave per SIMD, or a kilobyte of scratch spills when
+        // forced): 8 channels fit in 124 and run four waves per SIMD.
+        const bool small = (long long)B * npos <= 131072;
+        const int per = (Cout == 8 && small) ? 4 : 8;
         dim3 g1(cpn_cdiv(npos, 256), Cout / per, B);
         const size_t wb = wbytes / (Cout / per);
         if (per == 4)
