@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void conv4d_pooled_kernel(const float* __restr
 // stride-1 3x3x3x3 fast path (57 of the 63 Conv4d calls of a get_z): one thread computes COUT output channels of
 // its position (blockIdx.y = channel group), so every input value is read once per tap instead of once per (tap,
 // output channel); the weights are staged in LDS as [cin][tap][branch][cout] and read as wave-uniform (broadcast)
-// 16-byte vectors.  COUT = all channels when the volume alone fills the chip (training batches); at B = 1 a 16^4
-// volume is 1 024 waves = ONE per SIMD, so the channels are split over 4 (2) groups for latency hiding.
+// 16-byte vectors.  COUT = 8 (4 at B = 1 with 8 channels, where a 16^4 volume is 1 024 waves = ONE per SIMD): more
+// channels per thread would read the inputs fewer times but do not fit the register budget of 4 waves per SIMD.
 template <int COUT>
 __global__ __launch_bounds__(256, 4) void conv4d_k3s1_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                           const float* __restrict__ bq, const float* __restrict__ ws,
@@ -808,11 +808,8 @@ extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, cons
         if (per == 4)
             hipLaunchKernelGGL(conv4d_k3s1_kernel<4>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
                                y, stats);
-        else if (per == 8)
-            hipLaunchKernelGGL(conv4d_k3s1_kernel<8>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
-                               y, stats);
         else
-            hipLaunchKernelGGL(conv4d_k3s1_kernel<32>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
+            hipLaunchKernelGGL(conv4d_k3s1_kernel<8>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
                                y, stats);
     } else if (s > 1 && scratch) {
         float* psv = scratch;
