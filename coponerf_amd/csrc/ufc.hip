@@ -324,14 +324,37 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(
     const float g = gamma[o];
     double a[4] = {0.0, 0.0, 0.0, 0.0};
     const size_t base = ((size_t)b * Cout + o) * npos;
-    for (long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x; pos < npos;
-         pos += (long long)gridDim.x * blockDim.x) {
-        const float dz = out[base + pos] > 0.0f ? dout[base + pos] : 0.0f;
-        const float yh = (y[base + pos] - mean) * rstd;
-        a[0] += (double)(dz * g);
-        a[1] += (double)(dz * g * yh);
-        a[2] += (double)(dz * yh);
-        a[3] += (double)dz;
+    if ((npos & 3) == 0) {
+        // 16-byte loads, fp32 partial sums over the four elements of a load (then double): the three operand streams
+        // are all this kernel does
+        const long long n4 = npos >> 2;
+        const f32x4* o4 = reinterpret_cast<const f32x4*>(out + base);
+        const f32x4* d4 = reinterpret_cast<const f32x4*>(dout + base);
+        const f32x4* y4 = reinterpret_cast<const f32x4*>(y + base);
+        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+            const f32x4 ov = o4[q], dv = d4[q], yv = y4[q];
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dz = ov[e] > 0.0f ? dv[e] : 0.0f;
+                s0 += dz;
+                s1 += dz * ((yv[e] - mean) * rstd);
+            }
+            a[0] += (double)(s0 * g);
+            a[1] += (double)(s1 * g);
+            a[2] += (double)s1;
+            a[3] += (double)s0;
+        }
+    } else {
+        for (long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x; pos < npos;
+             pos += (long long)gridDim.x * blockDim.x) {
+            const float dz = out[base + pos] > 0.0f ? dout[base + pos] : 0.0f;
+            const float yh = (y[base + pos] - mean) * rstd;
+            a[0] += (double)(dz * g);
+            a[1] += (double)(dz * g * yh);
+            a[2] += (double)(dz * yh);
+            a[3] += (double)dz;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -859,7 +882,7 @@ extern "C" int cpn_gn_relu_bwd(const float* y, const float* out, const float* do
                 "cpn_gn_relu_bwd: null pointer");
     CPN_REQUIRE(B > 0 && B < 65536 && C > 0 && C < 65536 && npos > 0, CPN_E_SHAPE, "cpn_gn_relu_bwd: bad shape");
     const hipStream_t st = (hipStream_t)stream;
-    const unsigned bx = (unsigned)std::min<long long>(cpn_cdiv(npos, 256), 64);
+    const unsigned bx = (unsigned)std::min<long long>(cpn_cdiv(npos, 4096), 16);       // 4 x 16-byte loads per thread
     hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel, dim3(bx, C, B), dim3(256), 0, st, y, out, dout, stats, gn_w, eps, B, C,
                        npos, red);
     CPN_LAUNCH_CHECK("cpn_gn_relu_bwd(reduce)");
