@@ -38,7 +38,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_hid_grad_combine": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_wgrad_skinny_f16": [_P, _P, _I, ctypes.c_longlong, _P, _P, _P],
-    "cpn_wgrad_small_f32": [_P, _P, ctypes.c_longlong, _P, _P],
+    "cpn_local_hidden_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],

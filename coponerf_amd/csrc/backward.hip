@@ -121,48 +121,109 @@ __global__ __launch_bounds__(256) void wgrad_skinny_f16_kernel(const __half* __r
     }
 }
 
-// dW (128, 16) = d^T (128, M) . L (M, 16), fp32.  thread = 4 consecutive output rows n (one 16-byte load of d per row
-// of the slab) x all 16 columns; 8 row lanes per block; four rows in flight per thread; the row of L is wave-uniform.
-// The 8 row lanes meet in LDS, one global atomic pass per block (global atomics from every thread cost 3x the kernel).
-__global__ __launch_bounds__(256) void wgrad_small_f32_kernel(const float* __restrict__ d, const float* __restrict__ L,
-                                                              long long M, long long rows_per_block,
-                                                              float* __restrict__ dW) {
+// Backward of cpn_local_hidden (out = fp16(relu(W . L(row) + b + add[ray]))) in ONE pass over the incoming gradient:
+//   d[row, n] = out[row, n] > 0 ? ds[row, n] / scale : 0          (ds fp16, carries the pass's power-of-two scale)
+//   dW[n, k] += sum_rows d[row, n] * L[row, k],  db[n] += sum_rows d,  dadd[ray, n] = sum over the ray's V*S rows
+// L(row) is rebuilt from loc8 / coords9 exactly as the forward kernel builds it (channel order of CoPoNeRF.py:445).  The
+// autograd form materialised d as fp32 (1 GB), the 16-wide input rows (134 MB), and ran a GEMM and two reductions over
+// them.  block = `rays_per_block` rays; thread = 4 output rows n x one of 8 row lanes; a ray's 8 lane sums meet in LDS.
+__global__ __launch_bounds__(256) void local_hidden_bwd_kernel(
+    const __half* __restrict__ ds, const __half* __restrict__ out, const float* __restrict__ loc8,
+    const float* __restrict__ coords9, const float* __restrict__ scale, int V, int R, int S, int nrays, int rays_per_block,
+    float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dadd) {
     __shared__ float red[128 * 16];
-    const int n4 = threadIdx.x & 31, rl = threadIdx.x >> 5;                // 32 threads cover a 512-byte row of d
+    __shared__ float rsum[8][128];
+    const int n4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
     for (int i = threadIdx.x; i < 128 * 16; i += 256) red[i] = 0.0f;
-    __syncthreads();
-    const long long m0 = (long long)blockIdx.x * rows_per_block;
-    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    const float inv = 1.0f / scale[0];
+    const int rpr = V * S;
     f32x4 acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;
-    for (long long m = m0 + rl * U; m < m1; m += 8 * U) {
-        f32x4 dv[U];
+    f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ray_lo = blockIdx.x * rays_per_block;
+    const int ray_hi = min(ray_lo + rays_per_block, nrays);
+    for (int ray = ray_lo; ray < ray_hi; ++ray) {
+        const int b = ray / R, r = ray - b * R;
+        f32x4 racc = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int U = 4;
+        for (int m = rl * U; m < rpr; m += 8 * U) {
+            half4 dv[U], ov[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            dv[u] = m + u < m1 ? *reinterpret_cast<const f32x4*>(d + (m + u) * 128 + n4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < U; ++u) {
+                const size_t row = (size_t)ray * rpr + min(m + u, rpr - 1);
+                dv[u] = *reinterpret_cast<const half4*>(ds + row * 128 + n4 * 4);
+                ov[u] = *reinterpret_cast<const half4*>(out + row * 128 + n4 * 4);
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (m + u >= m1) break;
-            const float* lp = L + (m + u) * 16;
+            for (int u = 0; u < U; ++u) {
+                if (m + u >= rpr) break;
+                const half4 dh = dv[u], oh = ov[u];
+                f32x4 d;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lp + q * 4);
+                for (int e = 0; e < 4; ++e) d[e] = (float)oh[e] > 0.0f ? (float)dh[e] : 0.0f;
+                racc += d;
+                const int v = (m + u) / S, sm = (m + u) - v * S;
+                const size_t nr = ((size_t)(b * V + v)) * R + r;
+                const float* lp = loc8 + (nr * S + sm) * 8;
+                const float* c9 = coords9 + nr * 9;
+                const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp), l1 = *reinterpret_cast<const f32x4*>(lp + 4);
+                const float Lrow[16] = {l0[0], l0[1], l0[2], 0.f, 0.f, 0.f, c9[0], c9[1], c9[2], l0[3], l1[0], l1[1], l1[2],
+                                        c9[6], c9[7], c9[8]};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[q * 4 + e] += dv[u] * l4[e];
+                for (int k = 0; k < 16; ++k) acc[k] += d * Lrow[k];
+            }
+        }
+        bacc += racc;
+        if (dadd) {
+            __syncthreads();                                  // previous ray's sums are consumed
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rsum[rl][n4 * 4 + e] = racc[e];
+            __syncthreads();
+            if (threadIdx.x < 128) {
+                float t = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t += rsum[q][threadIdx.x];
+                dadd[(size_t)ray * 128 + threadIdx.x] = t * inv;
             }
         }
     }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(&red[(n4 * 4 + i) * 16 + k], acc[k][i]);
+        for (int e = 0; e < 4; ++e) atomicAdd(&red[(n4 * 4 + e) * 16 + k], acc[k][e]);
     __syncthreads();
-    for (int i = threadIdx.x; i < 128 * 16; i += 256) atomicAdd(dW + i, red[i]);
+    for (int i = threadIdx.x; i < 128 * 16; i += 256) atomicAdd(dW + i, red[i] * inv);
+    __syncthreads();
+    // bias gradient: reuse rsum
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rsum[rl][n4 * 4 + e] = bacc[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += rsum[q][threadIdx.x];
+        atomicAdd(db + threadIdx.x, t * inv);
+    }
 }
 
 }  // namespace
+
+extern "C" int cpn_local_hidden_bwd(const uint16_t* ds, const uint16_t* out, const float* loc8, const float* coords9,
+                                    const float* scale, int B, int V, int R, int S, float* dW, float* db, float* dadd,
+                                    void* stream) {
+    CPN_REQUIRE(ds && out && loc8 && coords9 && scale && dW && db, CPN_E_ARG, "cpn_local_hidden_bwd: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0, CPN_E_SHAPE, "cpn_local_hidden_bwd: bad shape");
+    CPN_REQUIRE(((uintptr_t)ds % 8) == 0 && ((uintptr_t)out % 8) == 0 && ((uintptr_t)loc8 % 16) == 0, CPN_E_ARG,
+                "cpn_local_hidden_bwd: operands must be aligned");
+    const int nrays = B * R;
+    const int rpb = std::max(1, (nrays + 2047) / 2048);
+    hipLaunchKernelGGL(local_hidden_bwd_kernel, dim3((nrays + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                       (const __half*)ds, (const __half*)out, loc8, coords9, scale, V, R, S, nrays, rpb, dW, db, dadd);
+    CPN_LAUNCH_CHECK("cpn_local_hidden_bwd");
+    return 0;
+}
 
 extern "C" int cpn_wgrad_skinny_f16(const uint16_t* dY, const uint16_t* X, int ldx, long long M, float* dW, float* db,
                                     void* stream) {
@@ -178,16 +239,6 @@ extern "C" int cpn_wgrad_skinny_f16(const uint16_t* dY, const uint16_t* X, int l
     return 0;
 }
 
-extern "C" int cpn_wgrad_small_f32(const float* d, const float* L, long long M, float* dW, void* stream) {
-    CPN_REQUIRE(d && L && dW, CPN_E_ARG, "cpn_wgrad_small_f32: null pointer");
-    CPN_REQUIRE(M > 0, CPN_E_SHAPE, "cpn_wgrad_small_f32: M must be positive");
-    CPN_REQUIRE(((uintptr_t)L % 16) == 0, CPN_E_ARG, "cpn_wgrad_small_f32: L must be 16-byte aligned");
-    const long long rpb = std::max<long long>(64, (M + 1023) / 1024);
-    const unsigned grid = (unsigned)((M + rpb - 1) / rpb);
-    hipLaunchKernelGGL(wgrad_small_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d, L, M, rpb, dW);
-    CPN_LAUNCH_CHECK("cpn_wgrad_small_f32");
-    return 0;
-}
 
 extern "C" long long cpn_gather_bwd_chunks(int R, int S);
 

@@ -195,12 +195,15 @@ class LocalHiddenFn(Function):
         loc8, coords9, out = ctx.saved_tensors
         B, V, R, S = ctx.dims
         ds = ctx.gs.scaled16(dout.contiguous()).to(torch.float16)
-        d = torch.ops.aten.threshold_backward(ds, out, 0).float() * (1.0 / ctx.gs.s)      # fp32, true scale from here on
-        L = build_local_coords(loc8, coords9, B, V, R, S).contiguous()
-        dW = torch.zeros(128, 16, dtype=torch.float32, device=d.device)
-        call("cpn_wgrad_small_f32", d.data_ptr(), L.data_ptr(), d.shape[0], dW.data_ptr(), _stream())
-        dadd = d.view(B * R, V * S, 128).sum(1) if ctx.has_add else None
-        return None, None, dW, d.sum(0), dadd, None, None
+        dev = ds.device
+        # ReLU mask, un-scaling, the 128 x 16 weight gradient, the bias gradient and the per-ray sum in one pass over ds
+        dW = torch.zeros(128, 16, dtype=torch.float32, device=dev)
+        db = torch.zeros(128, dtype=torch.float32, device=dev)
+        dadd = torch.empty(B * R, 128, dtype=torch.float32, device=dev) if ctx.has_add else None
+        scale = ctx.gs.s.reshape(1).float().contiguous()
+        call("cpn_local_hidden_bwd", ds.data_ptr(), out.data_ptr(), loc8.data_ptr(), coords9.data_ptr(), scale.data_ptr(),
+             B, V, R, S, dW.data_ptr(), db.data_ptr(), 0 if dadd is None else dadd.data_ptr(), _stream())
+        return None, None, dW, db, dadd, None, None
 
 
 class AttendHiddenFn(Function):

@@ -199,8 +199,11 @@ int cpn_hid_grad_combine(const uint16_t* dkey, const uint16_t* hid, const float*
  *   dW (128,128) fp32 += dY^T . X,  db (128) fp32 += column sums of dY (or NULL);  dY (M,128) fp16, X (M,ldx) fp16 of
  *   which the first 128 columns are used.  Both outputs are accumulated: the caller zeroes them.                      */
 int cpn_wgrad_skinny_f16(const uint16_t* dY, const uint16_t* X, int ldx, long long M, float* dW, float* db, void* stream);
-/*   dW (128,16) fp32 += d^T . L,  d (M,128) fp32, L (M,16) fp32                                                     */
-int cpn_wgrad_small_f32(const float* d, const float* L, long long M, float* dW, void* stream);
+/* backward of cpn_local_hidden in one pass: ds, out (rows,128) fp16 (incoming gradient carrying `scale[0]`, a device
+ * scalar, and the forward output for the ReLU mask), loc8 / coords9 as in the forward -> dW (128,16), db (128) fp32
+ * ACCUMULATED (caller zeroes), dadd (B*R,128) fp32 written (per-ray sum, NULL when the layer had no `add`).          */
+int cpn_local_hidden_bwd(const uint16_t* ds, const uint16_t* out, const float* loc8, const float* coords9,
+                         const float* scale, int B, int V, int R, int S, float* dW, float* db, float* dadd, void* stream);
 
 /* gradient of cpn_gather_rows w.r.t. the feature maps: dxin (rows, ldx) fp16 -> accumulated into dmap0..3
  * (N,h,w,C) fp32 NHWC, which the caller zeroes first.  No coordinate gradient (CoPoNeRF.py:380-381).
