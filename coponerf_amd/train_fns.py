@@ -165,15 +165,6 @@ class LinearF32Fn(Function):
         return dX, d.t() @ Xa, (d.sum(0) if ctx.has_b else None), (d if ctx.has_res else None), None, None
 
 
-def build_local_coords(loc8, coords9, B, V, R, S):
-    """(B*V,R,S,8), (B*V,R,9) -> L (B*R*V*S, 16) in the GEMM row order; channel order of CoPoNeRF.py:445."""
-    lc = loc8.view(B, V, R, S, 8).permute(0, 2, 1, 3, 4)                       # (B,R,V,S,8)
-    c9 = coords9.view(B, V, R, 9).permute(0, 2, 1, 3)[:, :, :, None, :].expand(-1, -1, -1, S, -1)
-    z3 = torch.zeros_like(lc[..., :3])
-    L = torch.cat([lc[..., 0:3], z3, c9[..., 0:3], lc[..., 3:7], c9[..., 6:9]], dim=-1)
-    return L.reshape(B * R * V * S, 16)
-
-
 class LocalHiddenFn(Function):
     """out = fp16(relu(W . L(row) + b + add[ray])) through cpn_local_hidden."""
 
