@@ -515,6 +515,9 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
     const int4* boxes = bbox + (size_t)img * plan.maxchunks * 4 + lvl;
 
     auto drain = [&](int n) {
+#ifdef CPN_GBWD_NO_DRAIN                                       // timing-only ablation (tools/gbwd_bench.py): scan phase alone
+        if (n >= 0) return;
+#endif
         // raw halves are carried across the iteration and converted at use, so the loads of batch i+1 stay in
         // flight during the accumulation of batch i (a conversion at the load would wait for it there)
         __half cur[NB], nxt[NB];

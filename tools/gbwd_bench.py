@@ -1,6 +1,24 @@
-"""Microbenchmark of cpn_gather_rows_bwd on training-shaped inputs (B pairs x R random rays x S samples)."""
+"""Microbenchmark of cpn_gather_rows_bwd on training-shaped inputs (B pairs x R random rays x S samples); with
+`--build` (where hipcc is) a variant without the accumulation phase is built into tools/_build/ and timed beside it:
+the difference is what the LDS read-modify-writes cost, the rest is the chunk / row scan."""
+import ctypes
 import os
+import subprocess
 import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tools", "_build", "libgbwd_nodrain.so")
+if "--build" in sys.argv:
+    src = os.path.join(ROOT, "coponerf_amd", "csrc")
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    objs = []
+    for f, extra in (("error.cpp", []), ("backward.hip", ["-DCPN_GBWD_NO_DRAIN"])):
+        o = os.path.join(ROOT, "tools", "_build", "gbwd_" + f.split(".")[0] + ".o")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
+                               os.path.join(src, f), "-o", o] + extra)
+        objs.append(o)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", SO])
+    sys.exit(0)
+sys.path.insert(0, ROOT)
 import torch
 from coponerf_amd import synthetic as syn
 from coponerf_amd.render import RenderEngine
@@ -19,14 +37,24 @@ shapes = [(2 * B, 16, 16, 256), (2 * B, 32, 32, 256), (2 * B, 64, 64, 256), (2 *
 st = torch.cuda.current_stream().cuda_stream
 from coponerf_amd import _hip
 boxes = torch.empty(B * 2 * _hip.lib().cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=dev)
-for cfg in [""]:
+P, I = ctypes.c_void_p, ctypes.c_int
+variants = [("product", None)]
+if os.path.exists(SO):
+    fn = ctypes.CDLL(SO).cpn_gather_rows_bwd
+    fn.argtypes = [P, I, I, I, P, P, I, I, I, I, I, I, P, P, P, P, P, P]
+    variants.append(("no accumulation (scan only)", fn))
+for cfg, fn in variants:
     ts = []
     for it in range(4):
         dm = [torch.zeros(s, device=dev) for s in shapes]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        call("cpn_gather_rows_bwd", dx.data_ptr(), 896, H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), B, 2, R, S,
-             0, B * R, dm[0].data_ptr(), dm[1].data_ptr(), dm[2].data_ptr(), dm[3].data_ptr(), boxes.data_ptr(), st)
+        args = (dx.data_ptr(), 896, H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), B, 2, R, S,
+                0, B * R, dm[0].data_ptr(), dm[1].data_ptr(), dm[2].data_ptr(), dm[3].data_ptr(), boxes.data_ptr(), st)
+        if fn is None:
+            call("cpn_gather_rows_bwd", *args)
+        else:
+            fn(*args)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
