@@ -47,7 +47,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_conv_wgrad_planes": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_dwconv3x3_wgrad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "cpn_dwconv3x3_tokens": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
-    "cpn_dwconv3x3_tokens_wgrad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_dwconv3x3_tokens_wgrad": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_dual_softmax": [_P, _I, _I, _I, _P, _P, _P, _P],
     "cpn_dual_softmax_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
@@ -113,6 +113,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_conv4d_scratch.restype = ctypes.c_longlong
     handle.cpn_conv_wgrad_scratch.argtypes = [_I, _I]
     handle.cpn_conv_wgrad_scratch.restype = ctypes.c_longlong
+    handle.cpn_dwconv3x3_tokens_wgrad_scratch.argtypes = [_I, _I, _I]
+    handle.cpn_dwconv3x3_tokens_wgrad_scratch.restype = ctypes.c_longlong
     handle.cpn_last_error.argtypes = []
     handle.cpn_last_error.restype = ctypes.c_char_p
     got = handle.cpn_abi_version()

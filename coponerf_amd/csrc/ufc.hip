@@ -556,66 +556,108 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 // The same depthwise convolution directly on the TOKEN layout (B, L = H*W, C) the feed-forward blocks work in
 // (aggregation.py:18-28 transposes to (B,C,H,W), runs the grouped Conv2d and transposes back).  With the channel
-// innermost a thread = (position, 4 channels) reads nine coalesced float4 rows: no transposed copies on either side,
+// innermost the reads are coalesced float4 rows: no transposed copies on either side,
 // and the library's depthwise kernel (0.76 ms for 4 x 1024 x 64 x 64, 12x the streaming time) is not needed.
 //   flip = 0: y = b + sum_ij w[c][i][j] * x[p + (i-1, j-1)]        (forward)
 //   flip = 1: y =     sum_ij w[c][2-i][2-j] * x[p + (i-1, j-1)]    (data gradient: correlation with the flipped taps)
 // ------------------------------------------------------------------------------------------------
+// thread = (run of DW_RUN consecutive x positions of one image row, 4 channels): the 36 taps of its channels are loaded
+// once, and the three input rows slide through registers (3 new 16-byte loads per output instead of 9)
+constexpr int DW_RUN = 8;
 __global__ __launch_bounds__(256) void dwconv3x3_tokens_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, int H, int W, int C4,
                                                                long long total, int flip, float* __restrict__ y) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c4 = (int)(idx % C4);
-    const long long pos = idx / C4;                           // b * H*W + yy * W + xx
-    const int xx = (int)(pos % W);
-    const int yy = (int)((pos / W) % H);
-    const int C = C4 * 4;
-    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    float wr[4][9];
+    long long t = idx / C4;
+    const int runs = (W + DW_RUN - 1) / DW_RUN;
+    const int xr = (int)(t % runs); t /= runs;
+    const int yy = (int)(t % H);
+    const long long bimg = t / H;
+    const int C = C4 * 4, x0 = xr * DW_RUN;
+    const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wr[9];                                              // wr[tap][channel e]
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wr[e][t] = w[(c4 * 4 + e) * 9 + (flip ? 8 - t : t)];
+        for (int e = 0; e < 4; ++e) wr[tp][e] = w[(c4 * 4 + e) * 9 + (flip ? 8 - tp : tp)];
+    const float* xb = x + (bimg * H * W) * C + c4 * 4;
+    auto col = [&](int X, f32x4 (&v)[3]) {                     // the three rows of column X (zeros outside the image)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int Y = yy + i - 1, X = xx + j - 1;
-            if (Y < 0 || Y >= H || X < 0 || X >= W) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (pos + (long long)(i - 1) * W + (j - 1)) * C + c4 * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += wr[e][i * 3 + j] * v[e];
+        for (int i = 0; i < 3; ++i) {
+            const int Y = yy + i - 1;
+            v[i] = (X >= 0 && X < W && Y >= 0 && Y < H) ? *reinterpret_cast<const f32x4*>(xb + ((long long)Y * W + X) * C)
+                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    *reinterpret_cast<f32x4*>(y + pos * C + c4 * 4) = acc;
+    };
+    f32x4 c0[3], c1[3], c2[3];
+    col(x0 - 1, c0);
+    col(x0, c1);
+#pragma unroll
+    for (int k = 0; k < DW_RUN; ++k) {
+        const int X = x0 + k;
+        if (X >= W) break;
+        col(X + 1, c2);
+        f32x4 acc = b4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc += wr[i * 3] * c0[i] + wr[i * 3 + 1] * c1[i] + wr[i * 3 + 2] * c2[i];
+        *reinterpret_cast<f32x4*>(y + ((bimg * H + yy) * W + X) * C + c4 * 4) = acc;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { c0[i] = c1[i]; c1[i] = c2[i]; }
+    }
 }
 
-// weight / bias gradient in the token layout: block = (slab of positions) x (256 consecutive channels), thread = channel
+// weight / bias gradient in the token layout: block = (image row, 256 consecutive channels), thread = channel; the
+// 3 x 3 input window slides along the row (3 new loads per position).  Each block leaves 10 partial sums per channel
+// in `partial` (rows x C x 10); a second launch reduces them in a fixed order (deterministic, no atomics).
 __global__ __launch_bounds__(256) void dwconv3x3_tokens_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                     int H, int W, int C, long long npos, int slab,
-                                                                     float* __restrict__ dw, float* __restrict__ db) {
+                                                                     int H, int W, int C, float* __restrict__ partial) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= C) return;
-    const long long p0 = (long long)blockIdx.x * slab;
-    const long long p1 = p0 + slab < npos ? p0 + slab : npos;
+    const long long rowid = blockIdx.x;                       // b * H + yy
+    const int yy = (int)(rowid % H);
+    const float* xr = x + (rowid - yy) * W * C + c;           // image base (+ channel)
+    const float* dr = dy + rowid * W * C + c;
     float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (long long pos = p0; pos < p1; ++pos) {
-        const int xx = (int)(pos % W);
-        const int yy = (int)((pos / W) % H);
-        const float g = dy[pos * C + c];
+    auto col = [&](int X, float (&v)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int Y = yy + i - 1;
+            v[i] = (X >= 0 && X < W && Y >= 0 && Y < H) ? xr[((long long)Y * W + X) * C] : 0.0f;
+        }
+    };
+    float c0[3], c1[3], c2[3];
+    col(-1, c0);
+    col(0, c1);
+#pragma unroll 4
+    for (int X = 0; X < W; ++X) {
+        col(X + 1, c2);
+        const float g = dr[(long long)X * C];
         a[9] += g;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int Y = yy + i - 1, X = xx + j - 1;
-                if (Y >= 0 && Y < H && X >= 0 && X < W) a[i * 3 + j] += g * x[(pos + (long long)(i - 1) * W + (j - 1)) * C + c];
-            }
+        for (int i = 0; i < 3; ++i) {
+            a[i * 3] += g * c0[i];
+            a[i * 3 + 1] += g * c1[i];
+            a[i * 3 + 2] += g * c2[i];
+            c0[i] = c1[i];
+            c1[i] = c2[i];
+        }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) atomicAdd(dw + c * 9 + t, a[t]);
-    if (db) atomicAdd(db + c, a[9]);
+    for (int t = 0; t < 10; ++t) partial[(rowid * C + c) * 10 + t] = a[t];
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_tokens_wgrad_reduce_kernel(const float* __restrict__ partial, long long rows,
+                                                                            int C, float* __restrict__ dw,
+                                                                            float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;             // (channel, term)
+    if (i >= C * 10) return;
+    float acc = 0.0f;
+    for (long long r = 0; r < rows; ++r) acc += partial[r * C * 10 + i];
+    const int c = i / 10, t = i - c * 10;
+    if (t < 9) dw[c * 9 + t] = acc;
+    else if (db) db[c] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1122,7 +1164,7 @@ extern "C" int cpn_dwconv3x3_tokens(const float* x, const float* w, const float*
     CPN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, CPN_E_SHAPE, "cpn_dwconv3x3_tokens: need C %% 4 == 0");
     CPN_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0, CPN_E_ARG,
                 "cpn_dwconv3x3_tokens: pointers must be 16-byte aligned");
-    const long long total = (long long)B * H * W * (C / 4);
+    const long long total = (long long)B * H * ((W + DW_RUN - 1) / DW_RUN) * (C / 4);
     CPN_REQUIRE(total / 256 < (1LL << 31), CPN_E_SHAPE, "cpn_dwconv3x3_tokens: too large");
     hipLaunchKernelGGL(dwconv3x3_tokens_kernel, dim3((unsigned)cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
                        bias, H, W, C / 4, total, flip, y);
@@ -1130,15 +1172,17 @@ extern "C" int cpn_dwconv3x3_tokens(const float* x, const float* w, const float*
     return 0;
 }
 
-extern "C" int cpn_dwconv3x3_tokens_wgrad(const float* x, const float* dy, int B, int H, int W, int C, float* dw, float* db,
-                                          void* stream) {
-    CPN_REQUIRE(x && dy && dw, CPN_E_ARG, "cpn_dwconv3x3_tokens_wgrad: null pointer");
+extern "C" long long cpn_dwconv3x3_tokens_wgrad_scratch(int B, int H, int C) { return (long long)B * H * C * 10; }
+
+extern "C" int cpn_dwconv3x3_tokens_wgrad(const float* x, const float* dy, int B, int H, int W, int C, float* partial,
+                                          float* dw, float* db, void* stream) {
+    CPN_REQUIRE(x && dy && dw && partial, CPN_E_ARG, "cpn_dwconv3x3_tokens_wgrad: null pointer");
     CPN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, CPN_E_SHAPE, "cpn_dwconv3x3_tokens_wgrad: bad shape");
-    const long long npos = (long long)B * H * W;
-    const int slab = (int)std::max<long long>(16, cpn_cdiv(npos, 192));
-    dim3 grid((unsigned)cpn_cdiv(npos, slab), (unsigned)cpn_cdiv(C, 256));
-    hipLaunchKernelGGL(dwconv3x3_tokens_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, dy, H, W, C, npos, slab, dw,
-                       db);
+    const long long rows = (long long)B * H;
+    dim3 grid((unsigned)rows, (unsigned)cpn_cdiv(C, 256));
+    hipLaunchKernelGGL(dwconv3x3_tokens_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, dy, H, W, C, partial);
+    hipLaunchKernelGGL(dwconv3x3_tokens_wgrad_reduce_kernel, dim3((unsigned)cpn_cdiv(C * 10, 256)), dim3(256), 0,
+                       (hipStream_t)stream, partial, rows, C, dw, db);
     CPN_LAUNCH_CHECK("cpn_dwconv3x3_tokens_wgrad");
     return 0;
 }

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
+from . import _hip
 from ._hip import call
 
 
@@ -249,10 +250,12 @@ class DwConvTokensFn(Function):
             dx = torch.empty_like(xc)
             call("cpn_dwconv3x3_tokens", dyc.data_ptr(), wc.data_ptr(), 0, B, ctx.size, ctx.size, C, 1, dx.data_ptr(), _stream())
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw = torch.zeros(C, 9, dtype=torch.float32, device=xc.device)
-            db = torch.zeros(C, dtype=torch.float32, device=xc.device) if ctx.has_b else None
-            call("cpn_dwconv3x3_tokens_wgrad", xc.data_ptr(), dyc.data_ptr(), B, ctx.size, ctx.size, C, dw.data_ptr(),
-                 0 if db is None else db.data_ptr(), _stream())
+            dw = torch.empty(C, 9, dtype=torch.float32, device=xc.device)
+            db = torch.empty(C, dtype=torch.float32, device=xc.device) if ctx.has_b else None
+            part = torch.empty(_hip.lib().cpn_dwconv3x3_tokens_wgrad_scratch(B, ctx.size, C), dtype=torch.float32,
+                               device=xc.device)
+            call("cpn_dwconv3x3_tokens_wgrad", xc.data_ptr(), dyc.data_ptr(), B, ctx.size, ctx.size, C, part.data_ptr(),
+                 dw.data_ptr(), 0 if db is None else db.data_ptr(), _stream())
             dw = dw.view(ctx.wshape)
         return dx, dw, db, None
 

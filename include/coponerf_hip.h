@@ -261,9 +261,11 @@ int cpn_dwconv3x3_wgrad(const float* x, const float* dy, int N, int C, int H, in
  * data gradient w_flipped (*) dy (flip = 1, bias NULL).  w (C,9).  C % 4 == 0.                                        */
 int cpn_dwconv3x3_tokens(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int flip, float* y,
                          void* stream);
-/* its weight / bias gradient: dw (C,9), db (C, may be NULL) are ACCUMULATED into (the caller zeroes them)             */
-int cpn_dwconv3x3_tokens_wgrad(const float* x, const float* dy, int B, int H, int W, int C, float* dw, float* db,
-                               void* stream);
+/* its weight / bias gradient: dw (C,9), db (C, may be NULL), overwritten; partial = scratch of
+ * cpn_dwconv3x3_tokens_wgrad_scratch(B,H,C) floats (per-row partial sums, reduced in a fixed order)                  */
+long long cpn_dwconv3x3_tokens_wgrad_scratch(int B, int H, int C);
+int cpn_dwconv3x3_tokens_wgrad(const float* x, const float* dy, int B, int H, int W, int C, float* partial, float* dw,
+                               float* db, void* stream);
 
 /* dual softmax of the pose branch's cross attention (models/backbone.py:296-330), a (B,L,M) fp32:
  * f = softmax(a, dim=-1) * softmax(a, dim=-2); rstat (B,L,2) / cstat (B,M,2) receive (max, sum exp) per row / column
