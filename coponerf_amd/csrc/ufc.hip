@@ -759,18 +759,21 @@ __global__ __launch_bounds__(256) void soft_argmax_rows_kernel(const float* __re
     }
 }
 
-// block = 64 target pixels x 4 source groups; online softmax per thread, 4 partials merged through LDS
-__global__ __launch_bounds__(256) void soft_argmax_cols_kernel(const float* __restrict__ c, int h, float beta,
-                                                               float* __restrict__ out) {
+// Column-direction reductions over a (rows x T) matrix: block = CR_COLS columns x CR_GROUPS row groups (a wave reads four
+// 64-byte row segments per instruction), online softmax per thread, partials merged through LDS.  With 64 columns x 4
+// groups (round 1) a 4096 x 4096 matrix was 64 workgroups whose threads each walked 1024 rows: 0.39 ms for 67 MB.
+constexpr int CR_COLS = 16, CR_GROUPS = 64;
+__global__ __launch_bounds__(CR_COLS * CR_GROUPS) void soft_argmax_cols_kernel(const float* __restrict__ c, int h, float beta,
+                                                                               float* __restrict__ out) {
     const int T = h * h;
     const int b = blockIdx.y;
-    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int g = threadIdx.x >> 6;
-    __shared__ float part[4][4][64];
+    const int l = threadIdx.x % CR_COLS, g = threadIdx.x / CR_COLS;
+    const int t = blockIdx.x * CR_COLS + l;
+    __shared__ float part[CR_GROUPS][4][CR_COLS];
     float m = -INFINITY, se = 0.f, sx = 0.f, sy = 0.f;
     if (t < T) {
         const float* col = c + (size_t)b * T * T + t;
-        for (int s = g; s < T; s += 4) {
+        for (int s = g; s < T; s += CR_GROUPS) {
             const float v = col[(size_t)s * T];
             if (v > m) {
                 const float r = expf((m - v) / beta);
@@ -783,14 +786,14 @@ __global__ __launch_bounds__(256) void soft_argmax_cols_kernel(const float* __re
             sy += e * lin11(s / h, h);
         }
     }
-    const int l = threadIdx.x & 63;
     part[g][0][l] = m; part[g][1][l] = se; part[g][2][l] = sx; part[g][3][l] = sy;
     __syncthreads();
     if (g == 0 && t < T) {
-        float M = fmaxf(fmaxf(part[0][0][l], part[1][0][l]), fmaxf(part[2][0][l], part[3][0][l]));
+        float M = -INFINITY;
+        for (int q = 0; q < CR_GROUPS; ++q) M = fmaxf(M, part[q][0][l]);
         float E = 0.f, X = 0.f, Y = 0.f;
-        for (int q = 0; q < 4; ++q) {
-            const float r = expf((part[q][0][l] - M) / beta);
+        for (int q = 0; q < CR_GROUPS; ++q) {
+            const float r = part[q][0][l] == -INFINITY ? 0.0f : expf((part[q][0][l] - M) / beta);
             E += part[q][1][l] * r; X += part[q][2][l] * r; Y += part[q][3][l] * r;
         }
         out[((size_t)b * 2 + 0) * T + t] = X / E;
@@ -1041,38 +1044,42 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     }
 }
 
-// workgroup = 64 columns x 4 row groups (coalesced 256-byte row segments), 4 partials merged through LDS
-__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ a, const float* __restrict__ w, int L,
-                                                        int M, float* __restrict__ stat, int mode) {
+// workgroup = CR_COLS columns x CR_GROUPS row groups, partials merged through LDS (see soft_argmax_cols_kernel)
+__global__ __launch_bounds__(CR_COLS * CR_GROUPS) void col_stats_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                                        int L, int M, float* __restrict__ stat, int mode) {
     const int b = blockIdx.y;
-    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + l;
-    __shared__ float part[4][2][64];
+    const int l = threadIdx.x % CR_COLS, g = threadIdx.x / CR_COLS;
+    const int j = blockIdx.x * CR_COLS + l;
+    __shared__ float part[CR_GROUPS][2][CR_COLS];
     float m = -INFINITY, se = 0.f;
     if (j < M) {
         const float* col = a + (size_t)b * L * M + j;
         if (mode == 0) {
-            for (int i = g; i < L; i += 4) {
+            for (int i = g; i < L; i += CR_GROUPS) {
                 const float v = col[(size_t)i * M];
                 if (v > m) { se *= expf(m - v); m = v; }
                 se += expf(v - m);
             }
         } else {
             const float* wc = w + (size_t)b * L * M + j;
-            for (int i = g; i < L; i += 4) se += col[(size_t)i * M] * wc[(size_t)i * M];
+            for (int i = g; i < L; i += CR_GROUPS) se += col[(size_t)i * M] * wc[(size_t)i * M];
         }
     }
     part[g][0][l] = m; part[g][1][l] = se;
     __syncthreads();
     if (g == 0 && j < M) {
         if (mode == 0) {
-            const float Mx = fmaxf(fmaxf(part[0][0][l], part[1][0][l]), fmaxf(part[2][0][l], part[3][0][l]));
+            float Mx = -INFINITY;
+            for (int q = 0; q < CR_GROUPS; ++q) Mx = fmaxf(Mx, part[q][0][l]);
             float E = 0.f;
-            for (int q = 0; q < 4; ++q) E += part[q][1][l] * expf(part[q][0][l] - Mx);
+            for (int q = 0; q < CR_GROUPS; ++q)
+                E += part[q][0][l] == -INFINITY ? 0.0f : part[q][1][l] * expf(part[q][0][l] - Mx);
             stat[((size_t)b * M + j) * 2] = Mx;
             stat[((size_t)b * M + j) * 2 + 1] = E;
         } else {
-            stat[(size_t)b * M + j] = (part[0][1][l] + part[1][1][l]) + (part[2][1][l] + part[3][1][l]);
+            float E = 0.f;
+            for (int q = 0; q < CR_GROUPS; ++q) E += part[q][1][l];
+            stat[(size_t)b * M + j] = E;
         }
     }
 }
@@ -1194,7 +1201,8 @@ extern "C" int cpn_dual_softmax(const float* a, int B, int L, int M, float* rsta
     const hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)B * L, total = rows * M;
     hipLaunchKernelGGL(row_stats_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, a, (const float*)nullptr, rows, M, rstat, 0);
-    hipLaunchKernelGGL(col_stats_kernel, dim3(cpn_cdiv(M, 64), B), dim3(256), 0, st, a, (const float*)nullptr, L, M, cstat, 0);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(cpn_cdiv(M, CR_COLS), B), dim3(CR_COLS * CR_GROUPS), 0, st, a, (const float*)nullptr,
+                       L, M, cstat, 0);
     const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(total, 256), 16384);
     hipLaunchKernelGGL(dual_softmax_apply_kernel, dim3(blocks), dim3(256), 0, st, a, rstat, cstat, L, M, total, f);
     CPN_LAUNCH_CHECK("cpn_dual_softmax");
@@ -1209,7 +1217,7 @@ extern "C" int cpn_dual_softmax_bwd(const float* a, const float* rstat, const fl
     const hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)B * L, total = rows * M;
     hipLaunchKernelGGL(row_stats_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, f, df, rows, M, srow, 1);
-    hipLaunchKernelGGL(col_stats_kernel, dim3(cpn_cdiv(M, 64), B), dim3(256), 0, st, f, df, L, M, scol, 1);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(cpn_cdiv(M, CR_COLS), B), dim3(CR_COLS * CR_GROUPS), 0, st, f, df, L, M, scol, 1);
     const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(total, 256), 16384);
     hipLaunchKernelGGL(dual_softmax_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, a, rstat, cstat, df, srow, scol, L, M,
                        total, da);
@@ -1240,7 +1248,8 @@ extern "C" int cpn_soft_argmax_pair(const float* c, int B, int h, float beta, fl
     const hipStream_t st = (hipStream_t)stream;
     const int T = h * h;
     hipLaunchKernelGGL(soft_argmax_rows_kernel, dim3(T, B), dim3(256), 0, st, c, h, beta, t_to_s);
-    hipLaunchKernelGGL(soft_argmax_cols_kernel, dim3(cpn_cdiv(T, 64), B), dim3(256), 0, st, c, h, beta, s_to_t);
+    hipLaunchKernelGGL(soft_argmax_cols_kernel, dim3(cpn_cdiv(T, CR_COLS), B), dim3(CR_COLS * CR_GROUPS), 0, st, c, h, beta,
+                       s_to_t);
     CPN_LAUNCH_CHECK("cpn_soft_argmax_pair");
     return 0;
 }

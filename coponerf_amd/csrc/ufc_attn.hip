@@ -148,35 +148,66 @@ __global__ __launch_bounds__(256) void cross_rows_kernel(const float* __restrict
 }
 
 // ---- cross attention, column direction: trg_attn[b, t, h, :] = sum_s softmax_s(c[b,h,:,t])_s src_v[b, s, h, :] --------
-// thread = column t (coalesced reads down the rows), two passes: online (max, sum) then the weighted sum
+// block = XC_COLS columns x XC_GROUPS row groups: a thread walks rows s = g, g + XC_GROUPS, ... of its column with an
+// online softmax (running max, sum, C-vector), the groups' partials meet in LDS.  One thread per column (round-2 first
+// version) was 32 wavefronts on the whole chip for a (8, 256, 256) volume: 138 us per call.
+constexpr int XC_COLS = 16, XC_GROUPS = 16;
 template <int C>
-__global__ __launch_bounds__(64) void cross_cols_kernel(const float* __restrict__ c, const float* __restrict__ sv,
-                                                        int B, int H, int S, int T, float* __restrict__ out) {
-    extern __shared__ float svs[];                                    // S x C values of this (b, h)
-    const int t = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y % H, b = blockIdx.y / H;
-    for (int i = threadIdx.x; i < S * C; i += 64) svs[i] = sv[(((size_t)b * S + i / C) * H + h) * C + i % C];
+__global__ __launch_bounds__(XC_COLS * XC_GROUPS) void cross_cols_kernel(const float* __restrict__ c, const float* __restrict__ sv,
+                                                                        int B, int H, int S, int T, float* __restrict__ out) {
+    extern __shared__ float svs[];                                    // S x C values of this (b, h), then the partials
+    float* part = svs + (size_t)S * C;                                // [XC_GROUPS][C + 2][XC_COLS]
+    const int l = threadIdx.x % XC_COLS, g = threadIdx.x / XC_COLS;
+    const int t = blockIdx.x * XC_COLS + l, h = blockIdx.y % H, b = blockIdx.y / H;
+    for (int i = threadIdx.x; i < S * C; i += XC_COLS * XC_GROUPS) svs[i] = sv[(((size_t)b * S + i / C) * H + h) * C + i % C];
     __syncthreads();
-    if (t >= T) return;
-    const float* col = c + ((size_t)b * H + h) * S * T + t;
     float m = -INFINITY, z = 0.0f;
-    for (int s = 0; s < S; ++s) {
-        const float x = col[(size_t)s * T];
-        const float mn = fmaxf(m, x);
-        z = z * expf(m - mn) + expf(x - mn);
-        m = mn;
-    }
     float acc[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) acc[i] = 0.0f;
-    for (int s = 0; s < S; ++s) {
-        const float p = expf(col[(size_t)s * T] - m);
+    if (t < T) {
+        const float* col = c + ((size_t)b * H + h) * S * T + t;
+        for (int s = g; s < S; s += XC_GROUPS) {
+            const float x = col[(size_t)s * T];
+            if (x > m) {
+                const float r = expf(m - x);                          // 0 on the first row (m = -inf)
+                z *= r;
 #pragma unroll
-        for (int i = 0; i < C; ++i) acc[i] += p * svs[s * C + i];
+                for (int i = 0; i < C; ++i) acc[i] *= r;
+                m = x;
+            }
+            const float p = expf(x - m);
+            z += p;
+#pragma unroll
+            for (int i = 0; i < C; ++i) acc[i] += p * svs[s * C + i];
+        }
     }
-    const float iz = 1.0f / z;
-    float* o = out + (((size_t)b * T + t) * H + h) * C;
+    float* mine = part + (size_t)g * (C + 2) * XC_COLS + l;
+    mine[0] = m;
+    mine[XC_COLS] = z;
 #pragma unroll
-    for (int i = 0; i < C; ++i) o[i] = acc[i] * iz;
+    for (int i = 0; i < C; ++i) mine[(2 + i) * XC_COLS] = acc[i];
+    __syncthreads();
+    // merge: thread (l, g) finishes channels g, g + XC_GROUPS, ... of column l
+    if (t >= T) return;
+    float M = -INFINITY;
+    for (int q = 0; q < XC_GROUPS; ++q) M = fmaxf(M, part[(size_t)q * (C + 2) * XC_COLS + l]);
+    float Z = 0.0f;
+    float r[XC_GROUPS];
+#pragma unroll
+    for (int q = 0; q < XC_GROUPS; ++q) {
+        const float mq = part[(size_t)q * (C + 2) * XC_COLS + l];
+        r[q] = mq == -INFINITY ? 0.0f : expf(mq - M);
+        Z += part[(size_t)q * (C + 2) * XC_COLS + XC_COLS + l] * r[q];
+    }
+    const float iz = 1.0f / Z;
+    float* o = out + (((size_t)b * T + t) * H + h) * C;
+    for (int i = g; i < C; i += XC_GROUPS) {
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < XC_GROUPS; ++q) v += part[(size_t)q * (C + 2) * XC_COLS + (2 + i) * XC_COLS + l] * r[q];
+        o[i] = v * iz;
+    }
 }
 
 }  // namespace
@@ -209,7 +240,18 @@ extern "C" int cpn_cross_attention(const float* corr, const float* src_v, const 
     const hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cross_rows_kernel<32>, dim3(cpn_cdiv(S, 4), B * H), dim3(256), (size_t)4 * T * sizeof(float), s, corr,
                        trg_v, B, H, S, T, src_attn);
-    hipLaunchKernelGGL(cross_cols_kernel<32>, dim3(cpn_cdiv(T, 64), B * H), dim3(64), (size_t)S * 32 * sizeof(float), s, corr,
+    const size_t lds_cols = ((size_t)S * 32 + (size_t)XC_GROUPS * 34 * XC_COLS) * sizeof(float);      // <= 99 KiB at S = 512
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)cross_cols_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((512 * 32 + XC_GROUPS * 34 * XC_COLS) * sizeof(float)));
+        if (e != hipSuccess) {
+            cpn_set_error("cpn_cross_attention: cannot reserve LDS: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cross_cols_kernel<32>, dim3(cpn_cdiv(T, XC_COLS), B * H), dim3(XC_COLS * XC_GROUPS), lds_cols, s, corr,
                        src_v, B, H, S, T, trg_attn);
     CPN_LAUNCH_CHECK("cpn_cross_attention");
     return 0;
