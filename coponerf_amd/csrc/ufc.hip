@@ -677,12 +677,15 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = xr[c] / d;
 }
 
-// C (M x N) = A (M x K) . B (N x K)^T per batch; wave = 16 rows x 128 cols, block = 64 rows; K % 16 == 0
+// C (M x N) = A (M x K) . B (N x K)^T per batch; wave = 16 rows x 16*NT cols, block = 64 rows; K % 16 == 0.
+// NT = 8 for large problems (fewer re-reads of B), NT = 2 when 128-column tiles would leave most of the chip idle
+// (a 256 x 256 correlation is 8 workgroups at NT = 8); the operands of k block kb+16 are requested before the MFMAs of kb.
+template <int NT>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                           float* __restrict__ Cm, int M, int N, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
-    const int m0 = (blockIdx.y * 4 + wave) * 16, n0 = blockIdx.x * 128;
+    const int m0 = (blockIdx.y * 4 + wave) * 16, n0 = blockIdx.x * 16 * NT;
     if (m0 >= M) return;
     const float* Ab = A + (size_t)b * M * K;
     const float* Bb = Bm + (size_t)b * N * K;
@@ -691,29 +694,49 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     int ar = m0 + fi;
     ar = ar < M ? ar : M - 1;
     const float* ap = Ab + (size_t)ar * K + fg * 4;
-    f32x4 acc[8];
+    const float* bp[NT];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < K; kb += 16) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + kb);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int n = n0 + t * 16 + fi;
-            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (n < N) bv = *reinterpret_cast<const f32x4*>(Bb + (size_t)n * K + kb + fg * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], av[e], acc[t], 0, 0, 0);
-        }
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + t * 16 + fi;
+        bp[t] = Bb + (size_t)(n < N ? n : N - 1) * K + fg * 4;       // columns past N are computed and not stored
     }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int kb, f32x4& av, f32x4 (&bv)[NT]) {
+        av = *reinterpret_cast<const f32x4*>(ap + kb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bp[t] + kb);
+    };
+    auto step = [&](const f32x4& av, const f32x4 (&bv)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t][e], av[e], acc[t], 0, 0, 0);
+    };
+    f32x4 a0, a1, b0[NT], b1[NT];
+    load(0, a0, b0);
+    int kb = 0;
+    for (; kb + 32 <= K; kb += 32) {
+        load(kb + 16, a1, b1);
+        step(a0, b0);
+        if (kb + 32 < K) load(kb + 32, a0, b0);
+        step(a1, b1);
+    }
+    if (kb < K) step(a0, b0);
     const int m = m0 + fi;
     if (m >= M) return;
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < NT; ++t) {
+        const int nb = n0 + t * 16 + fg * 4;
+        if (nb + 3 < N && (N & 3) == 0) {
+            *reinterpret_cast<f32x4*>(Cb + (size_t)m * N + nb) = acc[t];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + t * 16 + fg * 4 + i;
-            if (n < N) Cb[(size_t)m * N + n] = acc[t][i];
+            for (int i = 0; i < 4; ++i)
+                if (nb + i < N) Cb[(size_t)m * N + nb + i] = acc[t][i];
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1235,8 +1258,13 @@ extern "C" int cpn_correlation(const float* src, const float* trg, int B, int L,
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, src, src_n, rows, C, eps);
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, trg, trg_n, rows, C, eps);
     CPN_LAUNCH_CHECK("cpn_correlation(normalise)");
-    dim3 grid(cpn_cdiv(L, 128), cpn_cdiv(L, 64), B);
-    hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(256), 0, st, src_n, trg_n, out, L, L, C);
+    if ((long long)B * cpn_cdiv(L, 128) * cpn_cdiv(L, 64) >= 512) {
+        dim3 grid(cpn_cdiv(L, 128), cpn_cdiv(L, 64), B);
+        hipLaunchKernelGGL(gemm_nt_f32_kernel<8>, grid, dim3(256), 0, st, src_n, trg_n, out, L, L, C);
+    } else {
+        dim3 grid(cpn_cdiv(L, 32), cpn_cdiv(L, 64), B);
+        hipLaunchKernelGGL(gemm_nt_f32_kernel<2>, grid, dim3(256), 0, st, src_n, trg_n, out, L, L, C);
+    }
     CPN_LAUNCH_CHECK("cpn_correlation(gemm)");
     return 0;
 }

@@ -313,6 +313,17 @@ class HipOps:
         if t.device.type != "cuda":
             raise RuntimeError("coponerf_amd UFC operators run on a HIP device only (tensor on %s)" % t.device)
 
+    def _stats(self, B, device):
+        """(B, 2) float64 zeros for one layer's GroupNorm sums.  A get_z call runs 63 Conv4d layers: their accumulators
+        are slices of one zeroed pool per HipOps instance (= per get_z call) instead of 63 fill launches."""
+        pool = getattr(self, "_stats_pool", None)
+        if pool is None or pool[0].shape[1] != B or pool[0].device != device or pool[1] >= pool[0].shape[0]:
+            pool = [torch.zeros(64, B, 2, device=device, dtype=torch.float64), 0]
+            self._stats_pool = pool
+        i = pool[1]
+        pool[1] = i + 1
+        return pool[0][i]
+
     def conv4d_gn_relu(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps):
         self._need_gpu(x)
         if _wants_grad(x, wq, bq, ws, bs, gn_w, gn_b):
@@ -326,7 +337,7 @@ class HipOps:
         o = lambda n: (n + 2 * p - k) // s + 1
         Hq2, Wq2, Hs2, Ws2 = o(Hq), o(Wq), o(Hs), o(Ws)
         y = torch.empty(B, Cout, Hq2, Wq2, Hs2, Ws2, device=x.device, dtype=torch.float32)
-        stats = torch.zeros(B, 2, device=x.device, dtype=torch.float64)
+        stats = self._stats(B, x.device)
         f = lambda t: t.detach().contiguous().float()
         wq_, bq_, ws_, bs_, gw, gb = f(wq), f(bq), f(ws), f(bs), f(gn_w), f(gn_b)
         from . import _hip
