@@ -64,7 +64,8 @@ CAM_STRIDE = 96
 CAM_TQ, CAM_M, CAM_AOWN, CAM_AOTH, CAM_KQ, CAM_KC, CAM_KO, CAM_KN = 0, 16, 32, 48, 64, 68, 72, 76
 XIN_K, XIN_STRIDE = 864, 896
 TAB_LD = 832
-ABI_VERSION = 1
+GN_SLOTS = 32              # CPN_GN_SLOTS of include/coponerf_hip.h
+ABI_VERSION = 2
 
 
 def declared_symbols() -> List[str]:

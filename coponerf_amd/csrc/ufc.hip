@@ -88,8 +88,11 @@ __global__ __launch_bounds__(256) void conv4d_kernel(const float* __restrict__ x
     if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(stats + b * 2, red[0] + red[2] + red[4] + red[6]);
-        atomicAdd(stats + b * 2 + 1, red[1] + red[3] + red[5] + red[7]);
+        // thousands of workgroups add into the same two doubles: spread them over CPN_GN_SLOTS accumulator pairs (the
+        // readers sum them); on one pair the atomics were 0.9 ms of a 12 ms get_z
+        double* dst = stats + ((size_t)b * CPN_GN_SLOTS + (blockIdx.x + blockIdx.y * 7) % CPN_GN_SLOTS) * 2;
+        atomicAdd(dst, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(dst + 1, red[1] + red[3] + red[5] + red[7]);
     }
 }
 
@@ -188,8 +191,11 @@ __global__ __launch_bounds__(256) void conv4d_pooled_kernel(const float* __restr
     if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(stats + b * 2, red[0] + red[2] + red[4] + red[6]);
-        atomicAdd(stats + b * 2 + 1, red[1] + red[3] + red[5] + red[7]);
+        // thousands of workgroups add into the same two doubles: spread them over CPN_GN_SLOTS accumulator pairs (the
+        // readers sum them); on one pair the atomics were 0.9 ms of a 12 ms get_z
+        double* dst = stats + ((size_t)b * CPN_GN_SLOTS + (blockIdx.x + blockIdx.y * 7) % CPN_GN_SLOTS) * 2;
+        atomicAdd(dst, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(dst + 1, red[1] + red[3] + red[5] + red[7]);
     }
 }
 
@@ -198,8 +204,8 @@ __global__ __launch_bounds__(256) void conv4d_pooled_kernel(const float* __restr
 // output channel); the weights are staged in LDS as [cin][tap][branch][cout] and read as wave-uniform (broadcast)
 // 16-byte vectors.  COUT = 8 (4 at B = 1 with 8 channels, where a 16^4 volume is 1 024 waves = ONE per SIMD): more
 // channels per thread would read the inputs fewer times but do not fit the register budget of 4 waves per SIMD.
-template <int COUT>
-__global__ __launch_bounds__(256, 4) void conv4d_k3s1_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+template <int COUT, bool PF>
+__global__ __launch_bounds__(256, PF ? 2 : 4) void conv4d_k3s1_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                           const float* __restrict__ bq, const float* __restrict__ ws,
                                                           const float* __restrict__ bs, int Cin, int Hq, int Wq,
                                                           int Hs, int Ws, int cout_total, float* __restrict__ y,
@@ -244,13 +250,15 @@ __global__ __launch_bounds__(256, 4) void conv4d_k3s1_kernel(const float* __rest
                 off[2 * t] = okq ? (((Y * Wq + X) * Hs + sy) * Ws + sx) * 4 : 0x7ffffff0;
                 off[2 * t + 1] = oks ? (((qy * Wq + qx) * Hs + U) * Ws + Vv) * 4 : 0x7ffffff0;
             }
-#pragma unroll 1
-        for (int c = 0; c < Cin; ++c) {
+        // the 18 taps of channel c+1 are requested before the FMAs of channel c (a channel is ~1 us of load latency and
+        // a few hundred cycles of math: at B = 1 nothing else hides it)
+        auto load_taps = [&](int c, float (&xv)[18]) {
             const int cbase = c * (int)npos * 4;              // scalar offset of the channel
-            float xv[18];
 #pragma unroll
             for (int t = 0; t < 18; ++t)
                 xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off[t], cbase, 0));
+        };
+        auto accumulate = [&](int c, const float (&xv)[18]) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ((c * 9 + t) * 2) * COUT);
@@ -263,6 +271,26 @@ __global__ __launch_bounds__(256, 4) void conv4d_k3s1_kernel(const float* __rest
                         acc[o4 * 4 + e] = __builtin_fmaf(bb[e], vs, __builtin_fmaf(a[e], vq, acc[o4 * 4 + e]));
                     if ((o4 & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // <= 4 weight vectors in flight
                 }
+            }
+        };
+        if (PF) {                                             // small launches (B = 1): latency, not occupancy, is the limit
+            float xa[18], xb2[18];
+            load_taps(0, xa);
+            int c = 0;
+#pragma unroll 1
+            for (; c + 2 <= Cin; c += 2) {
+                load_taps(c + 1, xb2);
+                accumulate(c, xa);
+                if (c + 2 < Cin) load_taps(c + 2, xa);
+                accumulate(c + 1, xb2);
+            }
+            if (c < Cin) accumulate(c, xa);
+        } else {                                              // large launches: 4 waves per SIMD hide the loads
+#pragma unroll 1
+            for (int c = 0; c < Cin; ++c) {
+                float xv[18];
+                load_taps(c, xv);
+                accumulate(c, xv);
             }
         }
 #pragma unroll
@@ -282,8 +310,11 @@ __global__ __launch_bounds__(256, 4) void conv4d_k3s1_kernel(const float* __rest
     if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(stats + b * 2, red[0] + red[2] + red[4] + red[6]);
-        atomicAdd(stats + b * 2 + 1, red[1] + red[3] + red[5] + red[7]);
+        // thousands of workgroups add into the same two doubles: spread them over CPN_GN_SLOTS accumulator pairs (the
+        // readers sum them); on one pair the atomics were 0.9 ms of a 12 ms get_z
+        double* dst = stats + ((size_t)b * CPN_GN_SLOTS + (blockIdx.x + blockIdx.y * 7) % CPN_GN_SLOTS) * 2;
+        atomicAdd(dst, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(dst + 1, red[1] + red[3] + red[5] + red[7]);
     }
 }
 
@@ -294,8 +325,13 @@ __global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const doub
     const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= npos) return;
     const double n = (double)Cout * (double)npos;
-    const double mean = stats[b * 2] / n;
-    const double var = stats[b * 2 + 1] / n - mean * mean;
+    double ssum = 0.0, ssq = 0.0;
+    for (int q = 0; q < CPN_GN_SLOTS; ++q) {
+        ssum += stats[((size_t)b * CPN_GN_SLOTS + q) * 2];
+        ssq += stats[((size_t)b * CPN_GN_SLOTS + q) * 2 + 1];
+    }
+    const double mean = ssum / n;
+    const double var = ssq / n - mean * mean;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const size_t idx = ((size_t)b * Cout + o) * npos + pos;
     const float v = (y[idx] - (float)mean) * rstd * gamma[o] + beta[o];
@@ -308,8 +344,13 @@ __global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const doub
 //   pass 2: dy = rstd_b * (dz*g_c - S1_b/n - yh*S2_b/n)
 // red: (B*2 + C*2) doubles, zero on entry.
 __device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, double n, float eps, float& mean, float& rstd) {
-    const double m = stats[b * 2] / n;
-    const double var = stats[b * 2 + 1] / n - m * m;
+    double ssum = 0.0, ssq = 0.0;
+    for (int q = 0; q < CPN_GN_SLOTS; ++q) {
+        ssum += stats[((size_t)b * CPN_GN_SLOTS + q) * 2];
+        ssq += stats[((size_t)b * CPN_GN_SLOTS + q) * 2 + 1];
+    }
+    const double m = ssum / n;
+    const double var = ssq / n - m * m;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
@@ -897,11 +938,14 @@ extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, cons
         dim3 g1(cpn_cdiv(npos, 256), Cout / per, B);
         const size_t wb = wbytes / (Cout / per);
         if (per == 4)
-            hipLaunchKernelGGL(conv4d_k3s1_kernel<4>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
-                               y, stats);
+            hipLaunchKernelGGL((conv4d_k3s1_kernel<4, true>), g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws,
+                               Cout, y, stats);
+        else if (small)
+            hipLaunchKernelGGL((conv4d_k3s1_kernel<8, true>), g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws,
+                               Cout, y, stats);
         else
-            hipLaunchKernelGGL(conv4d_k3s1_kernel<8>, g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws, Cout,
-                               y, stats);
+            hipLaunchKernelGGL((conv4d_k3s1_kernel<8, false>), g1, dim3(256), wb, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs, Ws,
+                               Cout, y, stats);
     } else if (s > 1 && scratch) {
         float* psv = scratch;
         float* pqv = scratch + (size_t)B * Cin * Hq * Wq * Os * Ps_;

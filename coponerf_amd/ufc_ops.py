@@ -108,14 +108,13 @@ class _Conv4dGnReluFn(Function):
                 flip = lambda w: w.detach().float().flip(-1, -2).transpose(0, 1).contiguous()
                 zb = torch.zeros(Cin, dtype=torch.float32, device=dev)
                 gx = torch.empty_like(x)
-                scratch = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+                scratch = torch.zeros(B, _hip.GN_SLOTS, 2, dtype=torch.float64, device=dev)
                 wq_t, ws_t = flip(wq), flip(ws)
                 call("cpn_conv4d", dy.data_ptr(), wq_t.data_ptr(), zb.data_ptr(), ws_t.data_ptr(), zb.data_ptr(), B, C, Cin,
                      Hq, Wq, Hs, Ws, 3, 1, 1, gx.data_ptr(), scratch.data_ptr(), 0, _stream())
             if need_w and Cin <= 32 and C <= 32 and Hs * Ws <= 256 and Hq * Wq <= 256 and min(Ws, Wq) >= 4:
                 # both separable branches on the HIP weight-gradient kernel; the query branch sees the volumes with
                 # the (query, support) index pairs swapped so that its 3x3 window runs over the last two dims too
-                from . import _hip
                 gwq = torch.empty(C, Cin, 3, 3, dtype=torch.float32, device=dev)
                 gws = torch.empty(C, Cin, 3, 3, dtype=torch.float32, device=dev)
                 gbs = torch.empty(C, dtype=torch.float32, device=dev)
@@ -314,11 +313,11 @@ class HipOps:
             raise RuntimeError("coponerf_amd UFC operators run on a HIP device only (tensor on %s)" % t.device)
 
     def _stats(self, B, device):
-        """(B, 2) float64 zeros for one layer's GroupNorm sums.  A get_z call runs 63 Conv4d layers: their accumulators
+        """(B, GN_SLOTS, 2) float64 zeros for one layer's GroupNorm sums.  A get_z call runs 63 Conv4d layers: their accumulators
         are slices of one zeroed pool per HipOps instance (= per get_z call) instead of 63 fill launches."""
         pool = getattr(self, "_stats_pool", None)
         if pool is None or pool[0].shape[1] != B or pool[0].device != device or pool[1] >= pool[0].shape[0]:
-            pool = [torch.zeros(64, B, 2, device=device, dtype=torch.float64), 0]
+            pool = [torch.zeros(64, B, _hip.GN_SLOTS, 2, device=device, dtype=torch.float64), 0]
             self._stats_pool = pool
         i = pool[1]
         pool[1] = i + 1

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 1
+#define CPN_ABI_VERSION 2
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -136,6 +136,7 @@ int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int 
  *       full-resolution NHWC fp16 map (N, H, W, 64)                                                               */
 #define CPN_TAB_LD    832
 #define CPN_NODE_PAD  4
+#define CPN_GN_SLOTS  32
 long long cpn_encode_table_nodes(int H, int W);
 int cpn_pack_encode_weights(const float* W, int ldw, uint16_t* wfrag, uint16_t* wtab, void* stream);
 int cpn_node_features(const uint16_t* map0, const uint16_t* map1, const uint16_t* map2, int H, int W, int nimg,
@@ -219,7 +220,8 @@ int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float
  * replaces conv4d.Conv4d / MaxPool4d / Encoder4D (models/conv4d.py:7-30, 57-163) and the einops rearrange copies
  * around them.  x (B,Cin,Hq,Wq,Hs,Ws) fp32; wq/ws (Cout,Cin,k,k), bq/bs (Cout): query / support 2-D kernels;
  * y (B,Cout,Hq',Wq',Hs',Ws') with n' = (n + 2p - k)/s + 1; gn_w/gn_b (Cout) GroupNorm affine;
- * stats (B,2) float64 scratch that MUST be zero on entry (sum, sum of squares per sample).
+ * stats (B, CPN_GN_SLOTS, 2) float64 scratch that MUST be zero on entry (sum, sum of squares per sample, spread over
+ * CPN_GN_SLOTS accumulator pairs that the consumers add up).
  * scratch: cpn_conv4d_scratch(...) floats for the pooled volumes of a strided layer (0 for stride 1; NULL = no scratch,
  * the pooling window is then re-evaluated per tap).                                                             */
 long long cpn_conv4d_scratch(int B, int Cin, int Hq, int Wq, int Hs, int Ws, int s);
