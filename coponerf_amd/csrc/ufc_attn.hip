@@ -210,11 +210,30 @@ __global__ __launch_bounds__(XC_COLS * XC_GROUPS) void cross_cols_kernel(const f
     }
 }
 
+// the nsplit partial (KV, Ksum) blocks of every (b, h) summed in a fixed order into one block: the apply kernel then reads
+// 4 KB per head instead of nsplit x 4 KB per workgroup (with 64 splits that was 268 MB of L2 reads per call)
+__global__ __launch_bounds__(256) void linear_attention_combine_kernel(const float* __restrict__ kv_part,
+                                                                       const float* __restrict__ ks_part, int nsplit, int Dv,
+                                                                       long long t1, long long t2, float* __restrict__ kv_sum,
+                                                                       float* __restrict__ ks_sum) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= t1 + t2) return;
+    const bool second = i >= t1;
+    if (second) i -= t1;
+    const int per = second ? LA_D : LA_D * Dv;
+    const float* part = second ? ks_part : kv_part;
+    const long long bh = i / per, e = i - bh * per;
+    float acc = 0.0f;
+    for (int sp = 0; sp < nsplit; ++sp) acc += part[(bh * nsplit + sp) * per + e];
+    (second ? ks_sum : kv_sum)[i] = acc;
+}
+
 }  // namespace
 
 extern "C" long long cpn_linear_attention_scratch(int B, int H, int Dv, int nsplit) {
-    return (long long)B * H * nsplit * LA_D * (Dv + 1);
+    return (long long)B * H * (nsplit + 1) * LA_D * (Dv + 1);
 }
+
 
 extern "C" int cpn_linear_attention(const float* q, const float* k, const float* v, int B, int L, int H, int Dv,
                                     int channel_major, float eps, int nsplit, float* scratch, float* out, void* stream) {
@@ -226,8 +245,18 @@ extern "C" int cpn_linear_attention(const float* q, const float* k, const float*
     float* ks_part = scratch + (size_t)B * H * nsplit * LA_D * Dv;
     hipLaunchKernelGGL(linear_attention_reduce_kernel, dim3(cpn_cdiv(Dv, 32), B * H, nsplit), dim3(256), 0, s, k, v, B, L, H,
                        Dv, channel_major, nsplit, kv_part, ks_part);
+    if (nsplit > 1) {
+        // fixed-order sum of the partials, once per head instead of once per apply workgroup
+        float* kv_sum = scratch + (size_t)B * H * nsplit * LA_D * (Dv + 1);
+        float* ks_sum = kv_sum + (size_t)B * H * LA_D * Dv;
+        const long long t1 = (long long)B * H * LA_D * Dv, t2 = (long long)B * H * LA_D;
+        hipLaunchKernelGGL(linear_attention_combine_kernel, dim3((unsigned)cpn_cdiv(t1 + t2, 256)), dim3(256), 0, s, kv_part,
+                           ks_part, nsplit, Dv, t1, t2, kv_sum, ks_sum);
+        kv_part = kv_sum;
+        ks_part = ks_sum;
+    }
     hipLaunchKernelGGL(linear_attention_apply_kernel, dim3(cpn_cdiv(L, 64), cpn_cdiv(Dv, 64), B * H), dim3(256), 0, s, q,
-                       kv_part, ks_part, B, L, H, Dv, channel_major, nsplit, eps, out);
+                       kv_part, ks_part, B, L, H, Dv, channel_major, nsplit > 1 ? 1 : nsplit, eps, out);
     CPN_LAUNCH_CHECK("cpn_linear_attention");
     return 0;
 }

@@ -398,7 +398,7 @@ class HipOps:
         if D != 32:
             raise ValueError("cpn_linear_attention is built for head dimension 32 (got %d)" % D)
         Dv = v_.shape[2] if channel_major else v_.shape[3]
-        nsplit = max(1, min(16, L // 256))
+        nsplit = max(1, min(64, L // 64))          # 64-token slabs: the reduce pass is latency-bound per slab
         scr = torch.empty(_hip.lib().cpn_linear_attention_scratch(B, H, Dv, nsplit), dtype=torch.float32, device=q.device)
         out = torch.empty_like(v_)
         call("cpn_linear_attention", q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), B, L, H, Dv, int(channel_major), float(eps),
