@@ -318,23 +318,45 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void conv4d_k3s1_kernel(const floa
     }
 }
 
+// mean / 1/std of sample b from its CPN_GN_SLOTS accumulator pairs, computed ONCE per workgroup (one slot per lane of the
+// first wave, shuffle reduction, LDS broadcast): every thread summing the slots itself doubled the readers' time.
+// Must be called by all threads of the block (contains a barrier).
+__device__ __forceinline__ void gn_block_stats(const double* __restrict__ stats, int b, double n, float eps, float& mean,
+                                               float& rstd) {
+    __shared__ float mr[2];
+    if (threadIdx.x < 64) {
+        double ssum = 0.0, ssq = 0.0;
+        if (threadIdx.x < CPN_GN_SLOTS) {
+            ssum = stats[((size_t)b * CPN_GN_SLOTS + threadIdx.x) * 2];
+            ssq = stats[((size_t)b * CPN_GN_SLOTS + threadIdx.x) * 2 + 1];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ssum += __shfl_xor(ssum, off);
+            ssq += __shfl_xor(ssq, off);
+        }
+        if (threadIdx.x == 0) {
+            const double m = ssum / n;
+            const double var = ssq / n - m * m;
+            mr[0] = (float)m;
+            mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    mean = mr[0];
+    rstd = mr[1];
+}
+
 __global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const double* __restrict__ stats,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, int Cout, long long npos, float* out) {
     const int b = blockIdx.z, o = blockIdx.y;
     const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float mean, rstd;
+    gn_block_stats(stats, b, (double)Cout * (double)npos, eps, mean, rstd);
     if (pos >= npos) return;
-    const double n = (double)Cout * (double)npos;
-    double ssum = 0.0, ssq = 0.0;
-    for (int q = 0; q < CPN_GN_SLOTS; ++q) {
-        ssum += stats[((size_t)b * CPN_GN_SLOTS + q) * 2];
-        ssq += stats[((size_t)b * CPN_GN_SLOTS + q) * 2 + 1];
-    }
-    const double mean = ssum / n;
-    const double var = ssq / n - mean * mean;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const size_t idx = ((size_t)b * Cout + o) * npos + pos;
-    const float v = (y[idx] - (float)mean) * rstd * gamma[o] + beta[o];
+    const float v = (y[idx] - mean) * rstd * gamma[o] + beta[o];
     out[idx] = fmaxf(v, 0.0f);
 }
 
@@ -343,25 +365,13 @@ __global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const doub
 //   pass 1: S1_b = sum dz*g_c, S2_b = sum dz*g_c*yh (over channels and positions);  dgamma_c = sum dz*yh, dbeta_c = sum dz
 //   pass 2: dy = rstd_b * (dz*g_c - S1_b/n - yh*S2_b/n)
 // red: (B*2 + C*2) doubles, zero on entry.
-__device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, double n, float eps, float& mean, float& rstd) {
-    double ssum = 0.0, ssq = 0.0;
-    for (int q = 0; q < CPN_GN_SLOTS; ++q) {
-        ssum += stats[((size_t)b * CPN_GN_SLOTS + q) * 2];
-        ssq += stats[((size_t)b * CPN_GN_SLOTS + q) * 2 + 1];
-    }
-    const double m = ssum / n;
-    const double var = ssq / n - m * m;
-    mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
-}
-
 __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(
     const float* __restrict__ y, const float* __restrict__ out, const float* __restrict__ dout,
     const double* __restrict__ stats, const float* __restrict__ gamma, float eps, int B, int Cout, long long npos,
     double* __restrict__ red) {
     const int b = blockIdx.z, o = blockIdx.y;
     float mean, rstd;
-    gn_mean_rstd(stats, b, (double)Cout * (double)npos, eps, mean, rstd);
+    gn_block_stats(stats, b, (double)Cout * (double)npos, eps, mean, rstd);
     const float g = gamma[o];
     double a[4] = {0.0, 0.0, 0.0, 0.0};
     const size_t base = ((size_t)b * Cout + o) * npos;
@@ -423,10 +433,10 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(
         dgamma[o] = (float)red[2 * B + o * 2];
         dbeta[o] = (float)red[2 * B + o * 2 + 1];
     }
-    if (pos >= npos) return;
     const double n = (double)Cout * (double)npos;
     float mean, rstd;
-    gn_mean_rstd(stats, b, n, eps, mean, rstd);
+    gn_block_stats(stats, b, n, eps, mean, rstd);           // block-wide: before the early return
+    if (pos >= npos) return;
     const float m1 = (float)(red[b * 2] / n), m2 = (float)(red[b * 2 + 1] / n);
     const size_t idx = ((size_t)b * Cout + o) * npos + pos;
     const float dz = out[idx] > 0.0f ? dout[idx] : 0.0f;
