@@ -388,8 +388,9 @@ __global__ __launch_bounds__(256) void hid_grad_combine_kernel(
 // Scatter-add of the gather gradient without atomic contention.
 // Global fp32 atomics collapse here (millions of rows land on a few hundred coarse pixels: 316 ms per training step)
 // and ds_add_f32 is ~10x slower than a plain LDS write on gfx950 (measured, tools/gbwd_bench.py), so accumulation is
-// made exclusive instead: ONE WAVE owns one (image, level, 8x8-pixel tile, 64-channel slice) accumulator in LDS
-// (16 KB fp32) with lane = channel, so its read-modify-writes need no atomics at all.
+// made exclusive instead: ONE WAVE owns one (image, level, 8x4-pixel tile, 64-channel slice) accumulator in LDS
+// (8 KB fp32; with 8x8 tiles LDS held the kernel at 2 waves per SIMD: 12.5 vs 9.0 ms per training step) with lane =
+// channel, so its read-modify-writes need no atomics at all.
 //   pass 1 (gather_bbox_kernel): per 64-row chunk and level, the pixel bounding box of the rows' 2x2 footprints.
 //   pass 2 (gather_rows_bwd_kernel): the wave
 //     A) tests 64 chunk boxes at a time against its tile (lane = chunk), and for the chunks that may touch it
@@ -397,7 +398,11 @@ __global__ __launch_bounds__(256) void hid_grad_combine_kernel(
 //     B) drains the queue NB rows at a time: the 128-byte channel slices of dxin for the NEXT NB rows are in flight
 //        while the current NB are accumulated.
 // Coarse levels are additionally split G ways over the rows; tiles are flushed once with global atomics.
-constexpr int TP = 8;        // tile side (pixels)
+#ifndef CPN_GBWD_TPY
+#define CPN_GBWD_TPY 4
+#endif
+constexpr int TP = 8;        // tile width (pixels)
+constexpr int TPY = CPN_GBWD_TPY;   // tile height: 8 x TPY x 64 ch x 4 B of LDS per wave decide the occupancy
 constexpr int TC = 64;       // channels per slice = lanes
 constexpr int QCAP = 128;    // descriptor queue entries per wave
 constexpr int NB = 16;       // rows per drain batch
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
     const float* __restrict__ sec_grid, int V, int R, int S, int ray0, int nrays, float* __restrict__ dmap0,
     float* __restrict__ dmap1, float* __restrict__ dmap2, float* __restrict__ dmap3, GatherBwdPlan plan,
     int nroles, const int4* __restrict__ bbox) {
-    __shared__ float tiles_lds[WAVES][TP * TP * TC];
+    __shared__ float tiles_lds[WAVES][TP * TPY * TC];
     __shared__ uint4 queue_lds[WAVES][QCAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tile = tiles_lds[wave];
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
     const int tidx = role % plan.tiles; role /= plan.tiles;
     const int g = role % G;
     const int img = role / G;
-    const int tx0 = (tidx % plan.tiles_x) * TP, ty0 = (tidx / plan.tiles_x) * TP;
+    const int tx0 = (tidx % plan.tiles_x) * TP, ty0 = (tidx / plan.tiles_x) * TPY;
     const int shift = 4 - lvl - (lvl == 3);
     const int Hl = H >> shift, Wl = W >> shift;
     const int C = (lvl == 3) ? 64 : 256;
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
     float* base = (lvl == 0) ? dmap0 : (lvl == 1) ? dmap1 : (lvl == 2) ? dmap2 : dmap3;
 
 #pragma unroll
-    for (int i = 0; i < TP * TP; ++i) tile[i * TC + lane] = 0.0f;
+    for (int i = 0; i < TP * TPY; ++i) tile[i * TC + lane] = 0.0f;
 
     const int b = img / V, vi = img - b * V;
     const int rlo = max(ray0, b * R) - b * R, rhi = min(ray0 + nrays, (b + 1) * R) - b * R;
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
         bool maybe = false;
         if (cb + lane < c_end) {
             const int4 bx = boxes[(size_t)(cb + lane) * 4];
-            maybe = (bx.z >= tx0) && (bx.x < tx0 + TP) && (bx.w >= ty0) && (bx.y < ty0 + TP);
+            maybe = (bx.z >= tx0) && (bx.x < tx0 + TP) && (bx.w >= ty0) && (bx.y < ty0 + TPY);
         }
         unsigned long long cmask = __ballot(maybe);
         while (cmask) {
@@ -572,13 +577,13 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
                 const int x0 = (int)xf, y0 = (int)yf;
                 const float fx = x - xf, fy = y - yf;
                 const int hx = x0 - tx0, hy = y0 - ty0;
-                if (hx >= -1 && hx < TP && hy >= -1 && hy < TP) {
+                if (hx >= -1 && hx < TP && hy >= -1 && hy < TPY) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int xi = x0 + (k & 1), yi = y0 + (k >> 1);
                         const float wk = ((k & 1) ? fx : 1.0f - fx) * ((k >> 1) ? fy : 1.0f - fy);
                         const bool in_img = (xi >= 0) && (xi < Wl) && (yi >= 0) && (yi < Hl);
-                        const bool in_tile = (xi >= tx0) && (xi < tx0 + TP) && (yi >= ty0) && (yi < ty0 + TP);
+                        const bool in_tile = (xi >= tx0) && (xi < tx0 + TP) && (yi >= ty0) && (yi < ty0 + TPY);
                         if (in_img && in_tile && wk != 0.0f) flags |= 1 << k;
                     }
                     desc.x = rf.row;
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
 
     float* m = base + (size_t)img * Hl * Wl * C + slice * TC + lane;
 #pragma unroll 4
-    for (int pix = 0; pix < TP * TP; ++pix) {
+    for (int pix = 0; pix < TP * TPY; ++pix) {
         const float v = tile[pix * TC + lane];
         const int gy = ty0 + (pix >> 3), gx = tx0 + (pix & 7);
         if (v != 0.0f && gy < Hl && gx < Wl) atomicAdd(m + ((size_t)gy * Wl + gx) * C, v);
@@ -667,7 +672,7 @@ extern "C" int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, 
         plan.lvl = l;
         plan.maxchunks = maxchunks;
         plan.tiles_x = (Wl + TP - 1) / TP;
-        plan.tiles = plan.tiles_x * ((Hl + TP - 1) / TP);
+        plan.tiles = plan.tiles_x * ((Hl + TPY - 1) / TPY);
         plan.slices = (l == 3 ? 64 : 256) / TC;
         const long long hits = cand / plan.tiles;                            // expected rows landing on one tile
         plan.G = (int)std::min<long long>(64, std::max<long long>(1, (hits + 1023) / 2048));

@@ -10,13 +10,15 @@ SO = os.path.join(ROOT, "tools", "_build", "libgbwd_nodrain.so")
 if "--build" in sys.argv:
     src = os.path.join(ROOT, "coponerf_amd", "csrc")
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    objs = []
-    for f, extra in (("error.cpp", []), ("backward.hip", ["-DCPN_GBWD_NO_DRAIN"])):
-        o = os.path.join(ROOT, "tools", "_build", "gbwd_" + f.split(".")[0] + ".o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-                               os.path.join(src, f), "-o", o] + extra)
-        objs.append(o)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", SO])
+    for tag, extra in (("nodrain", ["-DCPN_GBWD_NO_DRAIN"]), ("tpy8", ["-DCPN_GBWD_TPY=8"]), ("tpy2", ["-DCPN_GBWD_TPY=2"])):
+        objs = []
+        for f, ex in (("error.cpp", []), ("backward.hip", extra)):
+            o = os.path.join(ROOT, "tools", "_build", f"gbwd_{tag}_" + f.split(".")[0] + ".o")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
+                                   os.path.join(src, f), "-o", o] + ex)
+            objs.append(o)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs +
+                              ["-o", SO.replace("nodrain", tag)])
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import torch
@@ -39,10 +41,12 @@ from coponerf_amd import _hip
 boxes = torch.empty(B * 2 * _hip.lib().cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=dev)
 P, I = ctypes.c_void_p, ctypes.c_int
 variants = [("product", None)]
-if os.path.exists(SO):
-    fn = ctypes.CDLL(SO).cpn_gather_rows_bwd
-    fn.argtypes = [P, I, I, I, P, P, I, I, I, I, I, I, P, P, P, P, P, P]
-    variants.append(("no accumulation (scan only)", fn))
+for tag, label in (("nodrain", "no accumulation (scan only)"), ("tpy8", "8 x 8 pixel tiles (round 1)"), ("tpy2", "8 x 2 pixel tiles")):
+    so = SO.replace("nodrain", tag)
+    if os.path.exists(so):
+        fn = ctypes.CDLL(so).cpn_gather_rows_bwd
+        fn.argtypes = [P, I, I, I, P, P, I, I, I, I, I, I, P, P, P, P, P, P]
+        variants.append((label, fn))
 for cfg, fn in variants:
     ts = []
     for it in range(4):
