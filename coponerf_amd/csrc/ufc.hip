@@ -204,7 +204,11 @@ __global__ __launch_bounds__(256) void conv4d_pooled_kernel(const float* __restr
 // output channel); the weights are staged in LDS as [cin][tap][branch][cout] and read as wave-uniform (broadcast)
 // 16-byte vectors.  COUT = 8 (4 at B = 1 with 8 channels, where a 16^4 volume is 1 024 waves = ONE per SIMD): more
 // channels per thread would read the inputs fewer times but do not fit the register budget of 4 waves per SIMD.
-template <int COUT, bool PF>
+// DGRAD: the same kernel as the data gradient of the layer — input = dy, weights read IN PLACE as the transposed, flipped
+// filters (w'[o][c][tap] = w[c][o][8 - tap], the forward layer's (cout_fwd = Cin here, cin_fwd = cout_total, 3, 3)
+// tensors), no bias, no statistics.  The autograd wrapper used to build flipped copies, a zero bias and a statistics
+// buffer per layer: ~450 small launches per training step.
+template <int COUT, bool PF, bool DGRAD = false>
 __global__ __launch_bounds__(256, PF ? 2 : 4) void conv4d_k3s1_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                           const float* __restrict__ bq, const float* __restrict__ ws,
                                                           const float* __restrict__ bs, int Cin, int Hq, int Wq,
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void conv4d_k3s1_kernel(const floa
         int t = i / COUT;
         const int br = t & 1; t >>= 1;
         const int tap = t % 9, c = t / 9;
-        wl[i] = (br ? ws : wq)[((size_t)o * Cin + c) * 9 + tap];
+        wl[i] = DGRAD ? (br ? ws : wq)[((size_t)c * cout_total + o) * 9 + (8 - tap)]
+                      : (br ? ws : wq)[((size_t)o * Cin + c) * 9 + tap];
     }
     __syncthreads();
     const long long npos = (long long)Hq * Wq * Hs * Ws;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void conv4d_k3s1_kernel(const floa
         const int qy = (int)(t / Wq);
         float acc[COUT];
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) acc[o] = bq[o0 + o] + bs[o0 + o];
+        for (int o = 0; o < COUT; ++o) acc[o] = DGRAD ? 0.0f : bq[o0 + o] + bs[o0 + o];
         // The 18 taps of this position as 32-bit byte offsets into the batch element's (Cin, npos) block, read with
         // buffer loads (scalar base + per-lane offset; an out-of-range offset returns 0 = the zero padding).  Registers
         // are what limits this kernel: with 64-bit per-lane addresses it needed 512 VGPRs = one wave per SIMD.
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void conv4d_k3s1_kernel(const floa
             s2 += (double)acc[o] * acc[o];
         }
     }
+    if (DGRAD) return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         s1 += __shfl_xor(s1, off);
@@ -972,6 +978,30 @@ extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, cons
                            Pq_, Os, Ps_, y, stats);
     }
     CPN_LAUNCH_CHECK("cpn_conv4d");
+    return 0;
+}
+
+extern "C" int cpn_conv4d_dgrad(const float* dy, const float* wq, const float* ws, int B, int Cout, int Cin, int Hq, int Wq,
+                                int Hs, int Ws, float* dx, void* stream) {
+    CPN_REQUIRE(dy && wq && ws && dx, CPN_E_ARG, "cpn_conv4d_dgrad: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && Cin > 0 && Cout > 0 && Hq > 0 && Wq > 0 && Hs > 0 && Ws > 0, CPN_E_SHAPE,
+                "cpn_conv4d_dgrad: bad shape");
+    const long long npos = (long long)Hq * Wq * Hs * Ws;
+    // the data gradient is a k3 s1 p1 convolution of dy (Cout channels) producing Cin channels: channel groups of 8 (4)
+    CPN_REQUIRE((Cin % 4) == 0 && (long long)Cout * npos * 4 < 0x7ffffff0LL, CPN_E_SHAPE,
+                "cpn_conv4d_dgrad: need Cin %% 4 == 0 and a batch element below 2 GiB (Cin=%d)", Cin);
+    const int per = (Cin % 8) == 0 ? 8 : 4;
+    const size_t wb = (size_t)Cout * 9 * 2 * per * sizeof(float);
+    CPN_REQUIRE(wb <= 64 * 1024, CPN_E_SHAPE, "cpn_conv4d_dgrad: filter slice exceeds 64 KiB of LDS (Cout=%d)", Cout);
+    dim3 g1(cpn_cdiv(npos, 256), Cin / per, B);
+    const hipStream_t st = (hipStream_t)stream;
+    if (per == 4)
+        hipLaunchKernelGGL((conv4d_k3s1_kernel<4, false, true>), g1, dim3(256), wb, st, dy, wq, (const float*)nullptr, ws,
+                           (const float*)nullptr, Cout, Hq, Wq, Hs, Ws, Cin, dx, (double*)nullptr);
+    else
+        hipLaunchKernelGGL((conv4d_k3s1_kernel<8, false, true>), g1, dim3(256), wb, st, dy, wq, (const float*)nullptr, ws,
+                           (const float*)nullptr, Cout, Hq, Wq, Hs, Ws, Cin, dx, (double*)nullptr);
+    CPN_LAUNCH_CHECK("cpn_conv4d_dgrad");
     return 0;
 }
 

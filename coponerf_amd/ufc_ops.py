@@ -104,7 +104,13 @@ class _Conv4dGnReluFn(Function):
         gx = gwq = gbq = gws = gbs = None
         if k == 3 and s == 1 and p == 1:
             Bx, Cin, Hq, Wq, Hs, Ws = x.shape
-            if need_x:
+            if need_x and Cin % 4 == 0:
+                gx = torch.empty_like(x)
+                fw = lambda w: w.detach().contiguous().float()            # read in place (transposed, flipped) by the kernel
+                wq_c, ws_c = fw(wq), fw(ws)
+                call("cpn_conv4d_dgrad", dy.data_ptr(), wq_c.data_ptr(), ws_c.data_ptr(), B, C, Cin, Hq, Wq, Hs, Ws,
+                     gx.data_ptr(), _stream())
+            elif need_x:
                 flip = lambda w: w.detach().float().flip(-1, -2).transpose(0, 1).contiguous()
                 zb = torch.zeros(Cin, dtype=torch.float32, device=dev)
                 gx = torch.empty_like(x)

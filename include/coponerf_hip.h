@@ -235,6 +235,10 @@ int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const f
 int cpn_conv4d(const float* x, const float* wq, const float* bq, const float* ws, const float* bs, int B, int Cin,
                int Cout, int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, float* scratch,
                void* stream);
+/* data gradient of the k3 s1 p1 Conv4d (the layer's two (Cout,Cin,3,3) filters read in place, transposed and flipped):
+ * dy (B,Cout,Hq,Wq,Hs,Ws) -> dx (B,Cin,Hq,Wq,Hs,Ws); Cin % 4 == 0                                                  */
+int cpn_conv4d_dgrad(const float* dy, const float* wq, const float* ws, int B, int Cout, int Cin, int Hq, int Wq, int Hs,
+                     int Ws, float* dx, void* stream);
 int cpn_gn_relu(const float* y, const double* stats, const float* gn_w, const float* gn_b, float eps, int B, int C,
                 long long npos, float* out, void* stream);
 /* backward of GroupNorm(1 group) + ReLU (autograd of models/conv4d.py:150-158): y pre-normalisation volume, out the

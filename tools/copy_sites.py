@@ -7,6 +7,8 @@ from torch.utils._python_dispatch import TorchDispatchMode
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from coponerf_amd import CoPoNeRF, synthetic as syn      # noqa: E402
 
+MIN_ELEMS = int(os.environ.get("MIN_ELEMS", 1 << 16))
+BY_COUNT = os.environ.get("BY_COUNT", "0") == "1"
 WATCH = {"copy_", "clone", "_to_copy", "cat", "add", "add_", "mul", "sum", "fill_", "zero_", "zeros", "zeros_like", "stack"}
 
 
@@ -21,7 +23,7 @@ class Rec(TorchDispatchMode):
         name = func.__name__.split(".")[0]
         if name in WATCH:
             t = out if torch.is_tensor(out) else (args[0] if args and torch.is_tensor(args[0]) else None)
-            if t is not None and t.is_cuda and t.numel() >= 1 << 16:
+            if t is not None and t.is_cuda and t.numel() >= MIN_ELEMS:
                 frame = "(autograd)"
                 for fs in reversed(traceback.extract_stack(limit=40)):
                     if "coponerf_amd" in fs.filename:
@@ -49,6 +51,8 @@ with rec:
     (model(inp, val=False)["rgb"] - inp["query"]["rgb"]).abs().mean().backward()
 tot = sum(rec.bytes.values())
 print(f"{sum(rec.agg.values())} watched ops on tensors >= 64 K elements, {tot / 1e9:.2f} GB of outputs")
-for key, b in rec.bytes.most_common(int(sys.argv[1]) if len(sys.argv) > 1 else 45):
+items = rec.agg.most_common if BY_COUNT else rec.bytes.most_common
+for key, _ in items(int(sys.argv[1]) if len(sys.argv) > 1 else 45):
+    b = rec.bytes[key]
     name, shape, frame = key
     print(f"{b / 1e6:9.1f} MB x{rec.agg[key]:4d} {name:10s} {str(shape):28s} {frame}")
