@@ -83,6 +83,7 @@ class _Conv4dGnReluFn(Function):
         y, out, stats = ops._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps, keep_pre=True)
         ctx.save_for_backward(x, wq, bq, ws, bs, gn_w, y, out, stats)
         ctx.cfg = (k, s, p, eps)
+        ctx.ops = ops
         return out
 
     @staticmethod
@@ -93,7 +94,7 @@ class _Conv4dGnReluFn(Function):
         npos = y[0, 0].numel()
         dev = y.device
         dout = dout.contiguous().float()
-        red = torch.zeros(B * 2 + C * 2, dtype=torch.float64, device=dev)
+        red = ctx.ops._zeros64(B * 2 + C * 2, dev)            # zeroed accumulators from the per-call pool
         dy = torch.empty_like(y)
         dgw = torch.empty(C, dtype=torch.float32, device=dev)
         dgb = torch.empty(C, dtype=torch.float32, device=dev)
@@ -328,6 +329,17 @@ class HipOps:
         i = pool[1]
         pool[1] = i + 1
         return pool[0][i]
+
+    def _zeros64(self, n, device):
+        """n float64 zeros carved from a pooled, once-zeroed buffer (the backward of every Conv4d layer needs a few
+        dozen zeroed accumulators: one fill per 64 KB instead of one per layer)."""
+        pool = getattr(self, "_z64_pool", None)
+        if pool is None or pool[0].device != device or pool[1] + n > pool[0].numel():
+            pool = [torch.zeros(max(8192, n), device=device, dtype=torch.float64), 0]
+            self._z64_pool = pool
+        i = pool[1]
+        pool[1] = i + ((n + 1) // 2) * 2                      # keep 16-byte alignment
+        return pool[0][i:i + n]
 
     def conv4d_gn_relu(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps):
         self._need_gpu(x)
