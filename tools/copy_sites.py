@@ -41,14 +41,25 @@ shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
 model.load_state_dict(syn.make_full_weights(shapes), strict=True)
 model = model.to(dev).train()
 mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (o.to(dev) if torch.is_tensor(o) else o)
-inp = mv(syn.make_inputs(4, 256, 256, 4096, seed=61))
-for _ in range(1):
-    model.zero_grad(set_to_none=True)
-    (model(inp, val=False)["rgb"] - inp["query"]["rgb"]).abs().mean().backward()
-model.zero_grad(set_to_none=True)
+GETZ = os.environ.get("GETZ", "0") == "1"          # profile one inference get_z at B = 1 instead of a training step
+inp = mv(syn.make_inputs(1 if GETZ else 4, 256, 256, 4096, seed=61))
+if GETZ:
+    model.eval()
+
+
+def step():
+    if GETZ:
+        with torch.no_grad():
+            model.get_z(inp)
+    else:
+        model.zero_grad(set_to_none=True)
+        (model(inp, val=False)["rgb"] - inp["query"]["rgb"]).abs().mean().backward()
+
+
+step()
 rec = Rec()
 with rec:
-    (model(inp, val=False)["rgb"] - inp["query"]["rgb"]).abs().mean().backward()
+    step()
 tot = sum(rec.bytes.values())
 print(f"{sum(rec.agg.values())} watched ops on tensors >= 64 K elements, {tot / 1e9:.2f} GB of outputs")
 items = rec.agg.most_common if BY_COUNT else rec.bytes.most_common
