@@ -42,6 +42,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_transpose_pairs": [_P, _I, _I, _I, _P, _P],
     "cpn_conv4d_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_gn_relu": [_P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P],
     "cpn_gn_relu_bwd": [_P, _P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],

@@ -882,6 +882,30 @@ __global__ __launch_bounds__(CR_COLS * CR_GROUPS) void soft_argmax_cols_kernel(c
 }
 
 // ------------------------------------------------------------------------------------------------
+// (N, P, Q) -> (N, Q, P) batched matrix transpose = swapping the (query, support) index pairs of a 4-D correlation
+// volume, x.permute(0,1,4,5,2,3).contiguous() in the reference's notation (aggregation.py:275, 349 and every
+// `rearrange` around conv4d.py).  32 x 32 tiles through LDS, coalesced on both sides; ATen's strided copy for this
+// permutation runs at 0.8 TB/s and there are ~170 of them in a training step.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_pairs_kernel(const float* __restrict__ x, int P, int Q, float* __restrict__ y) {
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * P * Q;
+    const int q0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + ty + i * 8, q = q0 + tx;
+        if (p < P && q < Q) tile[ty + i * 8][tx] = x[base + (size_t)p * Q + q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = q0 + ty + i * 8, p = p0 + tx;
+        if (p < P && q < Q) y[base + (size_t)q * P + p] = tile[tx][ty + i * 8];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bilinear resize with align_corners=True of `planes` independent (h, w) images: F.interpolate as used by
 // interpolate4d / forward_attention (aggregation.py:49-56, 285, 293, 299).  thread = output pixel; HBM-bound.
 // ------------------------------------------------------------------------------------------------
@@ -1002,6 +1026,15 @@ extern "C" int cpn_conv4d_dgrad(const float* dy, const float* wq, const float* w
         hipLaunchKernelGGL((conv4d_k3s1_kernel<8, false, true>), g1, dim3(256), wb, st, dy, wq, (const float*)nullptr, ws,
                            (const float*)nullptr, Cout, Hq, Wq, Hs, Ws, Cin, dx, (double*)nullptr);
     CPN_LAUNCH_CHECK("cpn_conv4d_dgrad");
+    return 0;
+}
+
+extern "C" int cpn_transpose_pairs(const float* x, int N, int P, int Q, float* y, void* stream) {
+    CPN_REQUIRE(x && y, CPN_E_ARG, "cpn_transpose_pairs: null pointer");
+    CPN_REQUIRE(N > 0 && N < 65536 && P > 0 && Q > 0, CPN_E_SHAPE, "cpn_transpose_pairs: bad shape (N=%d)", N);
+    hipLaunchKernelGGL(transpose_pairs_kernel, dim3(cpn_cdiv(Q, 32), cpn_cdiv(P, 32), N), dim3(256), 0, (hipStream_t)stream, x, P,
+                       Q, y);
+    CPN_LAUNCH_CHECK("cpn_transpose_pairs");
     return 0;
 }
 

@@ -150,7 +150,8 @@ def _map_to_tokens(x):
 def _corr_to_maps(corr):
     """(B,H,Hs,Ws,Ht,Wt) -> (B, H*Ht*Wt, Hs, Ws)."""
     B, H, Hs, Ws, Ht, Wt = corr.shape
-    return corr.permute(0, 1, 4, 5, 2, 3).reshape(B, H * Ht * Wt, Hs, Ws)
+    from .ufc_ops import swap_pairs
+    return swap_pairs(corr).reshape(B, H * Ht * Wt, Hs, Ws)
 
 
 class UFCLayer(nn.Module):
@@ -218,6 +219,7 @@ class UFCLayer(nn.Module):
 
     def forward(self, corr, src, trg, ops):             # aggregation.py:342-356
         t4 = lambda x: x.permute(0, 1, 4, 5, 2, 3)
+        from .ufc_ops import swap_pairs as _swap              # t4(x).contiguous() as one transpose kernel
         if corr.is_cuda and TWO_STREAMS and torch.cuda.is_current_stream_capturing():
             # Inside a HIP-graph capture (coponerf_amd/graphs.py) the source and target attention passes — independent,
             # and made of kernels that each fill a fraction of the chip (16^4 volumes, a few hundred workgroups) — are
@@ -228,14 +230,14 @@ class UFCLayer(nn.Module):
             side = _side_stream(corr.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                corr_trg, trg_r = self._attention(t4(corr).contiguous(), trg, ops)
+                corr_trg, trg_r = self._attention(_swap(corr), trg, ops)
             corr_src, src_r = self._attention(corr, src, ops)
             cur.wait_stream(side)
             corr_trg.record_stream(cur)
             trg_r.record_stream(cur)
         else:
             corr_src, src_r = self._attention(corr, src, ops)
-            corr_trg, trg_r = self._attention(t4(corr).contiguous(), trg, ops)
+            corr_trg, trg_r = self._attention(_swap(corr), trg, ops)
         corr_r = corr_src + t4(corr_trg)
         corr_r = corr_r + self.feat_to_corr1(ops.correlation_tokens(src_r, trg_r, self.fs), ops)
         corr_r = corr_r + self.mlp_refine_corr(corr_r, ops)

@@ -129,8 +129,8 @@ class _Conv4dGnReluFn(Function):
                 xf = x.detach().contiguous().float()
                 call("cpn_conv_wgrad_planes", xf.data_ptr(), dy.data_ptr(), B, Cin, C, Hq * Wq, Hs, Ws, part.data_ptr(),
                      gws.data_ptr(), gbs.data_ptr(), _stream())
-                xt = xf.permute(0, 1, 4, 5, 2, 3).contiguous()
-                dt = dy.permute(0, 1, 4, 5, 2, 3).contiguous()
+                xt = _swap_pairs_hip(xf)
+                dt = _swap_pairs_hip(dy)
                 call("cpn_conv_wgrad_planes", xt.data_ptr(), dt.data_ptr(), B, Cin, C, Hs * Ws, Hq, Wq, part.data_ptr(),
                      gwq.data_ptr(), 0, _stream())
                 gbq = gbs
@@ -227,6 +227,37 @@ class DwConv3x3Fn(Function):
             call("cpn_dwconv3x3_wgrad", xf.data_ptr(), dy.data_ptr(), N, C, H, W, dw.data_ptr(),
                  0 if db is None else db.data_ptr(), _stream())
         return dx, dw, db
+
+
+def _swap_pairs_hip(x):
+    """(B,C,a,b,c,d) fp32 -> contiguous (B,C,c,d,a,b) on cpn_transpose_pairs (any layout in: made contiguous first)."""
+    xc = x.contiguous().float()
+    B, C, a, b, c, d = xc.shape
+    y = torch.empty(B, C, c, d, a, b, dtype=torch.float32, device=xc.device)
+    if B * C >= 65536:
+        return xc.permute(0, 1, 4, 5, 2, 3).contiguous()
+    call("cpn_transpose_pairs", xc.data_ptr(), B * C, a * b, c * d, y.data_ptr(), _stream())
+    return y
+
+
+class SwapPairsFn(Function):
+    """x.permute(0,1,4,5,2,3).contiguous() of a 4-D correlation volume as one coalesced transpose kernel; the gradient is
+    the same swap applied to the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _swap_pairs_hip(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _swap_pairs_hip(dy)
+
+
+def swap_pairs(x):
+    """Contiguous (B,C,c,d,a,b) from (B,C,a,b,c,d): HIP transpose on the GPU, the library permute elsewhere."""
+    if x.is_cuda and x.dim() == 6:
+        return SwapPairsFn.apply(x) if torch.is_grad_enabled() and x.requires_grad else _swap_pairs_hip(x)
+    return x.permute(0, 1, 4, 5, 2, 3).contiguous()
 
 
 class DwConvTokensFn(Function):

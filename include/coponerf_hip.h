@@ -235,6 +235,10 @@ int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const f
 int cpn_conv4d(const float* x, const float* wq, const float* bq, const float* ws, const float* bs, int B, int Cin,
                int Cout, int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, float* scratch,
                void* stream);
+/* x (N, P, Q) fp32 -> y (N, Q, P): the (query, support) pair swap of a 4-D volume, (B,C,Hq,Wq,Hs,Ws) ->
+ * (B,C,Hs,Ws,Hq,Wq) with N = B*C, P = Hq*Wq, Q = Hs*Ws (x.permute(0,1,4,5,2,3).contiguous(), models/aggregation.py:349) */
+int cpn_transpose_pairs(const float* x, int N, int P, int Q, float* y, void* stream);
+
 /* data gradient of the k3 s1 p1 Conv4d (the layer's two (Cout,Cin,3,3) filters read in place, transposed and flipped):
  * dy (B,Cout,Hq,Wq,Hs,Ws) -> dx (B,Cin,Hq,Wq,Hs,Ws); Cin % 4 == 0                                                  */
 int cpn_conv4d_dgrad(const float* dy, const float* wq, const float* ws, int B, int Cout, int Cin, int Hq, int Wq, int Hs,
