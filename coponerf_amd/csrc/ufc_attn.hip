@@ -24,11 +24,16 @@ __device__ __forceinline__ size_t v_index(bool cm, int b, int l, int h, int dv, 
 
 // ---- phase 1: per (b, h, 32-wide dv tile, l split): partial KV (32 x 32) and partial Ksum (32) ---------------------
 // thread = (d, 4 dv columns); K and V rows of a 32-token tile are staged in LDS
+// BWD (the backward's dKV / dKsum): k is phi(Q)'s source, v the output gradient, every token's value row is scaled by
+// tok_scale[b,h,l] (= L Z_l) instead of 1/L and enters the row sum with weight tok_wt[b,h,l] (= dden_l) instead of 1
+template <bool BWD>
 __global__ __launch_bounds__(256) void linear_attention_reduce_kernel(
     const float* __restrict__ k, const float* __restrict__ v, int B, int L, int H, int Dv, int cm, int nsplit,
-    float* __restrict__ kv_part, float* __restrict__ ks_part) {
+    const float* __restrict__ tok_scale, const float* __restrict__ tok_wt, float* __restrict__ kv_part,
+    float* __restrict__ ks_part) {
     __shared__ float ks[32][LA_D + 1];
     __shared__ float vs[32][33];
+    __shared__ float wt[32], sc[32];
     const int tid = threadIdx.x;
     const int dvt = blockIdx.x, h = blockIdx.y % H, b = blockIdx.y / H, sp = blockIdx.z;
     const int d = tid >> 3, c4 = (tid & 7) * 4;
@@ -37,6 +42,14 @@ __global__ __launch_bounds__(256) void linear_attention_reduce_kernel(
     const float invL = 1.0f / (float)L;
     float acc[4] = {0, 0, 0, 0}, ksum = 0.0f;
     for (int lt = l0; lt < l1; lt += 32) {
+        if (BWD) {
+            if (tid < 32) {
+                const int l = lt + tid;
+                sc[tid] = l < l1 ? tok_scale[((size_t)b * H + h) * L + l] : 0.0f;
+                wt[tid] = l < l1 ? tok_wt[((size_t)b * H + h) * L + l] : 0.0f;
+            }
+            __syncthreads();
+        }
         // stage 32 tokens: K (32 x 32, token-major always) and V (32 x 32 slice)
         for (int i = tid; i < 32 * 32; i += 256) {
             const int tl = i >> 5, e = i & 31;
@@ -47,13 +60,13 @@ __global__ __launch_bounds__(256) void linear_attention_reduce_kernel(
             // channel-major: consecutive threads walk l (contiguous); token-major: consecutive threads walk dv
             const int tl = cm ? (i & 31) : (i >> 5), e = cm ? (i >> 5) : (i & 31);
             const int l = lt + tl, dv = dvt * 32 + e;
-            vs[tl][e] = (l < l1 && dv < Dv) ? v[v_index(cm, b, l, h, dv, L, H, Dv)] * invL : 0.0f;
+            vs[tl][e] = (l < l1 && dv < Dv) ? v[v_index(cm, b, l, h, dv, L, H, Dv)] * (BWD ? sc[tl] : invL) : 0.0f;
         }
         __syncthreads();
 #pragma unroll 8
         for (int tl = 0; tl < 32; ++tl) {
             const float kd = ks[tl][d];
-            ksum += kd;
+            ksum += BWD ? kd * wt[tl] : kd;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] += kd * vs[tl][c4 + j];
         }
@@ -70,6 +83,8 @@ __global__ __launch_bounds__(256) void linear_attention_reduce_kernel(
 
 // ---- phase 2: out[l, h, dv] = L * (Q_l . KV[:, dv]) / (Q_l . Ksum + eps) ---------------------------------------------
 // block = (b, h, 64-token tile, 64-wide dv tile); the split partials are summed in a fixed order (deterministic)
+// BWD (the backward's dV): q is phi(K)'s source, kv_part is dKV and out[l, h, dv] = (phi(K)_l . dKV[:, dv]) / L
+template <bool BWD>
 __global__ __launch_bounds__(256) void linear_attention_apply_kernel(
     const float* __restrict__ q, const float* __restrict__ kv_part, const float* __restrict__ ks_part, int B, int L,
     int H, int Dv, int cm, int nsplit, float eps, float* __restrict__ out) {
@@ -99,14 +114,14 @@ __global__ __launch_bounds__(256) void linear_attention_apply_kernel(
         qs[tl][d] = l < L ? elu1(q[(((size_t)b * L + l) * H + h) * LA_D + d]) : 0.0f;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 64 && !BWD) {
         float s = 0.0f;
 #pragma unroll
         for (int d = 0; d < LA_D; ++d) s += qs[tid][d] * kss[d];
         zs[tid] = 1.0f / (s + eps);
     }
     __syncthreads();
-    const float fL = (float)L;
+    const float fL = (float)L, invL = 1.0f / (float)L;
     for (int i = tid; i < 64 * 64; i += 256) {
         // channel-major output: consecutive threads walk l; token-major: consecutive threads walk dv
         const int tl = cm ? (i & 63) : (i >> 6), e = cm ? (i >> 6) : (i & 63);
@@ -115,8 +130,82 @@ __global__ __launch_bounds__(256) void linear_attention_apply_kernel(
         float s = 0.0f;
 #pragma unroll
         for (int d = 0; d < LA_D; ++d) s += qs[tl][d] * kvs[d][e];
-        out[v_index(cm, b, l, h, dv, L, H, Dv)] = s * zs[tl] * fL;
+        out[v_index(cm, b, l, h, dv, L, H, Dv)] = BWD ? s * invL : s * zs[tl] * fL;
     }
+}
+
+// ---- backward helper: T[l, :] = X[l, :] . M^T  (X: (L x Dv) values or output gradients, M: (32 x Dv) KV or dKV) ----------
+// block = (b, h, 64-token tile); thread = (token, 8 of the 32 d).  Epilogues:
+//   MODE 0 (X = dOut, M = KV, a = q):  a_l = phi(Q)_l . T_l,  Z_l = 1 / (phi(Q)_l . Ksum + eps),  dden_l = -L a_l Z_l^2,
+//          dq_l = (L Z_l T_l + dden_l Ksum) phi'(q_l);  tok_scale = L Z_l and tok_wt = dden_l feed the dKV / dKsum reduce
+//   MODE 1 (X = V,    M = dKV, a = k): dk_l = (T_l / L + dKsum) phi'(k_l)
+// phi'(x) = 1 (x > 0) or exp(x) = phi(x)
+template <int MODE>
+__global__ __launch_bounds__(256) void linear_attention_tokens_kernel(
+    const float* __restrict__ x, const float* __restrict__ m, const float* __restrict__ msum, const float* __restrict__ a,
+    int B, int L, int H, int Dv, int cm, float eps, float* __restrict__ da, float* __restrict__ tok_scale,
+    float* __restrict__ tok_wt) {
+    __shared__ float xs[64][65];
+    __shared__ float ms[LA_D][65];
+    const int tid = threadIdx.x;
+    const int lt = blockIdx.x * 64, h = blockIdx.y % H, b = blockIdx.y / H;
+    const int tl = tid >> 2, d0 = (tid & 3) * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    const float* mb = m + (size_t)(b * H + h) * LA_D * Dv;
+    for (int dv0 = 0; dv0 < Dv; dv0 += 64) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int t = cm ? (i & 63) : (i >> 6), e = cm ? (i >> 6) : (i & 63);
+            const int l = lt + t, dv = dv0 + e;
+            xs[t][e] = (l < L && dv < Dv) ? x[v_index(cm, b, l, h, dv, L, H, Dv)] : 0.0f;
+        }
+        for (int i = tid; i < LA_D * 64; i += 256) {
+            const int d = i >> 6, e = i & 63;
+            ms[d][e] = dv0 + e < Dv ? mb[(size_t)d * Dv + dv0 + e] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int e = 0; e < 64; ++e) {
+            const float xv = xs[tl][e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += xv * ms[d0 + j][e];
+        }
+        __syncthreads();
+    }
+    const int l = lt + tl;
+    const bool live = l < L;
+    const size_t row = (((size_t)b * L + (live ? l : 0)) * H + h) * LA_D + d0;
+    float raw[8], phi[8], sum8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        raw[j] = live ? a[row + j] : 0.0f;
+        phi[j] = elu1(raw[j]);
+        sum8[j] = msum[(size_t)(b * H + h) * LA_D + d0 + j];
+    }
+    float out[8];
+    if (MODE == 0) {
+        float at = 0.0f, den = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { at += phi[j] * acc[j]; den += phi[j] * sum8[j]; }
+        at += __shfl_xor(at, 1); at += __shfl_xor(at, 2);
+        den += __shfl_xor(den, 1); den += __shfl_xor(den, 2);
+        const float z = 1.0f / (den + eps), fL = (float)L;
+        const float dden = -fL * at * z * z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = fL * z * acc[j] + dden * sum8[j];
+        if (live && (tid & 3) == 0) {
+            tok_scale[((size_t)b * H + h) * L + l] = fL * z;
+            tok_wt[((size_t)b * H + h) * L + l] = dden;
+        }
+    } else {
+        const float invL = 1.0f / (float)L;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = acc[j] * invL + sum8[j];
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) da[row + j] = out[j] * (raw[j] > 0.0f ? 1.0f : phi[j]);
 }
 
 // ---- cross attention, row direction: src_attn[b, s, h, :] = sum_t softmax_t(c[b,h,s,:])_t trg_v[b, t, h, :] ------------
@@ -243,8 +332,8 @@ extern "C" int cpn_linear_attention(const float* q, const float* k, const float*
     const hipStream_t s = (hipStream_t)stream;
     float* kv_part = scratch;
     float* ks_part = scratch + (size_t)B * H * nsplit * LA_D * Dv;
-    hipLaunchKernelGGL(linear_attention_reduce_kernel, dim3(cpn_cdiv(Dv, 32), B * H, nsplit), dim3(256), 0, s, k, v, B, L, H,
-                       Dv, channel_major, nsplit, kv_part, ks_part);
+    hipLaunchKernelGGL(linear_attention_reduce_kernel<false>, dim3(cpn_cdiv(Dv, 32), B * H, nsplit), dim3(256), 0, s, k, v, B,
+                       L, H, Dv, channel_major, nsplit, (const float*)nullptr, (const float*)nullptr, kv_part, ks_part);
     if (nsplit > 1) {
         // fixed-order sum of the partials, once per head instead of once per apply workgroup
         float* kv_sum = scratch + (size_t)B * H * nsplit * LA_D * (Dv + 1);
@@ -255,9 +344,69 @@ extern "C" int cpn_linear_attention(const float* q, const float* k, const float*
         kv_part = kv_sum;
         ks_part = ks_sum;
     }
-    hipLaunchKernelGGL(linear_attention_apply_kernel, dim3(cpn_cdiv(L, 64), cpn_cdiv(Dv, 64), B * H), dim3(256), 0, s, q,
-                       kv_part, ks_part, B, L, H, Dv, channel_major, nsplit > 1 ? 1 : nsplit, eps, out);
+    hipLaunchKernelGGL(linear_attention_apply_kernel<false>, dim3(cpn_cdiv(L, 64), cpn_cdiv(Dv, 64), B * H), dim3(256), 0, s,
+                       q, kv_part, ks_part, B, L, H, Dv, channel_major, nsplit > 1 ? 1 : nsplit, eps, out);
     CPN_LAUNCH_CHECK("cpn_linear_attention");
+    return 0;
+}
+
+// scratch of the backward: two partial/combined (KV, Ksum) sets (the recomputed forward one and the gradient one) and the two
+// per-token scalars
+extern "C" long long cpn_linear_attention_bwd_scratch(int B, int L, int H, int Dv, int nsplit) {
+    return 2 * cpn_linear_attention_scratch(B, H, Dv, nsplit) + 2LL * B * H * L;
+}
+
+// VJP of cpn_linear_attention: dq, dk (B, L, H, 32) and dv (layout of v) from dout (layout of out).  With P = phi(Q),
+// N = phi(K), KV = sum_s N_s (x) V_s / L, Ks = sum_s N_s, Z_l = 1 / (P_l . Ks + eps), out_l = L Z_l P_l . KV:
+//   T_l = dout_l . KV^T,  a_l = P_l . T_l,  dden_l = -L a_l Z_l^2,  dP_l = L Z_l T_l + dden_l Ks
+//   dKV = sum_l P_l (x) (L Z_l dout_l),  dKs = sum_l dden_l P_l
+//   dN_s = V_s . dKV^T / L + dKs,  dV_s = N_s . dKV / L
+// (reference: autograd through models/aggregation.py:84-117.)  Launches: reduce + combine (KV, Ks again), tokens<0>, reduce<BWD>
+// + combine, tokens<1>, apply<BWD>; every operand is read in its native layout.
+extern "C" int cpn_linear_attention_bwd(const float* q, const float* k, const float* v, const float* dout, int B, int L, int H,
+                                        int Dv, int channel_major, float eps, int nsplit, float* scratch, float* dq, float* dk,
+                                        float* dv, void* stream) {
+    CPN_REQUIRE(q && k && v && dout && scratch && dq && dk && dv, CPN_E_ARG, "cpn_linear_attention_bwd: null pointer");
+    CPN_REQUIRE(B > 0 && L > 0 && H > 0 && Dv > 0 && nsplit > 0 && nsplit <= 64 && (long long)B * H < 65536, CPN_E_SHAPE,
+                "cpn_linear_attention_bwd: bad shape");
+    const hipStream_t s = (hipStream_t)stream;
+    const size_t set = (size_t)cpn_linear_attention_scratch(B, H, Dv, nsplit);
+    const size_t parts = (size_t)B * H * nsplit * LA_D * Dv, partsum = (size_t)B * H * nsplit * LA_D * (Dv + 1);
+    const long long t1 = (long long)B * H * LA_D * Dv, t2 = (long long)B * H * LA_D;
+    float* tok_scale = scratch + 2 * set;
+    float* tok_wt = tok_scale + (size_t)B * H * L;
+    const float* sums[2][2];
+    for (int pass = 0; pass < 2; ++pass) {
+        float* base = scratch + pass * set;
+        float* kv_part = base;
+        float* ks_part = base + parts;
+        if (pass == 0)
+            hipLaunchKernelGGL(linear_attention_reduce_kernel<false>, dim3(cpn_cdiv(Dv, 32), B * H, nsplit), dim3(256), 0, s, k,
+                               v, B, L, H, Dv, channel_major, nsplit, (const float*)nullptr, (const float*)nullptr, kv_part,
+                               ks_part);
+        else
+            hipLaunchKernelGGL(linear_attention_reduce_kernel<true>, dim3(cpn_cdiv(Dv, 32), B * H, nsplit), dim3(256), 0, s, q,
+                               dout, B, L, H, Dv, channel_major, nsplit, (const float*)tok_scale, (const float*)tok_wt,
+                               kv_part, ks_part);
+        if (nsplit > 1) {
+            float* kv_sum = base + partsum;
+            float* ks_sum = kv_sum + t1;
+            hipLaunchKernelGGL(linear_attention_combine_kernel, dim3((unsigned)cpn_cdiv(t1 + t2, 256)), dim3(256), 0, s,
+                               kv_part, ks_part, nsplit, Dv, t1, t2, kv_sum, ks_sum);
+            kv_part = kv_sum;
+            ks_part = ks_sum;
+        }
+        sums[pass][0] = kv_part;
+        sums[pass][1] = ks_part;
+        if (pass == 0)
+            hipLaunchKernelGGL(linear_attention_tokens_kernel<0>, dim3(cpn_cdiv(L, 64), B * H), dim3(256), 0, s, dout,
+                               sums[0][0], sums[0][1], q, B, L, H, Dv, channel_major, eps, dq, tok_scale, tok_wt);
+    }
+    hipLaunchKernelGGL(linear_attention_tokens_kernel<1>, dim3(cpn_cdiv(L, 64), B * H), dim3(256), 0, s, v, sums[1][0],
+                       sums[1][1], k, B, L, H, Dv, channel_major, eps, dk, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(linear_attention_apply_kernel<true>, dim3(cpn_cdiv(L, 64), cpn_cdiv(Dv, 64), B * H), dim3(256), 0, s, k,
+                       sums[1][0], sums[1][1], B, L, H, Dv, channel_major, 1, eps, dv);
+    CPN_LAUNCH_CHECK("cpn_linear_attention_bwd");
     return 0;
 }
 

@@ -43,6 +43,62 @@ class _HipForwardVjp(Function):
         return (None, None) + tuple(next(it) if n else None for n in need)
 
 
+class _CorrelationFn(Function):
+    """correlation_tokens with a closed-form backward on the normalised tokens the forward kernel already wrote:
+    C = sn tn^T, sn = s / (|s| + eps)  =>  dsn = dC tn, dtn = dC^T sn, ds = dsn / (|s| + eps) - sn (sn . dsn) / |s|.
+    (The library VJP re-ran the L x L x C forward product first.)"""
+
+    @staticmethod
+    def forward(ctx, ops, src, trg, fs):
+        out, sn, tn = ops._correlation(src, trg, fs)
+        ctx.save_for_backward(src, trg, sn, tn)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        src, trg, sn, tn = ctx.saved_tensors
+        B, L, _ = src.shape
+        dC = gout.reshape(B, L, L)
+
+        def through_norm(x, xn, dxn):
+            r = x.norm(dim=-1, p=2, keepdim=True)
+            return dxn / (r + 1e-5) - xn * ((xn * dxn).sum(-1, keepdim=True) / r.clamp_min(1e-30))
+
+        ds = through_norm(src, sn, torch.bmm(dC, tn)) if ctx.needs_input_grad[1] else None
+        dt = through_norm(trg, tn, torch.bmm(dC.transpose(1, 2), sn)) if ctx.needs_input_grad[2] else None
+        return None, ds, dt, None
+
+
+def _linear_attention_splits(L):
+    return max(1, min(64, L // 64))          # 64-token slabs: the reduce pass is latency-bound per slab
+
+
+class _LinearAttentionFn(Function):
+    """linear_attention with cpn_linear_attention_bwd as its VJP (the library VJP re-ran the forward as ~15 ATen ops
+    and differentiated those: 8 ms of the training step)."""
+
+    @staticmethod
+    def forward(ctx, ops, q, k, v, channel_major, eps):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        ctx.save_for_backward(q, k, v)
+        ctx.cm, ctx.eps = channel_major, eps
+        with torch.no_grad():
+            return ops.linear_attention(q, k, v, channel_major, eps)
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, k, v = ctx.saved_tensors
+        B, L, H, _ = q.shape
+        Dv = v.shape[2] if ctx.cm else v.shape[3]
+        nsplit = _linear_attention_splits(L)
+        g = gout.contiguous().float()
+        scr = torch.empty(_hip.lib().cpn_linear_attention_bwd_scratch(B, L, H, Dv, nsplit), dtype=torch.float32, device=q.device)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        call("cpn_linear_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), g.data_ptr(), B, L, H, Dv, int(ctx.cm),
+             float(ctx.eps), nsplit, scr.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _stream())
+        return None, dq, dk, dv, None, None
+
+
 def _wants_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
 
@@ -311,18 +367,6 @@ class _ResizeFn(Function):
                                                                  list(ctx.in_shape), True, None, None), None
 
 
-def _linear_attention_lib(q, k, v, channel_major, eps=1e-6):
-    """Library-op statement of cpn_linear_attention (only its VJP is ever used: training backward)."""
-    if channel_major:
-        v = v.permute(0, 3, 1, 2)
-    Q, K = F.elu(q) + 1, F.elu(k) + 1
-    L = v.shape[1]
-    KV = torch.einsum("nshd,nshv->nhdv", K, v / L)
-    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
-    out = torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * L
-    return out.permute(0, 2, 3, 1) if channel_major else out
-
-
 def _cross_attention_lib(c, src_v, trg_v):
     return (torch.einsum("bhst,bthc->bshc", c.softmax(-1), trg_v), torch.einsum("bhst,bshc->bthc", c.softmax(-2), src_v))
 
@@ -333,12 +377,6 @@ def _conv_map_lib(rgb, w, b):
     mean = torch.tensor((0.485, 0.456, 0.406), device=x.device).view(1, 3, 1, 1)
     std = torch.tensor((0.229, 0.224, 0.225), device=x.device).view(1, 3, 1, 1)
     return F.conv2d((x - mean) / std, w, b, stride=1, padding=3)
-
-
-def _correlation_lib(src, trg, fs):
-    n = lambda t: t / (t.norm(dim=-1, p=2, keepdim=True) + 1e-5)
-    return torch.einsum("bsc,btc->bst", n(src), n(trg)).reshape(src.shape[0], 1, fs, fs, fs, fs)
-
 
 
 class HipOps:
@@ -407,8 +445,10 @@ class HipOps:
     def correlation_tokens(self, src, trg, fs):
         self._need_gpu(src)
         if _wants_grad(src, trg):
-            return _HipForwardVjp.apply(lambda a, b: self.correlation_tokens(a, b, fs),
-                                        lambda a, b: _correlation_lib(a, b, fs), src.float(), trg.float())
+            return _CorrelationFn.apply(self, src.float(), trg.float(), fs)
+        return self._correlation(src, trg, fs)[0]
+
+    def _correlation(self, src, trg, fs):
         B, L, C = src.shape
         s_ = src.contiguous().float()
         t_ = trg.contiguous().float()
@@ -416,7 +456,7 @@ class HipOps:
         sn, tn = torch.empty_like(s_), torch.empty_like(t_)
         call("cpn_correlation", s_.data_ptr(), t_.data_ptr(), B, L, C, 1e-5, sn.data_ptr(), tn.data_ptr(),
              out.data_ptr(), _stream())
-        return out
+        return out, sn, tn
 
     def conv_map(self, rgb, w, b, want_nhwc16=False):
         """conv_map of get_z (CoPoNeRF.py:69, 182-187) on cpn_conv_map7x7: rgb (N,H,W,3) in [-1,1] as the input dict
@@ -438,16 +478,13 @@ class HipOps:
         q, k (B,L,H,32); v / result (B,L,H,Dv) or, channel_major, (B,H,Dv,L)."""
         self._need_gpu(q)
         if _wants_grad(q, k, v):
-            return _HipForwardVjp.apply(lambda a, b, c: self.linear_attention(a, b, c, channel_major, eps),
-                                        lambda a, b, c: _linear_attention_lib(a, b, c, channel_major, eps),
-                                        q.float(), k.float(), v.float())
-        from . import _hip
+            return _LinearAttentionFn.apply(self, q.float(), k.float(), v.float(), channel_major, eps)
         q_, k_, v_ = q.contiguous().float(), k.contiguous().float(), v.contiguous().float()
         B, L, H, D = q_.shape
         if D != 32:
             raise ValueError("cpn_linear_attention is built for head dimension 32 (got %d)" % D)
         Dv = v_.shape[2] if channel_major else v_.shape[3]
-        nsplit = max(1, min(64, L // 64))          # 64-token slabs: the reduce pass is latency-bound per slab
+        nsplit = _linear_attention_splits(L)
         scr = torch.empty(_hip.lib().cpn_linear_attention_scratch(B, H, Dv, nsplit), dtype=torch.float32, device=q.device)
         out = torch.empty_like(v_)
         call("cpn_linear_attention", q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), B, L, H, Dv, int(channel_major), float(eps),

@@ -309,6 +309,12 @@ int cpn_soft_argmax_pair_bwd(const float* c, int B, int h, float beta, const flo
 long long cpn_linear_attention_scratch(int B, int H, int Dv, int nsplit);
 int cpn_linear_attention(const float* q, const float* k, const float* v, int B, int L, int H, int Dv,
                          int channel_major, float eps, int nsplit, float* scratch, float* out, void* stream);
+/* VJP of K9 (autograd through models/aggregation.py:84-117 in the reference): dout has out's layout, dv has v's;
+ * dq, dk (B, L, H, 32).  scratch: cpn_linear_attention_bwd_scratch(B, L, H, Dv, nsplit) floats.  All three are overwritten. */
+long long cpn_linear_attention_bwd_scratch(int B, int L, int H, int Dv, int nsplit);
+int cpn_linear_attention_bwd(const float* q, const float* k, const float* v, const float* dout, int B, int L, int H, int Dv,
+                             int channel_major, float eps, int nsplit, float* scratch, float* dq, float* dk, float* dv,
+                             void* stream);
 
 /* ---- K10: cost-volume cross attention of UFCLayer.forward_cross (models/aggregation.py:327-328) -------------------
  * corr (B, H, S, T) fp32; src_v (B, S, H, C), trg_v (B, T, H, C), C == 32

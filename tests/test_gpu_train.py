@@ -162,6 +162,13 @@ def test_ufc_operator_gradients_match_oracle(dev):
     src, trg = syn.normal((2, 64, 32), seed=88), syn.normal((2, 64, 32), seed=89)
     both("correlation_tokens", [src, trg], lambda f, t: f(t[0], t[1], 8))
     both("soft_argmax_pair", [syn.normal((2, 1, 8, 8, 8, 8), seed=80) * 0.05], lambda f, t: f(t[0]))
+    # linear attention, both value layouts, ragged L / Dv and more than one token slab (L >= 128 -> nsplit 2)
+    q, k = syn.normal((2, 150, 3, 32), seed=60), syn.normal((2, 150, 3, 32), seed=61)
+    both("linear_attention", [q, k, syn.normal((2, 150, 3, 40), seed=62)], lambda f, t: f(t[0], t[1], t[2]))
+    both("linear_attention", [q, k, syn.normal((2, 3, 72, 150), seed=63)], lambda f, t: f(t[0], t[1], t[2], True))
+    both("linear_attention", [q[:, :33], k[:, :33], syn.normal((2, 33, 3, 32), seed=64)], lambda f, t: f(t[0], t[1], t[2]))
+    both("cross_attention", [syn.normal((2, 3, 40, 56), seed=65) * 2.0, syn.normal((2, 40, 3, 32), seed=66),
+                             syn.normal((2, 56, 3, 32), seed=67)], lambda f, t: f(t[0], t[1], t[2]))
     both("resize_bilinear", [syn.normal((2, 3, 8, 8), seed=79)], lambda f, t: f(t[0], 16))
     both("dual_softmax", [syn.normal((2, 70, 130), seed=78) * 2.0], lambda f, t: f(t[0]))
 
