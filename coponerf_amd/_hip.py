@@ -38,6 +38,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_hid_grad_combine": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_wgrad_skinny_f16": [_P, _P, _I, ctypes.c_longlong, _P, _P, _P],
+    "cpn_wgrad_tall_f16": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
     "cpn_local_hidden_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -117,6 +118,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
     handle.cpn_conv4d_scratch.argtypes = [_I] * 7
     handle.cpn_conv4d_scratch.restype = ctypes.c_longlong
+    handle.cpn_wgrad_tall_scratch.argtypes = [_I, _I]
+    handle.cpn_wgrad_tall_scratch.restype = ctypes.c_longlong
     handle.cpn_conv_wgrad_scratch.argtypes = [_I, _I]
     handle.cpn_conv_wgrad_scratch.restype = ctypes.c_longlong
     handle.cpn_dwconv3x3_tokens_wgrad_scratch.argtypes = [_I, _I, _I]

@@ -27,6 +27,7 @@ UNITS = [
     ("encoder.hip", []),
     ("input.hip", []),
     ("backward.hip", []),
+    ("wgrad_tall.hip", []),
 ]
 
 

@@ -332,6 +332,22 @@ class RenderEngine:
              g["pe6"].data_ptr(), g["loc8"].data_ptr(), s)
         return g
 
+    def _start_host_copy(self, t):
+        """Device->host copy of `t` into pinned memory on the side stream, ordered after the work queued so far; returns
+        (host tensor, event to synchronize on before handing it out)."""
+        dev = t.device
+        if self._copy_stream is None or self._copy_stream.device != dev:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            host.copy_(t, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        return host, done
+
     # ---- the differentiable render pass (training; gradients to the render weights and to z) ------------
     def render_train(self, params: Dict[str, torch.Tensor], ctx_c2w, ctx_K, qry_c2w, qry_K, uv,
                      z: Sequence[torch.Tensor], rel_pose, val: bool, S: int, H: int, W: int) -> Dict[str, torch.Tensor]:
@@ -345,6 +361,7 @@ class RenderEngine:
         if B * R > 32768:
             raise ValueError("render_train keeps all activations of the call: at most 32768 rays per call")
         g = self._geometry(ctx_c2w, ctx_K, qry_c2w, qry_K, uv, rel_pose, val, S, H, W)
+        pixel_val_cpu, copy_done = self._start_host_copy(g["pixel_val"])    # the caller contract's CPU copy, off the main stream
         dims = (B, V, R, S)
         gs = GradScale(self.grad_scale_target)      # one scale for all fp16 activation gradients of this pass
         hp = HidGradParts()                         # rank-one gradients of hid, combined in its producer's backward
@@ -395,8 +412,9 @@ class RenderEngine:
         raw = LinearF32Fn.apply(x, P["phi.lin_out.weight"], P["phi.lin_out.bias"], None, True, False)     # (nray, 3)
         valid = g["overlaps"].view(B, V, R).any(dim=1).float()
         rgb = raw.view(B, R, 3) * valid[..., None] + (1 - valid[..., None])
+        copy_done.synchronize()
         return {"rgb": rgb.view(B, 1, R, 3), "valid_mask": valid[..., None], "pixel_val": g["pixel_val"],
-                "pixel_val_cpu": g["pixel_val"].cpu(), "pt": g["pt"], "at_wt": w1, "coords": g["coords9"],
+                "pixel_val_cpu": pixel_val_cpu, "pt": g["pt"], "at_wt": w1, "coords": g["coords9"],
                 "z_local": zl, "Tq": g["Tq"], "sec_grid": g["sec_grid"], "rgb_raw": raw, "host": g["host"]}
 
     # ---- the render pass -------------------------------------------------------------------------
@@ -445,16 +463,7 @@ class RenderEngine:
 
         # the caller contract wants pixel_val on the CPU (CoPoNeRF.py:490): start the 8*N*R*S-byte device->host copy
         # now, into pinned memory on a side stream, so it overlaps the GEMMs instead of stalling the step's tail
-        if self._copy_stream is None or self._copy_stream.device != dev:
-            self._copy_stream = torch.cuda.Stream(device=dev)
-        pixel_val_cpu = torch.empty(pixel_val.shape, dtype=f32, pin_memory=True)
-        geom_done = torch.cuda.Event()
-        geom_done.record()
-        with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(geom_done)
-            pixel_val_cpu.copy_(pixel_val, non_blocking=True)
-            copy_done = torch.cuda.Event()
-            copy_done.record()
+        pixel_val_cpu, copy_done = self._start_host_copy(pixel_val)
 
         nray_total = B * R
         zl = torch.empty(nray_total, 416, dtype=f32, device=dev)

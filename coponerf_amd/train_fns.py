@@ -64,6 +64,18 @@ def _mm_f32(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
     return torch.mm(a16, b16, out_dtype=torch.float32)
 
 
+def _wgrad_tall(d16: torch.Tensor, x16: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """dW (N, K) fp32 = d16^T (N, M) . x16 (M, K) / scale on cpn_wgrad_tall_f16 (N % 208 == 0, K % 128 == 0; the library's
+    split-K GEMM runs the 832 x 896 x 4.2 M case at 500 TFLOP/s, 12.5 ms of the training step)."""
+    M, N = d16.shape
+    K = x16.shape[1]
+    part = torch.empty(_hip.lib().cpn_wgrad_tall_scratch(N, K), dtype=torch.float32, device=d16.device)
+    dW = torch.empty(N, K, dtype=torch.float32, device=d16.device)
+    call("cpn_wgrad_tall_f16", d16.data_ptr(), N, x16.data_ptr(), K, M, N, K, scale.reshape(1).data_ptr(), part.data_ptr(),
+         dW.data_ptr(), _stream())
+    return dW
+
+
 def _data_grad(d16: torch.Tensor, W16: torch.Tensor) -> torch.Tensor:
     """dA (M, lda) = d16 (M, N) . W16 (N, lda), fp16 in / fp32 accumulate / fp16 out.  It is the forward GEMM with the
     roles of N and K swapped, so it runs on cpn_gemm_f16 with the transposed weight image (hipBLASLt reaches 355 TFLOP/s
@@ -131,7 +143,10 @@ class GemmFn(Function):
             call("cpn_wgrad_skinny_f16", d16.data_ptr(), A16.data_ptr(), 128, d16.shape[0], dW.data_ptr(), db.data_ptr(),
                  _stream())
             return dA, dW[:, :ctx.K] * inv, (db * inv if ctx.needs_input_grad[2] else None), None, None, None, None, None
-        dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[1] and d16.shape[1] % 208 == 0 and A16.shape[1] % 128 == 0 and d16.is_contiguous():
+            dW = _wgrad_tall(d16, A16, ctx.gs.s)[:, :ctx.K]              # the 832 x 896 first layer in its gather form
+        else:
+            dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
         db = d.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[2] else None
         return dA, dW, db, None, None, None, None, None
 
@@ -304,7 +319,7 @@ class EncodeFn(Function):
         # the bias gradient rides on the weight-gradient GEMM: a column of ones in the (zero) padding of the re-gathered
         # input makes dW_full[:, K] the column sums of d16 (a separate reduction over the 7 GB gradient cost 1.5 ms)
         xin[:, ctx.K].fill_(1.0)
-        dWf = _mm_f32(d16.t(), xin) * inv
+        dWf = _wgrad_tall(d16, xin, ctx.gs.s)
         del xin
         dW = dWf[:, :ctx.K] if ctx.needs_input_grad[4] else None
         db = dWf[:, ctx.K].contiguous() if ctx.needs_input_grad[5] else None

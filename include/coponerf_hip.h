@@ -200,6 +200,13 @@ int cpn_hid_grad_combine(const uint16_t* dkey, const uint16_t* hid, const float*
  *   dW (128,128) fp32 += dY^T . X,  db (128) fp32 += column sums of dY (or NULL);  dY (M,128) fp16, X (M,ldx) fp16 of
  *   which the first 128 columns are used.  Both outputs are accumulated: the caller zeroes them.                      */
 int cpn_wgrad_skinny_f16(const uint16_t* dY, const uint16_t* X, int ldx, long long M, float* dW, float* db, void* stream);
+/* weight gradient of the 832-wide first encoder layer (dW of query_encode_latent, models/CoPoNeRF.py:437-438 under autograd):
+ *   dW (N, K) fp32 = dY^T . X / scale[0]  (scale NULL -> 1), written;  dY (M, ldy) fp16 of which N columns are used, X (M, ldx)
+ *   fp16 of which K columns are used;  N % 208 == 0, K % 128 == 0 (832 x 896 on the render path), 16-byte aligned rows.
+ *   part: cpn_wgrad_tall_scratch(N, K) floats (per-row-slab partial sums, added in a fixed order: deterministic).        */
+long long cpn_wgrad_tall_scratch(int N, int K);
+int cpn_wgrad_tall_f16(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, long long M, int N, int K, const float* scale,
+                       float* part, float* dW, void* stream);
 /* backward of cpn_local_hidden in one pass: ds, out (rows,128) fp16 (incoming gradient carrying `scale[0]`, a device
  * scalar, and the forward output for the ReLU mask), loc8 / coords9 as in the forward -> dW (128,16), db (128) fp32
  * ACCUMULATED (caller zeroes), dadd (B*R,128) fp32 written (per-ray sum, NULL when the layer had no `add`).          */

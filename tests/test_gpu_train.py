@@ -328,6 +328,33 @@ def test_skinny_weight_gradient_kernels(M):
     assert float((db.cpu().double() - wantb).abs().max()) <= 2e-4 * max(1.0, float(wantb.abs().max()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 65, 1024, 16 * 64 * 3 + 37, 150001])
+def test_tall_weight_gradient_kernel(M):
+    """cpn_wgrad_tall_f16 (dW = dY^T . X / scale over M rows, the 832 x 896 first-layer gradient) against float64."""
+    from coponerf_amd import _hip
+    from coponerf_amd._hip import call
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M)
+    N, K, ldy, ldx = 416, 256, 424, 264                            # two n tiles, two k tiles; padded row strides
+    dY = (torch.randn(M, ldy, generator=g) * 0.5).half()
+    X = torch.randn(M, ldx, generator=g).half()
+    s = torch.cuda.current_stream().cuda_stream
+    dYd, Xd = dY.to(dev), X.to(dev)
+    scale = torch.tensor([4.0], device=dev)
+    part = torch.empty(_hip.lib().cpn_wgrad_tall_scratch(N, K), device=dev)
+    dW = torch.empty(N, K, device=dev)
+    call("cpn_wgrad_tall_f16", dYd.data_ptr(), ldy, Xd.data_ptr(), ldx, M, N, K, scale.data_ptr(), part.data_ptr(),
+         dW.data_ptr(), s)
+    want = dY[:, :N].double().t() @ X[:, :K].double() / 4.0
+    err = float((dW.cpu().double() - want).abs().max())
+    assert err <= 2e-4 * max(1.0, float(want.abs().max())), err
+    dW2 = torch.empty_like(dW)
+    call("cpn_wgrad_tall_f16", dYd.data_ptr(), ldy, Xd.data_ptr(), ldx, M, N, K, scale.data_ptr(), part.data_ptr(),
+         dW2.data_ptr(), s)
+    assert torch.equal(dW, dW2)                                    # fixed summation order
+
+
 def test_table_form_training_matches_gather_form(dev):
     """render_train with the first layer on the node tables (EncodeFn: no gathered input in the forward pass, re-gathered
     once in the backward) gives the gradients of the gather + GEMM form (GatherFn + GemmFn): same formulation of the

@@ -1,6 +1,6 @@
 """Where the small launches of a training step come from: torch.profiler over one step (batch 4 x 4096 rays), device time
 aggregated by (aten op, input shapes) — the shapes identify the layer for the autograd-side launches, which carry no
-Python stack.  Usage: python tools/train_ops.py [--top N] [--all]   (default: elementwise / copy / reduce ops only)"""
+Python stack.  Usage: python tools/train_ops.py [--top N] [--all | --fns]   (default: elementwise / copy / reduce ops only)"""
 import argparse
 import collections
 import os
@@ -15,6 +15,8 @@ from coponerf_amd import CoPoNeRF, synthetic as syn      # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--top", type=int, default=60)
 ap.add_argument("--all", action="store_true")
+ap.add_argument("--kernels", action="store_true", help="device time by kernel name")
+ap.add_argument("--fns", action="store_true", help="device time (inclusive) by autograd Function node instead of by aten op")
 ap.add_argument("--getz", type=int, default=0, metavar="B", help="profile one inference get_z at batch B instead of a training step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -50,6 +52,27 @@ SMALL = ("copy_", "add", "add_", "mul", "mul_", "fill_", "zero_", "sum", "div", 
          "gelu_backward", "native_layer_norm", "native_layer_norm_backward", "permute", "relu", "sigmoid", "addcmul_",
          "addcdiv_", "lerp_", "_foreach_add_", "_foreach_mul_", "_foreach_addcmul_", "_foreach_addcdiv_", "_foreach_sqrt",
          "_foreach_div_", "_foreach_lerp_", "_foreach_norm")
+if a.kernels:
+    ker = collections.defaultdict(lambda: [0, 0.0])
+    for ev in prof.events():
+        if ev.device_type == torch.autograd.DeviceType.CUDA:
+            ker[ev.name[:110]][0] += 1
+            ker[ev.name[:110]][1] += ev.device_time_total
+    print(f"{sum(t for _, t in ker.values()) / 1e3:.2f} ms of kernel time")
+    for name, (n, t) in sorted(ker.items(), key=lambda kv: -kv[1][1])[:a.top]:
+        print(f"{t / 1e3:8.3f} ms x{n:4d}  {name}")
+    sys.exit(0)
+if a.fns:
+    fn = collections.defaultdict(lambda: [0, 0.0])
+    for ev in prof.events():
+        if ev.name.startswith("aten::") or ev.device_type != torch.autograd.DeviceType.CPU:
+            continue
+        if "Backward" in ev.name or ev.name.endswith("Fn") or ev.name.startswith("_"):
+            fn[ev.name][0] += 1
+            fn[ev.name][1] += getattr(ev, "device_time_total", 0) or 0
+    for name, (n, t) in sorted(fn.items(), key=lambda kv: -kv[1][1])[:a.top]:
+        print(f"{t / 1e3:8.3f} ms x{n:4d}  {name}")
+    sys.exit(0)
 agg = collections.defaultdict(lambda: [0, 0.0, ""])
 tot = 0.0
 for ev in prof.events():
