@@ -462,7 +462,11 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int WG_MAXC = 32;           // Cin, Cout <= 32
 constexpr int WG_MAXP = 256;          // H * W <= 256
-constexpr int WG_BLOCKS = 256;        // workgroups (= partial sums) per call
+#ifndef CPN_WG_BLOCKS
+#define CPN_WG_BLOCKS 512
+#endif
+constexpr int WG_BLOCKS = CPN_WG_BLOCKS;   // workgroups (= partial sums) per call
+template <int CI, int CO>                 // channel counts rounded up to 8 or 32: the staging registers of one plane
 __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, int Cin, int Cout, int G, int H, int W, int nplanes,
     float* __restrict__ partial) {
@@ -494,33 +498,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
     const int hoff = (sy + 1) * (W + 2) + sx + 1;
     const int y0 = (k_lo * 4 + lk) / W, x0 = (k_lo * 4 + lk) - y0 * W;
 
-    for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
+    // a plane's Cin + Cout values of this thread's position travel through registers: all loads of a plane are issued
+    // together, and the next plane's are in flight under the MFMA loop of the current one (the first version loaded and
+    // stored channel by channel: Cin + Cout serialized HBM round trips per plane, 55 - 100 us per call for operands that
+    // stream in 2 - 8 us)
+    float vx[CI], vd[CO];
+    const size_t cs = (size_t)G * P;
+    auto load_plane = [&](int pl) {
         const int b = pl / G, g = pl - b * G;
+        const float* xp = x + (((size_t)b * Cin) * G + g) * P + (stg ? tid : 0);
+        const float* dp = dy + (((size_t)b * Cout) * G + g) * P + (stg ? tid : 0);
+#pragma unroll
+        for (int c = 0; c < CI; ++c) vx[c] = xp[(c < Cin ? c : Cin - 1) * cs];        // surplus slots repeat the last channel
+#pragma unroll
+        for (int o = 0; o < CO; ++o) vd[o] = dp[(o < Cout ? o : Cout - 1) * cs];
+    };
+    if ((int)blockIdx.x < nplanes) load_plane(blockIdx.x);
+    for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
         __syncthreads();                              // previous plane fully consumed (and the zero fill done)
         if (stg) {
-            const float* xp = x + (((size_t)b * Cin) * G + g) * P + tid;
-            const float* dp = dy + (((size_t)b * Cout) * G + g) * P + tid;
-            const size_t cs = (size_t)G * P;
-            for (int c = 0; c < Cin; ++c) xs[c * XS + hoff] = xp[c * cs];
-            for (int o = 0; o < Cout; ++o) ds[o * DS + tid] = dp[o * cs];
+#pragma unroll
+            for (int c = 0; c < CI; ++c)
+                if (c < Cin) xs[c * XS + hoff] = vx[c];
+#pragma unroll
+            for (int o = 0; o < CO; ++o)
+                if (o < Cout) ds[o * DS + tid] = vd[o];
         }
         __syncthreads();
+        if (pl + (int)gridDim.x < nplanes) load_plane(pl + gridDim.x);
+        // operands of k step ks for this lane: gradient value av (rows are zero-padded past P: no predicate) and the 9
+        // taps of the haloed input plane (positions past P read tap window (0,0) — finite values times av = 0).  The
+        // next step's 10 LDS reads are issued before the current step's 9 MFMAs (predicated reads + a wait before every
+        // MFMA ran this loop at a quarter of the MFMA rate)
         int yy = y0, xx = x0;
-        for (int ks = k_lo; ks < k_hi; ++ks) {
+        auto read_step = [&](int ks, float& av, float (&bv)[9]) {
             const int pos = ks * 4 + lk;
-            const bool live = pos < P;
-            const float av = live ? arow[pos] : 0.0f;
-            bsum += av;
-            const float* bp = brow + yy * (W + 2) + xx;          // tap (0,0) of the haloed plane
+            av = arow[pos];
+            const float* bp = brow + (pos < P ? yy * (W + 2) + xx : 0);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float bv = live ? bp[i * (W + 2) + j] : 0.0f;
-                    acc[i * 3 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i * 3 + j], 0, 0, 0);
-                }
+                for (int j = 0; j < 3; ++j) bv[i * 3 + j] = bp[i * (W + 2) + j];
             xx += 4;
-            while (xx >= W) { xx -= W; ++yy; }
+            const bool wrap = xx >= W;                 // W >= 4: at most one row per step
+            xx -= wrap ? W : 0;
+            yy += wrap ? 1 : 0;
+        };
+        float av, bv[9];
+        if (k_lo < k_hi) read_step(k_lo, av, bv);
+        for (int ks = k_lo; ks < k_hi; ++ks) {
+            float an = 0.0f, bn[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ks + 1 < k_hi) read_step(ks + 1, an, bn);
+            bsum += av;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+            av = an;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bv[t] = bn[t];
         }
     }
     // partial sums of this workgroup: [Cout*Cin*9 weights | Cout biases]; D[m = lk*4 + e][n = ln]: m -> output
@@ -552,20 +586,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
     for (int i = tid; i < nw + Cout; i += 256) mine[i] = red[i];
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw,
-                                                                int Cout, float* __restrict__ dw,
-                                                                float* __restrict__ db) {
-    // 64 outputs per workgroup, the partial sums of the nblocks producers split over 4 waves
-    __shared__ float sh[4][64];
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw,
+                                                                 int Cout, float* __restrict__ dw,
+                                                                 float* __restrict__ db) {
+    // 64 outputs per workgroup, the partial sums of the nblocks producers split over 16 waves, 8 loads in flight per thread
+    // (4 waves walking 64 partials each one load at a time took 17 us per call)
+    __shared__ float sh[16][64];
     const int j = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + j;
     float sacc = 0.0f;
-    if (i < nw + Cout)
-        for (int b = part; b < nblocks; b += 4) sacc += partial[(size_t)b * (nw + Cout) + i];
+    if (i < nw + Cout) {
+        const size_t ld = (size_t)(nw + Cout);
+        int b = part;
+        for (; b + 16 * 7 < nblocks; b += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + 16 * u) * ld + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sacc += v[u];
+        }
+        for (; b < nblocks; b += 16) sacc += partial[(size_t)b * ld + i];
+    }
     sh[part][j] = sacc;
     __syncthreads();
     if (part == 0 && i < nw + Cout) {
-        const float v = sh[0][j] + sh[1][j] + sh[2][j] + sh[3][j];
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += sh[q][j];
         if (i < nw) dw[i] = v;
         else if (db) db[i - nw] = v;
     }
@@ -1274,22 +1321,31 @@ extern "C" int cpn_conv_wgrad_planes(const float* x, const float* dy, int B, int
     const size_t lds = std::max((size_t)CT * 16 * XS + (size_t)MT * 16 * DS, (size_t)Cout * Cin * 9 + Cout) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_planes_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) {
-            cpn_set_error("cpn_conv_wgrad_planes: cannot reserve LDS: %s", hipGetErrorString(e));
-            return (int)e;
+        for (const void* k : {(const void*)conv_wgrad_planes_kernel<8, 8>, (const void*)conv_wgrad_planes_kernel<8, 32>,
+                              (const void*)conv_wgrad_planes_kernel<32, 8>, (const void*)conv_wgrad_planes_kernel<32, 32>}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) {
+                cpn_set_error("cpn_conv_wgrad_planes: cannot reserve LDS: %s", hipGetErrorString(e));
+                return (int)e;
+            }
         }
         attr_set = true;
     }
     const int nplanes = B * G;
     const int blocks = std::min(nplanes, WG_BLOCKS);
     const hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_planes_kernel, dim3(blocks), dim3(256), lds, st, x, dy, Cin, Cout, G, H, W, nplanes,
-                       partial);
+    const dim3 grid(blocks), block(256);
+    if (Cin <= 8 && Cout <= 8)
+        hipLaunchKernelGGL((conv_wgrad_planes_kernel<8, 8>), grid, block, lds, st, x, dy, Cin, Cout, G, H, W, nplanes, partial);
+    else if (Cin <= 8)
+        hipLaunchKernelGGL((conv_wgrad_planes_kernel<8, 32>), grid, block, lds, st, x, dy, Cin, Cout, G, H, W, nplanes, partial);
+    else if (Cout <= 8)
+        hipLaunchKernelGGL((conv_wgrad_planes_kernel<32, 8>), grid, block, lds, st, x, dy, Cin, Cout, G, H, W, nplanes, partial);
+    else
+        hipLaunchKernelGGL((conv_wgrad_planes_kernel<32, 32>), grid, block, lds, st, x, dy, Cin, Cout, G, H, W, nplanes, partial);
     CPN_LAUNCH_CHECK("cpn_conv_wgrad_planes");
     const int nw = Cout * Cin * 9;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cpn_cdiv(nw + Cout, 64)), dim3(256), 0, st, partial, blocks, nw, Cout,
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cpn_cdiv(nw + Cout, 64)), dim3(1024), 0, st, partial, blocks, nw, Cout,
                        dw, db);
     CPN_LAUNCH_CHECK("cpn_conv_wgrad_planes(reduce)");
     return 0;
