@@ -16,7 +16,8 @@
 //   fragments = lane (fi, fg) takes rows fg*4 .. +3 and 16 + fg*4 .. +3 of a 32-row step (any row <-> k assignment works as
 //               long as both operands use the same one): a 32-lane read group then touches 8 CONSECUTIVE rows, which the
 //               row strides (416 B / 288 B, odd multiples of 32 B) spread over all 64 banks
-//   grid      = 4 x 7 output tiles x 16 row slabs; the 28 tiles of a slab sit on ONE XCD (workgroup id % 8) and walk the
+//   grid      = 4 x 7 output tiles x 16 row slabs (832 x 896; 8 x 1 x 64 for the transposed 1664 x 128 key-map gradient); the
+//               tiles of a slab sit on ONE XCD (workgroup id % 8) and walk the
 //               slab's rows together, so each operand tile comes from HBM once and from that XCD's L2 afterwards (cached
 //               loads: non-temporal ones re-fetched every tile's operands, 3x slower)
 //   result    = per-slab partial sums, summed in a fixed order by a second kernel (deterministic; also applies 1/scale)
@@ -34,10 +35,12 @@ constexpr int WT_ROWS = 64;                 // rows per LDS stage (two 32-row MF
 constexpr int WT_N = 208, WT_K = 128;       // output tile of a workgroup: 13 x 8 MFMA tiles
 constexpr int WT_LDA = 208;                 // dY stage row stride in halves: 416 B = 13 x 32 B
 constexpr int WT_LDB = 144;                 // X stage row stride in halves: 288 B = 9 x 32 B
-#ifndef CPN_WT_SLABS
-#define CPN_WT_SLABS 16
-#endif
-constexpr int WT_SLABS = CPN_WT_SLABS;      // per XCD: WT_SLABS / 8 slabs x 28 workgroups of 45 KB LDS on 32 CUs
+// row slabs: as many as fill ~512 workgroup slots (2 per CU), a multiple of 8 so that every XCD holds whole slabs
+static inline int wt_slabs(int N, int K) {
+    const int tiles = (N / WT_N) * (K / WT_K);
+    const int s = (512 / tiles) / 8 * 8;
+    return s < 8 ? 8 : (s > 64 ? 64 : s);
+}
 constexpr int WT_ASEGS = WT_N / 8, WT_BSEGS = WT_K / 8;      // 16-byte segments per stage row
 
 typedef short short4v __attribute__((ext_vector_type(4)));
@@ -52,17 +55,17 @@ __device__ __forceinline__ half8 read_fragment(const _Float16* tile, int ld, int
 
 __global__ __launch_bounds__(256, 2) void wgrad_tall_f16_kernel(const _Float16* __restrict__ dY, int ldy,
                                                                 const _Float16* __restrict__ X, int ldx, long long M,
-                                                                int ntn, int ntk, float* __restrict__ part) {
+                                                                int ntn, int ntk, int nslab, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) _Float16 sa[WT_ROWS * WT_LDA];
     __shared__ __attribute__((aligned(16))) _Float16 sb[WT_ROWS * WT_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
-    // workgroup -> (slab, tile): ids congruent mod 8 share an XCD; an XCD holds WT_SLABS / 8 slabs x all tiles
+    // workgroup -> (slab, tile): ids congruent mod 8 share an XCD; an XCD holds nslab / 8 slabs x all tiles
     const int tiles = ntn * ntk;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int slab = xcd * (WT_SLABS / 8) + j / tiles, tile = j % tiles;
+    const int slab = xcd * (nslab / 8) + j / tiles, tile = j % tiles;
     const int tn = tile % ntn, tk = tile / ntn;
-    const long long per = ((M + WT_SLABS - 1) / WT_SLABS + WT_ROWS - 1) / WT_ROWS * WT_ROWS;
+    const long long per = ((M + nslab - 1) / nslab + WT_ROWS - 1) / WT_ROWS * WT_ROWS;
     const long long row0 = slab * per, row1 = row0 + per < M ? row0 + per : M;
 
     f32x4 acc[13][2];
@@ -158,20 +161,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_tall_f16_kernel(const _Float16* 
 }
 
 // dW = (sum over slabs, in order) / scale[0]
-__global__ __launch_bounds__(256) void wgrad_tall_reduce_kernel(const float* __restrict__ part, long long n4,
+__global__ __launch_bounds__(256) void wgrad_tall_reduce_kernel(const float* __restrict__ part, long long n4, int nslab,
                                                                 const float* __restrict__ scale, float* __restrict__ dW) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
-#pragma unroll
-    for (int q = 1; q < WT_SLABS; ++q) s += reinterpret_cast<const f32x4*>(part)[q * n4 + i];
+#pragma unroll 8
+    for (int q = 1; q < nslab; ++q) s += reinterpret_cast<const f32x4*>(part)[q * n4 + i];
     const float inv = scale ? 1.0f / scale[0] : 1.0f;
     reinterpret_cast<f32x4*>(dW)[i] = s * inv;
 }
 
 }  // namespace
 
-extern "C" long long cpn_wgrad_tall_scratch(int N, int K) { return (long long)WT_SLABS * N * K; }
+extern "C" long long cpn_wgrad_tall_scratch(int N, int K) {
+    return (N < WT_N || K < WT_K || N % WT_N || K % WT_K) ? 0 : (long long)wt_slabs(N, K) * N * K;
+}
 
 extern "C" int cpn_wgrad_tall_f16(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, long long M, int N, int K,
                                   const float* scale, float* part, float* dW, void* stream) {
@@ -182,12 +187,12 @@ extern "C" int cpn_wgrad_tall_f16(const uint16_t* dY, int ldy, const uint16_t* X
     CPN_REQUIRE(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)part % 16) == 0 &&
                     ((uintptr_t)dW % 16) == 0, CPN_E_ARG, "cpn_wgrad_tall_f16: operands must be 16-byte aligned");
     const hipStream_t s = (hipStream_t)stream;
-    const int ntn = N / WT_N, ntk = K / WT_K;
-    hipLaunchKernelGGL(wgrad_tall_f16_kernel, dim3(WT_SLABS * ntn * ntk), dim3(256), 0, s, (const _Float16*)dY, ldy,
-                       (const _Float16*)X, ldx, M, ntn, ntk, part);
+    const int ntn = N / WT_N, ntk = K / WT_K, nslab = wt_slabs(N, K);
+    hipLaunchKernelGGL(wgrad_tall_f16_kernel, dim3(nslab * ntn * ntk), dim3(256), 0, s, (const _Float16*)dY, ldy,
+                       (const _Float16*)X, ldx, M, ntn, ntk, nslab, part);
     const long long n4 = (long long)N * K / 4;
     hipLaunchKernelGGL(wgrad_tall_reduce_kernel, dim3((unsigned)cpn_cdiv(n4, 256)), dim3(256), 0, s, (const float*)part, n4,
-                       scale, dW);
+                       nslab, scale, dW);
     CPN_LAUNCH_CHECK("cpn_wgrad_tall_f16");
     return 0;
 }

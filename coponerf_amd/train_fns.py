@@ -143,8 +143,13 @@ class GemmFn(Function):
             call("cpn_wgrad_skinny_f16", d16.data_ptr(), A16.data_ptr(), 128, d16.shape[0], dW.data_ptr(), db.data_ptr(),
                  _stream())
             return dA, dW[:, :ctx.K] * inv, (db * inv if ctx.needs_input_grad[2] else None), None, None, None, None, None
-        if ctx.needs_input_grad[1] and d16.shape[1] % 208 == 0 and A16.shape[1] % 128 == 0 and d16.is_contiguous():
+        n_out, k_in = d16.shape[1], A16.shape[1]
+        both = d16.is_contiguous() and A16.is_contiguous()
+        if ctx.needs_input_grad[1] and both and n_out % 208 == 0 and k_in % 128 == 0:
             dW = _wgrad_tall(d16, A16, ctx.gs.s)[:, :ctx.K]              # the 832 x 896 first layer in its gather form
+        elif ctx.needs_input_grad[1] and both and k_in % 208 == 0 and n_out % 128 == 0:
+            # 128 x 1664 (key map over the paired hidden rows): the same kernel on the transposed problem, dW^T = A^T . d
+            dW = _wgrad_tall(A16, d16, ctx.gs.s).t()[:, :ctx.K]
         else:
             dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
         db = d.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[2] else None
