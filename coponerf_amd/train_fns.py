@@ -330,7 +330,9 @@ class EncodeFn(Function):
         db = dWf[:, ctx.K].contiguous() if ctx.needs_input_grad[5] else None
         g = [None] * 4
         if any(ctx.needs_input_grad[:4]):
-            dA = _data_grad(d16, W16)                            # (rows, 896) fp16, scaled
+            # (rows, 832) fp16, scaled: the gather reads feature channels only (768 + 64); the encoding columns have no
+            # gradient path (poses / detached points), so their 64 columns of the product are not formed
+            dA = _data_grad(d16, W16[:, :832].contiguous())
             del d16
             dmaps = [torch.zeros(n, h, w_, c, dtype=torch.float32, device=dA.device) for (n, c, h, w_) in ctx.shapes]
             boxes = torch.empty(B * V * _hip.lib().cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=dA.device)
