@@ -43,7 +43,7 @@ P, I = ctypes.c_void_p, ctypes.c_int
 variants = [("product", None)]
 for tag, label in (("nodrain", "no accumulation (scan only)"), ("tpy8", "8 x 8 pixel tiles (round 1)"), ("tpy2", "8 x 2 pixel tiles")):
     so = SO.replace("nodrain", tag)
-    if os.path.exists(so):
+    if os.path.exists(so) and "--product-only" not in sys.argv:
         fn = ctypes.CDLL(so).cpn_gather_rows_bwd
         fn.argtypes = [P, I, I, I, P, P, I, I, I, I, I, I, P, P, P, P, P, P]
         variants.append((label, fn))
