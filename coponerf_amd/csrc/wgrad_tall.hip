@@ -92,8 +92,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tall_f16_kernel(const _Float16* 
             for (int p = 0; p < 4; ++p) rb[p] = u32x4{(unsigned)r0, 1u, 2u, (unsigned)p};
             return;
         }
-        // rows past the slab are read from its last row (always in bounds) and zeroed: no divergent loads (a select-free
-        // fast path for whole stages measured 15 % slower: the loop is sensitive to where the loads are scheduled)
+        // rows past the slab are read from its last row (always in bounds) and zeroed: no divergent loads.  The selects make
+        // the compiler wait for each load right here, i.e. BEFORE the MFMA phase; moving them into stage() lets the loads fly
+        // under the MFMAs (loads + fragments + MFMA without staging: 5.9 -> 4.6 ms) and yet the whole kernel gets slower
+        // (9.0 -> 11.3 ms; a select-free fast path for whole stages: 10.4 ms) — measured, not understood
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const long long r = r0 + arow + 8 * p;
