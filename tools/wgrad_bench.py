@@ -1,6 +1,6 @@
 """cpn_wgrad_tall_f16 on the training shape (832 x 896 over 4.2 M rows) against torch.mm (hipBLASLt) on the same operands.
 `--build` (where hipcc is) compiles the timing-only phase ablations of csrc/wgrad_tall.hip into tools/_build/; they are timed
-when present.  Usage: python tools/wgrad_bench.py [--build] [launches ...]"""
+when present.  Usage: python tools/wgrad_bench.py [--build] [--product-only] [launches ...]"""
 import ctypes
 import os
 import subprocess
