@@ -299,6 +299,157 @@ __global__ __launch_bounds__(XC_COLS * XC_GROUPS) void cross_cols_kernel(const f
     }
 }
 
+// ---- backward of the cross attention (training) -------------------------------------------------------------------------
+// With P1 = softmax_t(c), P2 = softmax_s(c), src_attn = P1 tv, trg_attn = P2^T sv and incoming gradients g1 (of src_attn),
+// g2 (of trg_attn):
+//   dtv[t] = sum_s P1[s,t] g1[s],   dsv[s] = sum_t P2[s,t] g2[t],
+//   dc[s,t] = P1[s,t] (g1[s].tv[t] - g1[s].src_attn[s]) + P2[s,t] (sv[s].g2[t] - g2[t].trg_attn[t])
+// (the library VJP re-ran both softmaxes and einsums and differentiated them: ~25 launches per call on 256 x 256 maps).
+// Three launches: row / column statistics and the two subtracted dot products; a row-oriented kernel for dc and dsv; a
+// column-oriented one for dtv.
+constexpr int XB_C = 32;                  // channels per head
+constexpr int XB_LD = XB_C + 1;           // LDS row stride (floats): threads of a wave read the same channel of 16 rows
+
+// stats[(b*H + h)][0..2][S] = row max, 1 / row sum, g1.src_attn;  [3..5][T] = column max, 1 / column sum, g2.trg_attn
+__global__ __launch_bounds__(256) void cross_bwd_stats_kernel(const float* __restrict__ c, const float* __restrict__ sa,
+                                                              const float* __restrict__ ta, const float* __restrict__ g1,
+                                                              const float* __restrict__ g2, int H, int S, int T,
+                                                              float* __restrict__ stats) {
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* cm = c + (size_t)blockIdx.x * S * T;
+    float* st = stats + (size_t)blockIdx.x * 3 * (S + T);
+    for (int s = wave; s < S; s += 4) {                               // rows: one wave each
+        const float* row = cm + (size_t)s * T;
+        float m = -INFINITY;
+        for (int t = lane; t < T; t += 64) m = fmaxf(m, row[t]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float z = 0.0f;
+        for (int t = lane; t < T; t += 64) z += expf(row[t] - m);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+        float r = 0.0f;
+        if (lane < XB_C) {
+            const size_t o = (((size_t)b * S + s) * H + h) * XB_C + lane;
+            r = g1[o] * sa[o];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) r += __shfl_xor(r, o);
+        if (lane == 0) { st[s] = m; st[S + s] = 1.0f / z; st[2 * S + s] = r; }
+    }
+    float* sc = st + 3 * S;
+    for (int t = threadIdx.x; t < T; t += 256) {                      // columns: one thread each, online max / sum
+        float m = -INFINITY, z = 0.0f;
+        for (int s = 0; s < S; ++s) {
+            const float x = cm[(size_t)s * T + t];
+            if (x > m) { z *= expf(m - x); m = x; }
+            z += expf(x - m);
+        }
+        const float* gp = g2 + (((size_t)b * T + t) * H + h) * XB_C;
+        const float* ap = ta + (((size_t)b * T + t) * H + h) * XB_C;
+        float r = 0.0f;
+#pragma unroll
+        for (int i = 0; i < XB_C; ++i) r += gp[i] * ap[i];
+        sc[t] = m; sc[T + t] = 1.0f / z; sc[2 * T + t] = r;
+    }
+}
+
+// block = (b, h, 16 rows): thread (row r, column lane cl) walks t = cl, cl + 16, ...; dc written, dsv reduced over the lanes
+__global__ __launch_bounds__(256) void cross_bwd_rows_kernel(const float* __restrict__ c, const float* __restrict__ sv,
+                                                             const float* __restrict__ tv, const float* __restrict__ g1,
+                                                             const float* __restrict__ g2, const float* __restrict__ stats,
+                                                             int H, int S, int T, float* __restrict__ dc,
+                                                             float* __restrict__ dsv) {
+    extern __shared__ float xb[];                                     // tv and g2 of this (b, h): 2 x T x XB_LD
+    float* tvs = xb;
+    float* g2s = xb + (size_t)T * XB_LD;
+    const int bh = blockIdx.y, h = bh % H, b = bh / H;
+    for (int i = threadIdx.x; i < T * XB_C; i += 256) {
+        const int t = i / XB_C, k = i - t * XB_C;
+        const size_t o = (((size_t)b * T + t) * H + h) * XB_C + k;
+        tvs[t * XB_LD + k] = tv[o];
+        g2s[t * XB_LD + k] = g2[o];
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int s = blockIdx.x * 16 + r;
+    const bool live = s < S;
+    const int sc_ = live ? s : S - 1;
+    const float* st = stats + (size_t)bh * 3 * (S + T);
+    const float m1 = st[sc_], iz1 = st[S + sc_], r1 = st[2 * S + sc_];
+    const float* sc = st + 3 * S;
+    float gv[XB_C], sw[XB_C], acc[XB_C];
+    const size_t so = (((size_t)b * S + sc_) * H + h) * XB_C;
+#pragma unroll
+    for (int k = 0; k < XB_C; ++k) { gv[k] = g1[so + k]; sw[k] = sv[so + k]; acc[k] = 0.0f; }
+    const float* crow = c + ((size_t)bh * S + sc_) * T;
+    float* drow = dc + ((size_t)bh * S + sc_) * T;
+    for (int t = cl; t < T; t += 16) {
+        const float x = crow[t];
+        const float p1 = expf(x - m1) * iz1, p2 = expf(x - sc[t]) * sc[T + t];
+        float d1 = 0.0f, d2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < XB_C; ++k) {
+            const float gk = g2s[t * XB_LD + k];
+            d1 += gv[k] * tvs[t * XB_LD + k];
+            d2 += sw[k] * gk;
+            acc[k] += p2 * gk;
+        }
+        if (live) drow[t] = p1 * (d1 - r1) + p2 * (d2 - sc[2 * T + t]);
+    }
+#pragma unroll
+    for (int k = 0; k < XB_C; ++k) {
+        float v = acc[k];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        acc[k] = v;
+    }
+    if (live && cl == 0) {
+#pragma unroll
+        for (int k = 0; k < XB_C; ++k) dsv[so + k] = acc[k];
+    }
+}
+
+// block = (b, h, 16 columns): thread (column cl, row group rg of 16) walks s = rg, rg + 16, ...; the groups meet in LDS
+__global__ __launch_bounds__(256) void cross_bwd_cols_kernel(const float* __restrict__ c, const float* __restrict__ g1,
+                                                             const float* __restrict__ stats, int H, int S, int T,
+                                                             float* __restrict__ dtv) {
+    extern __shared__ float xb[];                                     // g1 of this (b, h): S x XB_LD, then the partials
+    float* g1s = xb;
+    float* part = xb + (size_t)S * XB_LD;                             // [16 groups][XB_C][16 columns]
+    const int bh = blockIdx.y, h = bh % H, b = bh / H;
+    for (int i = threadIdx.x; i < S * XB_C; i += 256) {
+        const int s = i / XB_C, k = i - s * XB_C;
+        g1s[s * XB_LD + k] = g1[(((size_t)b * S + s) * H + h) * XB_C + k];
+    }
+    __syncthreads();
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + cl;
+    const float* st = stats + (size_t)bh * 3 * (S + T);
+    float acc[XB_C];
+#pragma unroll
+    for (int k = 0; k < XB_C; ++k) acc[k] = 0.0f;
+    if (t < T) {
+        const float* col = c + (size_t)bh * S * T + t;
+        for (int s = rg; s < S; s += 16) {
+            const float p1 = expf(col[(size_t)s * T] - st[s]) * st[S + s];
+#pragma unroll
+            for (int k = 0; k < XB_C; ++k) acc[k] += p1 * g1s[s * XB_LD + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < XB_C; ++k) part[(rg * XB_C + k) * 16 + cl] = acc[k];
+    __syncthreads();
+    // thread (cl, rg) finishes channels rg and rg + 16 of column cl
+    if (t >= T) return;
+    for (int k = rg; k < XB_C; k += 16) {
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += part[(q * XB_C + k) * 16 + cl];
+        dtv[(((size_t)b * T + t) * H + h) * XB_C + k] = v;
+    }
+}
+
 // the nsplit partial (KV, Ksum) blocks of every (b, h) summed in a fixed order into one block: the apply kernel then reads
 // 4 KB per head instead of nsplit x 4 KB per workgroup (with 64 splits that was 268 MB of L2 reads per call)
 __global__ __launch_bounds__(256) void linear_attention_combine_kernel(const float* __restrict__ kv_part,
@@ -432,5 +583,39 @@ extern "C" int cpn_cross_attention(const float* corr, const float* src_v, const 
     hipLaunchKernelGGL(cross_cols_kernel<32>, dim3(cpn_cdiv(T, XC_COLS), B * H), dim3(XC_COLS * XC_GROUPS), lds_cols, s, corr,
                        src_v, B, H, S, T, trg_attn);
     CPN_LAUNCH_CHECK("cpn_cross_attention");
+    return 0;
+}
+
+extern "C" long long cpn_cross_attention_bwd_scratch(int B, int H, int S, int T) { return 3LL * B * H * (S + T); }
+
+// VJP of cpn_cross_attention (autograd through models/aggregation.py:327-328): g_src / g_trg are the gradients of src_attn /
+// trg_attn, which are passed back in (forward outputs) for the two subtracted dot products; dcorr, dsrc_v, dtrg_v are written.
+extern "C" int cpn_cross_attention_bwd(const float* corr, const float* src_v, const float* trg_v, const float* src_attn,
+                                       const float* trg_attn, const float* g_src, const float* g_trg, int B, int H, int S,
+                                       int T, int C, float* scratch, float* dcorr, float* dsrc_v, float* dtrg_v, void* stream) {
+    CPN_REQUIRE(corr && src_v && trg_v && src_attn && trg_attn && g_src && g_trg && scratch && dcorr && dsrc_v && dtrg_v,
+                CPN_E_ARG, "cpn_cross_attention_bwd: null pointer");
+    CPN_REQUIRE(B > 0 && H > 0 && S > 0 && T > 0 && C == XB_C && (long long)B * H < 65536 && S <= 512 && T <= 512, CPN_E_SHAPE,
+                "cpn_cross_attention_bwd: need C == 32, S, T <= 512 (got C=%d S=%d T=%d)", C, S, T);
+    const hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int rows_lds = 2 * 512 * XB_LD * 4, cols_lds = (512 * XB_LD + 16 * XB_C * 16) * 4;
+        hipError_t e = hipFuncSetAttribute((const void*)cross_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)cross_bwd_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cols_lds);
+        if (e != hipSuccess) {
+            cpn_set_error("cpn_cross_attention_bwd: cannot reserve LDS: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cross_bwd_stats_kernel, dim3(B * H), dim3(256), 0, s, corr, src_attn, trg_attn, g_src, g_trg, H, S, T,
+                       scratch);
+    hipLaunchKernelGGL(cross_bwd_rows_kernel, dim3(cpn_cdiv(S, 16), B * H), dim3(256), (size_t)2 * T * XB_LD * sizeof(float), s,
+                       corr, src_v, trg_v, g_src, g_trg, (const float*)scratch, H, S, T, dcorr, dsrc_v);
+    hipLaunchKernelGGL(cross_bwd_cols_kernel, dim3(cpn_cdiv(T, 16), B * H), dim3(256),
+                       ((size_t)S * XB_LD + 16 * XB_C * 16) * sizeof(float), s, corr, g_src, (const float*)scratch, H, S, T, dtrg_v);
+    CPN_LAUNCH_CHECK("cpn_cross_attention_bwd");
     return 0;
 }

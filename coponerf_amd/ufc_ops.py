@@ -99,6 +99,31 @@ class _LinearAttentionFn(Function):
         return None, dq, dk, dv, None, None
 
 
+class _CrossAttentionFn(Function):
+    """cross_attention with cpn_cross_attention_bwd as its VJP (three launches; the library VJP re-ran both softmaxes and
+    einsums as ~25 ATen ops per call)."""
+
+    @staticmethod
+    def forward(ctx, ops, c, src_v, trg_v):
+        c, src_v, trg_v = c.contiguous(), src_v.contiguous(), trg_v.contiguous()
+        with torch.no_grad():
+            sa, ta = ops.cross_attention(c, src_v, trg_v)
+        ctx.save_for_backward(c, src_v, trg_v, sa, ta)
+        return sa, ta
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        c, sv, tv, sa, ta = ctx.saved_tensors
+        B, H, S, T = c.shape
+        g1 = torch.zeros_like(sa) if g1 is None else g1.contiguous().float()
+        g2 = torch.zeros_like(ta) if g2 is None else g2.contiguous().float()
+        scr = torch.empty(_hip.lib().cpn_cross_attention_bwd_scratch(B, H, S, T), dtype=torch.float32, device=c.device)
+        dc, dsv, dtv = torch.empty_like(c), torch.empty_like(sv), torch.empty_like(tv)
+        call("cpn_cross_attention_bwd", c.data_ptr(), sv.data_ptr(), tv.data_ptr(), sa.data_ptr(), ta.data_ptr(), g1.data_ptr(),
+             g2.data_ptr(), B, H, S, T, sv.shape[-1], scr.data_ptr(), dc.data_ptr(), dsv.data_ptr(), dtv.data_ptr(), _stream())
+        return None, dc, dsv, dtv
+
+
 def _wants_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
 
@@ -367,10 +392,6 @@ class _ResizeFn(Function):
                                                                  list(ctx.in_shape), True, None, None), None
 
 
-def _cross_attention_lib(c, src_v, trg_v):
-    return (torch.einsum("bhst,bthc->bshc", c.softmax(-1), trg_v), torch.einsum("bhst,bshc->bthc", c.softmax(-2), src_v))
-
-
 def _conv_map_lib(rgb, w, b):
     """Library-op statement of cpn_conv_map7x7 (only its VJP is used): CoPoNeRF.py:182-187."""
     x = (rgb.permute(0, 3, 1, 2) + 1) / 2.
@@ -496,7 +517,7 @@ class HipOps:
         c (B,H,S,T), src_v (B,S,H,32), trg_v (B,T,H,32) -> (B,S,H,32), (B,T,H,32)."""
         self._need_gpu(c)
         if _wants_grad(c, src_v, trg_v):
-            return _HipForwardVjp.apply(self.cross_attention, _cross_attention_lib, c.float(), src_v.float(), trg_v.float())
+            return _CrossAttentionFn.apply(self, c.float(), src_v.float(), trg_v.float())
         c_, s_, t_ = c.contiguous().float(), src_v.contiguous().float(), trg_v.contiguous().float()
         B, H, S, T = c_.shape
         src_attn, trg_attn = torch.empty_like(s_), torch.empty_like(t_)

@@ -328,6 +328,13 @@ int cpn_linear_attention_bwd(const float* q, const float* k, const float* v, con
  *   src_attn (B, S, H, C) = softmax over t of corr . trg_v ;  trg_attn (B, T, H, C) = softmax over s of corr, transposed . src_v */
 int cpn_cross_attention(const float* corr, const float* src_v, const float* trg_v, int B, int H, int S, int T, int C,
                         float* src_attn, float* trg_attn, void* stream);
+/* VJP of K10 (autograd through models/aggregation.py:327-328): g_src / g_trg = gradients of src_attn / trg_attn (the forward
+ * outputs, passed back in); dcorr (B,H,S,T), dsrc_v (B,S,H,C), dtrg_v (B,T,H,C) are written.
+ * scratch: cpn_cross_attention_bwd_scratch(B, H, S, T) floats.  C == 32, S, T <= 512.                                      */
+long long cpn_cross_attention_bwd_scratch(int B, int H, int S, int T);
+int cpn_cross_attention_bwd(const float* corr, const float* src_v, const float* trg_v, const float* src_attn,
+                            const float* trg_attn, const float* g_src, const float* g_trg, int B, int H, int S, int T, int C,
+                            float* scratch, float* dcorr, float* dsrc_v, float* dtrg_v, void* stream);
 
 /* ---- f3: conv_map, the 7x7 3 -> 64 convolution behind the full-resolution feature level (CoPoNeRF.py:69, 182-187) -----
  * rgb (N, H, W, 3) fp32 in [-1, 1] exactly as the input dict holds it; fused (rgb+1)/2, ImageNet normalisation
