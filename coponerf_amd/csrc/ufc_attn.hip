@@ -311,15 +311,20 @@ constexpr int XB_C = 32;                  // channels per head
 constexpr int XB_LD = XB_C + 1;           // LDS row stride (floats): threads of a wave read the same channel of 16 rows
 
 // stats[(b*H + h)][0..2][S] = row max, 1 / row sum, g1.src_attn;  [3..5][T] = column max, 1 / column sum, g2.trg_attn
+// grid (XB_PARTS, B*H): a block takes 1/XB_PARTS of the rows (one wave per row) and of the columns (32 columns x 8 row
+// groups, online max / sum per thread, merged in LDS) — one block per (b, h) was 32 blocks on the chip, 100 us
+constexpr int XB_PARTS = 8;
 __global__ __launch_bounds__(256) void cross_bwd_stats_kernel(const float* __restrict__ c, const float* __restrict__ sa,
                                                               const float* __restrict__ ta, const float* __restrict__ g1,
                                                               const float* __restrict__ g2, int H, int S, int T,
                                                               float* __restrict__ stats) {
-    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    __shared__ float pm[8][32], pz[8][32];
+    const int bh = blockIdx.y, h = bh % H, b = bh / H, part = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* cm = c + (size_t)blockIdx.x * S * T;
-    float* st = stats + (size_t)blockIdx.x * 3 * (S + T);
-    for (int s = wave; s < S; s += 4) {                               // rows: one wave each
+    const float* cm = c + (size_t)bh * S * T;
+    float* st = stats + (size_t)bh * 3 * (S + T);
+    const int sper = (S + XB_PARTS - 1) / XB_PARTS, s_lo = part * sper, s_hi = min(S, s_lo + sper);
+    for (int s = s_lo + wave; s < s_hi; s += 4) {                      // rows: one wave each
         const float* row = cm + (size_t)s * T;
         float m = -INFINITY;
         for (int t = lane; t < T; t += 64) m = fmaxf(m, row[t]);
@@ -339,19 +344,35 @@ __global__ __launch_bounds__(256) void cross_bwd_stats_kernel(const float* __res
         if (lane == 0) { st[s] = m; st[S + s] = 1.0f / z; st[2 * S + s] = r; }
     }
     float* sc = st + 3 * S;
-    for (int t = threadIdx.x; t < T; t += 256) {                      // columns: one thread each, online max / sum
+    const int tper = (T + XB_PARTS - 1) / XB_PARTS, t_lo = part * tper, t_hi = min(T, t_lo + tper);
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    for (int t0 = t_lo; t0 < t_hi; t0 += 32) {                         // columns: 32 at a time, 8 row groups each
+        const int t = t0 + cl;
         float m = -INFINITY, z = 0.0f;
-        for (int s = 0; s < S; ++s) {
-            const float x = cm[(size_t)s * T + t];
-            if (x > m) { z *= expf(m - x); m = x; }
-            z += expf(x - m);
-        }
-        const float* gp = g2 + (((size_t)b * T + t) * H + h) * XB_C;
-        const float* ap = ta + (((size_t)b * T + t) * H + h) * XB_C;
-        float r = 0.0f;
+        if (t < t_hi)
+            for (int s = rg; s < S; s += 8) {
+                const float x = cm[(size_t)s * T + t];
+                if (x > m) { z *= expf(m - x); m = x; }
+                z += expf(x - m);
+            }
+        pm[rg][cl] = m;
+        pz[rg][cl] = z;
+        __syncthreads();
+        if (rg == 0 && t < t_hi) {
+            float M = pm[0][cl];
 #pragma unroll
-        for (int i = 0; i < XB_C; ++i) r += gp[i] * ap[i];
-        sc[t] = m; sc[T + t] = 1.0f / z; sc[2 * T + t] = r;
+            for (int q = 1; q < 8; ++q) M = fmaxf(M, pm[q][cl]);
+            float Z = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Z += pm[q][cl] == -INFINITY ? 0.0f : pz[q][cl] * expf(pm[q][cl] - M);
+            const float* gp = g2 + (((size_t)b * T + t) * H + h) * XB_C;
+            const float* ap = ta + (((size_t)b * T + t) * H + h) * XB_C;
+            float r = 0.0f;
+#pragma unroll
+            for (int i = 0; i < XB_C; ++i) r += gp[i] * ap[i];
+            sc[t] = M; sc[T + t] = 1.0f / Z; sc[2 * T + t] = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -610,8 +631,8 @@ extern "C" int cpn_cross_attention_bwd(const float* corr, const float* src_v, co
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(cross_bwd_stats_kernel, dim3(B * H), dim3(256), 0, s, corr, src_attn, trg_attn, g_src, g_trg, H, S, T,
-                       scratch);
+    hipLaunchKernelGGL(cross_bwd_stats_kernel, dim3(XB_PARTS, B * H), dim3(256), 0, s, corr, src_attn, trg_attn, g_src, g_trg, H,
+                       S, T, scratch);
     hipLaunchKernelGGL(cross_bwd_rows_kernel, dim3(cpn_cdiv(S, 16), B * H), dim3(256), (size_t)2 * T * XB_LD * sizeof(float), s,
                        corr, src_v, trg_v, g_src, g_trg, (const float*)scratch, H, S, T, dcorr, dsrc_v);
     hipLaunchKernelGGL(cross_bwd_cols_kernel, dim3(cpn_cdiv(T, 16), B * H), dim3(256),
