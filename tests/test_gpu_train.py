@@ -169,6 +169,11 @@ def test_ufc_operator_gradients_match_oracle(dev):
     both("linear_attention", [q[:, :33], k[:, :33], syn.normal((2, 33, 3, 32), seed=64)], lambda f, t: f(t[0], t[1], t[2]))
     both("cross_attention", [syn.normal((2, 3, 40, 56), seed=65) * 2.0, syn.normal((2, 40, 3, 32), seed=66),
                              syn.normal((2, 56, 3, 32), seed=67)], lambda f, t: f(t[0], t[1], t[2]))
+    # the shapes of the training step: 256 x 256 cost volumes, 8 heads; 1024 tokens with 256-wide channel-major values (16 slabs)
+    both("cross_attention", [syn.normal((1, 8, 256, 256), seed=55) * 3.0, syn.normal((1, 256, 8, 32), seed=56),
+                             syn.normal((1, 256, 8, 32), seed=57)], lambda f, t: f(t[0], t[1], t[2]))
+    both("linear_attention", [syn.normal((1, 1024, 8, 32), seed=58), syn.normal((1, 1024, 8, 32), seed=59),
+                              syn.normal((1, 8, 256, 1024), seed=54)], lambda f, t: f(t[0], t[1], t[2], True))
     both("resize_bilinear", [syn.normal((2, 3, 8, 8), seed=79)], lambda f, t: f(t[0], 16))
     both("dual_softmax", [syn.normal((2, 70, 130), seed=78) * 2.0], lambda f, t: f(t[0]))
 
