@@ -389,3 +389,26 @@ def test_table_form_training_matches_gather_form(dev):
     for k in g_t:
         rel_err = float((g_t[k] - g_g[k]).norm() / (g_g[k].norm() + 1e-20))
         assert rel_err <= 2e-2, (k, rel_err)
+
+
+@pytest.mark.gpu
+def test_backward_entry_points_reject_bad_shapes():
+    """The training-side entry points fail loudly (RuntimeError carrying cpn_last_error's reason) on shapes outside their
+    tile sets instead of computing something else."""
+    from coponerf_amd import _hip
+    from coponerf_amd._hip import call
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(64, 512, dtype=torch.float16, device=dev)
+    f = torch.zeros(1 << 16, dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError, match="208"):                      # N = 100: not a multiple of the 208-row tile
+        call("cpn_wgrad_tall_f16", a.data_ptr(), 512, a.data_ptr(), 512, 64, 100, 128, 0, f.data_ptr(), f.data_ptr(), st)
+    with pytest.raises(RuntimeError, match="null"):
+        call("cpn_wgrad_tall_f16", 0, 512, a.data_ptr(), 512, 64, 208, 128, 0, f.data_ptr(), f.data_ptr(), st)
+    with pytest.raises(RuntimeError, match="C == 32"):                  # cross attention: 16 channels per head
+        call("cpn_cross_attention_bwd", f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(),
+             f.data_ptr(), 1, 1, 8, 8, 16, f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), st)
+    with pytest.raises(RuntimeError, match="bad shape"):
+        call("cpn_linear_attention_bwd", f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), 1, 0, 1, 8, 0, 1e-6, 1,
+             f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), st)
+    assert _hip.lib().cpn_wgrad_tall_scratch(100, 128) == 0
