@@ -59,6 +59,11 @@ def parse_args(argv=None):
                     help="first encoder layer as gather + 835->832 GEMM instead of the projected-table form")
     ap.add_argument("--no-image", action="store_true", help="skip the secondary image-pipeline figures (get_z + render)")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-ref-loop", action="store_true",
+                    help="skip the secondary measurement of the reference callers' chunked loop (test.py:164-212)")
+    ap.add_argument("--rig", choices=("narrow", "wide"), default="narrow",
+                    help="camera rig of the synthetic pairs: RealEstate10K-like (configs[1]) or ACID-like wide baseline "
+                         "(configs[3])")
     ap.add_argument("--train-steps", type=int, default=3,
                     help="steps of the secondary training measurement in render mode (0 = skip)")
     return ap.parse_args(argv)
@@ -190,7 +195,7 @@ def run(args):
     model._engine.lanes = args.lanes
     model._engine.tables = not args.no_tables
 
-    inp_cpu = syn.make_inputs(B, H, H, 0, seed=100 + rank, full_image=True)
+    inp_cpu = syn.make_inputs(B, H, H, 0, seed=100 + rank, full_image=True, rig=args.rig)
     z_cpu, rel_cpu, flow_cpu = syn.make_latents(B, H, H, seed=200 + rank)
     inp, z, rel, flow = _to(inp_cpu, dev), _to(z_cpu, dev), rel_cpu.to(dev), _to(flow_cpu, dev)
     R = inp["query"]["uv"].shape[2]
@@ -219,15 +224,18 @@ def run(args):
     exec_per_ray = S * 6637056.0 + 4300000.0
     if tables:
         exec_per_ray -= S * 4 * 2.0 * 832 * (768 - 12)
+    cfg_name = ("configs[4]" if H == 512 else "configs[3]" if args.rig == "wide" else "configs[1]") \
+        if (H, S) in ((256, 64), (512, 128)) else "custom"
     line = {
-        "metric": f"rendered rays/sec (RealEstate10K-shaped {H}x{H} stereo pair, full-image render, {S} samples/ray)",
+        "metric": f"rendered rays/sec ({'ACID' if args.rig == 'wide' else 'RealEstate10K'}-shaped {H}x{H} stereo pair, "
+                  f"full-image render, {S} samples/ray)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f16 (fp16-input/fp32-accumulate MFMA for the per-sample MLPs; f32 decoder; f64 geometry island)",
         "data": "synthetic",
-        "config": {"workload": f"configs[1]: {H}x{H} stereo pair, full-image render {R} rays x {S} samples, "
-                               f"{B} pair(s) per GPU, render path only (z/rel_pose/flow given, val=True)",
+        "config": {"workload": f"{cfg_name}: {H}x{H} stereo pair ({args.rig} rig), full-image render {R} rays x {S} "
+                               f"samples, {B} pair(s) per GPU, render path only (z/rel_pose/flow given, val=True)",
                    "chunk_rays": args.chunk_rays, "lanes": args.lanes, "pairs_per_gpu": B,
                    "first_layer": "projected tables + K=80 MFMA (cpn_encode_hidden)" if tables
                                   else "gather + 835->832 GEMM"},
@@ -293,6 +301,11 @@ def run(args):
             line["image_rays_per_s_getz_graph"] = nimg * R / pdt
             line["image_ms_getz_graph"] = 1e3 * pdt / nimg
 
+    # ---- secondary figure: the loop the reference's callers run (test.py:164-212): get_z once, then 18 forward() calls
+    #      on torch.chunk(uv, 18) with the callers' del / .cpu() / per-key concat, at batch 1 and batch 2 (test.py:130)
+    if H == 256 and not args.no_ref_loop and B == 1:
+        line["ref_loop"] = ref_loop_block(model, syn, dev, rank, H, inp, z, rel, flow, elapsed / args.steps)
+
     if rank == 0:
         line.update(roofline_block(prof, args, tables))
         if args.cpu_rays > 0 and world == 1:          # CPU baseline: rank 0 at N = 1 only
@@ -313,6 +326,51 @@ def run(args):
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------------------
+def ref_loop_block(model, syn, dev, rank, H, inp1, z1, rel1, flow1, single_call_s):
+    """coponerf_amd/evalloop.py (= /root/reference test.py:164-212) on the bench's pair: per batch size the render part
+    (18 forward calls + join) with latents given, get_z of the batch, and the whole image (get_z + loop)."""
+    from coponerf_amd.evalloop import render_in_chunks
+    res = {"chunks": 18, "single_call_ms": 1e3 * single_call_s}
+    for nb in (1, 2):
+        if nb == 1:
+            inp, lat = inp1, (z1, rel1, flow1)
+        else:
+            inp = _to(syn.make_inputs(nb, H, H, 0, seed=400 + rank, full_image=True), dev)
+            zc, rc, fc = syn.make_latents(nb, H, H, seed=500 + rank)
+            lat = (_to(zc, dev), rc.to(dev), _to(fc, dev))
+        R = inp["query"]["uv"].shape[2]
+        for _ in range(2):
+            out = render_in_chunks(model, inp, 18, latents=lat)
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = render_in_chunks(model, inp, 18, latents=lat)
+        torch.cuda.synchronize()
+        render_ms = (time.perf_counter() - t0) / n * 1e3
+        with torch.no_grad():
+            for _ in range(2):
+                model.get_z(inp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                model.get_z(inp)
+            torch.cuda.synchronize()
+            getz_ms = (time.perf_counter() - t0) / 3 * 1e3
+            t0 = time.perf_counter()
+            for _ in range(3):
+                out = render_in_chunks(model, inp, 18)               # get_z inside, as the caller runs it
+            torch.cuda.synchronize()
+            image_ms = (time.perf_counter() - t0) / 3 * 1e3
+        res[f"batch{nb}"] = {"render_ms_per_batch": render_ms, "render_rays_per_s": nb * R / (render_ms * 1e-3),
+                              "get_z_ms": getz_ms, "image_ms_per_batch": image_ms,
+                              "image_rays_per_s_ref_loop": nb * R / (image_ms * 1e-3),
+                              "render_vs_single_call": render_ms / (nb * 1e3 * single_call_s)}
+        del out
+    return res
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -95,25 +95,34 @@ class CoPoNeRF(nn.Module):
         self._engine = RenderEngine()
         self.H = self.W = None
 
+    @property
+    def _param_epoch(self) -> int:
+        """Counts RenderEngine.invalidate() calls (load_state_dict, dist.broadcast_parameters, manual): captured get_z
+        graphs (graphs.py) are keyed on it, they hold the weights' values too."""
+        return self._engine.epoch
+
     # ------------------------------------------------------------------------------------------
     def _render_params(self) -> Dict[str, torch.Tensor]:
         # the Parameter OBJECTS are stable across .to()/.cuda()/load_state_dict (those rewrite .data in place), so the
         # walk over the 636 parameters of the module tree is done once, not on every ray chunk of a full-image render
-        rp = self.__dict__.get("_rp_cache")
-        if rp is None or any(self._parameters_changed(rp)):
-            rp = {k: v for k, v in self.named_parameters() if k.split(".")[0] in RENDER_PARAM_PREFIXES}
-            self.__dict__["_rp_cache"] = rp
+        c = self.__dict__.get("_rp_cache")
+        if c is not None:
+            rp, owners = c
+            # a replaced Parameter (`model.key_map.weight = nn.Parameter(...)`, a swapped sub-module) shows up as a
+            # different object in its owner's _parameters: ~40 identity comparisons per call
+            if all(mod._parameters.get(leaf) is p for (mod, leaf), p in zip(owners, rp.values())):
+                return rp
+        rp = {k: v for k, v in self.named_parameters() if k.split(".")[0] in RENDER_PARAM_PREFIXES}
+        owners = []
+        for k in rp:
+            path, leaf = k.rsplit(".", 1)
+            owners.append((self.get_submodule(path), leaf))
+        self.__dict__["_rp_cache"] = (rp, owners)
         return rp
-
-    def _parameters_changed(self, rp):
-        # a replaced Parameter (e.g. `model.phi.lin_out.weight = nn.Parameter(...)`) shows up as a different object
-        yield self.query_encode_latent.weight is not rp["query_encode_latent.weight"]
-        yield self.phi.lin_out.weight is not rp["phi.lin_out.weight"]
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         out = super().load_state_dict(state_dict, strict=strict, assign=assign)
-        self._engine.invalidate()               # packed fp16 weights / tables are derived from the parameters
-        self._param_epoch = getattr(self, "_param_epoch", 0) + 1       # captured get_z graphs (graphs.py) are dropped
+        self._engine.invalidate()      # packed fp16 weights / tables are derived from the parameters; bumps _param_epoch
         return out
 
     def get_z(self, input, val: bool = False, ops=None):

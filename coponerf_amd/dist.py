@@ -49,19 +49,27 @@ def grads_finite(params: Iterable[torch.nn.Parameter], group=None) -> bool:
 def guard_and_clip(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, group=None):
     """The reference's invalid-gradient guard (wrapper.py:44-58) and `clip_grad_norm_` (wrapper.py:142-146) from ONE
     pass over the gradients: per-tensor 2-norms (`torch._foreach_norm`, a handful of launches for the 570 tensors),
-    combined in float64.  NaN / Inf entries make their tensor's norm non-finite, so `finite` is exactly "no gradient
-    holds a NaN or an Inf" without squaring anything in fp32 (a sum of squares would overflow for large-but-finite
-    gradients).  The flag is MIN-all-reduced: every rank takes the same branch.  Clipping (per rank, BEFORE the
+    combined in float64.  NaN / Inf entries make their tensor's norm non-finite, so `finite` means "no gradient holds
+    a NaN or an Inf and no TENSOR's fp32 sum of squares overflows" (a tensor whose 2-norm exceeds ~1.8e19 also skips
+    the step; the reference would clip it to norm 1 instead — such a step is lost either way).  The flag is
+    MIN-all-reduced, by every rank whether or not it has gradients: every rank takes the same branch.  Clipping (per rank, BEFORE the
     exchange, like the reference) scales the gradients in place by min(1, max_norm / (norm + 1e-6)).
     Returns (finite: bool, total_norm: float64 tensor)."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
-        return True, torch.zeros((), dtype=torch.float64)
-    norms = torch.stack(torch._foreach_norm(grads)).double()
-    total = norms.square().sum().sqrt()
-    ok = torch.isfinite(total).float()
+    plist = list(params)
+    grads = [p.grad for p in plist if p.grad is not None]
+    if grads:
+        norms = torch.stack(torch._foreach_norm(grads)).double()
+        total = norms.square().sum().sqrt()
+        ok = torch.isfinite(total).float()
+    else:
+        # a rank without gradients still takes part in the flag exchange: the others are blocked in it
+        dev = plist[0].device if plist else "cpu"
+        total = torch.zeros((), dtype=torch.float64, device=dev)
+        ok = torch.ones((), dtype=torch.float32, device=dev)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if not grads:
+        return bool(ok.item() > 0), total
     finite = bool(ok.item() > 0)
     if finite and max_norm and max_norm > 0:
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0).float()
@@ -75,7 +83,8 @@ def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 
     Parameters without a gradient are skipped like wrapper.py:26 does.  The flat buckets need the SAME set of
     gradients on every rank (the reference's per-parameter loop hangs just the same when one rank lacks a gradient
     another has): one MAX all-reduce of the has-gradient mask establishes the union, and a rank missing one of those
-    gradients contributes zeros for it (its own `.grad` stays None)."""
+    gradients contributes zeros for it and RECEIVES the average as its `.grad`, so the optimizers of all ranks update
+    the same set of parameters and the replicas stay identical."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     world = dist.get_world_size(group)
@@ -92,12 +101,10 @@ def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 
     for p, u in zip(plist, union):
         if not u:
             continue
-        if p.grad is not None:
-            grads.append(p.grad.data)
-            owned.append(True)
-        else:
-            grads.append(torch.zeros_like(p.data))
-            owned.append(False)
+        if p.grad is None:
+            p.grad = torch.zeros_like(p.data)
+        grads.append(p.grad.data)
+        owned.append(True)
     handles = []
     for bucket in _buckets(list(zip(grads, owned)), bucket_bytes, key=lambda t: t[0]):
         flat = torch.cat([g.reshape(-1) for g, _ in bucket])

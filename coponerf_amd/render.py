@@ -169,6 +169,7 @@ class RenderEngine:
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops)
         self.profile: Optional[Dict[str, list]] = None
         self._copy_stream: Optional[torch.cuda.Stream] = None
+        self.epoch = 0                  # invalidate() calls so far (captured get_z graphs are keyed on it)
 
     # ---- caches --------------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
@@ -189,6 +190,13 @@ class RenderEngine:
         self._maps, self._tabs = [], []
         self._l3_hint = None
         self._hostc = None
+        self.epoch += 1
+
+    def __deepcopy__(self, memo):
+        # caches, streams and workspace are derived state: a copied model gets a fresh engine with the same settings
+        new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables)
+        new.grad_scale_target = self.grad_scale_target
+        return new
 
     def _host_inputs(self, *mats):
         """Host copies of the call's 4x4 inputs.  The device->host read is a stream synchronisation, and a full-image
@@ -581,10 +589,8 @@ class RenderEngine:
             for ray0 in range(0, nray_total, C):
                 run_chunk(ray0, bf, s)
         else:
-            for lane in range(nlanes):
-                self._lane_streams[lane].wait_event(geom_done)          # geometry + zl allocation precede this point
             ready = torch.cuda.Event()
-            ready.record()                                              # weights / maps / zl exist on the main stream
+            ready.record()                              # geometry, weights, maps and zl are queued on the main stream
             for ci, ray0 in enumerate(range(0, nray_total, C)):
                 lane = ci % nlanes
                 st = self._lane_streams[lane]

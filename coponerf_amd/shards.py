@@ -116,10 +116,19 @@ class BatchAssembler:
         self.frames = torch.empty(batch, 3, Hs, Ws, 3, dtype=torch.uint8, pin_memory=pin)
         self.ray_pix = torch.empty(batch, rays, dtype=torch.int32, pin_memory=pin)
         self.small = torch.empty(batch, 3, 32, dtype=torch.float32, pin_memory=pin)       # c2w (16) + K (16) per frame
+        # the H2D copies of to_model_input() read the pinned staging asynchronously: the next fill() must not overwrite
+        # it before they have run (the GPU queue is a whole training step deep)
+        self._uploaded: Optional[torch.cuda.Event] = None
+
+    def _wait_uploaded(self) -> None:
+        if self._uploaded is not None:
+            self._uploaded.synchronize()
+            self._uploaded = None
 
     def fill(self, b: int, shard: Shard, ids: Sequence[int], rng: np.random.Generator) -> None:
         """Host side of one sample: three row-slices of the mmap, the ray selection, 3 x 32 floats."""
         S = self.side
+        self._wait_uploaded()
         for j, fid in enumerate(ids):
             self.frames[b, j].numpy()[...] = shard.frames[fid]                  # mmap page cache -> pinned staging, one copy
             self.small[b, j, :16] = torch.from_numpy(np.asarray(shard.c2w[fid]).reshape(16).copy())
@@ -133,6 +142,9 @@ class BatchAssembler:
         frames = self.frames.to(self.dev, non_blocking=True)
         pix = self.ray_pix.to(self.dev, non_blocking=True)
         small = self.small.to(self.dev, non_blocking=True)
+        if self.dev.type == "cuda":
+            self._uploaded = torch.cuda.Event()
+            self._uploaded.record()
         ctx = torch.empty(B, 2, S, S, 3, dtype=torch.float32, device=self.dev)
         qrgb = torch.empty(B, 1, R, 3, dtype=torch.float32, device=self.dev)
         call("cpn_prepare_input", frames.data_ptr(), B, self.Hs, self.Ws, self.y0, self.x0, S, S, R, pix.data_ptr(),

@@ -29,6 +29,15 @@ class TrainStep:
         self.bucket_bytes = bucket_bytes
         self.group = group
         self.timing: Optional[Dict[str, list]] = None                    # set to {} to collect HIP-event timings
+        # fp16 activation gradients carry a static per-pass scale (train_fns.GradScale).  If they overflow the guard
+        # skips the step and the next pass would pick the same scale: back the target off (x 1/4 per skipped step, down
+        # to 1) and restore it (x 2 every `growth_interval` good steps) like an AMP GradScaler does.
+        self.skipped_in_a_row = 0
+        self.skipped_total = 0
+        self.growth_interval = 200
+        self._good = 0
+        eng = getattr(model, "_engine", None)
+        self._scale_ceiling = float(eng.grad_scale_target) if eng is not None else 0.0
 
     def _ev(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -57,12 +66,33 @@ class TrainStep:
             self.opt.step()
         else:
             e3 = e4 = self._ev() if timed else None
+        self._adapt_grad_scale(stepped)
         self.opt.zero_grad(set_to_none=True)
         e5 = self._ev() if timed else None
         if timed:
             self.timing.setdefault("events", []).append((e0, e1, e2, e3, e4, e5))
         return {"loss": loss.detach(), "stepped": stepped, "collectives": ncoll, "allreduce_bytes": nbytes,
-                "at_wt": out["at_wt"].detach()}
+                "at_wt": out["at_wt"].detach(), "skipped_in_a_row": self.skipped_in_a_row}
+
+    def _adapt_grad_scale(self, stepped: bool) -> None:
+        eng = getattr(self.model, "_engine", None)
+        if eng is None:
+            return
+        if stepped:
+            self.skipped_in_a_row = 0
+            self._good += 1
+            if self._good >= self.growth_interval and eng.grad_scale_target < self._scale_ceiling:
+                eng.grad_scale_target = min(self._scale_ceiling, eng.grad_scale_target * 2.0)
+                self._good = 0
+            return
+        self.skipped_in_a_row += 1
+        self.skipped_total += 1
+        self._good = 0
+        eng.grad_scale_target = max(1.0, eng.grad_scale_target / 4.0)
+        if self.skipped_in_a_row in (3, 10, 100):
+            import warnings
+            warnings.warn(f"coponerf_amd.TrainStep: {self.skipped_in_a_row} consecutive steps skipped by the "
+                          f"finite-gradient guard (fp16 gradient scale target now {eng.grad_scale_target:g})")
 
     def timing_summary(self) -> Dict[str, float]:
         """Mean milliseconds per phase over the recorded steps (call after torch.cuda.synchronize())."""

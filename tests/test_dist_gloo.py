@@ -41,12 +41,24 @@ def _worker(rank, world, port, q):
         next(model.parameters()).grad[0, 0] = float("nan")
     finite_after_nan = cd.grads_finite(model.parameters())   # False on BOTH ranks: same branch, no deadlock
     # ---- ranks with DIFFERENT sets of gradients (rank 1 also trains the last Linear): no hang, the rank without the
-    #      gradient contributes zeros and keeps .grad None; large-but-finite gradients still count as finite
+    #      gradient contributes zeros and RECEIVES the average (both replicas then take the same optimizer step);
+    #      large-but-finite gradients still count as finite
     model.zero_grad(set_to_none=True)
     (model(x) if rank == 1 else model[:3](x)).sum().backward()
     local = None if model[3].weight.grad is None else model[3].weight.grad.clone()
     cd.average_gradients(model.parameters(), bucket_bytes=512)
-    uneven_ok = (model[3].weight.grad is None) if rank == 0 else bool(torch.allclose(model[3].weight.grad, local / world))
+    src = local if rank == 1 else torch.zeros_like(model[3].weight)
+    dist.broadcast(src, 1)
+    uneven_ok = model[3].weight.grad is not None and bool(torch.allclose(model[3].weight.grad, src / world))
+    # a rank WITHOUT any gradient still joins the guard's flag exchange (the others are blocked in it)
+    saved = [p.grad for p in model.parameters()]
+    if rank == 0:
+        for p in model.parameters():
+            p.grad = None
+    fin0, _ = cd.guard_and_clip(model.parameters(), max_norm=0.0)
+    uneven_ok = uneven_ok and fin0 is True
+    for p, g in zip(model.parameters(), saved):
+        p.grad = g
     model[0].weight.grad.fill_(1e30)                   # squares overflow fp32; the values themselves are finite
     big_finite = cd.grads_finite(model.parameters())
     # guard + clip in one pass: equals clip_grad_norm_ on finite gradients, reports the NaN on both ranks
