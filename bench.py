@@ -330,10 +330,13 @@ def run(args):
 
 # --------------------------------------------------------------------------------------------------------------
 def ref_loop_block(model, syn, dev, rank, H, inp1, z1, rel1, flow1, single_call_s):
-    """coponerf_amd/evalloop.py (= /root/reference test.py:164-212) on the bench's pair: per batch size the render part
-    (18 forward calls + join) with latents given, get_z of the batch, and the whole image (get_z + loop)."""
+    """coponerf_amd/evalloop.py (= /root/reference test.py:164-212) on the bench's pair, at batch 1 and at the batch 2
+    test.py:130 uses: 18 forward(val=True) calls on torch.chunk(uv, 18) with the callers' del / .cpu() / per-key concat.
+    `render_ms` = calls + join with latents given (wall clock until the GPU has drained), `release_ms` = dropping the
+    joined result (the callers' 67 MB CPU pixel_val), `image_ms` = get_z + calls + join as one loop iteration of the
+    caller runs, releases included."""
     from coponerf_amd.evalloop import render_in_chunks
-    res = {"chunks": 18, "single_call_ms": 1e3 * single_call_s}
+    res = {"chunks": 18, "single_call_ms": 1e3 * single_call_s, "call_lanes": model._engine.call_lanes}
     for nb in (1, 2):
         if nb == 1:
             inp, lat = inp1, (z1, rel1, flow1)
@@ -344,13 +347,19 @@ def ref_loop_block(model, syn, dev, rank, H, inp1, z1, rel1, flow1, single_call_
         R = inp["query"]["uv"].shape[2]
         for _ in range(2):
             out = render_in_chunks(model, inp, 18, latents=lat)
+            del out
         torch.cuda.synchronize()
-        n = 5
-        t0 = time.perf_counter()
+        n, t_loop, t_free = 6, [], []
         for _ in range(n):
+            t0 = time.perf_counter()
             out = render_in_chunks(model, inp, 18, latents=lat)
-        torch.cuda.synchronize()
-        render_ms = (time.perf_counter() - t0) / n * 1e3
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            del out
+            t2 = time.perf_counter()
+            t_loop.append(1e3 * (t1 - t0))
+            t_free.append(1e3 * (t2 - t1))
+        render_ms, release_ms = sum(t_loop) / n, sum(t_free) / n
         with torch.no_grad():
             for _ in range(2):
                 model.get_z(inp)
@@ -361,15 +370,16 @@ def ref_loop_block(model, syn, dev, rank, H, inp1, z1, rel1, flow1, single_call_
             torch.cuda.synchronize()
             getz_ms = (time.perf_counter() - t0) / 3 * 1e3
             t0 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(4):
                 out = render_in_chunks(model, inp, 18)               # get_z inside, as the caller runs it
+                del out
             torch.cuda.synchronize()
-            image_ms = (time.perf_counter() - t0) / 3 * 1e3
-        res[f"batch{nb}"] = {"render_ms_per_batch": render_ms, "render_rays_per_s": nb * R / (render_ms * 1e-3),
+            image_ms = (time.perf_counter() - t0) / 4 * 1e3
+        res[f"batch{nb}"] = {"render_ms_per_batch": render_ms, "render_ms_min_max": [min(t_loop), max(t_loop)],
+                              "release_ms": release_ms, "render_rays_per_s": nb * R / (render_ms * 1e-3),
                               "get_z_ms": getz_ms, "image_ms_per_batch": image_ms,
                               "image_rays_per_s_ref_loop": nb * R / (image_ms * 1e-3),
                               "render_vs_single_call": render_ms / (nb * 1e3 * single_call_s)}
-        del out
     return res
 
 

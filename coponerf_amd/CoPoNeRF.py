@@ -143,19 +143,25 @@ class CoPoNeRF(nn.Module):
         self.H, self.W = ctx["rgb"].shape[2], ctx["rgb"].shape[3]    # what get_z records (models/CoPoNeRF.py:180)
         rp = self._render_params()
         train = torch.is_grad_enabled() and (any(p.requires_grad for p in rp.values()) or any(t.requires_grad for t in z))
-        run = self._engine.render_train if train else self._engine.render          # same forward kernels either way
-        core = run(rp, ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], z,
-                   rel_pose, val, self.npoints, self.H, self.W)
+        args = (rp, ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], z, rel_pose, val,
+                self.npoints, self.H, self.W)
+        # same forward kernels either way; the training pass wraps them in autograd Functions
+        core = self._engine.render_train(*args) if train else self._engine.render(*args, debug=debug, inp=input, flow=flow)
         out = {"flow": flow, "uv": qry["uv"], "coords": core["coords"]}
         out["pixel_val"] = core["pixel_val_cpu"]                  # models/CoPoNeRF.py:490 (callers expect a CPU tensor)
         out["at_wts"] = [core["at_wt"]]
         host = core["host"]                                       # O(B) inverses done with the host pose algebra
-        out.update(aux_outputs(input, flow, core["at_wt"], core["pt"], core["Tq"], host["inv_Kq"], host["inv_qc2w"]))
+        if train:
+            out.update(aux_outputs(input, flow, core["at_wt"], core["pt"], core["Tq"], host["inv_Kq"], host["inv_qc2w"]))
+        else:
+            out.update(core["aux"])
         out["at_wt"] = core["at_wt"]
         out["valid_mask"] = core["valid_mask"]
         out["rgb"] = core["rgb"]
         out["z"] = z
-        out["rel_pose_flip"] = _rigid_inverse(rel_pose)
+        flip = host.get("rel_pose_flip")
+        # differentiable on the device when a pose loss may need it, else from the cached host pose algebra
+        out["rel_pose_flip"] = _rigid_inverse(rel_pose) if (flip is None or (torch.is_grad_enabled() and rel_pose.requires_grad)) else flip
         out["rel_pose"] = rel_pose
         out["gt_rel_pose"] = host["gt_rel_pose"]                  # models/CoPoNeRF.py:570-574
         out["gt_rel_pose_flip"] = host["gt_rel_pose_flip"]

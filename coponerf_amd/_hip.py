@@ -18,7 +18,7 @@ _P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
 # name -> argtypes (every function returns int status except the two noted below)
 SIGNATURES: Dict[str, List] = {
-    "cpn_project_rays": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_project_rays": [_P, _P, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P],
     "cpn_sample_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cpn_nchw_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
     "cpn_pack_weight_f16": [_P, _I, _I, _P, _I, _P],
@@ -35,6 +35,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_attend_hidden": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_linear_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
+    "cpn_lightfield_decode": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_ray_outputs": [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_hid_grad_combine": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_wgrad_skinny_f16": [_P, _P, _I, ctypes.c_longlong, _P, _P, _P],
@@ -69,8 +71,10 @@ CAM_STRIDE = 96
 CAM_TQ, CAM_M, CAM_AOWN, CAM_AOTH, CAM_KQ, CAM_KC, CAM_KO, CAM_KN = 0, 16, 32, 48, 64, 68, 72, 76
 XIN_K, XIN_STRIDE = 864, 896
 TAB_LD = 832
+RAYC_STRIDE = 64
+LIGHTFIELD_PACK_FLOATS = 128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16
 GN_SLOTS = 32              # CPN_GN_SLOTS of include/coponerf_hip.h
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def declared_symbols() -> List[str]:

@@ -1,8 +1,11 @@
 """Auxiliary outputs of CoPoNeRF.forward that only feed the cycle/ssim losses and the summaries.
 
 <0.5 % of the reference's time: cycle-consistency masks from the flows, the
-attention-weighted expected 3-D point and its reprojections.  They stay stock PyTorch ops on device tensors —
-no per-batch Python loops and no host syncs, unlike /root/reference utils_training/utils.py:52-69,260-276.
+attention-weighted expected 3-D point and its reprojections.  Inference (`ray_outputs`): the per-ray part is ONE
+kernel (cpn_ray_outputs, csrc/rayout.hip) — as ~30 stock launches it cost the host more than a 3 641-ray forward()
+call of the reference's evaluation loop takes on the GPU; the per-image part (flow upsampling, cycle masks) stays stock
+ops, computed once per flow pair.  Training (`aux_outputs`): stock differentiable PyTorch ops on device tensors — no
+per-batch Python loops and no host syncs, unlike /root/reference utils_training/utils.py:52-69,260-276.
 Cites: models/CoPoNeRF.py:230-236,493-541; utils_training/utils.py:140-170,576-602,642-671;
 utils_training/geometry.py:395-406.
 """
@@ -56,19 +59,24 @@ _FLOW_CACHE: Dict[str, tuple] = {}
 
 
 def _flow_products(flow: Sequence[torch.Tensor], width: int):
-    """(cycle mask of view 2, flow upsampled to 256x256): functions of the flows alone, so a full-image render that
-    calls forward() once per ray chunk with the same `flow` tensors computes them once."""
+    return flow_products(flow, width)[0]
+
+
+def flow_products(flow: Sequence[torch.Tensor], width: int):
+    """((cycle mask of view 2, flow upsampled to 256x256), cache hit?): functions of the flows alone, so a full-image
+    render that calls forward() once per ray chunk with the same `flow` tensors computes them once."""
     key = tuple((f._version, tuple(f.shape)) for f in flow[:2]) + (width,)
     hit = _FLOW_CACHE.get("entry")
     # the entry holds the flow tensors themselves and is matched on IDENTITY (+ version): a new pair's flows that
     # happen to be allocated at a freed pair's addresses can never hit it
     if hit is not None and hit[0] == key and hit[3][0] is flow[0] and hit[3][1] is flow[1]:
-        return hit[1], hit[2]
+        return (hit[1], hit[2]), True
     _, mask2 = cycle_masks(flow, width)
-    flow_up = F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])
+    mask2 = mask2.contiguous()
+    flow_up = (F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])).contiguous()
     if not any(f.requires_grad for f in flow[:2]):
         _FLOW_CACHE["entry"] = (key, mask2, flow_up, (flow[0], flow[1]))
-    return mask2, flow_up
+    return (mask2, flow_up), False
 
 
 def aux_outputs(inp: Dict, flow: Sequence[torch.Tensor], at_wt: torch.Tensor, pt: torch.Tensor,
@@ -103,3 +111,33 @@ def aux_outputs(inp: Dict, flow: Sequence[torch.Tensor], at_wt: torch.Tensor, pt
         "mask_c2": inb[..., 0] & inb[..., 1], "C2_pts_to_C1": src.transpose(1, 2), "at_wt_max": at_max,
         "depth_ray": torch.clamp(depth_ray, 0, 10)[..., None],
     }
+
+
+@torch.no_grad()
+def ray_outputs(inp: Dict, flow_prods, at_wt: torch.Tensor, pt: torch.Tensor, rayc: torch.Tensor,
+                uv_rows) -> Dict[str, torch.Tensor]:
+    """Same outputs as aux_outputs() from one cpn_ray_outputs launch (inference path).  flow_prods: flow_products(...)[0];
+    rayc: the (B, RAYC_STRIDE) block of render.build_ray_constants; uv_rows: (float32 uv storage, batch stride) as the
+    geometry kernels read it."""
+    from ._hip import call
+    ctx = inp["context"]
+    B, V = ctx["rgb"].shape[:2]
+    N, R, S = at_wt.shape
+    dev = at_wt.device
+    mask2, flow_up = flow_prods
+    if mask2.dtype != torch.bool or flow_up.dtype != torch.float32 or tuple(flow_up.shape) != (B, 2, 256, 256):
+        raise ValueError("ray_outputs: unexpected flow products")
+    f32 = torch.float32
+    at_max = torch.empty(N, R, 1, dtype=torch.int64, device=dev)
+    depth = torch.empty(B, R, 1, dtype=f32, device=dev)
+    t1 = torch.empty(B, R, 2, dtype=f32, device=dev)
+    t2 = torch.empty(B, R, 2, dtype=f32, device=dev)
+    c21 = torch.empty(B, R, 2, dtype=f32, device=dev)
+    mc2 = torch.empty(B, R, dtype=torch.bool, device=dev)
+    mm = torch.empty(B, R, dtype=torch.bool, device=dev)
+    uvc, uvs = uv_rows
+    call("cpn_ray_outputs", at_wt.data_ptr(), pt.data_ptr(), uvc.data_ptr(), uvs, rayc.data_ptr(), mask2.data_ptr(),
+         flow_up.data_ptr(), B, V, R, S, at_max.data_ptr(), depth.data_ptr(), t1.data_ptr(), t2.data_ptr(), mc2.data_ptr(),
+         mm.data_ptr(), c21.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return {"matchability_cycle_mask": mm, "T_to_C1_pts": t1, "T_to_C2_pts": t2, "mask_c2": mc2, "C2_pts_to_C1": c21,
+            "at_wt_max": at_max, "depth_ray": depth}

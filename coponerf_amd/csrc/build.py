@@ -22,6 +22,7 @@ UNITS = [
     ("gemm_f16.hip", []),
     ("attend.hip", []),
     ("linear_f32.hip", []),
+    ("rayout.hip", []),
     ("ufc.hip", []),
     ("ufc_attn.hip", []),
     ("encoder.hip", []),

@@ -69,7 +69,7 @@ __device__ __forceinline__ void normalize3(float v[3]) {
     v[0] = v[0] / n; v[1] = v[1] / n; v[2] = v[2] / n;
 }
 
-__global__ void project_rays_kernel(const float* __restrict__ cam, const float* __restrict__ uv,
+__global__ void project_rays_kernel(const float* __restrict__ cam, const float* __restrict__ uv, long long uv_bstride,
                                     int B, int V, int R, float* __restrict__ coords9,
                                     float* __restrict__ seg, uint8_t* __restrict__ overlaps) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,7 +82,7 @@ __global__ void project_rays_kernel(const float* __restrict__ cam, const float* 
     const float* T = c + CPN_CAM_TQ;
     const float fx = c[CPN_CAM_KQ], fy = c[CPN_CAM_KQ + 1], cx = c[CPN_CAM_KQ + 2], cy = c[CPN_CAM_KQ + 3];
     const float* Kn = c + CPN_CAM_KN;
-    const float u = uv[((size_t)b * R + r) * 2 + 0], v = uv[((size_t)b * R + r) * 2 + 1];
+    const float u = uv[(size_t)b * uv_bstride + (size_t)r * 2 + 0], v = uv[(size_t)b * uv_bstride + (size_t)r * 2 + 1];
 
     // Pluecker embedding of the query ray in this context frame (geometry.py:236-245)
     const float one = 1.0f;
@@ -248,13 +248,14 @@ __global__ void mask_rgb_kernel(const float* __restrict__ rgb_raw, int ld, const
 
 }  // namespace
 
-extern "C" int cpn_project_rays(const float* cam, const float* uv, int B, int V, int R,
+extern "C" int cpn_project_rays(const float* cam, const float* uv, long long uv_batch_stride, int B, int V, int R,
                                 float* coords9, float* seg, uint8_t* overlaps, void* stream) {
     CPN_REQUIRE(cam && uv && coords9 && seg && overlaps, CPN_E_ARG, "cpn_project_rays: null pointer");
     CPN_REQUIRE(B > 0 && V == 2 && R > 0, CPN_E_SHAPE, "cpn_project_rays: need B>0, V==2, R>0 (got %d,%d,%d)", B, V, R);
+    CPN_REQUIRE(uv_batch_stride >= 2LL * R, CPN_E_SHAPE, "cpn_project_rays: uv_batch_stride %lld < 2R", uv_batch_stride);
     const long long total = (long long)B * V * R;
     hipLaunchKernelGGL(project_rays_kernel, dim3(cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       cam, uv, B, V, R, coords9, seg, overlaps);
+                       cam, uv, uv_batch_stride, B, V, R, coords9, seg, overlaps);
     CPN_LAUNCH_CHECK("cpn_project_rays");
     return 0;
 }

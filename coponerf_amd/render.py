@@ -7,7 +7,9 @@ PyTorch is used for device memory, the current HIP stream and a handful of O(B) 
 """
 from __future__ import annotations
 
+import ctypes
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -56,7 +58,7 @@ def _upload(host: Dict[str, torch.Tensor], dev) -> Dict[str, torch.Tensor]:
         stage[off:off + t.numel()] = t.reshape(-1)
         off += t.numel()
     flat = stage.to(dev, non_blocking=True)
-    out, off = {}, 0
+    out, off = {"_flat": flat}, 0
     for k, t in host.items():
         out[k] = flat[off:off + t.numel()].view(t.shape)
         off += t.numel()
@@ -71,6 +73,32 @@ def host_pose_products(ctx_c2w: torch.Tensor, qry_c2w: torch.Tensor, qry_K: torc
     return {"gt_rel_pose": torch.inverse(ctx_c2w[:, 0]) @ ctx_c2w[:, 1],
             "gt_rel_pose_flip": torch.inverse(torch.inverse(ctx_c2w[:, -1]) @ ctx_c2w[:, 0]),
             "inv_Kq": torch.inverse(qry_K[:, 0, :3, :3]), "inv_qc2w": torch.inverse(qry_c2w[:, 0])}
+
+
+def build_ray_constants(prods: Dict[str, torch.Tensor], ctx_K: torch.Tensor, Tq: torch.Tensor) -> torch.Tensor:
+    """(B, RAYC_STRIDE) float32 block of cpn_ray_outputs (include/coponerf_hip.h): what the per-ray auxiliary outputs
+    need of the O(B) pose algebra (CoPoNeRF.py:508-521)."""
+    B = ctx_K.shape[0]
+    c = torch.zeros(B, _hip.RAYC_STRIDE, dtype=torch.float32)
+    c[:, 0:4] = prods["inv_qc2w"][:, 2, :]
+    c[:, 4:13] = prods["inv_Kq"].reshape(B, 9)
+    c[:, 13:22] = ctx_K[:, 0, :3, :3].reshape(B, 9)
+    c[:, 22:31] = ctx_K[:, 1, :3, :3].reshape(B, 9)
+    c[:, 31:47] = Tq[:, 0].reshape(B, 16)
+    c[:, 47:63] = Tq[:, 1].reshape(B, 16)
+    return c
+
+
+def _uv_rows(uv: torch.Tensor, B: int, R: int) -> Tuple[torch.Tensor, int]:
+    """Query pixels (B,1,R,2) -> (float32 tensor whose storage the kernels read, batch stride in floats).  A ray chunk of
+    a larger array (torch.chunk(uv_full, 18, dim=2), /root/reference test.py:177) is read in place through its stride."""
+    u = uv.detach()
+    if u.dtype != torch.float32:
+        u = u.float()
+    u = u.view(B, R, 2) if u.dim() == 4 and u.shape[1] == 1 and u.stride(3) == 1 and u.stride(2) == 2 else u.reshape(B, R, 2).contiguous()
+    if u.stride(2) != 1 or u.stride(1) != 2 or (B > 1 and u.stride(0) < 2 * R):
+        u = u.contiguous()
+    return u, (u.stride(0) if B > 1 else 2 * R)
 
 
 def _rigid_inverse(m: torch.Tensor) -> torch.Tensor:
@@ -126,6 +154,105 @@ def build_camera_block(ctx_c2w: torch.Tensor, ctx_K: torch.Tensor, qry_c2w: torc
 
 
 # ----------------------------------------------------------------------------------------------
+def _flat_tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _flat_tensors(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _flat_tensors(o)
+
+
+class PendingHostTensor(torch.Tensor):
+    """The caller contract's `pixel_val` (a CPU tensor, /root/reference models/CoPoNeRF.py:490) while its asynchronous
+    device->host copy may still be running on the copy stream.  The reference's `.cpu()` blocks the host once per
+    forward() call — 18 times per image in its own evaluation loop (test.py:176-190).  This subclass defers that wait to
+    the first operation that touches the VALUES (any torch function, `.numpy()`, `torch.cat`, indexing ...): it
+    synchronises on the copy's event there and then behaves as the plain pinned CPU tensor it wraps.  Metadata
+    (`shape`, `device`, `dtype`, `size()`, `dim()`) and `.cpu()` on this already-CPU tensor do not wait.
+    `RenderEngine.lazy_pixel_val = False` (or COPONERF_EAGER_PIXEL_VAL=1) hands out a plain tensor after the wait."""
+
+    _NO_WAIT = frozenset(("shape", "device", "dtype", "size", "dim", "numel", "ndim", "is_cuda", "is_pinned", "stride",
+                          "is_contiguous", "element_size", "nelement", "ndimension", "layout", "requires_grad", "is_cpu",
+                          "names", "is_sparse", "is_quantized", "is_meta", "grad_fn", "grad", "is_leaf", "is_complex",
+                          "is_floating_point", "__len__"))
+
+    @staticmethod
+    def wrap(host: torch.Tensor, ready) -> "PendingHostTensor":
+        t = torch.Tensor._make_subclass(PendingHostTensor, host)
+        t._cpn_ready = ready
+        return t
+
+    @staticmethod
+    def _cat_as_copies_arrive(tensors, dim=0, out=None):
+        """`torch.cat` of the callers' join (test.py:207: the per-chunk pixel_val along dim -3), chunk by chunk: each
+        piece is copied into the result as soon as ITS device->host copy has landed, so the 67 MB host concatenation of a
+        256x256x64 image runs under the GPU work of the later chunks instead of after the last one.  Same result as
+        torch.cat; anything but a plain list of same-dtype PendingHostTensors falls back to it (returns None)."""
+        if out is not None or not isinstance(tensors, (list, tuple)) or len(tensors) < 2 or not all(
+                isinstance(t, PendingHostTensor) and t.dtype == tensors[0].dtype and t.dim() == tensors[0].dim()
+                for t in tensors):
+            return None
+        nd = tensors[0].dim()
+        d = dim + nd if dim < 0 else dim
+        if not 0 <= d < nd:
+            return None
+        with torch._C.DisableTorchFunctionSubclass():
+            shape = list(tensors[0].shape)
+            for t in tensors[1:]:
+                if any(a != b for i, (a, b) in enumerate(zip(t.shape, shape)) if i != d):
+                    return None
+            shape[d] = sum(int(t.shape[d]) for t in tensors)
+            # the result comes from torch's caching PINNED-host allocator like the pieces: a fresh 67 MB malloc is an
+            # mmap whose first touch page-faults and whose release is an munmap (10-90 ms each on a virtualised host)
+            res = torch.empty(shape, dtype=tensors[0].dtype, pin_memory=tensors[0].is_pinned())
+            outer = int(math.prod(shape[:d]))
+            unit = int(math.prod(shape[d + 1:])) * res.element_size()          # bytes of one index along d
+            plain = outer <= 64 and res.is_contiguous() and all(t.is_contiguous() for t in tensors)
+            off = 0
+            for t in tensors:
+                t.wait()
+                n = int(t.shape[d])
+                if plain:
+                    # one memmove per outer index: a 3.7 MB piece split over torch's intra-op pool takes anything from
+                    # 0.3 to 100 ms on a 128-thread host (tools/host_cat_probe.py), a single-threaded copy 0.4 ms
+                    src, dst = t.data_ptr(), res.data_ptr() + off * unit
+                    for o in range(outer):
+                        ctypes.memmove(dst + o * shape[d] * unit, src + o * n * unit, n * unit)
+                else:
+                    res.narrow(d, off, n).copy_(t)
+                off += n
+        return res
+
+    def wait(self) -> torch.Tensor:
+        ev = self.__dict__.get("_cpn_ready")
+        if ev is not None:
+            ev.synchronize()
+            self.__dict__["_cpn_ready"] = None
+        return self
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if name == "__get__":                                   # property getters: Tensor.shape.__get__ ...
+            name = getattr(getattr(func, "__self__", None), "__name__", "")
+        if name == "cpu" and len(args) == 1 and not kwargs:
+            return args[0]                                      # already on the CPU: Tensor.cpu() returns self
+        if func is torch.cat:
+            joined = cls._cat_as_copies_arrive(*args, **kwargs)
+            if joined is not None:
+                return joined
+        if name not in cls._NO_WAIT:
+            for t in _flat_tensors((args, kwargs)):
+                if isinstance(t, PendingHostTensor):
+                    t.wait()
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
 class RenderEngine:
     """Owns the device-side caches (packed fp16 weights, NHWC fp16 feature maps, workspace) of one model."""
 
@@ -164,16 +291,27 @@ class RenderEngine:
         self._wgen = 0                  # bumped whenever the packed weights are rebuilt (the tables depend on them)
         self._l3_hint = None            # (z[3] tensor, its version, NHWC fp16 copy) handed over by get_z's conv_map kernel
         self._hostc = None              # (input tensors, their versions, host copies) of the last call's 4x4 inputs
+        self._camc = None               # the device-side products of those inputs (_camera)
         self._ws: Dict[str, torch.Tensor] = {}
         self._interval: Dict[Tuple[int, str], torch.Tensor] = {}
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops)
         self.profile: Optional[Dict[str, list]] = None
         self._copy_stream: Optional[torch.cuda.Stream] = None
+        # pixel_val is handed to the caller as a PendingHostTensor (waits for its copy at the first use of the values)
+        self.lazy_pixel_val = os.environ.get("COPONERF_EAGER_PIXEL_VAL", "0") != "1"
         self.epoch = 0                  # invalidate() calls so far (captured get_z graphs are keyed on it)
+        # consecutive render() calls alternate over this many HIP streams (render() docstring); 1 = the caller's stream
+        self.call_lanes = int(os.environ.get("COPONERF_CALL_LANES", "2"))
+        self._call_streams: List[torch.cuda.Stream] = []
+        self._call_idx = 0
+        self._ws_prefix = ""            # workspace of the call lane in flight
+        self._misses = 0                # cache rebuilds so far (a call that rebuilt something must wait for the caller's stream)
+        self._uv_seen = None            # (query-pixel base tensor, its version) of the last call
 
     # ---- caches --------------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
         n = int(math.prod(shape))
+        name = self._ws_prefix + name
         t = self._ws.get(name)
         if t is None or t.numel() < n or t.dtype != dtype or t.device != device:
             t = torch.empty(n, dtype=dtype, device=device)
@@ -190,12 +328,13 @@ class RenderEngine:
         self._maps, self._tabs = [], []
         self._l3_hint = None
         self._hostc = None
+        self._camc = None
         self.epoch += 1
 
     def __deepcopy__(self, memo):
         # caches, streams and workspace are derived state: a copied model gets a fresh engine with the same settings
         new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables)
-        new.grad_scale_target = self.grad_scale_target
+        new.grad_scale_target, new.call_lanes, new.lazy_pixel_val = self.grad_scale_target, self.call_lanes, self.lazy_pixel_val
         return new
 
     def _host_inputs(self, *mats):
@@ -210,15 +349,39 @@ class RenderEngine:
         self._hostc = (mats, tuple(None if m is None else m._version for m in mats), host)
         return host
 
+    def _camera(self, ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose, val: bool, H: int, dev) -> Dict[str, torch.Tensor]:
+        """Device copies of everything the O(B) host pose algebra produces for a call (camera block, Tq, the output-side
+        inverses, the ray constants of cpn_ray_outputs, rel_pose_flip): ONE pinned upload, cached on the identity and
+        version of the five input tensors — a full-image render is 18 forward() calls with the same cameras
+        (/root/reference test.py:176-190).  The entries are views of one flat buffer that is also handed to the caller
+        (gt_rel_pose ...): an in-place write to any of them bumps the buffer's version and drops the entry."""
+        mats = (ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
+        c = self._camc
+        if c is not None and c[1] == (bool(val), H, dev) and c[3]["_flat"]._version == c[2] and all(
+                (a is b) and (a is None or a._version == v) for a, b, v in zip(c[0][0], mats, c[0][1])):
+            return c[3]
+        self._misses += 1
+        hc2w, hK, hqc2w, hqK, hrel = self._host_inputs(*mats)
+        cam_cpu, Tq_cpu = build_camera_block(hc2w, hK, hqc2w, hqK, hrel, val, H)
+        prods = host_pose_products(hc2w, hqc2w, hqK)
+        host = dict(prods, cam=cam_cpu, Tq=Tq_cpu, rayc=build_ray_constants(prods, hK, Tq_cpu))
+        if hrel is not None:
+            host["rel_pose_flip"] = _rigid_inverse(hrel)
+        up = _upload(host, dev)
+        self._camc = ((mats, tuple(None if m is None else m._version for m in mats)), (bool(val), H, dev),
+                      up["_flat"]._version, up)
+        return up
+
     def adopt_level3(self, z3: torch.Tensor, nhwc16: torch.Tensor) -> None:
         """get_z's conv_map kernel already wrote the full-resolution level as NHWC fp16: use it for THIS z3 tensor
         (matched by identity and version) instead of converting it again."""
         self._l3_hint = (z3, z3._version, nhwc16)
 
     def _weights(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        key = tuple((k, id(p), p.data_ptr(), p._version) for k, p in sorted(params.items()))
+        key = tuple((id(p), p.data_ptr(), p._version) for p in params.values())
         if key == self._wkey:
             return self._w
+        self._misses += 1
         dev = params["query_encode_latent.weight"].device
         w: Dict[str, torch.Tensor] = {}
         s = _stream()
@@ -266,6 +429,17 @@ class RenderEngine:
                 w[f"phi.blocks.{k}.{fc}.w"] = f32(f"phi.blocks.{k}.{fc}.weight")
                 w[f"phi.blocks.{k}.{fc}.b"] = f32(f"phi.blocks.{k}.{fc}.bias")
         w["phi.lin_out.w"], w["phi.lin_out.b"] = f32("phi.lin_out.weight"), f32("phi.lin_out.bias")
+        # the whole decoder as one block for cpn_lightfield_decode (layout: include/coponerf_hip.h)
+        wout = torch.zeros(16, 128, dtype=torch.float32, device=dev)
+        wout[:3] = w["phi.lin_out.w"]
+        bout = torch.zeros(16, dtype=torch.float32, device=dev)
+        bout[:3] = w["phi.lin_out.b"]
+        parts = [w["phi.lin_in.w"], w["phi.lin_in.b"]]
+        for k in range(3):
+            parts += [w[f"phi.lin_z.{k}.w"], w[f"phi.lin_z.{k}.b"], w[f"phi.blocks.{k}.fc_0.w"], w[f"phi.blocks.{k}.fc_0.b"],
+                      w[f"phi.blocks.{k}.fc_1.w"], w[f"phi.blocks.{k}.fc_1.b"]]
+        w["phi.pack"] = torch.cat([t.reshape(-1) for t in parts + [wout, bout]])
+        assert w["phi.pack"].numel() == _hip.LIGHTFIELD_PACK_FLOATS
         # ---- "project, then interpolate" form of the first layer (csrc/encode.hip): MFMA fragments of the
         #      full-resolution / point-encoding columns and the table projection weights of the three coarse levels
         W1 = f32("query_encode_latent.weight").reshape(832, 835)
@@ -285,6 +459,7 @@ class RenderEngine:
         key = tuple((t._version, tuple(t.shape)) for t in z) + (self._wgen if self.tables else -1,)
         if key == self._mkey and len(self._mrefs) == len(z) and all(a is b for a, b in zip(self._mrefs, z)):
             return self._maps, self._tabs
+        self._misses += 1
         maps, tabs, s = [], [], _stream()
         hint = self._l3_hint
         for i, t in enumerate(z):
@@ -318,22 +493,20 @@ class RenderEngine:
         B, _, R, _ = uv.shape
         N = B * V
         s = _stream()
-        hc2w, hK, hqc2w, hqK, hrel = self._host_inputs(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
-        cam_cpu, Tq_cpu = build_camera_block(hc2w, hK, hqc2w, hqK, hrel, val, H)
-        up = _upload(dict(host_pose_products(hc2w, hqc2w, hqK), cam=cam_cpu, Tq=Tq_cpu), dev)
+        up = self._camera(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose, val, H, dev)
         cam = up["cam"]
         ikey = (S, str(dev))
         if ikey not in self._interval:
             self._interval[ikey] = torch.linspace(0, 1, S).to(dev)
         interval = self._interval[ikey]
-        uvc = uv.detach().float().reshape(B, R, 2).contiguous()
+        uvc, uvs = _uv_rows(uv, B, R)
         f32 = torch.float32
         g = {"coords9": torch.empty(N, R, 9, dtype=f32, device=dev), "seg": torch.empty(N, R, 4, dtype=f32, device=dev),
              "overlaps": torch.empty(N, R, dtype=torch.uint8, device=dev),
              "pixel_val": torch.empty(N, R, S, 2, dtype=f32, device=dev), "pt": torch.empty(N, R, S, 3, dtype=f32, device=dev),
              "sec_grid": torch.empty(N, R, S, 2, dtype=f32, device=dev), "pe6": torch.empty(N, R, S, 6, dtype=f32, device=dev),
              "loc8": torch.empty(N, R, S, 8, dtype=f32, device=dev), "Tq": up["Tq"], "host": up}
-        call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), B, V, R, g["coords9"].data_ptr(), g["seg"].data_ptr(),
+        call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), uvs, B, V, R, g["coords9"].data_ptr(), g["seg"].data_ptr(),
              g["overlaps"].data_ptr(), s)
         call("cpn_sample_geometry", cam.data_ptr(), g["coords9"].data_ptr(), g["seg"].data_ptr(), interval.data_ptr(),
              B, V, R, S, H, W, g["pixel_val"].data_ptr(), g["pt"].data_ptr(), g["sec_grid"].data_ptr(),
@@ -426,32 +599,86 @@ class RenderEngine:
                 "z_local": zl, "Tq": g["Tq"], "sec_grid": g["sec_grid"], "rgb_raw": raw, "host": g["host"]}
 
     # ---- the render pass -------------------------------------------------------------------------
+    def _call_stream(self, dev) -> Optional[torch.cuda.Stream]:
+        if self.call_lanes <= 1:
+            return None
+        if len(self._call_streams) != self.call_lanes or self._call_streams[0].device != dev:
+            self._call_streams = [torch.cuda.Stream(device=dev) for _ in range(self.call_lanes)]
+        self._call_idx = (self._call_idx + 1) % self.call_lanes
+        return self._call_streams[self._call_idx]
+
     @torch.no_grad()
     def render(self, params: Dict[str, torch.Tensor], ctx_c2w, ctx_K, qry_c2w, qry_K, uv, z: Sequence[torch.Tensor],
-               rel_pose, val: bool, S: int, H: int, W: int) -> Dict[str, torch.Tensor]:
+               rel_pose, val: bool, S: int, H: int, W: int, debug: bool = False, inp: Optional[Dict] = None,
+               flow=None) -> Dict[str, torch.Tensor]:
         """uv (B,1,R,2) on the device; 4x4 inputs on any device.  Returns device tensors:
         rgb (B,1,R,3), valid_mask (B,R,1), pixel_val (N,R,S,2), pt (N,R,S,3), at_wt (N,R,S),
-        coords (N,R,9), z_local (B*R,416), Tq (B,V,4,4) (device copy of the host pose algebra)."""
+        coords (N,R,9), z_local (B*R,416), Tq (B,V,4,4) (device copy of the host pose algebra); `pixel_val_cpu` is the
+        pinned CPU copy (a PendingHostTensor while the copy stream may still be writing it); with `inp` and `flow` given,
+        `aux` = the per-ray auxiliary outputs (aux_outputs.ray_outputs).  debug=True adds sec_grid / rgb_raw.
+
+        Consecutive calls are independent (a full-image render is 18 of them in the reference's callers, test.py:176-190),
+        so they alternate over `call_lanes` HIP streams: the small per-ray kernels and the tails of the persistent
+        per-sample kernels of one call run under the next call's kernels (18-call loop: 28.7 -> 25.5 ms, the time of ONE
+        full-image call).  Stream discipline: (1) everything cached (packed weights, feature tables, camera block, flow
+        products) is looked up / rebuilt on the CALLER's stream before the switch; (2) the call's stream waits for the
+        caller's stream only if one of those lookups missed or the query-pixel tensor is new — otherwise all inputs were
+        already ordered before an earlier call and a wait would serialise the call behind its predecessor; (3) outputs are
+        allocated on the call's stream and `record_stream`-ed for the caller's; (4) the caller's stream waits for the
+        call's completion event (no host wait)."""
         dev = uv.device
         if dev.type != "cuda":
             raise RuntimeError("coponerf_amd renders on a HIP device only (got uv on %s)" % dev)
         B, _, R, _ = uv.shape
         if z[0].shape[0] != B * V or len(z) != 4:
             raise ValueError("expected 4 latent maps with a leading dimension of B*2")
-        N = B * V
-        s = _stream()
+        main = torch.cuda.current_stream()
+        miss0 = self._misses
         w = self._weights(params)
         maps, tabs = self._feature_maps(z, w)
-
-        hc2w, hK, hqc2w, hqK, hrel = self._host_inputs(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
-        cam_cpu, Tq_cpu = build_camera_block(hc2w, hK, hqc2w, hqK, hrel, val, H)
-        up = _upload(dict(host_pose_products(hc2w, hqc2w, hqK), cam=cam_cpu, Tq=Tq_cpu), dev)
-        cam = up["cam"]
+        up = self._camera(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose, val, H, dev)
         ikey = (S, str(dev))
         if ikey not in self._interval:
             self._interval[ikey] = torch.linspace(0, 1, S).to(dev)       # CPU linspace, as the oracle's
-        interval = self._interval[ikey]
-        uvc = uv.detach().float().reshape(B, R, 2).contiguous()
+            self._misses += 1
+        uvc, uvs = _uv_rows(uv, B, R)
+        fp = None
+        if flow is not None and inp is not None:
+            from .aux_outputs import flow_products
+            fp, hit = flow_products(flow, inp["context"]["rgb"].shape[-2])
+            self._misses += 0 if hit else 1
+        base = uv._base if uv._base is not None else uv
+        seen = self._uv_seen
+        fresh = self._misses != miss0 or seen is None or seen[0] is not base or seen[1] != base._version or \
+            uvc.untyped_storage().data_ptr() != uv.untyped_storage().data_ptr()
+        self._uv_seen = (base, base._version)
+        pre = (w, maps, tabs, up, self._interval[ikey], uvc, uvs, fp)
+        side = self._call_stream(dev)
+        if side is None:
+            self._ws_prefix = ""
+            return self._render_body(pre, B, R, S, H, W, dev, debug, inp)
+        if fresh:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for st in self._call_streams:                # every lane: the next call on the other lane skips its wait
+                st.wait_event(ready)
+        self._ws_prefix = f"c{self._call_idx}."
+        with torch.cuda.stream(side):
+            out = self._render_body(pre, B, R, S, H, W, dev, debug, inp)
+            for t in _flat_tensors([v for k, v in out.items() if k not in ("host", "pixel_val_cpu", "uv_rows")]):
+                if t.is_cuda:
+                    t.record_stream(main)
+            done = torch.cuda.Event()
+            done.record(side)
+        main.wait_event(done)
+        return out
+
+    def _render_body(self, pre, B, R, S, H, W, dev, debug, inp) -> Dict[str, torch.Tensor]:
+        """The launches of one render call on the current stream; `pre` = what render() resolved from the caches."""
+        w, maps, tabs, up, interval, uvc, uvs, fp = pre
+        N = B * V
+        s = _stream()
+        cam = up["cam"]
 
         f32, f16 = torch.float32, torch.float16
         coords9 = torch.empty(N, R, 9, dtype=f32, device=dev)
@@ -463,7 +690,7 @@ class RenderEngine:
         sec_grid = self._buf("sec_grid", (N, R, S, 2), f32, dev)
         pe6 = self._buf("pe6", (N, R, S, 6), f32, dev)
         loc8 = self._buf("loc8", (N, R, S, 8), f32, dev)
-        call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), B, V, R, coords9.data_ptr(), seg.data_ptr(),
+        call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), uvs, B, V, R, coords9.data_ptr(), seg.data_ptr(),
              overlaps.data_ptr(), s)
         call("cpn_sample_geometry", cam.data_ptr(), coords9.data_ptr(), seg.data_ptr(), interval.data_ptr(),
              B, V, R, S, H, W, pixel_val.data_ptr(), pt.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(),
@@ -603,29 +830,21 @@ class RenderEngine:
                 done.record(self._lane_streams[lane])
                 main.wait_event(done)
 
-        # ---- light-field decoder phi over all rays (lightfield.py:131-167), exact fp32
-        c18 = torch.zeros(nray_total, 32, dtype=f32, device=dev)
-        c18[:, :18] = coords9.view(B, V, R, 9).permute(0, 2, 1, 3).reshape(nray_total, 18)
-        x = self._buf("phi_x", (nray_total, 128), f32, dev)
-        net = self._buf("phi_net", (nray_total, 128), f32, dev)
-        rgb_raw = self._buf("rgb_raw", (nray_total, 4), f32, dev)
-
-        def lin(X, ldx, wn, Y, ldy, n_out, k, res=None, relu_in=0):
-            call("cpn_linear_f32", X.data_ptr(), ldx, w[wn + ".w"].data_ptr(), w[wn + ".w"].shape[1],
-                 w[wn + ".b"].data_ptr(), _ptr(res), ldy if res is not None else 0, Y.data_ptr(), ldy,
-                 nray_total, n_out, k, relu_in, 0, s)
-
-        lin(c18, 32, "phi.lin_in", x, 128, 128, 32)
-        for k in range(3):
-            lin(zl, 416, f"phi.lin_z.{k}", x, 128, 128, 416, res=x)
-            lin(x, 128, f"phi.blocks.{k}.fc_0", net, 128, 128, 128, relu_in=1)
-            lin(net, 128, f"phi.blocks.{k}.fc_1", x, 128, 128, 128, res=x, relu_in=1)
-        lin(x, 128, "phi.lin_out", rgb_raw, 4, 3, 128, relu_in=1)
+        # ---- light-field decoder phi over all rays (lightfield.py:131-167) + white background, exact fp32, one launch
         rgb = torch.empty(B, 1, R, 3, dtype=f32, device=dev)
         valid = torch.empty(B, R, 1, dtype=f32, device=dev)
-        call("cpn_mask_rgb", rgb_raw.data_ptr(), 4, overlaps.data_ptr(), B, V, R, rgb.data_ptr(), valid.data_ptr(), s)
-        copy_done.synchronize()
-        return {"rgb": rgb, "valid_mask": valid, "pixel_val": pixel_val, "pixel_val_cpu": pixel_val_cpu, "pt": pt,
-                "at_wt": at_wt,
-                "coords": coords9, "z_local": zl, "Tq": up["Tq"], "host": up, "sec_grid": sec_grid.clone(),
-                "rgb_raw": rgb_raw[:, :3].clone()}
+        rgb_raw = torch.empty(nray_total, 3, dtype=f32, device=dev) if debug else None
+        call("cpn_lightfield_decode", coords9.data_ptr(), zl.data_ptr(), w["phi.pack"].data_ptr(), overlaps.data_ptr(),
+             B, V, R, rgb.data_ptr(), valid.data_ptr(), _ptr(rgb_raw), s)
+        if self.lazy_pixel_val:
+            pixel_val_cpu = PendingHostTensor.wrap(pixel_val_cpu, copy_done)
+        else:
+            copy_done.synchronize()
+        out = {"rgb": rgb, "valid_mask": valid, "pixel_val": pixel_val, "pixel_val_cpu": pixel_val_cpu, "pt": pt, "at_wt": at_wt, "coords": coords9, "z_local": zl, "Tq": up["Tq"],
+               "host": up, "uv_rows": (uvc, uvs)}
+        if fp is not None:
+            from .aux_outputs import ray_outputs
+            out["aux"] = ray_outputs(inp, fp, at_wt, pt, up["rayc"], (uvc, uvs))
+        if debug:
+            out["sec_grid"], out["rgb_raw"] = sec_grid.clone(), rgb_raw
+        return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 2
+#define CPN_ABI_VERSION 3
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -54,11 +54,12 @@ const char* cpn_last_error(void);
 /* ---- K1: query rays -> Pluecker coords + clipped epipolar segment ------------------------------
  * replaces geometry.plucker_embedding (utils_training/geometry.py:236-245, :426-433, :409-419, :353-371),
  * epipolar.project_rays (models/epipolar.py:175-253) and the start/end scrub (models/CoPoNeRF.py:279-291).
- *   cam     (N, CPN_CAM_STRIDE)        uv (B,R,2) pixels (x = column, y = row)
+ *   cam     (N, CPN_CAM_STRIDE)        uv: pixel (x = column, y = row) of ray r of pair b at uv[b*uv_batch_stride + 2r]
+ *                                      (2R for a dense (B,R,2) array; a ray chunk of a larger array passes its stride)
  *   coords9 (N,R,9)  = dir3 | moment3 | origin3
  *   seg     (N,R,4)  = start.xy | end.xy in [-1,1], NaN/Inf -> 0
  *   overlaps(N,R)    uint8 0/1                                                                   */
-int cpn_project_rays(const float* cam, const float* uv, int B, int V, int R,
+int cpn_project_rays(const float* cam, const float* uv, long long uv_batch_stride, int B, int V, int R,
                      float* coords9, float* seg, uint8_t* overlaps, void* stream);
 
 /* ---- K1b: per-sample geometry -------------------------------------------------------------------
@@ -178,6 +179,37 @@ int cpn_linear_f32(const float* X, int ldx, const float* W, int ldw, const float
 /* ---- output masking: rgb = rgb*valid + (1-valid), valid = any_v overlaps (CoPoNeRF.py:562-566) ------ */
 int cpn_mask_rgb(const float* rgb_raw, int ld, const uint8_t* overlaps, int B, int V, int R,
                  float* rgb, float* valid, void* stream);
+
+/* ---- the light-field decoder with the output masking, ONE launch (round 3) ---------------------------------
+ * replaces lightfield.ResnetFC.forward (models/lightfield.py:131-167; ResnetBlockFC :52-61) on
+ * [coords of view 0 | coords of view 1 | z_local ; z_local] (models/CoPoNeRF.py:547-560) and the white background of
+ * rays no context view sees (:562-566).  Exact fp32 (v_mfma_f32_16x16x4_f32), same operation order as the
+ * layer-by-layer cpn_linear_f32 chain + cpn_mask_rgb it supersedes on the inference path.
+ *   coords9 (N,R,9)   z_local (B*R,416)   overlaps (N,R) uint8
+ *   wpack: CPN_LIGHTFIELD_PACK_FLOATS floats = lin_in W[128][32] (18 columns used, rest zero) b[128] |
+ *          3 x { lin_z W[128][416] (the two 416-column halves of the reference's 832 summed) b[128] |
+ *                fc_0 W[128][128] b[128] | fc_1 W[128][128] b[128] } | lin_out W[16][128] (rows 3.. zero) b[16]
+ *   rgb (B,1,R,3)   valid (B,R,1) float 0/1   rgb_raw (B*R,3) or NULL: the decoder output before masking        */
+#define CPN_LIGHTFIELD_PACK_FLOATS (128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16)
+int cpn_lightfield_decode(const float* coords9, const float* z_local, const float* wpack, const uint8_t* overlaps,
+                          int B, int V, int R, float* rgb, float* valid, float* rgb_raw, void* stream);
+
+/* ---- auxiliary per-ray outputs, ONE launch (round 3) -----------------------------------------------------
+ * replaces models/CoPoNeRF.py:493-541: at_wt.argmax, the attention-weighted expected 3-D point
+ * (clamp(pt,-100,100), summed over samples and views), its depth in the query camera
+ * (utils_training/geometry.py:395-406), batch_project_to_other_img into both context views
+ * (utils_training/utils.py:140-170), generate_mask_from_confidence_score (:260-276) and flow2kps (:52-69).
+ *   at_wt (N,R,S)   pt (N,R,S,3)   uv: pixel (x,y) of ray r of pair b at uv[b*uv_batch_stride + 2 r]
+ *   rayc (B, CPN_RAYC_STRIDE): row 2 of inv(query cam2world) (4) | inv(K_query[:3,:3]) (9) | K_ctx0 (9) | K_ctx1 (9) |
+ *        Tq[:,0] (16) | Tq[:,1] (16)      (O(B) host pose algebra, like the camera block)
+ *   mask2 (B,256,256) uint8/bool: cycle-consistency mask of view 2; flow_up (B,2,256,256): flow[1] at 256x256
+ *   at_wt_max (N,R) int64   depth_ray (B,R) clamped to [0,10]   t_to_c1, t_to_c2, c2_to_c1 (B,R,2)
+ *   mask_c2, match_mask (B,R) uint8 0/1                                                                         */
+#define CPN_RAYC_STRIDE 64
+int cpn_ray_outputs(const float* at_wt, const float* pt, const float* uv, long long uv_batch_stride, const float* rayc,
+                    const uint8_t* mask2, const float* flow_up, int B, int V, int R, int S, long long* at_wt_max,
+                    float* depth_ray, float* t_to_c1, float* t_to_c2, uint8_t* mask_c2, uint8_t* match_mask,
+                    float* c2_to_c1, void* stream);
 
 /* ==== training: backward of the two non-GEMM stages (plain GEMM gradients use hipBLASLt via torch.matmul) ==== */
 

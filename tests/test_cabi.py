@@ -22,7 +22,7 @@ def test_library_is_built_and_exports_header_symbols():
 def test_argument_errors_are_status_codes_not_crashes():
     lib = _hip.lib()
     # null pointers are rejected before any launch (works without a GPU)
-    assert lib.cpn_project_rays(None, None, 1, 2, 4, None, None, None, None) == -1
+    assert lib.cpn_project_rays(None, None, 8, 1, 2, 4, None, None, None, None) == -1
     assert b"null" in lib.cpn_last_error()
     with pytest.raises(RuntimeError, match="cpn_gemm_f16"):
         _hip.call("cpn_gemm_f16", 16, 8, 16, 8, 16, 16, 8, 4, 100, 30, 0, 0, None)   # K not a multiple of 32

@@ -490,7 +490,7 @@ def test_segment_clipper_edge_cases_on_device(dev):
     c9 = torch.empty(2 * n, 1, 9, device=dev)
     seg = torch.empty(2 * n, 1, 4, device=dev)
     ov = torch.empty(2 * n, 1, dtype=torch.uint8, device=dev)
-    call("cpn_project_rays", camd.data_ptr(), uvd.data_ptr(), n, 2, 1, c9.data_ptr(), seg.data_ptr(), ov.data_ptr(),
+    call("cpn_project_rays", camd.data_ptr(), uvd.data_ptr(), 2, n, 2, 1, c9.data_ptr(), seg.data_ptr(), ov.data_ptr(),
          torch.cuda.current_stream().cuda_stream)
     c9, seg, ov = c9.cpu().view(n, 2, 9), seg.cpu().view(n, 2, 4), ov.cpu().view(n, 2)
     scrub = lambda t: torch.where(torch.isfinite(t), t, torch.zeros_like(t))

@@ -109,3 +109,129 @@ def test_two_lanes_equal_one_lane(dev):
     for k in ("rgb", "at_wt", "pixel_val", "valid_mask", "depth_ray"):
         assert torch.equal(a[k], b[k]), k
     assert torch.equal(a["_core"]["z_local"], b["_core"]["z_local"])
+
+
+def test_fused_decoder_equals_layer_chain(dev):
+    """cpn_lightfield_decode (one launch) against the cpn_linear_f32 chain + cpn_mask_rgb it replaced (the form the
+    training pass still runs): same MFMA sequence, so bit for bit."""
+    from coponerf_amd import CoPoNeRF, _hip
+    from coponerf_amd._hip import call
+    torch.manual_seed(3)
+    m = CoPoNeRF.CoPoNeRF(n_view=2)
+    m.load_state_dict(syn.make_render_weights(), strict=False)
+    m = m.to(dev).eval()
+    w = m._engine._weights(m._render_params())
+    B, R = 2, 1237                                               # not a multiple of 16: ragged last workgroup
+    n = B * R
+    coords9 = torch.randn(2 * B, R, 9, device=dev)
+    zl = torch.randn(n, 416, device=dev) * 3
+    overlaps = (torch.rand(2 * B, R, device=dev) < 0.4).to(torch.uint8)
+    s = torch.cuda.current_stream().cuda_stream
+    rgb, valid, raw = (torch.empty(B, 1, R, 3, device=dev), torch.empty(B, R, 1, device=dev), torch.empty(n, 3, device=dev))
+    call("cpn_lightfield_decode", coords9.data_ptr(), zl.data_ptr(), w["phi.pack"].data_ptr(), overlaps.data_ptr(),
+         B, 2, R, rgb.data_ptr(), valid.data_ptr(), raw.data_ptr(), s)
+    # reference chain
+    c18 = torch.zeros(n, 32, device=dev)
+    c18[:, :18] = coords9.view(B, 2, R, 9).permute(0, 2, 1, 3).reshape(n, 18)
+    x, net, raw4 = torch.empty(n, 128, device=dev), torch.empty(n, 128, device=dev), torch.empty(n, 4, device=dev)
+
+    def lin(X, ldx, wn, Y, ldy, n_out, k, res=None, relu_in=0):
+        call("cpn_linear_f32", X.data_ptr(), ldx, w[wn + ".w"].data_ptr(), w[wn + ".w"].shape[1], w[wn + ".b"].data_ptr(),
+             0 if res is None else res.data_ptr(), ldy if res is not None else 0, Y.data_ptr(), ldy, n, n_out, k, relu_in, 0, s)
+
+    lin(c18, 32, "phi.lin_in", x, 128, 128, 32)
+    for k in range(3):
+        lin(zl, 416, f"phi.lin_z.{k}", x, 128, 128, 416, res=x)
+        lin(x, 128, f"phi.blocks.{k}.fc_0", net, 128, 128, 128, relu_in=1)
+        lin(net, 128, f"phi.blocks.{k}.fc_1", x, 128, 128, 128, res=x, relu_in=1)
+    lin(x, 128, "phi.lin_out", raw4, 4, 3, 128, relu_in=1)
+    rgb2, valid2 = torch.empty_like(rgb), torch.empty_like(valid)
+    call("cpn_mask_rgb", raw4.data_ptr(), 4, overlaps.data_ptr(), B, 2, R, rgb2.data_ptr(), valid2.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(raw, raw4[:, :3])
+    assert torch.equal(rgb, rgb2) and torch.equal(valid, valid2)
+    # and against plain fp32 torch
+    P = {k: v.float() for k, v in m.state_dict().items() if k.startswith("phi.")}
+    xx = c18[:, :18] @ P["phi.lin_in.weight"].T + P["phi.lin_in.bias"]
+    zz = torch.cat((zl, zl), 1)
+    for k in range(3):
+        xx = xx + zz @ P[f"phi.lin_z.{k}.weight"].T + P[f"phi.lin_z.{k}.bias"]
+        h = torch.relu(xx) @ P[f"phi.blocks.{k}.fc_0.weight"].T + P[f"phi.blocks.{k}.fc_0.bias"]
+        xx = xx + torch.relu(h) @ P[f"phi.blocks.{k}.fc_1.weight"].T + P[f"phi.blocks.{k}.fc_1.bias"]
+    want = torch.relu(xx) @ P["phi.lin_out.weight"].T + P["phi.lin_out.bias"]
+    assert (raw - want).abs().max() <= 1e-4 * (1 + want.abs().max())
+
+
+@pytest.mark.parametrize("B,S", [(1, 64), (2, 32), (1, 128)])
+def test_ray_outputs_kernel_equals_stock_ops(B, S, dev):
+    """cpn_ray_outputs against the differentiable stock-op form (aux_outputs, the training path) on the same inputs."""
+    from coponerf_amd.aux_outputs import aux_outputs, ray_outputs, flow_products
+    from coponerf_amd.render import build_camera_block, build_ray_constants, host_pose_products, _uv_rows
+    H, R = 256, 777
+    inp_c = syn.make_inputs(B, H, H, R, seed=81)
+    _, _, flow_c = syn.make_latents(B, H, H, seed=82)
+    inp, flow = to_device(inp_c, dev), to_device(flow_c, dev)
+    g = torch.Generator().manual_seed(5)
+    at_wt = torch.softmax(torch.randn(B, R, 2 * S, generator=g) * 2, -1).view(B, R, 2, S).permute(0, 2, 1, 3).reshape(2 * B, R, S)
+    at_wt[0, :7] = at_wt[0, :7, :1]                                        # ties: the first index wins
+    pt = torch.randn(2 * B, R, S, 3, generator=g) * torch.tensor([1.0, 1.0, 3.0]) + torch.tensor([0.0, 0.0, 2.5])
+    pt[1, 3] = 1e6                                                          # clamped to 100
+    at_wt, pt = at_wt.contiguous().to(dev), pt.contiguous().to(dev)
+    ctx, qry = inp_c["context"], inp_c["query"]
+    cam, Tq = build_camera_block(ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"],
+                                 torch.eye(4).repeat(B, 1, 1), False, H)
+    prods = host_pose_products(ctx["cam2world"], qry["cam2world"], qry["intrinsics"])
+    rayc = build_ray_constants(prods, ctx["intrinsics"], Tq).to(dev)
+    want = aux_outputs(inp, flow, at_wt, pt, Tq.to(dev), prods["inv_Kq"].to(dev), prods["inv_qc2w"].to(dev))
+    got = ray_outputs(inp, flow_products(flow, H)[0], at_wt, pt, rayc, _uv_rows(inp["query"]["uv"], B, R))
+    torch.cuda.synchronize()
+    assert torch.equal(got["at_wt_max"], want["at_wt_max"]) and got["at_wt_max"].dtype == torch.int64
+    assert (got["depth_ray"] - want["depth_ray"]).abs().max() <= 1e-5
+    for k in ("T_to_C1_pts", "T_to_C2_pts"):
+        assert got[k].shape == want[k].shape
+        e = (got[k] - want[k]).abs() / (1.0 + want[k].abs())
+        # two fp32 evaluation orders of a projective division: equal to rounding except where w ~ 0 amplifies it
+        assert float(e.median()) <= 1e-6 and float(e.max()) <= 2e-3, (k, float(e.median()), float(e.max()))
+    # integer pixel decisions: equal unless the reprojected pixel sits within rounding of a pixel edge
+    frac = (want["T_to_C2_pts"] - want["T_to_C2_pts"].trunc()).abs()
+    safe = ((frac > 1e-3) & (frac < 1 - 1e-3)).all(-1)
+    for k in ("mask_c2", "matchability_cycle_mask"):
+        assert got[k].dtype == torch.bool and got[k].shape == want[k].shape
+        assert torch.equal(got[k][safe], want[k][safe]), k
+    assert (got["C2_pts_to_C1"] - want["C2_pts_to_C1"])[safe].abs().max() <= 1e-4
+    assert safe.float().mean() > 0.95
+
+
+def test_call_lanes_do_not_race_across_images(reexported, dev):
+    """Consecutive forward() calls alternate over HIP streams (RenderEngine.call_lanes).  Three different images rendered
+    back to back in 18-call loops, inputs freed and reallocated in between and no host synchronisation anywhere, must
+    equal the same images rendered with one call each on the caller's stream."""
+    model, H = reexported, 64
+    model.npoints = 32
+    eng = model._engine
+    assert eng.call_lanes >= 2
+    cases = []
+    for i in range(3):
+        inp = syn.make_inputs(1 + (i % 2), H, H, 0, seed=90 + i, full_image=True, rig="wide" if i == 1 else "narrow")
+        lat = syn.make_latents(1 + (i % 2), H, H, seed=95 + i)
+        cases.append((inp, lat))
+    want = []
+    eng.call_lanes = 1
+    try:
+        for inp_c, lat_c in cases:
+            inp, (z, rel, flow) = to_device(inp_c, dev), (to_device(t, dev) for t in lat_c)
+            with torch.no_grad():
+                o = model(inp, z=z, rel_pose=rel, val=True, flow=flow)
+            want.append({k: o[k].clone() for k in ("rgb", "at_wt", "pixel_val", "depth_ray", "mask_c2", "T_to_C2_pts")})
+            del inp, z, rel, flow, o
+    finally:
+        eng.call_lanes = 2
+    for rep in range(3):
+        got = []
+        for inp_c, lat_c in cases:
+            inp, lat = to_device(inp_c, dev), tuple(to_device(t, dev) for t in lat_c)      # fresh device tensors each time
+            got.append(render_in_chunks(model, inp, 18, latents=lat))
+            del inp, lat                                                                   # their blocks are reused next
+        for g, w in zip(got, want):
+            for k, v in w.items():
+                assert torch.equal(g[k], v), (rep, k)

@@ -48,3 +48,48 @@ def test_forward_requires_hip_device():
     z, rel, flow = syn.make_latents(1, 64, 64)
     with torch.no_grad(), pytest.raises(RuntimeError, match="HIP device"):
         m(inp, z=z, rel_pose=rel, val=True, flow=flow)
+
+
+def test_pending_host_tensor_waits_at_first_use_of_values():
+    """render.PendingHostTensor: `.cpu()` / metadata do not wait for the copy event, the first value access does, once."""
+    from coponerf_amd.render import PendingHostTensor
+
+    class FakeEvent:
+        def __init__(self):
+            self.waits = 0
+
+        def synchronize(self):
+            self.waits += 1
+
+    ev = FakeEvent()
+    host = torch.arange(24, dtype=torch.float32).view(2, 3, 2, 2)
+    t = PendingHostTensor.wrap(host, ev)
+    assert isinstance(t, torch.Tensor) and t.device.type == "cpu"
+    assert t.shape == (2, 3, 2, 2) and t.dtype == torch.float32 and t.size(1) == 3 and t.dim() == 4
+    assert t.cpu() is t                                   # the caller's `.cpu()` (test.py:194) neither copies nor waits
+    assert ev.waits == 0
+    other = PendingHostTensor.wrap(host.clone() + 100, FakeEvent())
+    joined = torch.cat([t, other], dim=-3)                # the caller's join (test.py:207)
+    assert ev.waits == 1 and type(joined) is torch.Tensor and joined.shape == (2, 6, 2, 2)
+    assert torch.equal(joined, torch.cat([host, host + 100], dim=1))
+    mixed = torch.cat([PendingHostTensor.wrap(host.clone(), FakeEvent()), host + 1], dim=0)     # not all pending: plain cat
+    assert type(mixed) is torch.Tensor and torch.equal(mixed, torch.cat([host, host + 1], dim=0))
+    assert torch.equal(joined[:, :3], host) and torch.equal(joined[:, 3:], host + 100)
+    assert float(t.sum()) == float(host.sum()) and ev.waits == 1          # waited once, then a plain pinned tensor
+    assert torch.equal(torch.from_numpy(t.numpy()), host)
+    t2 = PendingHostTensor.wrap(host.clone(), FakeEvent())
+    assert torch.equal(t2[0], host[0]) and t2._cpn_ready is None
+
+
+def test_uv_rows_reads_ray_chunks_in_place():
+    from coponerf_amd.render import _uv_rows
+    full = torch.arange(2 * 1 * 10 * 2, dtype=torch.float32).view(2, 1, 10, 2)
+    chunk = torch.chunk(full, 3, dim=2)[1]                # rays 4..7 of both pairs: batch stride 20 floats
+    u, stride = _uv_rows(chunk, 2, 4)
+    assert stride == 20 and u.data_ptr() == chunk.data_ptr()
+    assert torch.equal(u, chunk[:, 0])
+    u1, s1 = _uv_rows(full[:1].double(), 1, 10)           # other dtypes are converted
+    assert s1 == 20 and u1.dtype == torch.float32 and u1.is_contiguous()
+    weird = full.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)   # (x, y) not adjacent in memory
+    u2, s2 = _uv_rows(weird, 2, 10)
+    assert u2.is_contiguous() and s2 == 20 and torch.equal(u2, full[:, 0])

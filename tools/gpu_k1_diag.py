@@ -30,7 +30,7 @@ mism("torch cpu vs torch gpu: m", m_c, m_g)
 # HIP
 coords9 = torch.empty(N, R, 9, device=dev); seg = torch.empty(N, R, 4, device=dev); ov = torch.empty(N, R, dtype=torch.uint8, device=dev)
 camd = cam.to(dev); uvd = qry["uv"].reshape(B, R, 2).contiguous().to(dev)
-call("cpn_project_rays", camd.data_ptr(), uvd.data_ptr(), B, 2, R, coords9.data_ptr(), seg.data_ptr(), ov.data_ptr(), torch.cuda.current_stream().cuda_stream)
+call("cpn_project_rays", camd.data_ptr(), uvd.data_ptr(), 2 * R, B, 2, R, coords9.data_ptr(), seg.data_ptr(), ov.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 mism("hip vs torch cpu: d", coords9[..., 0:3], d_c)
 mism("hip vs torch gpu: d", coords9[..., 0:3], d_g)
