@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--pairs", type=int, default=None, help="stereo pairs per GPU (default 1 render, 4 train)")
+    ap.add_argument("--pair-by-pair", action="store_true",
+                    help="render the --pairs stereo pairs one forward() call each (different pairs: the feature tables "
+                         "are rebuilt for every call inside the timed region) instead of one batched call")
     ap.add_argument("--train-rays", type=int, default=4096, help="query rays per pair in a training step")
     ap.add_argument("--chunk-rays", type=int, default=16384)
     ap.add_argument("--lanes", type=int, default=1,
@@ -195,15 +198,24 @@ def run(args):
     model._engine.lanes = args.lanes
     model._engine.tables = not args.no_tables
 
-    inp_cpu = syn.make_inputs(B, H, H, 0, seed=100 + rank, full_image=True, rig=args.rig)
-    z_cpu, rel_cpu, flow_cpu = syn.make_latents(B, H, H, seed=200 + rank)
-    inp, z, rel, flow = _to(inp_cpu, dev), _to(z_cpu, dev), rel_cpu.to(dev), _to(flow_cpu, dev)
+    P = B if args.pair_by_pair else 1                      # forward() calls per step
+    Bc = 1 if args.pair_by_pair else B                     # pairs per call
+    jobs = []
+    for j in range(P):
+        ic = syn.make_inputs(Bc, H, H, 0, seed=100 + rank + 1000 * j, full_image=True, rig=args.rig)
+        zc, rc, fc = syn.make_latents(Bc, H, H, seed=200 + rank + 1000 * j)
+        jobs.append((ic, zc, rc, fc, _to(ic, dev), _to(zc, dev), rc.to(dev), _to(fc, dev)))
+    inp_cpu, z_cpu, rel_cpu, flow_cpu, inp, z, rel, flow = jobs[0]
     R = inp["query"]["uv"].shape[2]
     rays_per_step = B * R
 
     def step():
         with torch.no_grad():
-            return model(inp, z=z, rel_pose=rel, val=True, flow=flow)
+            out0 = None
+            for job in jobs:
+                o = model(job[4], z=job[5], rel_pose=job[6], val=True, flow=job[7])
+                out0 = o if out0 is None else out0
+            return out0
 
     for _ in range(args.warmup):
         out = step()
@@ -235,7 +247,8 @@ def run(args):
         "dtype": "f16 (fp16-input/fp32-accumulate MFMA for the per-sample MLPs; f32 decoder; f64 geometry island)",
         "data": "synthetic",
         "config": {"workload": f"{cfg_name}: {H}x{H} stereo pair ({args.rig} rig), full-image render {R} rays x {S} "
-                               f"samples, {B} pair(s) per GPU, render path only (z/rel_pose/flow given, val=True)",
+                               f"samples, {B} pair(s) per GPU{' rendered pair by pair' if args.pair_by_pair else ''}, "
+                               f"render path only (z/rel_pose/flow given, val=True)",
                    "chunk_rays": args.chunk_rays, "lanes": args.lanes, "pairs_per_gpu": B,
                    "first_layer": "projected tables + K=80 MFMA (cpn_encode_hidden)" if tables
                                   else "gather + 835->832 GEMM"},
@@ -309,7 +322,7 @@ def run(args):
     if rank == 0:
         line.update(roofline_block(prof, args, tables))
         if args.cpu_rays > 0 and world == 1:          # CPU baseline: rank 0 at N = 1 only
-            line.update(cpu_baseline_block(args, syn, inp_cpu, z_cpu, rel_cpu, flow_cpu, out, B, H, S))
+            line.update(cpu_baseline_block(args, syn, inp_cpu, z_cpu, rel_cpu, flow_cpu, out, Bc, H, S))
 
     # ---- secondary: configs[2] training step on the same ranks (exercises the RCCL gradient all-reduce at N > 1)
     if H == 256 and args.train_steps > 0:

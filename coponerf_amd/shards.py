@@ -9,7 +9,7 @@ are assembled in pinned memory and `cpn_prepare_input` (csrc/input.hip) crops, n
 The model-facing result is the reference's input dict: same keys, shapes, dtypes and values.
 
 Shard file = 64-byte magic/header length + JSON header + arrays at 64-byte aligned offsets:
-    frames (N, Hs, Ws, 3) uint8 | timestamps (N) int64 | c2w (N, 4, 4) float32 | intrinsics (N, 4) float32 (fx fy cx cy,
+    frames (N, Hs, Ws, 3) uint8 | timestamps (N) int64 | c2w (N, 4, 4) float32 | intrinsics (N, 4) float64 (fx fy cx cy,
     normalised by image size as in the RealEstate10K pose files)
 """
 from __future__ import annotations
@@ -30,7 +30,9 @@ def write_shard(path: str, frames_u8: np.ndarray, timestamps: np.ndarray, c2w: n
     assert frames_u8.ndim == 4 and frames_u8.shape[3] == 3
     arrays = {"frames": frames_u8, "timestamps": np.ascontiguousarray(timestamps, dtype=np.int64).reshape(n),
               "c2w": np.ascontiguousarray(c2w, dtype=np.float32).reshape(n, 4, 4),
-              "intrinsics": np.ascontiguousarray(intrinsics_norm, dtype=np.float32).reshape(n, 4)}
+              # float64 like the pose rows the reference parses (dataio.py:37-55): it un-normalises in float64 and
+              # rounds to float32 once, at the end — a float32 copy here moves fx by an ulp (tests/golden/input.npz)
+              "intrinsics": np.ascontiguousarray(intrinsics_norm, dtype=np.float64).reshape(n, 4)}
     order = np.argsort(arrays["timestamps"], kind="stable")          # frames sorted by time (dataio.py:264-268)
     arrays = {k: v[order] for k, v in arrays.items()}
     meta, off = {}, 0

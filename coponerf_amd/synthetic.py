@@ -223,3 +223,29 @@ def make_full_weights(shapes: Dict[str, Tuple], seed: int = 11) -> Dict[str, tor
         else:
             out[name] = uniform(shape, seed, -0.05, 0.05, stream=1000 + i)
     return out
+
+
+# --------------------------------------------------------------------------
+# a RealEstate10K-shaped scene for the input pipeline (coponerf_amd/shards.py): uint8 frames, timestamps, camera rows
+# --------------------------------------------------------------------------
+def make_scene(n: int = 140, Hs: int = 256, Ws: int = 455, seed: int = 5):
+    """(frames (n,Hs,Ws,3) uint8, timestamps (n) int64 out of order, w2c (n,3,4) float64, intrinsics (n,4) float64
+    normalised fx fy cx cy) — the contents of one scene of the reference's dataset (an .npz of frames named
+    '<timestamp>.png' + the pose rows 'timestamp fx fy cx cy k1 k2 w2c[12]', data/realestate10k_dataio.py:37-80)."""
+    frames = (_bits(n * Hs * Ws * 3, seed, 1) >> np.uint64(56)).astype(np.uint8).reshape(n, Hs, Ws, 3)
+    ts = permutation(n, seed + 1).astype(np.int64) * 33366 + 1000
+    ang = uniform((n,), seed, -0.3, 0.3, stream=2).numpy().astype(np.float64)
+    t = uniform((n, 3), seed, -1.0, 1.0, stream=3).numpy().astype(np.float64)
+    w2c = np.zeros((n, 3, 4))
+    for i in range(n):
+        w2c[i, :, :3] = _rot_y(float(ang[i]))
+        w2c[i, :, 3] = t[i]
+    intr = np.array([0.5, 0.89, 0.5, 0.5]) + uniform((n, 4), seed, -0.01, 0.01, stream=4).numpy().astype(np.float64)
+    return frames, ts, w2c, intr
+
+
+def scene_c2w(w2c: np.ndarray) -> np.ndarray:
+    """cam2world (n,4,4) float32 from the dataset's w2c rows, as the reference's Camera class forms it (float64 inverse)."""
+    m = np.tile(np.eye(4), (w2c.shape[0], 1, 1))
+    m[:, :3, :] = w2c
+    return np.linalg.inv(m).astype(np.float32)

@@ -3,7 +3,10 @@
 Follows /root/reference data/realestate10k_dataio.py:333-441 for ONE sample whose frame ids and ray selection are
 given: centre square crop (utils_training/data_util.py:116-121), `rgb.astype(np.float32) / 127.5 - 1` (:353, :437),
 query colours at the selected pixels (:385-390), intrinsics un-normalised by the frame size with the principal point
-divided by the crop scale (:51-55, :343-348).  Pinned by construction (numpy arithmetic, no third-party code)."""
+divided by the crop scale (:51-55, :343-348).  PINNED by tests/golden/input.npz: one sample produced by the reference's
+own `RealEstate10k.__getitem__` from a synthetic scene (tests/golden/make_golden_input.py), reproduced bit for bit in
+tests/test_input_golden.py.  Not restated: the `cv2.resize` of 360-row frames (:342-343; cv2 is not in this image and
+the shard format stores frames at 256x455)."""
 import numpy as np
 
 

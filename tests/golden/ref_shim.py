@@ -84,6 +84,11 @@ def install():
     sys.modules.setdefault("timm.models.layers", timm_layers)
 
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    # data/realestate10k_dataio.py and utils_training/data_util.py import these at module level; the functions pinned by
+    # make_golden_input.py (square crop, /127.5-1, intrinsics, frame / ray sampling) never call into them
+    for name in ("imageio", "skimage", "h5py"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["imageio"].imread = None
 
     tv = types.ModuleType("torchvision")
     tvm = types.ModuleType("torchvision.models")

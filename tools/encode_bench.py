@@ -18,15 +18,18 @@ def main():
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="both")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--rig", default="narrow")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     H = S = None
-    H, S, B, V = 256, 64, 1, 2
+    H, S, B, V = a.height, a.samples, 1, 2
     model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
     model.load_state_dict(syn.make_render_weights(), strict=False)
     model = model.to(dev).eval()
     eng = model._engine
-    inp = syn.make_inputs(B, H, H, 0, seed=100, full_image=True)
+    inp = syn.make_inputs(B, H, H, 0, seed=100, full_image=True, rig=a.rig)
     z, rel, flow = syn.make_latents(B, H, H, seed=200)
     mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (
         o.to(dev) if torch.is_tensor(o) else type(o)(mv(v) for v in o))
@@ -40,7 +43,7 @@ def main():
     rows2 = n * V * S * 2
     hid = torch.empty(rows2, 832, dtype=torch.float16, device=dev)
     s = torch.cuda.current_stream().cuda_stream
-    res = {"rays": n, "rows": rows2}
+    res = {"rays": n, "rows": rows2, "height": H, "samples": S, "rig": a.rig}
 
     def timeit(fn):
         for _ in range(3):
@@ -58,7 +61,7 @@ def main():
         def enc():
             call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(), H, H,
                  g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(), w["enc.frag"].data_ptr(),
-                 w["query_encode_latent.b"].data_ptr(), B, V, R, S, 16384, n, hid.data_ptr(), s)
+                 w["query_encode_latent.b"].data_ptr(), B, V, R, S, min(16384, R - n), n, hid.data_ptr(), s)
         ms = timeit(enc)
         res["encode_hidden_ms"] = ms
         res["encode_hidden_alg_tflops"] = 2.0 * rows2 * 832 * 835 / ms / 1e9
