@@ -472,17 +472,19 @@ def cpu_baseline_block(args, syn, inp_cpu, z_cpu, rel_cpu, flow_cpu, out, B, H, 
             return r, time.perf_counter() - c0
 
     ncpu = os.cpu_count() or 1
-    best_t, best_rate = 1, 0.0
+    best_t, best_rate, probe = 1, 0.0, {}
     for t in sorted({min(ncpu, c) for c in (8, 32, 96)}):
         torch.set_num_threads(t)
         cpu_run(32)                                              # warm-up at this thread count
         _, dt = cpu_run(128)
+        probe[str(t)] = 128 / dt
         if 128 / dt > best_rate:
             best_t, best_rate = t, 128 / dt
     torch.set_num_threads(best_t)
     n = int(max(256, min(args.cpu_rays, best_rate * 20.0)))
     ref, cpu_s = cpu_run(n)
     res = {"cpu_baseline": {"value": B * n / cpu_s, "unit": "rays/s", "cores": best_t, "kind": "port",
+                            "host_threads": ncpu, "thread_probe_rays_per_s": probe,
                             "sample": f"first {n} rays of each pair of the same {H}x{H}x{S} workload, "
                                       f"oracle/render_ref.py (PyTorch CPU ops), {best_t} of {ncpu} host "
                                       f"threads (best of a 3-point probe), {cpu_s:.1f} s"}}

@@ -11,7 +11,10 @@ from tests.helpers import GOLDEN, to_device
 pytestmark = pytest.mark.gpu
 
 # flows 0/1 are in pixels of the 64x64 grid (|flow| up to ~60), flows 2/3 normalised to [-1, 1]; measured 1.1e-5 px / 3.6e-7
-FLOW_TOL_PX, FLOW_TOL_NORM = 5e-4, 2e-5
+# fp32 path end to end: bars at ~8x what the MI355X measures against the upstream fixture (the test prints the values:
+# flows 1.1e-5 px / 3.8e-7 normalised, feature maps 7e-7 of their scale, rel_pose 9e-8; round 2 allowed 5e-3)
+FLOW_TOL_PX, FLOW_TOL_NORM = 1e-4, 3e-6
+Z_TOL, POSE_TOL = 5e-6, 1e-6
 
 
 @pytest.fixture(scope="module")
@@ -75,15 +78,21 @@ def test_get_z_and_render_end_to_end(dev):
     with torch.no_grad():
         z, rel_pose, flows = model.get_z(inp)
     strides = [(4, 2), (8, 4), (16, 8), (8, 16)]
+    zerr = []
     for i, t in enumerate(z):
         cs, ss = strides[i]
         g = torch.from_numpy(gold[f"z{i}_sample"])
-        assert (t[:, ::cs, ::ss, ::ss].cpu() - g).abs().max() <= 5e-3 * max(1.0, float(g.abs().max())), i
+        zerr.append(float((t[:, ::cs, ::ss, ::ss].cpu() - g).abs().max() / max(1.0, float(g.abs().max()))))
+    print("get_z feature-map max-abs errors / max(1, |z|max) vs upstream:", zerr)
+    for i, e in enumerate(zerr):
+        assert e <= Z_TOL, (i, zerr)
     ferr = [float((f.cpu() - torch.from_numpy(gold[f"flow{i}"])).abs().max()) for i, f in enumerate(flows)]
     print("get_z flow max-abs errors vs upstream:", ferr)
     for i, e in enumerate(ferr):
         assert e <= (FLOW_TOL_PX if i < 2 else FLOW_TOL_NORM), (i, ferr)
-    assert (rel_pose.cpu() - torch.from_numpy(gold["rel_pose"])).abs().max() <= 5e-3
+    perr = float((rel_pose.cpu() - torch.from_numpy(gold["rel_pose"])).abs().max())
+    print("get_z rel_pose max-abs error vs upstream:", perr)
+    assert perr <= POSE_TOL
     with torch.no_grad():
         out = model(inp, z=z, rel_pose=rel_pose, val=True, flow=flows)
         out2 = model(inp, val=True) if False else None
