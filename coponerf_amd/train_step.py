@@ -76,23 +76,23 @@ class TrainStep:
 
     def _adapt_grad_scale(self, stepped: bool) -> None:
         eng = getattr(self.model, "_engine", None)
-        if eng is None:
-            return
         if stepped:
             self.skipped_in_a_row = 0
             self._good += 1
-            if self._good >= self.growth_interval and eng.grad_scale_target < self._scale_ceiling:
+            if eng is not None and self._good >= self.growth_interval and eng.grad_scale_target < self._scale_ceiling:
                 eng.grad_scale_target = min(self._scale_ceiling, eng.grad_scale_target * 2.0)
                 self._good = 0
             return
         self.skipped_in_a_row += 1
         self.skipped_total += 1
         self._good = 0
-        eng.grad_scale_target = max(1.0, eng.grad_scale_target / 4.0)
+        if eng is not None:
+            eng.grad_scale_target = max(1.0, eng.grad_scale_target / 4.0)
         if self.skipped_in_a_row in (3, 10, 100):
             import warnings
+            scale = f" (fp16 gradient scale target now {eng.grad_scale_target:g})" if eng is not None else ""
             warnings.warn(f"coponerf_amd.TrainStep: {self.skipped_in_a_row} consecutive steps skipped by the "
-                          f"finite-gradient guard (fp16 gradient scale target now {eng.grad_scale_target:g})")
+                          f"finite-gradient guard{scale}")
 
     def timing_summary(self) -> Dict[str, float]:
         """Mean milliseconds per phase over the recorded steps (call after torch.cuda.synchronize())."""

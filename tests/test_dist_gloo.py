@@ -98,3 +98,80 @@ def test_bucketed_allreduce_and_finite_flag_world2():
         assert 1 <= ncoll < 6 and nb >= 1            # fewer collectives than the 6 gradient tensors
         assert finite_all is True and finite_after_nan is False
     assert res[0][-1] == [0, 2, 4] and res[1][-1] == [1, 3]
+
+
+class _TinyRenderer(torch.nn.Module):
+    """Stand-in with the drop-in model's call contract (model(model_input, val=False) -> {'rgb', 'at_wt'}), small enough
+    for two CPU ranks: coponerf_amd.train_step.TrainStep itself is what runs (wrapper.py:104-151)."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(2, 16)
+        self.b = torch.nn.Linear(16, 3)
+        self.unused = torch.nn.Linear(4, 4)                  # never reached by the loss: no gradient on any rank
+
+    def forward(self, inp, val=False):
+        uv = inp["query"]["uv"]
+        h = torch.tanh(self.a(uv / 64.0))
+        return {"rgb": self.b(h) * inp["scale"], "at_wt": h.detach()[..., :1]}
+
+
+def _train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coponerf_amd import dist as cd
+    from coponerf_amd.train_step import TrainStep
+    torch.manual_seed(10 + rank)                             # ranks start from different weights ...
+    model = _TinyRenderer()
+    cd.broadcast_parameters(model)                           # ... train.py:58-60
+    ref = _TinyRenderer()
+    ref.load_state_dict(model.state_dict())
+    step = TrainStep(model, lr=1e-2, clip_grad=0.05, bucket_bytes=256)
+    g = torch.Generator().manual_seed(100 + rank)            # independent batches per rank (train.py:84-97)
+    uv = torch.rand(2, 1, 32, 2, generator=g) * 64
+    gt = torch.rand(2, 1, 32, 3, generator=g)
+    batch = {"query": {"uv": uv}, "scale": torch.tensor(1.0)}
+    info = step(batch, gt)
+    # the same step by hand: per-rank clip BEFORE the exchange (wrapper.py:142-151), per-parameter SUM / world, Adam
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    loss = (gt - ref(batch)["rgb"]).abs().mean()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+    for p in ref.parameters():
+        if p.grad is not None:
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+            p.grad /= world
+    opt.step()
+    same = all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(model.parameters(), ref.parameters()))
+    w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    both = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(both, w)
+    replicas_equal = bool(torch.equal(both[0], both[1]))
+    # a NaN on ONE rank: every rank skips the update (same branch, no hang), nothing changes, the skip is counted
+    before = [p.detach().clone() for p in model.parameters()]
+    bad = {"query": {"uv": uv}, "scale": torch.tensor(float("nan") if rank == 1 else 1.0)}
+    info_bad = step(bad, gt)
+    unchanged = all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    info_ok = step(batch, gt)                                # and training goes on afterwards
+    q.put((rank, float(info["loss"]), bool(info["stepped"]), int(info["collectives"]), same, replicas_equal,
+           bool(info_bad["stepped"]), unchanged, int(info_bad["skipped_in_a_row"]), bool(info_ok["stepped"]),
+           int(info_ok["skipped_in_a_row"]), all(p.grad is None for p in model.parameters())))
+    dist.destroy_process_group()
+
+
+def test_train_step_world2_matches_reference_semantics_and_skips_together():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, loss, stepped, ncoll, same, replicas_equal, bad_stepped, unchanged, skipped, ok_stepped, skipped_after, cleared in res:
+        assert stepped and ncoll >= 1 and same and replicas_equal, res
+        assert bad_stepped is False and unchanged and skipped == 1, res          # BOTH ranks, though only rank 1 saw the NaN
+        assert ok_stepped and skipped_after == 0 and cleared, res
+    assert res[0][1] != res[1][1]                                                # the ranks really trained on different data
