@@ -61,6 +61,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_linear_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
     "cpn_cross_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "cpn_linear_attention_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
+    "cpn_qk_assemble": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_cross_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_conv_map7x7": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "cpn_prepare_input": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -58,6 +58,10 @@
 #ifndef CPN_ENCODE_ABLATE
 #define CPN_ENCODE_ABLATE 0
 #endif
+// 1 = the table taps of the next 64-channel slice are issued before the current slice is computed
+#ifndef CPN_ENCODE_PREFETCH
+#define CPN_ENCODE_PREFETCH 0
+#endif
 // images (own / other) per wave tile: 2 = 32-row wave tiles, 8 waves per CU; 1 = 16-row wave tiles, 16 waves per CU
 #ifndef CPN_ENCODE_MT
 #define CPN_ENCODE_MT 1
@@ -457,6 +461,28 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
                 }
             }
         };
+#if CPN_ENCODE_PREFETCH
+        // taps of slice n+1 in flight while slice n is computed (two register sets, 32 more VGPRs): the table reads that
+        // miss L2 take ~500 clocks from a warm Infinity Cache but ~1550 from HBM behind the kernel's own 7 GB write
+        // stream once other kernels have replaced the tables there (profiles/r03_pmc_encode_hidden_hot_vs_flushed.json)
+        TapData ta, tb;
+        issue_taps(0, ta);
+        for (int n = 0; n < NSLICE; n += 2) {
+            if (n + 1 < NSLICE) issue_taps(n + 1, tb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n > 0) store_slice(n - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_slice(n, ta);
+            if (n + 1 < NSLICE) {
+                if (n + 2 < NSLICE) issue_taps(n + 2, ta);
+                __builtin_amdgcn_sched_barrier(0);
+                store_slice(n);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_slice(n + 1, tb);
+            }
+        }
+        store_slice(NSLICE - 1);
+#else
         for (int n = 0; n < NSLICE; ++n) {
             TapData td;
             issue_taps(n, td);
@@ -466,6 +492,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
             compute_slice(n, td);
         }
         store_slice(NSLICE - 1);
+#endif
     }
 }
 

@@ -640,3 +640,46 @@ extern "C" int cpn_cross_attention_bwd(const float* corr, const float* src_v, co
     CPN_LAUNCH_CHECK("cpn_cross_attention_bwd");
     return 0;
 }
+
+// ---- q / k of UFCLayer.forward_attention from the LOW-resolution projection (round 3) -----------------------------
+// aggregation.py:276-281: q = q_proj(cat(interp(corr maps, fs), norm1(feat))) + pos_embed, same for k.  A Linear layer
+// acts per position on the channels, bilinear interpolation per channel on the positions: they commute, so the 2048
+// cost-volume channels are projected at their native Hs x Ws positions (16 x 16: 6 - 16x fewer FLOPs than at fs x fs) and
+// the 2d projected channels are upsampled instead.  This kernel does the upsampling (align_corners=True, the arithmetic
+// of cpn_resize_bilinear_ac), adds the feature half of the projection (+ bias) and the positional embedding and writes
+// q and k in the (B, L, H, 32) layout the linear attention reads.
+namespace {
+__global__ __launch_bounds__(256) void qk_assemble_kernel(const float* __restrict__ lin, const float* __restrict__ low,
+                                                          const float* __restrict__ pos, int L, int fs, int h, int w, int d,
+                                                          int dim, float* __restrict__ q, float* __restrict__ k) {
+    const int b = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;        // over (token, channel of [q | k])
+    if (idx >= (long long)L * 2 * d) return;
+    const int c = (int)(idx % (2 * d)), l = (int)(idx / (2 * d));
+    const int Y = l / fs, X = l - Y * fs;
+    const float sy = fs > 1 ? (float)(h - 1) / (float)(fs - 1) : 0.0f;
+    const float sx = fs > 1 ? (float)(w - 1) / (float)(fs - 1) : 0.0f;
+    const float fy = sy * (float)Y, fx = sx * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* p = low + ((size_t)b * 2 * d + c) * h * w;
+    const float top = p[y0 * w + x0] * (1.0f - lx) + p[y0 * w + x1] * lx;
+    const float bot = p[y1 * w + x0] * (1.0f - lx) + p[y1 * w + x1] * lx;
+    const float up = top * (1.0f - ly) + bot * ly;
+    const float v = (lin[((size_t)b * L + l) * 2 * d + c] + up) + pos[(size_t)l * dim + (c % dim)];
+    if (c < d) q[((size_t)b * L + l) * d + c] = v;
+    else k[((size_t)b * L + l) * d + (c - d)] = v;
+}
+}  // namespace
+
+extern "C" int cpn_qk_assemble(const float* lin, const float* low, const float* pos, int B, int fs, int h, int w, int nhead,
+                               int dim, float* q, float* k, void* stream) {
+    CPN_REQUIRE(lin && low && pos && q && k, CPN_E_ARG, "cpn_qk_assemble: null pointer");
+    CPN_REQUIRE(B > 0 && B < 65536 && fs > 0 && h > 0 && w > 0 && nhead > 0 && dim > 0, CPN_E_SHAPE, "cpn_qk_assemble: bad shape");
+    const int L = fs * fs, d = nhead * dim;
+    hipLaunchKernelGGL(qk_assemble_kernel, dim3(cpn_cdiv((long long)L * 2 * d, 256), B), dim3(256), 0, (hipStream_t)stream, lin,
+                       low, pos, L, fs, h, w, d, dim, q, k);
+    CPN_LAUNCH_CHECK("cpn_qk_assemble");
+    return 0;
+}

@@ -8,8 +8,9 @@ capture (coponerf_amd/getz.py) — really run side by side.  The reference has n
 `model.get_z` eagerly per pair (/root/reference test.py:173, wrapper.py:178).
 
 Contract: inference only (`torch.no_grad()`, `model.eval()`).  The graph reads the parameters in place, so in-place
-parameter updates are seen; `load_state_dict` / `RenderEngine.invalidate()` (writes that replace or bypass the
-tensors) drop the captured graphs through `CoPoNeRF._param_epoch`.
+parameter updates through torch ops bump the parameters' version counters and re-capture; `load_state_dict` /
+`RenderEngine.invalidate()` (writes that replace or bypass the tensors) drop the captured graphs through
+`CoPoNeRF._param_epoch`.
 """
 from __future__ import annotations
 
@@ -78,10 +79,15 @@ class GraphedGetZ:
         model = self.model
         if torch.is_grad_enabled() or model.training:
             raise RuntimeError("GraphedGetZ is the inference path: call it under torch.no_grad() with model.eval()")
-        key = (_signature(inp["context"]), getattr(model, "_param_epoch", 0))
+        # parameter epoch (load_state_dict / invalidate) + the sum of the parameters' version counters: an optimizer step or
+        # any other in-place update re-captures, because derived tensors the capture baked in (e.g. the concatenated q/k
+        # projection weights of UFCLayer._qk_weights) are rebuilt as NEW tensors when their sources change
+        if self.__dict__.get("_params") is None:
+            self._params = list(model.parameters())
+        key = (_signature(inp["context"]), getattr(model, "_param_epoch", 0), sum(p._version for p in self._params))
         rec = self._graphs.get(key)
         if rec is None:
-            self._graphs = {k: v for k, v in self._graphs.items() if k[1] == key[1]}      # stale parameter epochs go
+            self._graphs = {k: v for k, v in self._graphs.items() if k[1:] == key[1:]}    # stale parameter states go
             rec = self._graphs[key] = self._capture(inp)
         graph, static_in, out, nhwc, hw = rec
         _copy_into(static_in, inp["context"])

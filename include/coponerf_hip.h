@@ -355,6 +355,14 @@ int cpn_linear_attention_bwd(const float* q, const float* k, const float* v, con
                              int channel_major, float eps, int nsplit, float* scratch, float* dq, float* dk, float* dv,
                              void* stream);
 
+/* ---- q / k of UFCLayer.forward_attention (models/aggregation.py:276-281) from the low-resolution projection (round 3):
+ *   q | k = lin + upsample(low, fs x fs, bilinear, align_corners=True) + pos_embed
+ * lin (B, fs*fs, 2d): the feature half of [q_proj | k_proj] with the biases; low (B, 2d, h, w): the cost-volume half of the
+ * two projections applied at the volume's native h x w positions (a Linear layer commutes with the interpolation of
+ * aggregation.py:274: 6 - 16x fewer FLOPs); pos (fs*fs, dim); d = nhead*dim.  q, k (B, fs*fs, nhead, dim).          */
+int cpn_qk_assemble(const float* lin, const float* low, const float* pos, int B, int fs, int h, int w, int nhead, int dim,
+                    float* q, float* k, void* stream);
+
 /* ---- K10: cost-volume cross attention of UFCLayer.forward_cross (models/aggregation.py:327-328) -------------------
  * corr (B, H, S, T) fp32; src_v (B, S, H, C), trg_v (B, T, H, C), C == 32
  *   src_attn (B, S, H, C) = softmax over t of corr . trg_v ;  trg_attn (B, T, H, C) = softmax over s of corr, transposed . src_v */

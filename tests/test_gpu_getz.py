@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 
 # flows 0/1 are in pixels of the 64x64 grid (|flow| up to ~60), flows 2/3 normalised to [-1, 1]; measured 1.1e-5 px / 3.6e-7
 # fp32 path end to end: bars at ~8x what the MI355X measures against the upstream fixture (the test prints the values:
-# flows 1.1e-5 px / 3.8e-7 normalised, feature maps 7e-7 of their scale, rel_pose 9e-8; round 2 allowed 5e-3)
+# flows 1e-5 px / 3e-7 normalised, feature maps 8e-7 of their scale, rel_pose 1e-7 .. 5e-7 depending on the GEMM
+# association of the q/k projections; round 2 allowed 5e-3)
 FLOW_TOL_PX, FLOW_TOL_NORM = 1e-4, 3e-6
-Z_TOL, POSE_TOL = 5e-6, 1e-6
+Z_TOL, POSE_TOL = 5e-6, 3e-6
 
 
 @pytest.fixture(scope="module")

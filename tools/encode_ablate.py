@@ -42,6 +42,21 @@ def build():
             subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, err_o, "-o", out])
 
 
+PREFETCH = ((1, 16), (1, 12), (1, 8))          # (CPN_ENCODE_PREFETCH, waves per workgroup)
+
+
+def build_prefetch_variants():
+    src = os.path.join(ROOT, "coponerf_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    for pf, waves in PREFETCH + ((0, 12),):
+        obj, out = os.path.join(BUILD, f"encode_pf{pf}w{waves}.o"), os.path.join(BUILD, f"libencode_pf{pf}w{waves}.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_ENCODE_PREFETCH={pf}",
+                               f"-DCPN_ENCODE_WAVES={waves}", "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c",
+                               os.path.join(src, "encode.hip"), "-o", obj])
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, os.path.join(BUILD, "error.o"),
+                               "-o", out])
+
+
 def build_store_variants():
     src = os.path.join(ROOT, "coponerf_amd", "csrc")
     hipcc = "/opt/rocm/bin/hipcc"
@@ -56,6 +71,7 @@ def build_store_variants():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
+    ap.add_argument("--build-only", default="")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--ray0", type=int, default=16384, help="first ray of the timed chunk")
     ap.add_argument("--flush", action="store_true", help="stream 8 GB through the caches between launches (as the "
@@ -69,8 +85,10 @@ def main():
     ap.add_argument("--only", default="", help="substring filter on the variant label")
     a = ap.parse_args()
     if a.build:
-        build()
-        build_store_variants()
+        if a.build_only != "prefetch":
+            build()
+            build_store_variants()
+        build_prefetch_variants()
         return
     import torch
     from coponerf_amd import CoPoNeRF, synthetic as syn
@@ -99,6 +117,7 @@ def main():
     runs = [(f"mt{c[0]} w{c[1]} {k}: {what}", f"libencode_abl{k}_mt{c[0]}w{c[1]}.so")
             for c in CONFIGS for k, what in VARIANTS.items()]
     runs += [(f"store policy {st}", f"libencode_store{st}.so") for st in STORES]
+    runs += [(f"prefetch {pf} w{wv}", f"libencode_pf{pf}w{wv}.so") for pf, wv in PREFETCH + ((0, 12),)]
     wlib = wsink = None
     if a.warm == "plain":
         wlib = ctypes.CDLL(os.path.join(BUILD, "libwrite_bw.so"))
