@@ -74,7 +74,6 @@ XIN_K, XIN_STRIDE = 864, 896
 TAB_LD = 832
 RAYC_STRIDE = 64
 LIGHTFIELD_PACK_FLOATS = 128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16
-GN_SLOTS = 32              # CPN_GN_SLOTS of include/coponerf_hip.h
 ABI_VERSION = 3
 
 
@@ -126,6 +125,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
     handle.cpn_conv4d_scratch.argtypes = [_I] * 7
     handle.cpn_conv4d_scratch.restype = ctypes.c_longlong
+    handle.cpn_gn_stats_doubles.argtypes = [_I, _I, ctypes.c_longlong]
+    handle.cpn_gn_stats_doubles.restype = ctypes.c_longlong
     handle.cpn_wgrad_tall_scratch.argtypes = [_I, _I]
     handle.cpn_wgrad_tall_scratch.restype = ctypes.c_longlong
     handle.cpn_conv_wgrad_scratch.argtypes = [_I, _I]

@@ -16,6 +16,54 @@
 
 namespace {
 
+// GroupNorm statistics of sample b, DETERMINISTIC (round 3; the 32-slot atomicAdd scheme of round 2 summed the workgroup
+// partials in whatever order they arrived: two runs of get_z differed in the last bits).  stats layout (doubles):
+//   [2b], [2b+1]        sum / sum of squares of sample b, written once by the LAST workgroup of the sample to finish
+//   [2B + b]            arrival counter (zero on entry), bits of an unsigned long long
+//   [3B + 2(b W + w)..] partial pair of workgroup w of sample b, W = gridDim.x * gridDim.y
+// Every workgroup publishes its pair with returning exchanges (performed at the device-coherent level, like the atomic
+// adds they replace; the returned values are consumed, so they have completed before the counter is bumped), the
+// workgroup that draws the last ticket re-reads all W pairs with device-scope loads and sums them in a FIXED order
+// (thread t takes w = t, t + 256, ...; then a fixed LDS tree).  Must be called by all 256 threads of the workgroup.
+__device__ __forceinline__ void gn_publish(double s1, double s2, double* __restrict__ stats, int b) {
+    __shared__ int last_flag;
+    __shared__ double tree[2][256];
+    const unsigned W = gridDim.x * gridDim.y, me = blockIdx.x + gridDim.x * blockIdx.y, B = gridDim.z;
+    unsigned long long* part = reinterpret_cast<unsigned long long*>(stats + 3 * (size_t)B + 2 * ((size_t)b * W));
+    if (threadIdx.x == 0) {
+        const unsigned long long o1 = __hip_atomic_exchange(part + 2 * me, (unsigned long long)__double_as_longlong(s1),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long o2 = __hip_atomic_exchange(part + 2 * me + 1, (unsigned long long)__double_as_longlong(s2),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned zero;                                        // 0, but only known once both exchanges have returned
+        asm volatile("v_and_b32 %0, 0, %1\n\tv_and_b32 %0, %0, %2" : "=&v"(zero) : "v"((unsigned)o1), "v"((unsigned)o2));
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(stats + 2 * (size_t)B + b);
+        const unsigned long long ticket = __hip_atomic_fetch_add(cnt, 1ULL + zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = ticket == (unsigned long long)W - 1;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    double a1 = 0.0, a2 = 0.0;
+    for (unsigned w = threadIdx.x; w < W; w += 256) {
+        a1 += __longlong_as_double((long long)__hip_atomic_load(part + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        a2 += __longlong_as_double((long long)__hip_atomic_load(part + 2 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    tree[0][threadIdx.x] = a1;
+    tree[1][threadIdx.x] = a2;
+    __syncthreads();
+    for (int n = 128; n > 0; n >>= 1) {
+        if ((int)threadIdx.x < n) {
+            tree[0][threadIdx.x] += tree[0][threadIdx.x + n];
+            tree[1][threadIdx.x] += tree[1][threadIdx.x + n];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[2 * (size_t)b] = tree[0][0];
+        stats[2 * (size_t)b + 1] = tree[1][0];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv4d: y[b,o,qy,qx,sy,sx] = bq[o] + bs[o]
 //        + sum_{c,i,j} Wq[o,c,i,j] * Ps(x)[b,c, qy*s+i-p, qx*s+j-p, sy, sx]      (query branch, support dims pooled)
@@ -87,13 +135,7 @@ __global__ __launch_bounds__(256) void conv4d_kernel(const float* __restrict__ x
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // thousands of workgroups add into the same two doubles: spread them over CPN_GN_SLOTS accumulator pairs (the
-        // readers sum them); on one pair the atomics were 0.9 ms of a 12 ms get_z
-        double* dst = stats + ((size_t)b * CPN_GN_SLOTS + (blockIdx.x + blockIdx.y * 7) % CPN_GN_SLOTS) * 2;
-        atomicAdd(dst, red[0] + red[2] + red[4] + red[6]);
-        atomicAdd(dst + 1, red[1] + red[3] + red[5] + red[7]);
-    }
+    gn_publish(red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7], stats, b);
 }
 
 // Strided layers (k3 s2 on 32^4, k5 s4 on 64^4): the kernel above re-evaluates the s x s max-pool window for every tap
@@ -190,13 +232,7 @@ __global__ __launch_bounds__(256) void conv4d_pooled_kernel(const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // thousands of workgroups add into the same two doubles: spread them over CPN_GN_SLOTS accumulator pairs (the
-        // readers sum them); on one pair the atomics were 0.9 ms of a 12 ms get_z
-        double* dst = stats + ((size_t)b * CPN_GN_SLOTS + (blockIdx.x + blockIdx.y * 7) % CPN_GN_SLOTS) * 2;
-        atomicAdd(dst, red[0] + red[2] + red[4] + red[6]);
-        atomicAdd(dst + 1, red[1] + red[3] + red[5] + red[7]);
-    }
+    gn_publish(red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7], stats, b);
 }
 
 // stride-1 3x3x3x3 fast path (57 of the 63 Conv4d calls of a get_z): one thread computes COUT output channels of
@@ -315,38 +351,20 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void conv4d_k3s1_kernel(const floa
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // thousands of workgroups add into the same two doubles: spread them over CPN_GN_SLOTS accumulator pairs (the
-        // readers sum them); on one pair the atomics were 0.9 ms of a 12 ms get_z
-        double* dst = stats + ((size_t)b * CPN_GN_SLOTS + (blockIdx.x + blockIdx.y * 7) % CPN_GN_SLOTS) * 2;
-        atomicAdd(dst, red[0] + red[2] + red[4] + red[6]);
-        atomicAdd(dst + 1, red[1] + red[3] + red[5] + red[7]);
-    }
+    gn_publish(red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7], stats, b);
 }
 
-// mean / 1/std of sample b from its CPN_GN_SLOTS accumulator pairs, computed ONCE per workgroup (one slot per lane of the
-// first wave, shuffle reduction, LDS broadcast): every thread summing the slots itself doubled the readers' time.
+// mean / 1/std of sample b from its (sum, sum of squares) pair (gn_publish), computed ONCE per workgroup and broadcast
+// through LDS.
 // Must be called by all threads of the block (contains a barrier).
 __device__ __forceinline__ void gn_block_stats(const double* __restrict__ stats, int b, double n, float eps, float& mean,
                                                float& rstd) {
     __shared__ float mr[2];
-    if (threadIdx.x < 64) {
-        double ssum = 0.0, ssq = 0.0;
-        if (threadIdx.x < CPN_GN_SLOTS) {
-            ssum = stats[((size_t)b * CPN_GN_SLOTS + threadIdx.x) * 2];
-            ssq = stats[((size_t)b * CPN_GN_SLOTS + threadIdx.x) * 2 + 1];
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            ssum += __shfl_xor(ssum, off);
-            ssq += __shfl_xor(ssq, off);
-        }
-        if (threadIdx.x == 0) {
-            const double m = ssum / n;
-            const double var = ssq / n - m * m;
-            mr[0] = (float)m;
-            mr[1] = (float)(1.0 / sqrt(var + (double)eps));
-        }
+    if (threadIdx.x == 0) {
+        const double m = stats[2 * (size_t)b] / n;
+        const double var = stats[2 * (size_t)b + 1] / n - m * m;
+        mr[0] = (float)m;
+        mr[1] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
     mean = mr[0];
@@ -991,6 +1009,12 @@ extern "C" int cpn_resize_bilinear_ac(const float* src, float* dst, long long pl
                        h, w, H, W);
     CPN_LAUNCH_CHECK("cpn_resize_bilinear_ac");
     return 0;
+}
+
+// doubles of the `stats` argument of cpn_conv4d / cpn_conv4d_gn_relu (layout: gn_publish); an upper bound over the
+// kernel variants' grids: one workgroup per 256 output positions and output channel (group)
+extern "C" long long cpn_gn_stats_doubles(int B, int Cout, long long npos) {
+    return 3LL * B + 2LL * B * cpn_cdiv(npos, 256) * Cout;
 }
 
 extern "C" long long cpn_conv4d_scratch(int B, int Cin, int Hq, int Wq, int Hs, int Ws, int s) {

@@ -446,6 +446,23 @@ def make_pose_heads():
     return pose, nn.Sequential(*mlp([128, 64, 32, 6])), nn.Sequential(*mlp([128, 64, 32, 3]))
 
 
+_DET_OWNED = [False]
+
+
+def _conv_determinism(want: bool) -> None:
+    """Inference: restrict the convolution library to deterministic algorithms (ResNet trunk: +0.15 ms per pair on MI355X)
+    so that get_z as a whole is bit-reproducible — with val=True its pose decides the view-2 sample coordinates.  The
+    switch is process-wide and changing it makes the library re-select its kernels (~0.3 s), so it is flipped only when
+    the mode changes (inference <-> training), never per call, and only if this module was the one that set it."""
+    cd = torch.backends.cudnn
+    if want and not cd.deterministic:
+        cd.deterministic = True
+        _DET_OWNED[0] = True
+    elif not want and _DET_OWNED[0] and cd.deterministic:
+        cd.deterministic = False
+        _DET_OWNED[0] = False
+
+
 def get_z(model, input, ops):
     """Body of CoPoNeRF.get_z (CoPoNeRF.py:159-206) on the sub-modules of `model`."""
     rgb = input["context"]["rgb"]
@@ -454,7 +471,11 @@ def get_z(model, input, ops):
         raise ValueError("get_z supports 256x256 context images only, like the reference (SURVEY.md §0)")
     model.H, model.W = H, W
     x = imagenet_normalise((rgb.flatten(0, 1).permute(0, 3, 1, 2) + 1) / 2.)
-    z = model.encoder(x)[:3]
+    det = not torch.is_grad_enabled() and getattr(model, "deterministic_get_z", True)
+    _conv_determinism(det)
+    # x is an NHWC-strided view of the input image; the library's deterministic choice for the 7x7 stem in that layout is
+    # a 300 ms kernel on MI355X, in NCHW it is the usual one
+    z = model.encoder(x.contiguous() if det else x)[:3]
     # conv_map straight from the (N,H,W,3) image (normalisation fused); on the inference path the kernel also emits the
     # NHWC fp16 copy of this level, which the render engine adopts instead of re-laying the map out
     infer = not torch.is_grad_enabled()

@@ -196,7 +196,8 @@ class _Conv4dGnReluFn(Function):
                 flip = lambda w: w.detach().float().flip(-1, -2).transpose(0, 1).contiguous()
                 zb = torch.zeros(Cin, dtype=torch.float32, device=dev)
                 gx = torch.empty_like(x)
-                scratch = torch.zeros(B, _hip.GN_SLOTS, 2, dtype=torch.float64, device=dev)
+                scratch = torch.zeros(int(_hip.lib().cpn_gn_stats_doubles(B, Cin, Hq * Wq * Hs * Ws)), dtype=torch.float64,
+                                      device=dev)
                 wq_t, ws_t = flip(wq), flip(ws)
                 call("cpn_conv4d", dy.data_ptr(), wq_t.data_ptr(), zb.data_ptr(), ws_t.data_ptr(), zb.data_ptr(), B, C, Cin,
                      Hq, Wq, Hs, Ws, 3, 1, 1, gx.data_ptr(), scratch.data_ptr(), 0, _stream())
@@ -409,16 +410,18 @@ class HipOps:
         if t.device.type != "cuda":
             raise RuntimeError("coponerf_amd UFC operators run on a HIP device only (tensor on %s)" % t.device)
 
-    def _stats(self, B, device):
-        """(B, GN_SLOTS, 2) float64 zeros for one layer's GroupNorm sums.  A get_z call runs 63 Conv4d layers: their accumulators
-        are slices of one zeroed pool per HipOps instance (= per get_z call) instead of 63 fill launches."""
+    def _stats(self, B, Cout, npos, device):
+        """Zeroed float64 block for one layer's GroupNorm statistics (cpn_gn_stats_doubles: the sums, the arrival counters and
+        the per-workgroup partials of the deterministic reduction).  A get_z call runs 63 Conv4d layers: their blocks are
+        slices of one zeroed pool per HipOps instance (= per get_z call) instead of 63 fill launches."""
+        n = int(_hip.lib().cpn_gn_stats_doubles(B, Cout, npos))
         pool = getattr(self, "_stats_pool", None)
-        if pool is None or pool[0].shape[1] != B or pool[0].device != device or pool[1] >= pool[0].shape[0]:
-            pool = [torch.zeros(64, B, _hip.GN_SLOTS, 2, device=device, dtype=torch.float64), 0]
+        if pool is None or pool[0].device != device or pool[1] + n > pool[0].numel():
+            pool = [torch.zeros(max(n, 1 << 20), device=device, dtype=torch.float64), 0]
             self._stats_pool = pool
         i = pool[1]
-        pool[1] = i + 1
-        return pool[0][i]
+        pool[1] = i + n + (n & 1)
+        return pool[0][i:i + n]
 
     def _zeros64(self, n, device):
         """n float64 zeros carved from a pooled, once-zeroed buffer (the backward of every Conv4d layer needs a few
@@ -444,7 +447,7 @@ class HipOps:
         o = lambda n: (n + 2 * p - k) // s + 1
         Hq2, Wq2, Hs2, Ws2 = o(Hq), o(Wq), o(Hs), o(Ws)
         y = torch.empty(B, Cout, Hq2, Wq2, Hs2, Ws2, device=x.device, dtype=torch.float32)
-        stats = self._stats(B, x.device)
+        stats = self._stats(B, Cout, Hq2 * Wq2 * Hs2 * Ws2, x.device)
         f = lambda t: t.detach().contiguous().float()
         wq_, bq_, ws_, bs_, gw, gb = f(wq), f(bq), f(ws), f(bs), f(gn_w), f(gn_b)
         from . import _hip

@@ -137,7 +137,6 @@ int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int 
  *       full-resolution NHWC fp16 map (N, H, W, 64)                                                               */
 #define CPN_TAB_LD    832
 #define CPN_NODE_PAD  4
-#define CPN_GN_SLOTS  32
 long long cpn_encode_table_nodes(int H, int W);
 int cpn_pack_encode_weights(const float* W, int ldw, uint16_t* wfrag, uint16_t* wtab, void* stream);
 int cpn_node_features(const uint16_t* map0, const uint16_t* map1, const uint16_t* map2, int H, int W, int nimg,
@@ -259,11 +258,14 @@ int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float
  * replaces conv4d.Conv4d / MaxPool4d / Encoder4D (models/conv4d.py:7-30, 57-163) and the einops rearrange copies
  * around them.  x (B,Cin,Hq,Wq,Hs,Ws) fp32; wq/ws (Cout,Cin,k,k), bq/bs (Cout): query / support 2-D kernels;
  * y (B,Cout,Hq',Wq',Hs',Ws') with n' = (n + 2p - k)/s + 1; gn_w/gn_b (Cout) GroupNorm affine;
- * stats (B, CPN_GN_SLOTS, 2) float64 scratch that MUST be zero on entry (sum, sum of squares per sample, spread over
- * CPN_GN_SLOTS accumulator pairs that the consumers add up).
+ * stats: cpn_gn_stats_doubles(B, Cout, npos') float64, ZERO on entry.  On return stats[2b], stats[2b+1] = sum / sum of
+ * squares of sample b's (Cout, volume) slab; the rest is the arrival counters and per-workgroup partial pairs of the
+ * deterministic reduction (the last workgroup of a sample to finish sums the partials in a fixed order: two runs give
+ * the same bits).  cpn_gn_relu / cpn_gn_relu_bwd read the first 2B entries.
  * scratch: cpn_conv4d_scratch(...) floats for the pooled volumes of a strided layer (0 for stride 1; NULL = no scratch,
  * the pooling window is then re-evaluated per tap).                                                             */
 long long cpn_conv4d_scratch(int B, int Cin, int Hq, int Wq, int Hs, int Ws, int s);
+long long cpn_gn_stats_doubles(int B, int Cout, long long npos);
 int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
                        const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout,
                        int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, float* scratch,

@@ -180,11 +180,16 @@ def test_pipelined_images_equal_serial(dev):
         graphed2 = [out["rgb"].clone() for _, out in render_images(model, pairs[::-1], graph=True)]   # replay only
         again = serial_rgb(pairs[0])
     torch.cuda.synchronize()
-    # get_z accumulates its GroupNorm statistics with atomics: two runs of the SAME pair agree to rounding only
-    noise = float((again - serial[0]).abs().max())
+    # get_z is deterministic since round 3 (GroupNorm sums reduced in a fixed order): the same pair renders to the same
+    # bits, serially or with get_z on the side stream
+    assert torch.equal(again, serial[0])
+    # other schedules of the SAME arithmetic (batched over pairs, graph replay with the two attention passes side by
+    # side) run other library kernels (GEMM / convolution choices depend on the batch size): equal to fp32 rounding in
+    # get_z, which the fp16 render path turns into a few 1e-4 of rgb
+    noise = 1e-4
     assert len(piped) == 3 and len(batched) == 3
     for a, b in zip(serial, piped):
-        assert float((a - b).abs().max()) <= max(10 * noise, 1e-6), (float((a - b).abs().max()), noise)
+        assert torch.equal(a, b), float((a - b).abs().max())
     for a, b, c in zip(serial, graphed, graphed2[::-1]):
         assert float((a - b).abs().max()) <= max(10 * noise, 2e-5), (float((a - b).abs().max()), noise)
         assert float((a - c).abs().max()) <= max(10 * noise, 2e-5), (float((a - c).abs().max()), noise)
@@ -196,3 +201,26 @@ def test_pipelined_images_equal_serial(dev):
     for a, b in zip(serial, batched):
         assert float((a - b).abs().max()) <= max(10 * noise, 2e-5), (float((a - b).abs().max()), noise)
     assert float((serial[0] - serial[1]).abs().max()) > 1e-3
+
+
+def test_get_z_is_bit_reproducible(dev):
+    """Two get_z calls on the same pair give the same bits (features, flows, pose): the GroupNorm sums of the 63 Conv4d
+    layers are reduced in a fixed order by the last workgroup of each sample (csrc/ufc.hip gn_publish) — the per-slot
+    atomicAdd accumulation of round 2 made every run differ in the last bits, and with val=True the estimated pose feeds
+    the view-2 sample coordinates."""
+    from coponerf_amd import CoPoNeRF
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev).eval()
+    for B in (1, 2):
+        inp = to_device(syn.make_inputs(B, 256, 256, 64, seed=77 + B), dev)
+        runs = []
+        with torch.no_grad():
+            for _ in range(3):
+                z, rel, flow = model.get_z(inp)
+                runs.append([t.clone() for t in z] + [rel.clone()] + [f.clone() for f in flow])
+        torch.cuda.synchronize()
+        for other in runs[1:]:
+            for a, b in zip(runs[0], other):
+                assert torch.equal(a, b), (B, tuple(a.shape), float((a - b).abs().max()))
