@@ -43,11 +43,11 @@ SIGNATURES: Dict[str, List] = {
     "cpn_wgrad_tall_f16": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
     "cpn_local_hidden_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_transpose_pairs": [_P, _I, _I, _I, _P, _P],
     "cpn_conv4d_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    "cpn_gn_relu": [_P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P],
+    "cpn_gn_relu": [_P, _P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P],
     "cpn_gn_relu_bwd": [_P, _P, _P, _P, _P, _F, _I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P],
     "cpn_conv_wgrad_planes": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_dwconv3x3_wgrad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],

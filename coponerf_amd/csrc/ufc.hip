@@ -373,7 +373,8 @@ __device__ __forceinline__ void gn_block_stats(const double* __restrict__ stats,
 
 __global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const double* __restrict__ stats,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, int Cout, long long npos, float* out) {
+                                                      const float* __restrict__ res, float eps, int Cout, long long npos,
+                                                      float* out) {
     const int b = blockIdx.z, o = blockIdx.y;
     const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float mean, rstd;
@@ -381,7 +382,8 @@ __global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const doub
     if (pos >= npos) return;
     const size_t idx = ((size_t)b * Cout + o) * npos + pos;
     const float v = (y[idx] - mean) * rstd * gamma[o] + beta[o];
-    out[idx] = fmaxf(v, 0.0f);
+    // res: the residual the caller adds to the block's output (x + Encoder4D(x), aggregation.py:306,347-355) in the same pass
+    out[idx] = res ? res[idx] + fmaxf(v, 0.0f) : fmaxf(v, 0.0f);
 }
 
 // ---- backward of GroupNorm(1 group) + ReLU, two passes over the volume ---------------------------------------
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_tokens_kernel(const float* __re
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wr[tp][e] = w[(c4 * 4 + e) * 9 + (flip ? 8 - tp : tp)];
+        for (int e = 0; e < 4; ++e) wr[tp][e] = w[(c4 * 4 + e) * 9 + ((flip & 1) ? 8 - tp : tp)];
     const float* xb = x + (bimg * H * W) * C + c4 * 4;
     auto col = [&](int X, f32x4 (&v)[3]) {                     // the three rows of column X (zeros outside the image)
 #pragma unroll
@@ -724,6 +726,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_tokens_kernel(const float* __re
         f32x4 acc = b4;
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc += wr[i * 3] * c0[i] + wr[i * 3 + 1] * c1[i] + wr[i * 3 + 2] * c2[i];
+        if (flip & 2) {                                       // exact GELU of the feed-forward block (nn.GELU(), aggregation.py:180)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = 0.5f * acc[e] * (1.0f + erff(acc[e] * 0.70710678118654752440f));
+        }
         *reinterpret_cast<f32x4*>(y + ((bimg * H + yy) * W + X) * C + c4 * 4) = acc;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { c0[i] = c1[i]; c1[i] = c2[i]; }
@@ -1109,18 +1115,20 @@ extern "C" int cpn_transpose_pairs(const float* x, int N, int P, int Q, float* y
     return 0;
 }
 
-extern "C" int cpn_gn_relu(const float* y, const double* stats, const float* gn_w, const float* gn_b, float eps, int B,
-                           int C, long long npos, float* out, void* stream) {
+extern "C" int cpn_gn_relu(const float* y, const double* stats, const float* gn_w, const float* gn_b, const float* residual,
+                           float eps, int B, int C, long long npos, float* out, void* stream) {
     CPN_REQUIRE(y && stats && gn_w && gn_b && out, CPN_E_ARG, "cpn_gn_relu: null pointer");
     CPN_REQUIRE(B > 0 && B < 65536 && C > 0 && C < 65536 && npos > 0, CPN_E_SHAPE, "cpn_gn_relu: bad shape");
     dim3 grid(cpn_cdiv(npos, 256), C, B);
-    hipLaunchKernelGGL(gn_relu_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, stats, gn_w, gn_b, eps, C, npos, out);
+    hipLaunchKernelGGL(gn_relu_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, stats, gn_w, gn_b, residual, eps, C, npos,
+                       out);
     CPN_LAUNCH_CHECK("cpn_gn_relu");
     return 0;
 }
 
 extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
-                                  const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout, int Hq,
+                                  const float* gn_w, const float* gn_b, const float* residual, float eps, int B, int Cin,
+                                  int Cout, int Hq,
                                   int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, float* scratch,
                                   void* stream) {
     CPN_REQUIRE(gn_w && gn_b, CPN_E_ARG, "cpn_conv4d_gn_relu: null pointer");
@@ -1128,7 +1136,7 @@ extern "C" int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* 
     if (rc) return rc;
     auto co = [&](int n) { return (n + 2 * p - k) / s + 1; };
     const long long npos = (long long)co(Hq) * co(Wq) * co(Hs) * co(Ws);
-    return cpn_gn_relu(y, stats, gn_w, gn_b, eps, B, Cout, npos, y, stream);
+    return cpn_gn_relu(y, stats, gn_w, gn_b, residual, eps, B, Cout, npos, y, stream);
 }
 
 extern "C" int cpn_gn_relu_bwd(const float* y, const float* out, const float* dout, const double* stats,

@@ -103,11 +103,15 @@ class Encoder4D(nn.Module):
             nn.Sequential(Conv4d(levels[i], levels[i + 1], k, s, p), nn.GroupNorm(1, levels[i + 1]), nn.ReLU())
             for i in range(len(levels) - 1)])
 
-    def forward(self, x, ops):
-        for blk in self.conv4d:
+    def forward(self, x, ops, residual=None):
+        """residual: what the caller adds to the stack's output (`x + Encoder4D(x)`), handed to the last block so that
+        operators that can fold it into their normalisation pass do."""
+        last = len(self.conv4d) - 1
+        for i, blk in enumerate(self.conv4d):
             c4, gn = blk[0], blk[1]
-            x = ops.conv4d_gn_relu(x, c4.query_conv.weight, c4.query_conv.bias, c4.supp_conv.weight,
-                                   c4.supp_conv.bias, c4.k, c4.s, c4.p, gn.weight, gn.bias, gn.eps)
+            args = (x, c4.query_conv.weight, c4.query_conv.bias, c4.supp_conv.weight, c4.supp_conv.bias, c4.k, c4.s, c4.p,
+                    gn.weight, gn.bias, gn.eps)
+            x = ops.conv4d_gn_relu(*args, residual=residual) if (i == last and residual is not None) else ops.conv4d_gn_relu(*args)
         return x
 
 
@@ -177,6 +181,23 @@ class UFCLayer(nn.Module):
         self.pos_embed = nn.Parameter(torch.zeros(1, fs * fs, 1, self.dim))
         nn.init.trunc_normal_(self.pos_embed, std=.02)
 
+    def _feed_forward(self, seq, x):
+        """Linear -> DWConv 3x3 -> GELU -> Linear (aggregation.py:176-182).  Inference: the GELU rides in the DWConv
+        kernel's epilogue (one launch less per block, 20 per get_z)."""
+        if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
+            return seq(x)
+        from ._hip import call
+        h = seq[0](x)
+        B, L, C = h.shape
+        dw = seq[1]
+        if C % 4 or not h.is_contiguous():
+            return seq[3](seq[2](dw(h)))
+        y = torch.empty_like(h)
+        call("cpn_dwconv3x3_tokens", h.data_ptr(), dw.dwconv.weight.detach().reshape(C, 9).data_ptr(),
+             dw.dwconv.bias.detach().data_ptr(), B, dw.size, dw.size, C, 2, y.data_ptr(),
+             torch.cuda.current_stream().cuda_stream)
+        return seq[3](y)
+
     def _qk_weights(self, ncc: int):
         """[q_proj | k_proj] split by input: the cost-volume columns (2d, ncc), the feature columns (2d, d), the biases (2d)
         and the positional table (L, dim).  Under no_grad the concatenations are cached on the parameters' versions."""
@@ -229,8 +250,8 @@ class UFCLayer(nn.Module):
         msg_corr = msg_corr.reshape(B, H, Ht, Wt, Hs, Ws).permute(0, 1, 4, 5, 2, 3)
         msg_feat = feat_r + msg_feat
         msg_corr = corr + msg_corr
-        msg_feat = msg_feat + self.mlp(self.norm2(msg_feat))
-        msg_corr = msg_corr + self.mlp_corr(msg_corr, ops)
+        msg_feat = msg_feat + self._feed_forward(self.mlp, self.norm2(msg_feat))
+        msg_corr = self.mlp_corr(msg_corr, ops, residual=msg_corr)
         return msg_corr, msg_feat
 
     def _cross(self, corr, src, trg, ops):              # aggregation.py:312-340
@@ -247,8 +268,8 @@ class UFCLayer(nn.Module):
                                           .repeat_interleave(fs // hh, 3))
         src = src + up(src_attn, Hs)
         trg = trg + up(trg_attn, Ht)
-        src = src + self.mlp_cross(self.norm_cross2(src))
-        trg = trg + self.mlp_cross(self.norm_cross2(trg))
+        src = src + self._feed_forward(self.mlp_cross, self.norm_cross2(src))
+        trg = trg + self._feed_forward(self.mlp_cross, self.norm_cross2(trg))
         return src, trg
 
     def forward(self, corr, src, trg, ops):             # aggregation.py:342-356
@@ -273,11 +294,11 @@ class UFCLayer(nn.Module):
             corr_src, src_r = self._attention(corr, src, ops)
             corr_trg, trg_r = self._attention(_swap(corr), trg, ops)
         corr_r = corr_src + t4(corr_trg)
-        corr_r = corr_r + self.feat_to_corr1(ops.correlation_tokens(src_r, trg_r, self.fs), ops)
-        corr_r = corr_r + self.mlp_refine_corr(corr_r, ops)
+        corr_r = self.feat_to_corr1(ops.correlation_tokens(src_r, trg_r, self.fs), ops, residual=corr_r)
+        corr_r = self.mlp_refine_corr(corr_r, ops, residual=corr_r)
         src_r, trg_r = self._cross(corr_r, src_r, trg_r, ops)
-        corr_r = corr_r + self.feat_to_corr2(ops.correlation_tokens(src_r, trg_r, self.fs), ops)
-        corr_r = corr_r + self.mlp_refine_corr2(corr_r, ops)
+        corr_r = self.feat_to_corr2(ops.correlation_tokens(src_r, trg_r, self.fs), ops, residual=corr_r)
+        corr_r = self.mlp_refine_corr2(corr_r, ops, residual=corr_r)
         return corr_r, src_r, trg_r
 
 
@@ -296,13 +317,22 @@ def _interp4d(x, n, ops):                                # aggregation.py:49-56,
     return y.reshape(B, C, n, n, n, n).permute(0, 1, 4, 5, 2, 3)
 
 
+_GRID_CONSTS = {}
+
+
 def _mapping_to_flow(m):                                 # aggregation.py:30-48
+    """flow = (mapping + 1) * (size - 1) / 2 - pixel grid.  The pixel grid and the two scale factors are constants of
+    (H, W, device): cached, so the call is 2 launches instead of 11 (two aranges, six pointwise ops, a cat ...)."""
     B, _, H, W = m.shape
-    xs = torch.arange(W, device=m.device, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
-    ys = torch.arange(H, device=m.device, dtype=torch.float32).view(1, 1, H, 1).expand(B, 1, H, W)
-    fx = (m[:, 0:1].float() + 1) * (W - 1) / 2.0 - xs
-    fy = (m[:, 1:2].float() + 1) * (H - 1) / 2.0 - ys
-    return torch.cat((fx, fy), 1)
+    key = (H, W, str(m.device))
+    c = _GRID_CONSTS.get(key)
+    if c is None:
+        xs = torch.arange(W, device=m.device, dtype=torch.float32).view(1, 1, 1, W).expand(1, 1, H, W)
+        ys = torch.arange(H, device=m.device, dtype=torch.float32).view(1, 1, H, 1).expand(1, 1, H, W)
+        c = _GRID_CONSTS[key] = (torch.cat((xs, ys), 1).contiguous(),
+                                 torch.tensor([(W - 1) / 2.0, (H - 1) / 2.0], device=m.device).view(1, 2, 1, 1))
+    grid, half = c
+    return (m[:, :2].float() + 1) * half - grid          # same operation order per element as the reference
 
 
 class UFC(nn.Module):
@@ -324,11 +354,11 @@ class UFC(nn.Module):
         feats, corrs = [], []
         corr = src = trg = None
         for lvl, fs in enumerate((16, 32, 64)):
-            emb = self.embedding[lvl](ops.correlation_tokens(src_f[lvl], trg_f[lvl], fs), ops)
+            emb = self.embedding[lvl](ops.correlation_tokens(src_f[lvl], trg_f[lvl], fs), ops, residual=corr)
             if lvl == 0:
                 corr, src, trg = emb, src_f[0], trg_f[0]
             else:
-                corr = corr + emb
+                corr = emb
                 src = _interp_tokens(src, fs, ops) + src_f[lvl]
                 trg = _interp_tokens(trg, fs, ops) + trg_f[lvl]
             for layer in self.layers[lvl]:
@@ -350,22 +380,23 @@ def positional_encodings(fx, fy, cx, cy, n: int = 64):
     B = fx.shape[0]
     dev = fx.device
     hp, wp = cy * 2, cx * 2
-    # K = [[a,0,c],[0,b,d],[0,0,1]] in normalised coordinates; its inverse in closed form (the library inverse
-    # synchronises with the host, which also rules out HIP-graph capture of get_z)
-    a = ((fx / wp) * 2).squeeze(-1)
-    b = ((fy / hp) * 2).squeeze(-1)
-    c = ((cx / wp) * 2 - 1).squeeze(-1)
-    d = ((cy / hp) * 2 - 1).squeeze(-1)
-    zero, one = torch.zeros_like(a), torch.ones_like(a)
-    Kinv = torch.stack((torch.stack((1 / a, zero, -c / a), -1), torch.stack((zero, 1 / b, -d / b), -1),
-                        torch.stack((zero, zero, one), -1)), -2)                         # (B,3,3)
-    lin = torch.linspace(-1, 1, steps=n, device=dev)
-    xs = lin.repeat_interleave(n)                       # index k*n + j -> xs[k]
-    ys = lin.repeat(n)                                  #               -> ys[j]
-    pts = torch.stack((xs, ys, torch.ones_like(xs)), 0)                                  # (3, n*n)
-    w = Kinv @ pts                                                                       # (B,3,n*n)
-    p4, p3 = w[:, 0] / w[:, 2], w[:, 1] / w[:, 2]
-    return torch.stack((p3 * p3, p4 * p4, p3 * p4, p3, p4, torch.ones_like(p3)), dim=2)  # (B, n*n, 6)
+    # K = [[a,0,c],[0,b,d],[0,0,1]] in normalised coordinates; K^-1 applied to the grid point (x, y, 1) is
+    # ((x - c) / a, (y - d) / b, 1) in closed form (the library inverse synchronises with the host, which also rules out
+    # HIP-graph capture of get_z; a (B,3,3) @ (3, n*n) product for it is a dozen tiny launches)
+    a = (fx / wp) * 2                                   # (B,1)
+    b = (fy / hp) * 2
+    c = (cx / wp) * 2 - 1
+    d = (cy / hp) * 2 - 1
+    key = ("pe", n, str(dev))
+    g = _GRID_CONSTS.get(key)
+    if g is None:
+        lin = torch.linspace(-1, 1, steps=n, device=dev)
+        g = _GRID_CONSTS[key] = (lin.repeat_interleave(n)[None].contiguous(), lin.repeat(n)[None].contiguous(),
+                                 torch.ones(1, n * n, device=dev))
+    xs, ys, ones = g                                    # index k*n + j -> xs[k], ys[j]
+    p4 = (xs - c) / a                                   # (B, n*n)
+    p3 = (ys - d) / b
+    return torch.stack((p3 * p3, p4 * p4, p3 * p4, p3, p4, ones.expand(B, -1)), dim=2)  # (B, n*n, 6)
 
 
 class _Mlp(nn.Module):

@@ -434,13 +434,17 @@ class HipOps:
         pool[1] = i + ((n + 1) // 2) * 2                      # keep 16-byte alignment
         return pool[0][i:i + n]
 
-    def conv4d_gn_relu(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps):
+    def conv4d_gn_relu(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps, residual=None):
+        """residual: added to the output (x + Encoder4D(x) patterns); fused into the normalisation pass on the inference path."""
         self._need_gpu(x)
-        if _wants_grad(x, wq, bq, ws, bs, gn_w, gn_b):
-            return _Conv4dGnReluFn.apply(self, x.float(), wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps)
-        return self._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps)[0]
+        if _wants_grad(x, wq, bq, ws, bs, gn_w, gn_b) or (residual is not None and _wants_grad(residual)):
+            y = _Conv4dGnReluFn.apply(self, x.float(), wq, bq, ws, bs, gn_w, gn_b, k, s, p, eps)
+            return y if residual is None else residual + y
+        if residual is not None and not (residual.is_contiguous() and residual.dtype == torch.float32):
+            return residual + self._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps)[0]
+        return self._conv4d_gn_relu_hip(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps, residual=residual)[0]
 
-    def _conv4d_gn_relu_hip(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps, keep_pre=False):
+    def _conv4d_gn_relu_hip(self, x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps, keep_pre=False, residual=None):
         x = x.contiguous().float()
         B, Cin, Hq, Wq, Hs, Ws = x.shape
         Cout = wq.shape[0]
@@ -458,11 +462,13 @@ class HipOps:
             call("cpn_conv4d", x.data_ptr(), wq_.data_ptr(), bq_.data_ptr(), ws_.data_ptr(), bs_.data_ptr(), B, Cin, Cout,
                  Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(), stats.data_ptr(), scr_p, _stream())
             out = torch.empty_like(y)
-            call("cpn_gn_relu", y.data_ptr(), stats.data_ptr(), gw.data_ptr(), gb.data_ptr(), float(eps), B, Cout,
+            call("cpn_gn_relu", y.data_ptr(), stats.data_ptr(), gw.data_ptr(), gb.data_ptr(), 0, float(eps), B, Cout,
                  y[0, 0].numel(), out.data_ptr(), _stream())
             return y, out, stats
+        if residual is not None and tuple(residual.shape) != tuple(y.shape):
+            raise ValueError("conv4d_gn_relu: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
         call("cpn_conv4d_gn_relu", x.data_ptr(), wq_.data_ptr(), bq_.data_ptr(), ws_.data_ptr(), bs_.data_ptr(),
-             gw.data_ptr(), gb.data_ptr(), float(eps), B, Cin, Cout, Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(),
+             gw.data_ptr(), gb.data_ptr(), 0 if residual is None else residual.data_ptr(), float(eps), B, Cin, Cout, Hq, Wq, Hs, Ws, k, s, p, y.data_ptr(),
              stats.data_ptr(), scr_p, _stream())
         return y, stats
 

@@ -266,8 +266,10 @@ int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float
  * the pooling window is then re-evaluated per tap).                                                             */
 long long cpn_conv4d_scratch(int B, int Cin, int Hq, int Wq, int Hs, int Ws, int s);
 long long cpn_gn_stats_doubles(int B, int Cout, long long npos);
+/* residual (same shape as y) or NULL: added to the block's output in the normalisation pass, y = residual + ReLU(GN(conv)) —
+ * the `x + Encoder4D(...)` of models/aggregation.py:306, 347-355 without a separate add over the volume.              */
 int cpn_conv4d_gn_relu(const float* x, const float* wq, const float* bq, const float* ws, const float* bs,
-                       const float* gn_w, const float* gn_b, float eps, int B, int Cin, int Cout,
+                       const float* gn_w, const float* gn_b, const float* residual, float eps, int B, int Cin, int Cout,
                        int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* y, double* stats, float* scratch,
                        void* stream);
 
@@ -284,8 +286,8 @@ int cpn_transpose_pairs(const float* x, int N, int P, int Q, float* y, void* str
  * dy (B,Cout,Hq,Wq,Hs,Ws) -> dx (B,Cin,Hq,Wq,Hs,Ws); Cin % 4 == 0                                                  */
 int cpn_conv4d_dgrad(const float* dy, const float* wq, const float* ws, int B, int Cout, int Cin, int Hq, int Wq, int Hs,
                      int Ws, float* dx, void* stream);
-int cpn_gn_relu(const float* y, const double* stats, const float* gn_w, const float* gn_b, float eps, int B, int C,
-                long long npos, float* out, void* stream);
+int cpn_gn_relu(const float* y, const double* stats, const float* gn_w, const float* gn_b, const float* residual, float eps,
+                int B, int C, long long npos, float* out, void* stream);
 /* backward of GroupNorm(1 group) + ReLU (autograd of models/conv4d.py:150-158): y pre-normalisation volume, out the
  * forward output, dout its gradient, stats the forward sums; red (B*2 + C*2) float64 scratch, zero on entry ->
  * dy (B,C,npos), dgn_w (C), dgn_b (C)                                                                              */
@@ -309,7 +311,8 @@ int cpn_dwconv3x3_wgrad(const float* x, const float* dy, int N, int C, int H, in
 
 /* the same DWConv directly on the token layout x (B, H*W, C) fp32 the feed-forward blocks work in (the reference
  * transposes to (B,C,H,W) around a grouped Conv2d, aggregation.py:18-28): y = bias + w (*) x (flip = 0, forward) or the
- * data gradient w_flipped (*) dy (flip = 1, bias NULL).  w (C,9).  C % 4 == 0.                                        */
+ * data gradient w_flipped (*) dy (flip = 1, bias NULL).  w (C,9).  C % 4 == 0.  flip | 2: the exact GELU that follows the
+ * DWConv in the feed-forward block (aggregation.py:180, nn.GELU()) is applied to y in the same pass (inference).       */
 int cpn_dwconv3x3_tokens(const float* x, const float* w, const float* bias, int B, int H, int W, int C, int flip, float* y,
                          void* stream);
 /* its weight / bias gradient: dw (C,9), db (C, may be NULL), overwritten; partial = scratch of

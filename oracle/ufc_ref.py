@@ -52,9 +52,10 @@ class TorchOps:
     """The `ops` interface of coponerf_amd.getz with CPU restatements."""
 
     @staticmethod
-    def conv4d_gn_relu(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps):
+    def conv4d_gn_relu(x, wq, bq, ws, bs, k, s, p, gn_w, gn_b, eps, residual=None):
         y = conv4d(x, wq, bq, ws, bs, k, s, p)
-        return F.relu(F.group_norm(y, 1, gn_w, gn_b, eps))
+        out = F.relu(F.group_norm(y, 1, gn_w, gn_b, eps))
+        return out if residual is None else residual + out          # the caller's `x + Encoder4D(...)`
 
     @staticmethod
     def dual_softmax(a):
