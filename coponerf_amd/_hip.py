@@ -43,6 +43,10 @@ SIGNATURES: Dict[str, List] = {
     "cpn_wgrad_tall_f16": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
     "cpn_local_hidden_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "cpn_gather_rows_bwd_level3": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_scatter_rows_tables": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_node_features_bwd": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_gather_tail": [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_transpose_pairs": [_P, _I, _I, _I, _P, _P],
@@ -123,6 +127,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_linear_attention_bwd_scratch.restype = ctypes.c_longlong
     handle.cpn_gather_bwd_chunks.argtypes = [_I, _I]
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
+    handle.cpn_scatter_tables_boxes.argtypes = [_I, _I, _I, _I]
+    handle.cpn_scatter_tables_boxes.restype = ctypes.c_longlong
     handle.cpn_conv4d_scratch.argtypes = [_I] * 7
     handle.cpn_conv4d_scratch.restype = ctypes.c_longlong
     handle.cpn_gn_stats_doubles.argtypes = [_I, _I, ctypes.c_longlong]

@@ -432,6 +432,7 @@ constexpr int WAVES = 2;     // waves (= roles) per workgroup
 struct GatherBwdPlan {
     int lvl, tiles_x, tiles, slices, G;                    // roles of this launch: (img, g, tile, slice), slice fastest
     int maxchunks;                                         // chunk slots per image in the bbox scratch
+    int col0;                                              // first column of the level's channels in a gradient row
 };
 
 // the rows that read image `img`: idx in [0, 2*nr*S) -> (first j=0: own view at pixel_val, then j=1: other view at
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
     const int shift = 4 - lvl - (lvl == 3);
     const int Hl = H >> shift, Wl = W >> shift;
     const int C = (lvl == 3) ? 64 : 256;
-    const __half* dcol = dxin + (lvl == 3 ? 768 : lvl * 256) + slice * TC + lane;
+    const __half* dcol = dxin + plan.col0 + slice * TC + lane;
     float* base = (lvl == 0) ? dmap0 : (lvl == 1) ? dmap1 : (lvl == 2) ? dmap2 : dmap3;
 
 #pragma unroll
@@ -668,6 +669,35 @@ extern "C" int cpn_hid_grad_combine(const uint16_t* dkey, const uint16_t* hid, c
     return 0;
 }
 
+static int gather_rows_bwd_launch(const uint16_t* dxin, int ldx, int H, int W, const float* pixel_val, const float* sec_grid,
+                                  int B, int V, int R, int S, int ray0, int nrays, float* dmap0, float* dmap1, float* dmap2,
+                                  float* dmap3, int32_t* chunk_boxes, int first_level, int col3, void* stream) {
+    const int maxchunks = (int)cpn_gather_bwd_chunks(R, S);
+    const int nimg = B * V;
+    const long long nwaves = (long long)nimg * maxchunks;
+    hipLaunchKernelGGL(gather_bbox_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, H, W,
+                       pixel_val, sec_grid, V, R, S, ray0, nrays, maxchunks, nimg, (int4*)chunk_boxes);
+    const long long cand = 2LL * (long long)((nrays + B - 1) / B) * S;       // rows that read one image
+    for (int l = first_level; l < 4; ++l) {
+        GatherBwdPlan plan;
+        const int shift = 4 - l - (l == 3);
+        const int Hl = H >> shift, Wl = W >> shift;
+        plan.lvl = l;
+        plan.col0 = l == 3 ? col3 : l * 256;
+        plan.maxchunks = maxchunks;
+        plan.tiles_x = (Wl + TP - 1) / TP;
+        plan.tiles = plan.tiles_x * ((Hl + TPY - 1) / TPY);
+        plan.slices = (l == 3 ? 64 : 256) / TC;
+        const long long hits = cand / plan.tiles;                            // expected rows landing on one tile
+        plan.G = (int)std::min<long long>(64, std::max<long long>(1, (hits + 1023) / 2048));
+        const int nroles = nimg * plan.G * plan.tiles * plan.slices;
+        hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((nroles + WAVES - 1) / WAVES), dim3(64 * WAVES), 0,
+                           (hipStream_t)stream, (const __half*)dxin, ldx, H, W, pixel_val, sec_grid, V, R, S, ray0,
+                           nrays, dmap0, dmap1, dmap2, dmap3, plan, nroles, (const int4*)chunk_boxes);
+    }
+    return 0;
+}
+
 extern "C" int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float* pixel_val,
                                    const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays,
                                    float* dmap0, float* dmap1, float* dmap2, float* dmap3, int32_t* chunk_boxes,
@@ -681,29 +711,27 @@ extern "C" int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, 
                 "cpn_gather_rows_bwd: ray range outside B*R");
     const long long nrows = (long long)nrays * V * S * 2;
     CPN_REQUIRE(nrows < (1LL << 31), CPN_E_SHAPE, "cpn_gather_rows_bwd: chunk too large for 32-bit indexing");
-    const int maxchunks = (int)cpn_gather_bwd_chunks(R, S);
-    const int nimg = B * V;
-    const long long nwaves = (long long)nimg * maxchunks;
-    hipLaunchKernelGGL(gather_bbox_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, H, W,
-                       pixel_val, sec_grid, V, R, S, ray0, nrays, maxchunks, nimg, (int4*)chunk_boxes);
-    const long long cand = 2LL * (long long)((nrays + B - 1) / B) * S;       // rows that read one image
-    for (int l = 0; l < 4; ++l) {
-        GatherBwdPlan plan;
-        const int shift = 4 - l - (l == 3);
-        const int Hl = H >> shift, Wl = W >> shift;
-        plan.lvl = l;
-        plan.maxchunks = maxchunks;
-        plan.tiles_x = (Wl + TP - 1) / TP;
-        plan.tiles = plan.tiles_x * ((Hl + TPY - 1) / TPY);
-        plan.slices = (l == 3 ? 64 : 256) / TC;
-        const long long hits = cand / plan.tiles;                            // expected rows landing on one tile
-        plan.G = (int)std::min<long long>(64, std::max<long long>(1, (hits + 1023) / 2048));
-        const int nroles = nimg * plan.G * plan.tiles * plan.slices;
-        hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((nroles + WAVES - 1) / WAVES), dim3(64 * WAVES), 0,
-                           (hipStream_t)stream, (const __half*)dxin, ldx, H, W, pixel_val, sec_grid, V, R, S, ray0,
-                           nrays, dmap0, dmap1, dmap2, dmap3, plan, nroles, (const int4*)chunk_boxes);
-    }
+    gather_rows_bwd_launch(dxin, ldx, H, W, pixel_val, sec_grid, B, V, R, S, ray0, nrays, dmap0, dmap1, dmap2, dmap3,
+                           chunk_boxes, 0, 768, stream);
     CPN_LAUNCH_CHECK("cpn_gather_rows_bwd");
+    return 0;
+}
+
+// the full-resolution level alone (table-form backward of the first layer, csrc/encode_bwd.hip): its 64 gradient columns
+// start at column `col0` of the (rows, ldx) fp16 gradient
+extern "C" int cpn_gather_rows_bwd_level3(const uint16_t* dxin, int ldx, int col0, int H, int W, const float* pixel_val,
+                                          const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays,
+                                          float* dmap3, int32_t* chunk_boxes, void* stream) {
+    CPN_REQUIRE(dxin && pixel_val && sec_grid && dmap3 && chunk_boxes, CPN_E_ARG, "cpn_gather_rows_bwd_level3: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && (H % 16) == 0 && (W % 16) == 0 && col0 >= 0 && ldx >= col0 + 64,
+                CPN_E_SHAPE, "cpn_gather_rows_bwd_level3: bad shape");
+    CPN_REQUIRE(H <= 1024 && W <= 1024, CPN_E_SHAPE, "cpn_gather_rows_bwd_level3: maps larger than 1024 pixels a side");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_gather_rows_bwd_level3: ray range outside B*R");
+    CPN_REQUIRE((long long)nrays * V * S * 2 < (1LL << 31), CPN_E_SHAPE, "cpn_gather_rows_bwd_level3: chunk too large");
+    gather_rows_bwd_launch(dxin, ldx, H, W, pixel_val, sec_grid, B, V, R, S, ray0, nrays, dmap3, dmap3, dmap3, dmap3,
+                           chunk_boxes, 3, col0, stream);
+    CPN_LAUNCH_CHECK("cpn_gather_rows_bwd_level3");
     return 0;
 }
 

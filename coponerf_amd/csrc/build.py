@@ -19,6 +19,7 @@ UNITS = [
     ("geometry.hip", ["-ffp-contract=off"]),
     ("gather.hip", []),
     ("encode.hip", []),
+    ("encode_bwd.hip", []),
     ("gemm_f16.hip", []),
     ("attend.hip", []),
     ("linear_f32.hip", []),

@@ -1,0 +1,393 @@
+// Backward of the first encoder layer IN ITS TABLE FORM (round 3; training, BASELINE config 3).
+//
+// Forward (csrc/encode.hip): hid[row] = ReLU( sum_{t<4} a_t T[node_t] + W[:,768:835] . [gather_3 (64) | tanh(pt/5) (3)] + b )
+// with the node tables T = node_features . W[:, :768]^T.  Round 2 differentiated the layer in its ORIGINAL form
+// (/root/reference models/CoPoNeRF.py:312, 370, 384-397): re-gather the 835-channel rows (3.0 ms), weight gradient over
+// 4.2 M rows x 896 (9.1 ms), data gradient GEMM (6.2 ms), scatter of 832 columns into the four maps (9.1 ms).  In the
+// table form the 768 coarse channels never exist per row:
+//
+//   cpn_scatter_rows_tables   dT[node] += a_t * d[row]            (832-wide rows into the fp32 table gradient; the same
+//                             wave-owned LDS tiles as cpn_gather_rows_bwd: no atomic contention)
+//   (host) dW[:, :768] = dT^T . node_features,  dfeat = dT . W[:, :768]      two small GEMMs over 0.28 M nodes
+//   cpn_node_features_bwd     dfeat -> the three coarse maps (adjoint of cpn_node_features, as a gather: no atomics)
+//   cpn_gather_tail           [gather_3 | tanh(pt/5) | 1] per row, 128 wide, for the weight / bias gradient of the
+//                             K = 80 tail (the level-3 data gradient goes through cpn_gather_rows_bwd_level3)
+#include <algorithm>
+
+#include "common.h"
+#include "taps.h"
+
+namespace {
+
+constexpr int PAD = CPN_NODE_PAD;
+constexpr int TLD = CPN_TAB_LD;                    // 832
+
+struct NodeGridB {                                  // same geometry as encode.hip's NodeGrid
+    int Mx, My;
+    __host__ __device__ int w(int kind) const { return Mx + 1 + (kind ? 2 * PAD : 0); }
+    __host__ __device__ int h(int kind) const { return My + 1 + (kind ? 2 * PAD : 0); }
+    __host__ __device__ long long border_nodes() const { return (long long)(Mx + 1) * (My + 1); }
+    __host__ __device__ long long zeros_nodes() const { return (long long)(Mx + 1 + 2 * PAD) * (My + 1 + 2 * PAD); }
+    __host__ __device__ long long per_image() const { return border_nodes() + zeros_nodes(); }
+};
+
+// table coordinates (>= 0) of the node cell of sample coordinate g: EXACTLY node_taps() of encode.hip
+__device__ __forceinline__ void node_cell(float2 g, int kind, const NodeGridB ng, int& xi, int& yi, float& fx, float& fy) {
+    const int pad = kind ? PAD : 0;
+    float tx = (g.x + 1.0f) * (0.5f * (float)ng.Mx), ty = (g.y + 1.0f) * (0.5f * (float)ng.My);
+    tx = fminf(fmaxf(tx, (float)-pad), (float)(ng.Mx + pad));
+    ty = fminf(fmaxf(ty, (float)-pad), (float)(ng.My + pad));
+    const int x0 = min((int)floorf(tx), ng.Mx + pad - 1), y0 = min((int)floorf(ty), ng.My + pad - 1);
+    fx = tx - (float)x0;
+    fy = ty - (float)y0;
+    xi = x0 + pad;
+    yi = y0 + pad;
+}
+
+// rows that read image `img` (same enumeration as backward.hip): idx in [0, per) own view (kind 0, pixel_val),
+// [per, 2 per) other view (kind 1, sec_grid)
+struct RowRefT {
+    unsigned row;
+    float2 g;
+    int j;
+};
+__device__ __forceinline__ RowRefT row_of_t(int idx, int per, int S, int rlo, int b, int vi, int V, int R, int ray0,
+                                            const float* __restrict__ pixel_val, const float* __restrict__ sec_grid) {
+    RowRefT o;
+    o.j = idx >= per;
+    const int rem = idx - o.j * per;
+    const int rr = rem / S, sm = rem - rr * S;
+    const int r = rlo + rr;
+    const int v = o.j ? (V - 1 - vi) : vi;
+    const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + sm;
+    o.g = *reinterpret_cast<const float2*>((o.j ? sec_grid : pixel_val) + sidx * 2);
+    o.row = ((((unsigned)(b * R + r - ray0)) * V + v) * S + sm) * 2 + o.j;
+    return o;
+}
+
+// per 64-row chunk: the node-cell bounding box of its kind-0 rows and of its kind-1 rows (a chunk holds both kinds only
+// where it straddles idx = per)
+__global__ __launch_bounds__(256) void table_bbox_kernel(int H, int W, const float* __restrict__ pixel_val,
+                                                         const float* __restrict__ sec_grid, int V, int R, int S, int ray0,
+                                                         int nrays, int maxchunks, int nimg, int4* __restrict__ bbox) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int img = wid / maxchunks, c = wid - img * maxchunks;
+    if (img >= nimg) return;
+    const int b = img / V, vi = img - b * V;
+    const int rlo = max(ray0, b * R) - b * R, rhi = min(ray0 + nrays, (b + 1) * R) - b * R;
+    const int per = max(rhi - rlo, 0) * S, total = 2 * per;
+    const int idx = c * 64 + lane;
+    const NodeGridB ng{W >> 1, H >> 1};
+    int box[2][4] = {{1 << 30, 1 << 30, -(1 << 30), -(1 << 30)}, {1 << 30, 1 << 30, -(1 << 30), -(1 << 30)}};
+    if (idx < total) {
+        const RowRefT rf = row_of_t(idx, per, S, rlo, b, vi, V, R, ray0, pixel_val, sec_grid);
+        int xi, yi;
+        float fx, fy;
+        node_cell(rf.g, rf.j, ng, xi, yi, fx, fy);
+        box[rf.j][0] = xi; box[rf.j][1] = yi; box[rf.j][2] = xi + 1; box[rf.j][3] = yi + 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            box[k][0] = min(box[k][0], __shfl_xor(box[k][0], o)); box[k][1] = min(box[k][1], __shfl_xor(box[k][1], o));
+            box[k][2] = max(box[k][2], __shfl_xor(box[k][2], o)); box[k][3] = max(box[k][3], __shfl_xor(box[k][3], o));
+        }
+        if (lane == 0) bbox[((size_t)img * maxchunks + c) * 2 + k] = make_int4(box[k][0], box[k][1], box[k][2], box[k][3]);
+    }
+}
+
+constexpr int TP = 8, TPY = 4;      // tile of 8 x 4 nodes
+constexpr int TC = 64;              // channels per slice = lanes
+constexpr int QCAP = 128, NB = 16, WAVES = 2;
+
+struct ScatterPlan {
+    int kind, tiles_x, tiles, G, maxchunks;
+};
+
+// ONE wave owns one (image, kind, 8x4-node tile, 64-channel slice) fp32 accumulator in LDS (lane = channel): scan the
+// chunk boxes 64 at a time, queue the rows whose cell touches the tile, drain the queue 16 rows at a time with the next
+// 16 gradient slices in flight (the structure of gather_rows_bwd_kernel, backward.hip).
+__global__ __launch_bounds__(64 * WAVES) void scatter_tables_kernel(
+    const __half* __restrict__ d, int ldx, int H, int W, const float* __restrict__ pixel_val,
+    const float* __restrict__ sec_grid, int V, int R, int S, int ray0, int nrays, float* __restrict__ dtab,
+    ScatterPlan plan, int nroles, const int4* __restrict__ bbox) {
+    __shared__ float tiles_lds[WAVES][TP * TPY * TC];
+    __shared__ uint4 queue_lds[WAVES][QCAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* tile = tiles_lds[wave];
+    uint4* queue = queue_lds[wave];
+    int role = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
+    if (role >= nroles) return;
+    const int kind = plan.kind, G = plan.G;
+    const int slice = role % (TLD / TC); role /= (TLD / TC);
+    const int tidx = role % plan.tiles; role /= plan.tiles;
+    const int g = role % G;
+    const int img = role / G;
+    const int tx0 = (tidx % plan.tiles_x) * TP, ty0 = (tidx / plan.tiles_x) * TPY;
+    const NodeGridB ng{W >> 1, H >> 1};
+    const int nw = ng.w(kind), nh = ng.h(kind);
+    const __half* dcol = d + slice * TC + lane;
+
+#pragma unroll
+    for (int i = 0; i < TP * TPY; ++i) tile[i * TC + lane] = 0.0f;
+
+    const int b = img / V, vi = img - b * V;
+    const int rlo = max(ray0, b * R) - b * R, rhi = min(ray0 + nrays, (b + 1) * R) - b * R;
+    const int per = max(rhi - rlo, 0) * S, total = 2 * per;
+    // chunks that can hold rows of this kind
+    const int c_lo = kind ? per / 64 : 0, c_hi = kind ? (total + 63) / 64 : (per + 63) / 64;
+    const int nchunks = max(c_hi - c_lo, 0);
+    const int cpg = (nchunks + G - 1) / G;
+    const int c_begin = c_lo + g * cpg, c_end = min(c_hi, c_lo + (g + 1) * cpg);
+    const int4* boxes = bbox + (size_t)img * plan.maxchunks * 2 + kind;
+
+    auto drain = [&](int n) {
+        __half cur[NB], nxt[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) nxt[u] = dcol[(size_t)queue[min(u, n - 1)].x * ldx];
+        for (int i = 0; i < n; i += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) nxt[u] = dcol[(size_t)queue[min(i + NB + u, n - 1)].x * ldx];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (i + u >= n) break;
+                const float du = __half2float(cur[u]);
+                const uint4 q = queue[i + u];
+                const int pk = __builtin_amdgcn_readfirstlane((int)q.y);
+                const float hfx = __uint_as_float(q.z), hfy = __uint_as_float(q.w);
+                const int hx = (pk & 255) - 1, hy = ((pk >> 8) & 255) - 1;
+                float* t = tile + (hy * TP + hx) * TC + lane;
+                if (pk & (1 << 16)) t[0] += du * ((1.0f - hfx) * (1.0f - hfy));
+                if (pk & (2 << 16)) t[TC] += du * (hfx * (1.0f - hfy));
+                if (pk & (4 << 16)) t[TP * TC] += du * ((1.0f - hfx) * hfy);
+                if (pk & (8 << 16)) t[TP * TC + TC] += du * (hfx * hfy);
+            }
+        }
+    };
+
+    int qn = 0;
+    for (int cb = c_begin; cb < c_end; cb += 64) {
+        bool maybe = false;
+        if (cb + lane < c_end) {
+            const int4 bx = boxes[(size_t)(cb + lane) * 2];
+            maybe = (bx.z >= tx0) && (bx.x < tx0 + TP) && (bx.w >= ty0) && (bx.y < ty0 + TPY);
+        }
+        unsigned long long cmask = __ballot(maybe);
+        while (cmask) {
+            const int c = cb + (int)__builtin_ctzll(cmask);
+            cmask &= cmask - 1;
+            const int idx = c * 64 + lane;
+            uint4 desc = make_uint4(0, 0, 0, 0);
+            int flags = 0;
+            if (idx < total) {
+                const RowRefT rf = row_of_t(idx, per, S, rlo, b, vi, V, R, ray0, pixel_val, sec_grid);
+                if (rf.j == kind) {
+                    int xi, yi;
+                    float fx, fy;
+                    node_cell(rf.g, kind, ng, xi, yi, fx, fy);
+                    const int hx = xi - tx0, hy = yi - ty0;
+                    if (hx >= -1 && hx < TP && hy >= -1 && hy < TPY) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int xk = xi + (k & 1), yk = yi + (k >> 1);
+                            const float wk = ((k & 1) ? fx : 1.0f - fx) * ((k >> 1) ? fy : 1.0f - fy);
+                            const bool in_tile = (xk >= tx0) && (xk < tx0 + TP) && (yk >= ty0) && (yk < ty0 + TPY);
+                            if (in_tile && wk != 0.0f) flags |= 1 << k;
+                        }
+                        desc.x = rf.row;
+                        desc.y = (unsigned)((hx + 1) | ((hy + 1) << 8) | (flags << 16));
+                        desc.z = __float_as_uint(fx);
+                        desc.w = __float_as_uint(fy);
+                    }
+                }
+            }
+            const unsigned long long mask = __ballot(flags != 0);
+            if (mask) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (flags) queue[qn + pos] = desc;
+                __builtin_amdgcn_wave_barrier();
+                qn += __builtin_popcountll(mask);
+                if (qn > QCAP - 64) { drain(qn); qn = 0; }
+            }
+        }
+    }
+    if (qn) drain(qn);
+
+    float* m = dtab + ((size_t)img * ng.per_image() + (kind ? ng.border_nodes() : 0)) * TLD + slice * TC + lane;
+#pragma unroll 4
+    for (int pix = 0; pix < TP * TPY; ++pix) {
+        const float v = tile[pix * TC + lane];
+        const int gy = ty0 + (pix >> 3), gx = tx0 + (pix & 7);
+        if (v != 0.0f && gy < nh && gx < nw) {
+            if (G > 1) atomicAdd(m + ((size_t)gy * nw + gx) * TLD, v);
+            else m[((size_t)gy * nw + gx) * TLD] = v;           // the tile's only writer: dtab is zero on entry
+        }
+    }
+}
+
+// ---- adjoint of node_features_kernel as a gather: wave = one texel of one coarse level, lane = 4 channels ----------
+// dmap[img, ty, tx, c] = sum over the nodes of both tables of the image whose grid_sample footprint at this level
+// contains the texel, of weight * dfeat[node, lvl*256 + c].  The candidate nodes of texel tx are nx in
+// [p (tx - 1/2), p (tx + 3/2)) (p = node pitch of the level's texels: 8, 4, 2) plus, at the map edge of the border table,
+// everything beyond (clamped coordinates); each candidate is re-evaluated with the forward's own make_taps().
+__global__ __launch_bounds__(256) void node_features_bwd_kernel(const float* __restrict__ dfeat, int H, int W, int nimg,
+                                                                float* __restrict__ dmap0, float* __restrict__ dmap1,
+                                                                float* __restrict__ dmap2, long long nwaves) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const long long t0 = (long long)nimg * (H >> 4) * (W >> 4), t1 = (long long)nimg * (H >> 3) * (W >> 3);
+    const int lvl = wid < t0 ? 0 : (wid < t0 + t1 ? 1 : 2);
+    long long rem = wid - (lvl == 0 ? 0 : (lvl == 1 ? t0 : t0 + t1));
+    const int shift = 4 - lvl, Hl = H >> shift, Wl = W >> shift, p = 8 >> lvl;
+    const int tx = (int)(rem % Wl); rem /= Wl;
+    const int ty = (int)(rem % Hl);
+    const int img = (int)(rem / Hl);
+    const NodeGridB ng{W >> 1, H >> 1};
+    const int texel = ty * Wl + tx;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kind = 0; kind < 2; ++kind) {
+        const int pad = kind ? PAD : 0, nw = ng.w(kind);
+        int x_lo = max(p * tx - p, -pad), x_hi = min(p * tx + 2 * p, ng.Mx + pad);
+        int y_lo = max(p * ty - p, -pad), y_hi = min(p * ty + 2 * p, ng.My + pad);
+        if (!kind) {                                           // border padding: clamped coordinates pile up on the edge texels
+            if (tx == 0) x_lo = 0;
+            if (tx == Wl - 1) x_hi = ng.Mx;
+            if (ty == 0) y_lo = 0;
+            if (ty == Hl - 1) y_hi = ng.My;
+        }
+        const float* base = dfeat + ((size_t)img * ng.per_image() + (kind ? ng.border_nodes() : 0)) * 768 + lvl * 256 + lane * 4;
+        for (int ny = y_lo; ny <= y_hi; ++ny)
+            for (int nx = x_lo; nx <= x_hi; ++nx) {
+                const float gx = (float)(2 * nx - ng.Mx) / (float)ng.Mx, gy = (float)(2 * ny - ng.My) / (float)ng.My;
+                const Taps tp = make_taps(gx, gy, Wl, Hl, kind == 0);
+                float wsum = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wsum += (tp.off[k] == texel) ? tp.w[k] : 0.0f;
+                if (wsum != 0.0f) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)(ny + pad) * nw + (nx + pad)) * 768);
+                    acc += wsum * v;
+                }
+            }
+    }
+    float* out = (lvl == 0 ? dmap0 : lvl == 1 ? dmap1 : dmap2) + (((size_t)img * Hl + ty) * Wl + tx) * 256 + lane * 4;
+    *reinterpret_cast<f32x4*>(out) = acc;
+}
+
+// ---- the K = 80 tail of the layer's input per row, 128 fp16 wide: [gather_3 (64) | tanh(pt/5) (3) | 1 | 0 x 60] ----------
+// the arithmetic of encode_hidden_kernel's operand (4 texels blended in fp32 in tap order, one rounding to fp16)
+__global__ __launch_bounds__(256) void gather_tail_kernel(const __half* __restrict__ map3, int H, int W,
+                                                          const float* __restrict__ pixel_val,
+                                                          const float* __restrict__ sec_grid, const float* __restrict__ pe6,
+                                                          int V, int R, int S, int ray0, long long nrows,
+                                                          __half* __restrict__ xt) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * 16) return;
+    const int piece = (int)(idx & 15);
+    const long long row = idx >> 4;
+    const int j = (int)(row & 1);
+    long long t = row >> 1;
+    const int s = (int)(t % S); t /= S;
+    const int v = (int)(t % V); t /= V;
+    const long long ray = t + ray0;
+    const int b = (int)(ray / R), r = (int)(ray - (long long)b * R);
+    const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + s;
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.0f;
+    if (piece < 8) {
+        const float2 g = *reinterpret_cast<const float2*>((j ? sec_grid : pixel_val) + sidx * 2);
+        const Taps t3 = make_taps(g.x, g.y, W, H, j == 0);
+        const int img = b * V + (j ? V - 1 - v : v);
+        const __half* m3 = map3 + (size_t)img * H * W * 64 + piece * 8;
+        float a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const half8 tv = *reinterpret_cast<const half8*>(m3 + (size_t)(unsigned)t3.off[k] * 64);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a8[e] = fmaf((float)tv[e], t3.w[k], a8[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)a8[e];
+    } else if (piece == 8) {
+        const float* pe = pe6 + sidx * 6 + j * 3;
+        o[0] = (_Float16)pe[0]; o[1] = (_Float16)pe[1]; o[2] = (_Float16)pe[2];
+        o[3] = (_Float16)1.0f;                                 // the bias column
+    }
+    *reinterpret_cast<half8*>(xt + row * 128 + piece * 8) = o;
+}
+
+}  // namespace
+
+extern "C" long long cpn_scatter_tables_boxes(int B, int V, int R, int S) {
+    return (long long)B * V * ((2LL * R * S + 63) / 64) * 8;             // int32 entries of the chunk-box scratch
+}
+
+extern "C" int cpn_scatter_rows_tables(const uint16_t* d, int ldx, int H, int W, const float* pixel_val,
+                                       const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays, float* dtab,
+                                       int32_t* chunk_boxes, void* stream) {
+    CPN_REQUIRE(d && pixel_val && sec_grid && dtab && chunk_boxes, CPN_E_ARG, "cpn_scatter_rows_tables: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && (H % 16) == 0 && (W % 16) == 0 && ldx >= TLD, CPN_E_SHAPE,
+                "cpn_scatter_rows_tables: bad shape");
+    CPN_REQUIRE(H <= 1024 && W <= 1024, CPN_E_SHAPE, "cpn_scatter_rows_tables: maps larger than 1024 pixels a side");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_scatter_rows_tables: ray range outside B*R");
+    CPN_REQUIRE((long long)nrays * V * S * 2 < (1LL << 31), CPN_E_SHAPE, "cpn_scatter_rows_tables: chunk too large");
+    const hipStream_t st = (hipStream_t)stream;
+    const int maxchunks = (int)((2LL * R * S + 63) / 64), nimg = B * V;
+    const long long nwaves = (long long)nimg * maxchunks;
+    hipLaunchKernelGGL(table_bbox_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, H, W, pixel_val, sec_grid, V,
+                       R, S, ray0, nrays, maxchunks, nimg, (int4*)chunk_boxes);
+    const NodeGridB ng{W >> 1, H >> 1};
+    const long long cand = (long long)((nrays + B - 1) / B) * S;            // rows of one kind that read one image
+    for (int kind = 0; kind < 2; ++kind) {
+        ScatterPlan plan;
+        plan.kind = kind;
+        plan.maxchunks = maxchunks;
+        plan.tiles_x = (ng.w(kind) + TP - 1) / TP;
+        plan.tiles = plan.tiles_x * ((ng.h(kind) + TPY - 1) / TPY);
+        const long long hits = cand / plan.tiles;
+        plan.G = (int)std::min<long long>(64, std::max<long long>(1, (hits + 1023) / 2048));
+        const long long nroles = (long long)nimg * plan.G * plan.tiles * (TLD / TC);
+        CPN_REQUIRE(nroles < (1LL << 31), CPN_E_SHAPE, "cpn_scatter_rows_tables: too many roles");
+        hipLaunchKernelGGL(scatter_tables_kernel, dim3((unsigned)((nroles + WAVES - 1) / WAVES)), dim3(64 * WAVES), 0, st,
+                           (const __half*)d, ldx, H, W, pixel_val, sec_grid, V, R, S, ray0, nrays, dtab, plan, (int)nroles,
+                           (const int4*)chunk_boxes);
+    }
+    CPN_LAUNCH_CHECK("cpn_scatter_rows_tables");
+    return 0;
+}
+
+extern "C" int cpn_node_features_bwd(const float* dfeat, int H, int W, int nimg, float* dmap0, float* dmap1, float* dmap2,
+                                     void* stream) {
+    CPN_REQUIRE(dfeat && dmap0 && dmap1 && dmap2, CPN_E_ARG, "cpn_node_features_bwd: null pointer");
+    CPN_REQUIRE(nimg > 0 && H >= 16 && W >= 16 && (H % 16) == 0 && (W % 16) == 0, CPN_E_SHAPE,
+                "cpn_node_features_bwd: need H,W multiples of 16 (got H=%d W=%d)", H, W);
+    CPN_REQUIRE(((uintptr_t)dfeat % 16) == 0 && ((uintptr_t)dmap0 % 16) == 0 && ((uintptr_t)dmap1 % 16) == 0 &&
+                    ((uintptr_t)dmap2 % 16) == 0, CPN_E_ARG, "cpn_node_features_bwd: pointers must be 16-byte aligned");
+    const long long nwaves = (long long)nimg * ((long long)(H >> 4) * (W >> 4) + (long long)(H >> 3) * (W >> 3) +
+                                                (long long)(H >> 2) * (W >> 2));
+    hipLaunchKernelGGL(node_features_bwd_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dfeat,
+                       H, W, nimg, dmap0, dmap1, dmap2, nwaves);
+    CPN_LAUNCH_CHECK("cpn_node_features_bwd");
+    return 0;
+}
+
+extern "C" int cpn_gather_tail(const uint16_t* map3, int H, int W, const float* pixel_val, const float* sec_grid,
+                               const float* pe6, int B, int V, int R, int S, int ray0, int nrays, uint16_t* xt,
+                               void* stream) {
+    CPN_REQUIRE(map3 && pixel_val && sec_grid && pe6 && xt, CPN_E_ARG, "cpn_gather_tail: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H > 0 && W > 0, CPN_E_SHAPE, "cpn_gather_tail: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_gather_tail: ray range outside B*R");
+    CPN_REQUIRE(((uintptr_t)map3 % 16) == 0 && ((uintptr_t)xt % 16) == 0, CPN_E_ARG, "cpn_gather_tail: pointers must be 16-byte aligned");
+    const long long nrows = (long long)nrays * V * S * 2;
+    hipLaunchKernelGGL(gather_tail_kernel, dim3((unsigned)cpn_cdiv(nrows * 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __half*)map3, H, W, pixel_val, sec_grid, pe6, V, R, S, ray0, nrows, (__half*)xt);
+    CPN_LAUNCH_CHECK("cpn_gather_tail");
+    return 0;
+}

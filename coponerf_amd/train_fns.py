@@ -10,6 +10,8 @@ detached in the reference (models/CoPoNeRF.py:244, 380-381, 433), so geometry ru
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -46,6 +48,11 @@ class GradScale:
     def scaled16(self, d: torch.Tensor) -> torch.Tensor:
         """Incoming gradient -> the scaled representation (fp16 tensors already carry the scale)."""
         return d if d.dtype == torch.float16 else d * self.ensure(d)
+
+
+# first-layer backward in the table form (csrc/encode_bwd.hip); COPONERF_TABLE_BACKWARD=0 restores the round-2 form
+# (re-gather + 835-wide weight-gradient GEMM + data-gradient GEMM + 832-column scatter into the maps)
+TABLE_BACKWARD = os.environ.get("COPONERF_TABLE_BACKWARD", "1") != "0"
 
 
 class HidGradParts:
@@ -294,14 +301,81 @@ class EncodeFn(Function):
              pe6.data_ptr(), frag.data_ptr(), bc.data_ptr(), B, V, R, S, 0, nrays, hid.data_ptr(), s)
         W16 = torch.zeros(832, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
         call("cpn_pack_weight_f16", Wc.data_ptr(), 832, Wc.shape[1], W16.data_ptr(), _hip.XIN_STRIDE, s)
-        ctx.save_for_backward(maps[0], maps[1], maps[2], maps[3], pixel_val, sec_grid, pe6, W16, hid)
+        if TABLE_BACKWARD:
+            del tab, maps[0], maps[0], maps[0]                           # maps is now [level 3]
+            ctx.save_for_backward(maps[0], pixel_val, sec_grid, pe6, W16, hid, feat, wtab)
+        else:
+            ctx.save_for_backward(maps[0], maps[1], maps[2], maps[3], pixel_val, sec_grid, pe6, W16, hid)
+        ctx.table_bwd = TABLE_BACKWARD
         ctx.dims, ctx.HW, ctx.gs, ctx.hid_parts, ctx.K = dims, HW, gs, hid_parts, Wc.shape[1]
         ctx.shapes = [tuple(t.shape) for t in (z0, z1, z2, z3)]
         return hid
 
     @staticmethod
+    def _backward_tables(ctx, d16):
+        """The layer differentiated in its table form (csrc/encode_bwd.hip): one 832-wide scatter into the node tables,
+        two small GEMMs over the 0.28 M nodes, the adjoint of the node sampling, and the K = 80 tail (full-resolution
+        level, point encoding, bias) on 128-wide operands — instead of a re-gather, a 4.2 M x 832 x 896 weight-gradient
+        GEMM, a 4.2 M x 832 x 832 data-gradient GEMM and an 832-column scatter into four maps."""
+        m3, pixel_val, sec_grid, pe6, W16, hid, feat, wtab = ctx.saved_tensors
+        B, V, R, S = ctx.dims
+        H, Wd = ctx.HW
+        s = _stream()
+        dev = d16.device
+        lib = _hip.lib()
+        nimg = B * V
+        nodes = nimg * int(lib.cpn_encode_table_nodes(H, Wd))
+        gs = ctx.gs.s
+        # ---- table gradient (fp32, carries the pass's scale gs)
+        dT = torch.zeros(nodes, _hip.TAB_LD, dtype=torch.float32, device=dev)
+        boxes = torch.empty(int(lib.cpn_scatter_tables_boxes(B, V, R, S)), dtype=torch.int32, device=dev)
+        call("cpn_scatter_rows_tables", d16.data_ptr(), d16.shape[1], H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V,
+             R, S, 0, B * R, dT.data_ptr(), boxes.data_ptr(), s)
+        # a node sums up to thousands of rows: its own power-of-two scale for the fp16 GEMM operands (device side, no sync)
+        s2 = torch.exp2(torch.floor(torch.log2(4096.0 / dT.abs().amax().clamp_min(1e-30)))).clamp(2.0 ** -40, 2.0 ** 40)
+        dT16 = (dT * s2).to(torch.float16)
+        del dT
+        both = (gs * s2).reshape(1)
+        dWtab = _wgrad_tall(dT16, feat, both) if ctx.needs_input_grad[4] else None               # (832, 768)
+        g = [None] * 4
+        if any(ctx.needs_input_grad[:4]):
+            dfeat = _mm_f32(dT16, wtab)                                                          # (nodes, 768), scale gs*s2
+            shapes = ctx.shapes
+            dm = [torch.empty(n, h, w_, c, dtype=torch.float32, device=dev) for (n, c, h, w_) in shapes[:3]]
+            call("cpn_node_features_bwd", dfeat.data_ptr(), H, Wd, nimg, dm[0].data_ptr(), dm[1].data_ptr(), dm[2].data_ptr(), s)
+            del dfeat
+            inv2 = 1.0 / both
+            g[:3] = [m.mul_(inv2).permute(0, 3, 1, 2).contiguous() for m in dm]
+            # ---- full-resolution level: data gradient of its 64 columns, scattered into the map
+            Wt = torch.zeros(832, 128, dtype=torch.float16, device=dev)
+            Wt[:, :64] = W16[:, 768:832]
+            dA = _data_grad(d16, Wt)                                                             # (rows, 128) fp16, scale gs
+            n3, c3, h3, w3 = shapes[3]
+            dm3 = torch.zeros(n3, h3, w3, c3, dtype=torch.float32, device=dev)
+            boxes3 = torch.empty(B * V * lib.cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=dev)
+            call("cpn_gather_rows_bwd_level3", dA.data_ptr(), dA.shape[1], 0, H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
+                 B, V, R, S, 0, B * R, dm3.data_ptr(), boxes3.data_ptr(), s)
+            del dA
+            g[3] = dm3.mul_(1.0 / gs).permute(0, 3, 1, 2).contiguous()
+        dW = db = None
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            xt = torch.empty(d16.shape[0], 128, dtype=torch.float16, device=dev)
+            call("cpn_gather_tail", m3.data_ptr(), H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S,
+                 0, B * R, xt.data_ptr(), s)
+            dWt = _wgrad_tall(d16, xt, gs)                                                       # (832, 128)
+            if ctx.needs_input_grad[4]:
+                dW = torch.cat((dWtab, dWt[:, :ctx.K - 768]), dim=1)
+            if ctx.needs_input_grad[5]:
+                db = dWt[:, ctx.K - 768].contiguous()
+        return g[0], g[1], g[2], g[3], dW, db, None, None, None, None, None, None, None
+
+    @staticmethod
     def backward(ctx, dC):
-        m0, m1, m2, m3, pixel_val, sec_grid, pe6, W16, hid = ctx.saved_tensors
+        if ctx.table_bwd:
+            hid = ctx.saved_tensors[5]
+            pixel_val = sec_grid = None
+        else:
+            m0, m1, m2, m3, pixel_val, sec_grid, pe6, W16, hid = ctx.saved_tensors
         B, V, R, S = ctx.dims
         H, Wd = ctx.HW
         s = _stream()
@@ -316,6 +390,8 @@ class EncodeFn(Function):
         if ctx.hid_parts is not None:
             ctx.hid_parts.parts = []
         del d
+        if ctx.table_bwd:
+            return EncodeFn._backward_tables(ctx, d16)
         inv = 1.0 / ctx.gs.s
         rows = hid.shape[0]
         xin = torch.empty(rows, _hip.XIN_STRIDE, dtype=torch.float16, device=hid.device)

@@ -251,6 +251,30 @@ long long cpn_gather_bwd_chunks(int R, int S);
 int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float* pixel_val, const float* sec_grid,
                         int B, int V, int R, int S, int ray0, int nrays,
                         float* dmap0, float* dmap1, float* dmap2, float* dmap3, int32_t* chunk_boxes, void* stream);
+/* the full-resolution level alone: its 64 gradient columns start at column col0 of dxin (rows, ldx); dmap3 (N,H,W,64) fp32
+ * accumulated (caller zeroes); chunk_boxes as above.                                                                 */
+int cpn_gather_rows_bwd_level3(const uint16_t* dxin, int ldx, int col0, int H, int W, const float* pixel_val,
+                               const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays, float* dmap3,
+                               int32_t* chunk_boxes, void* stream);
+
+/* ---- backward of cpn_encode_hidden in its table form (round 3, csrc/encode_bwd.hip) ---------------------------------
+ * The layer is hid = ReLU(sum_t a_t T[node_t] + W[:,768:835].[gather_3 | tanh(pt/5)] + b) with T = node_features . W[:,:768]^T
+ * (replaces autograd through models/CoPoNeRF.py:312, 370, 384-397 for training).  d (rows, ldx >= 832) fp16 = gradient
+ * of the pre-activation (ReLU mask applied, carrying the pass's power-of-two scale).
+ *   cpn_scatter_rows_tables: dtab (N * cpn_encode_table_nodes(H,W), 832) fp32, ZERO on entry, += a_t * d[row] at the four
+ *       nodes of every row (own image -> border table, other image -> zeros table; the taps of cpn_encode_hidden).
+ *       chunk_boxes: scratch of cpn_scatter_tables_boxes(B,V,R,S) int32.
+ *   cpn_node_features_bwd: adjoint of cpn_node_features: dfeat (nodes, 768) fp32 -> dmap0..2 (N,h,w,256) fp32 NHWC,
+ *       OVERWRITTEN (every texel is written once: a gather over the nodes whose footprint holds it, no atomics).
+ *   cpn_gather_tail: xt (rows, 128) fp16 = [bilinear gather of the full-resolution map (64) | tanh(pt/5) (3) | 1 | 0 x 60],
+ *       the K = 80 operand of the forward kernel with a ones column for the bias gradient.                            */
+long long cpn_scatter_tables_boxes(int B, int V, int R, int S);
+int cpn_scatter_rows_tables(const uint16_t* d, int ldx, int H, int W, const float* pixel_val, const float* sec_grid, int B,
+                            int V, int R, int S, int ray0, int nrays, float* dtab, int32_t* chunk_boxes, void* stream);
+int cpn_node_features_bwd(const float* dfeat, int H, int W, int nimg, float* dmap0, float* dmap1, float* dmap2,
+                          void* stream);
+int cpn_gather_tail(const uint16_t* map3, int H, int W, const float* pixel_val, const float* sec_grid, const float* pe6,
+                    int B, int V, int R, int S, int ray0, int nrays, uint16_t* xt, void* stream);
 
 /* ==== get_z path: the 4-D operators of UFC =========================== */
 
