@@ -46,6 +46,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_gather_rows_bwd_level3": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_scatter_rows_tables": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_node_features_bwd": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_scale_to_f16": [_P, ctypes.c_longlong, _F, _P, _P, _P, _P],
     "cpn_gather_tail": [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_conv4d_gn_relu": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_conv4d": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -13,6 +13,7 @@
 //   cpn_gather_tail           [gather_3 | tanh(pt/5) | 1] per row, 128 wide, for the weight / bias gradient of the
 //                             K = 80 tail (the level-3 data gradient goes through cpn_gather_rows_bwd_level3)
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "taps.h"
@@ -100,38 +101,46 @@ __global__ __launch_bounds__(256) void table_bbox_kernel(int H, int W, const flo
 
 constexpr int TP = 8, TPY = 4;      // tile of 8 x 4 nodes
 constexpr int TC = 64;              // channels per slice = lanes
-constexpr int QCAP = 128, NB = 16, WAVES = 2;
+constexpr int SW = TLD / TC;        // 13 waves per workgroup: one per 64-channel slice of the 832-wide rows
+constexpr int QCAP = 2048;          // shared descriptor queue (32 KB)
+constexpr int NB = 16;              // rows per drain batch
 
 struct ScatterPlan {
     int kind, tiles_x, tiles, G, maxchunks;
+    int scan_only;                  // timing-only ablation (CPN_SCATTER_SCAN_ONLY=1 in the environment): rows are queued, not accumulated
 };
 
-// ONE wave owns one (image, kind, 8x4-node tile, 64-channel slice) fp32 accumulator in LDS (lane = channel): scan the
-// chunk boxes 64 at a time, queue the rows whose cell touches the tile, drain the queue 16 rows at a time with the next
-// 16 gradient slices in flight (the structure of gather_rows_bwd_kernel, backward.hip).
-__global__ __launch_bounds__(64 * WAVES) void scatter_tables_kernel(
+// ONE WORKGROUP of 13 waves owns one (image, kind, 8x4-node tile): wave w accumulates the 64-channel slice w of the rows
+// whose cell touches the tile in its own 8 KB fp32 LDS tile (lane = channel, no atomics).  The row search is done ONCE for
+// the 13 slices: 832 chunk boxes are tested per step (thread = chunk), the candidate chunks are handed out one per wave
+// (lane = row) and the rows that really touch the tile go into ONE shared queue, which all 13 waves then drain for their
+// slice (16 rows at a time, the next 16 gradient slices in flight) — the 13 x 128 bytes of a row are read by waves that
+// run together.  With one wave per (tile, slice) (first version: 9.6 ms per step) every slice repeated the search
+// (3.4 ms of the 9.6) and read its 128 bytes of a row on its own.
+__global__ __launch_bounds__(64 * SW) void scatter_tables_kernel(
     const __half* __restrict__ d, int ldx, int H, int W, const float* __restrict__ pixel_val,
     const float* __restrict__ sec_grid, int V, int R, int S, int ray0, int nrays, float* __restrict__ dtab,
-    ScatterPlan plan, int nroles, const int4* __restrict__ bbox) {
-    __shared__ float tiles_lds[WAVES][TP * TPY * TC];
-    __shared__ uint4 queue_lds[WAVES][QCAP];
+    ScatterPlan plan, const int4* __restrict__ bbox) {
+    __shared__ float tiles_lds[SW][TP * TPY * TC];
+    __shared__ uint4 queue[QCAP];
+    __shared__ int cand[64 * SW];
+    __shared__ int ncand[SW], wcount[SW];
+    __shared__ int qn_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tile = tiles_lds[wave];
-    uint4* queue = queue_lds[wave];
-    int role = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
-    if (role >= nroles) return;
+    int role = blockIdx.x;
     const int kind = plan.kind, G = plan.G;
-    const int slice = role % (TLD / TC); role /= (TLD / TC);
     const int tidx = role % plan.tiles; role /= plan.tiles;
     const int g = role % G;
     const int img = role / G;
     const int tx0 = (tidx % plan.tiles_x) * TP, ty0 = (tidx / plan.tiles_x) * TPY;
     const NodeGridB ng{W >> 1, H >> 1};
     const int nw = ng.w(kind), nh = ng.h(kind);
-    const __half* dcol = d + slice * TC + lane;
+    const __half* dcol = d + wave * TC + lane;
 
 #pragma unroll
     for (int i = 0; i < TP * TPY; ++i) tile[i * TC + lane] = 0.0f;
+    if (threadIdx.x == 0) qn_s = 0;
 
     const int b = img / V, vi = img - b * V;
     const int rlo = max(ray0, b * R) - b * R, rhi = min(ray0 + nrays, (b + 1) * R) - b * R;
@@ -142,8 +151,10 @@ __global__ __launch_bounds__(64 * WAVES) void scatter_tables_kernel(
     const int cpg = (nchunks + G - 1) / G;
     const int c_begin = c_lo + g * cpg, c_end = min(c_hi, c_lo + (g + 1) * cpg);
     const int4* boxes = bbox + (size_t)img * plan.maxchunks * 2 + kind;
+    __syncthreads();
 
-    auto drain = [&](int n) {
+    auto drain = [&](int n) {                                  // all waves, the same n queue entries, each for its slice
+        if (plan.scan_only) return;
         __half cur[NB], nxt[NB];
 #pragma unroll
         for (int u = 0; u < NB; ++u) nxt[u] = dcol[(size_t)queue[min(u, n - 1)].x * ldx];
@@ -169,55 +180,92 @@ __global__ __launch_bounds__(64 * WAVES) void scatter_tables_kernel(
         }
     };
 
-    int qn = 0;
-    for (int cb = c_begin; cb < c_end; cb += 64) {
-        bool maybe = false;
-        if (cb + lane < c_end) {
-            const int4 bx = boxes[(size_t)(cb + lane) * 2];
-            maybe = (bx.z >= tx0) && (bx.x < tx0 + TP) && (bx.w >= ty0) && (bx.y < ty0 + TPY);
+    for (int cb = c_begin; cb < c_end; cb += 64 * SW) {
+        // A1: thread = chunk, conservative box test; wave w compacts the candidates among its 64 chunks into cand[w][..]
+        //     in chunk order (a fixed layout whatever the wave timing: the per-node sums are formed in queue order, so
+        //     the result does not depend on scheduling)
+        {
+            const int c = cb + (int)threadIdx.x;
+            bool maybe = false;
+            if (c < c_end) {
+                const int4 bx = boxes[(size_t)c * 2];
+                maybe = (bx.z >= tx0) && (bx.x < tx0 + TP) && (bx.w >= ty0) && (bx.y < ty0 + TPY);
+            }
+            const unsigned long long m = __ballot(maybe);
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (maybe) cand[wave * 64 + pos] = c;
+            if (lane == 0) ncand[wave] = (int)__builtin_popcountll(m);
         }
-        unsigned long long cmask = __ballot(maybe);
-        while (cmask) {
-            const int c = cb + (int)__builtin_ctzll(cmask);
-            cmask &= cmask - 1;
-            const int idx = c * 64 + lane;
+        __syncthreads();
+        int prefix[SW + 1];
+        prefix[0] = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < SW; ++w2) prefix[w2 + 1] = prefix[w2] + ncand[w2];
+        const int totalc = prefix[SW];
+        // A2: the candidates in that order, 13 at a time: ONE wave evaluates the 64 rows of a chunk (lane = row); the rows
+        //     that touch the tile are appended to the shared queue in (candidate, row) order
+        for (int base = 0; base < totalc; base += SW) {
+            const int ci = base + wave;
             uint4 desc = make_uint4(0, 0, 0, 0);
             int flags = 0;
-            if (idx < total) {
-                const RowRefT rf = row_of_t(idx, per, S, rlo, b, vi, V, R, ray0, pixel_val, sec_grid);
-                if (rf.j == kind) {
-                    int xi, yi;
-                    float fx, fy;
-                    node_cell(rf.g, kind, ng, xi, yi, fx, fy);
-                    const int hx = xi - tx0, hy = yi - ty0;
-                    if (hx >= -1 && hx < TP && hy >= -1 && hy < TPY) {
+            if (ci < totalc) {
+                int slot = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int xk = xi + (k & 1), yk = yi + (k >> 1);
-                            const float wk = ((k & 1) ? fx : 1.0f - fx) * ((k >> 1) ? fy : 1.0f - fy);
-                            const bool in_tile = (xk >= tx0) && (xk < tx0 + TP) && (yk >= ty0) && (yk < ty0 + TPY);
-                            if (in_tile && wk != 0.0f) flags |= 1 << k;
+                for (int w2 = 1; w2 < SW; ++w2) slot += (ci >= prefix[w2]) ? 1 : 0;
+                const int c = cand[slot * 64 + (ci - prefix[slot])];
+                const int idx = c * 64 + lane;
+                if (idx < total) {
+                    const RowRefT rf = row_of_t(idx, per, S, rlo, b, vi, V, R, ray0, pixel_val, sec_grid);
+                    if (rf.j == kind) {
+                        int xi, yi;
+                        float fx, fy;
+                        node_cell(rf.g, kind, ng, xi, yi, fx, fy);
+                        const int hx = xi - tx0, hy = yi - ty0;
+                        if (hx >= -1 && hx < TP && hy >= -1 && hy < TPY) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int xk = xi + (k & 1), yk = yi + (k >> 1);
+                                const float wk = ((k & 1) ? fx : 1.0f - fx) * ((k >> 1) ? fy : 1.0f - fy);
+                                const bool in_tile = (xk >= tx0) && (xk < tx0 + TP) && (yk >= ty0) && (yk < ty0 + TPY);
+                                if (in_tile && wk != 0.0f) flags |= 1 << k;
+                            }
+                            desc.x = rf.row;
+                            desc.y = (unsigned)((hx + 1) | ((hy + 1) << 8) | (flags << 16));
+                            desc.z = __float_as_uint(fx);
+                            desc.w = __float_as_uint(fy);
                         }
-                        desc.x = rf.row;
-                        desc.y = (unsigned)((hx + 1) | ((hy + 1) << 8) | (flags << 16));
-                        desc.z = __float_as_uint(fx);
-                        desc.w = __float_as_uint(fy);
                     }
                 }
             }
             const unsigned long long mask = __ballot(flags != 0);
-            if (mask) {
+            if (lane == 0) wcount[wave] = (int)__builtin_popcountll(mask);
+            __syncthreads();
+            int off = qn_s, tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < SW; ++w2) {
+                const int n2 = wcount[w2];
+                off += (w2 < wave) ? n2 : 0;
+                tot += n2;
+            }
+            if (flags) {
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                if (flags) queue[qn + pos] = desc;
-                __builtin_amdgcn_wave_barrier();
-                qn += __builtin_popcountll(mask);
-                if (qn > QCAP - 64) { drain(qn); qn = 0; }
+                queue[off + pos] = desc;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) qn_s += tot;
+            __syncthreads();
+            if (qn_s > QCAP - 64 * SW) {                       // uniform across the workgroup: the next group always fits
+                drain(qn_s);
+                __syncthreads();
+                if (threadIdx.x == 0) qn_s = 0;
+                __syncthreads();
             }
         }
+        __syncthreads();
     }
-    if (qn) drain(qn);
+    if (qn_s) drain(qn_s);
 
-    float* m = dtab + ((size_t)img * ng.per_image() + (kind ? ng.border_nodes() : 0)) * TLD + slice * TC + lane;
+    float* m = dtab + ((size_t)img * ng.per_image() + (kind ? ng.border_nodes() : 0)) * TLD + wave * TC + lane;
 #pragma unroll 4
     for (int pix = 0; pix < TP * TPY; ++pix) {
         const float v = tile[pix * TC + lane];
@@ -321,7 +369,54 @@ __global__ __launch_bounds__(256) void gather_tail_kernel(const __half* __restri
     *reinterpret_cast<half8*>(xt + row * 128 + piece * 8) = o;
 }
 
+// ---- fp32 -> fp16 with a power-of-two scale chosen on the device: two passes over the data instead of the five of
+//      abs / amax / mul / convert as separate tensor ops (the table gradient is 0.94 GB at batch 4)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n4, unsigned* __restrict__ amax_bits) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+__device__ __forceinline__ float pow2_scale(unsigned amax_bits, float target) {
+    const float amax = fmaxf(__uint_as_float(amax_bits), 1e-30f);
+    return fminf(fmaxf(exp2f(floorf(log2f(target / amax))), 0x1p-40f), 0x1p40f);
+}
+
+__global__ __launch_bounds__(256) void scale_to_f16_kernel(const float* __restrict__ x, long long n4,
+                                                           const unsigned* __restrict__ amax_bits, float target,
+                                                           __half* __restrict__ y, float* __restrict__ scale_out) {
+    const float s = pow2_scale(*amax_bits, target);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)(v[e] * s);
+        reinterpret_cast<half4*>(y)[i] = o;
+    }
+}
+
 }  // namespace
+
+// y = fp16(x * s), s = 2^floor(log2(target / max|x|)) clamped to [2^-40, 2^40], written to scale_out[0]; amax_scratch: one
+// uint32, ZERO on entry.  n % 4 == 0, 16-byte aligned x and 8-byte aligned y.
+extern "C" int cpn_scale_to_f16(const float* x, long long n, float target, uint32_t* amax_scratch, uint16_t* y,
+                                float* scale_out, void* stream) {
+    CPN_REQUIRE(x && amax_scratch && y && scale_out, CPN_E_ARG, "cpn_scale_to_f16: null pointer");
+    CPN_REQUIRE(n > 0 && (n % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0 && target > 0.0f, CPN_E_SHAPE,
+                "cpn_scale_to_f16: need n %% 4 == 0 and aligned pointers");
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(n / 4, 256), 8192);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, amax_scratch);
+    hipLaunchKernelGGL(scale_to_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, amax_scratch, target,
+                       (__half*)y, scale_out);
+    CPN_LAUNCH_CHECK("cpn_scale_to_f16");
+    return 0;
+}
 
 extern "C" long long cpn_scatter_tables_boxes(int B, int V, int R, int S) {
     return (long long)B * V * ((2LL * R * S + 63) / 64) * 8;             // int32 entries of the chunk-box scratch
@@ -347,16 +442,16 @@ extern "C" int cpn_scatter_rows_tables(const uint16_t* d, int ldx, int H, int W,
     for (int kind = 0; kind < 2; ++kind) {
         ScatterPlan plan;
         plan.kind = kind;
+        plan.scan_only = getenv("CPN_SCATTER_SCAN_ONLY") != nullptr;
         plan.maxchunks = maxchunks;
         plan.tiles_x = (ng.w(kind) + TP - 1) / TP;
         plan.tiles = plan.tiles_x * ((ng.h(kind) + TPY - 1) / TPY);
         const long long hits = cand / plan.tiles;
         plan.G = (int)std::min<long long>(64, std::max<long long>(1, (hits + 1023) / 2048));
-        const long long nroles = (long long)nimg * plan.G * plan.tiles * (TLD / TC);
+        const long long nroles = (long long)nimg * plan.G * plan.tiles;               // workgroups of 13 waves
         CPN_REQUIRE(nroles < (1LL << 31), CPN_E_SHAPE, "cpn_scatter_rows_tables: too many roles");
-        hipLaunchKernelGGL(scatter_tables_kernel, dim3((unsigned)((nroles + WAVES - 1) / WAVES)), dim3(64 * WAVES), 0, st,
-                           (const __half*)d, ldx, H, W, pixel_val, sec_grid, V, R, S, ray0, nrays, dtab, plan, (int)nroles,
-                           (const int4*)chunk_boxes);
+        hipLaunchKernelGGL(scatter_tables_kernel, dim3((unsigned)nroles), dim3(64 * SW), 0, st, (const __half*)d, ldx, H, W,
+                           pixel_val, sec_grid, V, R, S, ray0, nrays, dtab, plan, (const int4*)chunk_boxes);
     }
     CPN_LAUNCH_CHECK("cpn_scatter_rows_tables");
     return 0;

@@ -332,8 +332,10 @@ class EncodeFn(Function):
         call("cpn_scatter_rows_tables", d16.data_ptr(), d16.shape[1], H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V,
              R, S, 0, B * R, dT.data_ptr(), boxes.data_ptr(), s)
         # a node sums up to thousands of rows: its own power-of-two scale for the fp16 GEMM operands (device side, no sync)
-        s2 = torch.exp2(torch.floor(torch.log2(4096.0 / dT.abs().amax().clamp_min(1e-30)))).clamp(2.0 ** -40, 2.0 ** 40)
-        dT16 = (dT * s2).to(torch.float16)
+        dT16 = torch.empty(nodes, _hip.TAB_LD, dtype=torch.float16, device=dev)
+        sc = torch.zeros(2, dtype=torch.float32, device=dev)                  # [amax bits scratch, chosen scale]
+        call("cpn_scale_to_f16", dT.data_ptr(), dT.numel(), 4096.0, sc.data_ptr(), dT16.data_ptr(), sc[1:].data_ptr(), s)
+        s2 = sc[1]
         del dT
         both = (gs * s2).reshape(1)
         dWtab = _wgrad_tall(dT16, feat, both) if ctx.needs_input_grad[4] else None               # (832, 768)
