@@ -217,6 +217,11 @@ def run(args):
                 out0 = o if out0 is None else out0
             return out0
 
+    # the headline loop runs every call on ONE stream (call_lanes = 1): with consecutive forward() calls alternating over
+    # two streams (the library default, made for the callers' 18-call loop) the tail of step i overlaps step i+1 and the
+    # per-kernel HIP-event timings behind `roofline` would include the other stream's kernels
+    lanes_default = model._engine.call_lanes
+    model._engine.call_lanes = 1
     for _ in range(args.warmup):
         out = step()
     _fence(distributed)
@@ -228,6 +233,17 @@ def run(args):
     elapsed = time.perf_counter() - t0
     prof, model._engine.profile = model._engine.profile, None
     elapsed = _max_over_ranks(elapsed, dev, distributed)
+    model._engine.call_lanes = lanes_default
+    overlapped = None
+    if lanes_default > 1 and not args.pair_by_pair:
+        for _ in range(2):
+            step()
+        _fence(distributed)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        _fence(distributed)
+        overlapped = _max_over_ranks(time.perf_counter() - t0, dev, distributed)
 
     value = rays_per_step * world * args.steps / elapsed
     tables = model._engine.tables
@@ -252,6 +268,7 @@ def run(args):
                    "chunk_rays": args.chunk_rays, "lanes": args.lanes, "pairs_per_gpu": B,
                    "first_layer": "projected tables + K=80 MFMA (cpn_encode_hidden)" if tables
                                   else "gather + 835->832 GEMM"},
+        "rays_per_s_calls_on_two_streams": None if overlapped is None else rays_per_step * world * args.steps / overlapped,
         "path_tflops": value * f_ray(S) / 1e12,          # algorithmic FLOPs of the reference formulation
         "executed_tflops": value * exec_per_ray / 1e12,  # what the kernels execute after the restructurings
     }
@@ -420,13 +437,18 @@ def roofline_block(prof, args, tables):
     # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (they cannot be read
     # live); a committed record is used only if it was taken on THIS kernel source and launch shape
     traffic, tsrc = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json" if tables else "r01_v4_traffic.json")
-    if os.path.exists(tpath):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True) if tables else \
+        [os.path.join(ROOT, "profiles", "r01_v4_traffic.json")]
+    for tpath in cands:
+        if not os.path.exists(tpath):
+            continue
         with open(tpath) as f:
             rec = json.load(f)
         same_src = rec.get("kernel_source_sha16") == sha if tables else True
         if same_src and rec.get("shape", {}).get("M") == rows:
             traffic, tsrc = rec["hbm_bytes"], os.path.relpath(tpath, ROOT)
+            break
     if tables:
         # What bounds this kernel is its HBM stream: 832 fp16 written per row (the node tables and the full-resolution
         # map it reads are L2 / Infinity-Cache resident: FETCH_SIZE x 2 = 0.43 GB per launch).  The canonical work of the
@@ -440,6 +462,8 @@ def roofline_block(prof, args, tables):
             "bound": "hbm", "kernel": "encode_hidden_kernel (query_encode_latent 835->832 + ReLU with the gathers fused)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": avg_ms, "launches": len(ms),
+            "timing_source": "HIP events on the launch stream inside the timed region of THIS (unprofiled) run; the same "
+                             "launches under rocprofv3 --kernel-trace run ~10 % slower (profiles/README.md)",
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_source_sha16": sha,
             "canonical_mfma_view": {"bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": achieved / F16_MFMA_PEAK_TFLOPS, "flops_per_launch": flops,

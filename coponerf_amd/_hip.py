@@ -128,8 +128,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_linear_attention_bwd_scratch.restype = ctypes.c_longlong
     handle.cpn_gather_bwd_chunks.argtypes = [_I, _I]
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
-    handle.cpn_scatter_tables_boxes.argtypes = [_I, _I, _I, _I]
-    handle.cpn_scatter_tables_boxes.restype = ctypes.c_longlong
+    handle.cpn_scatter_tables_scratch.argtypes = [_I] * 6
+    handle.cpn_scatter_tables_scratch.restype = ctypes.c_longlong
     handle.cpn_conv4d_scratch.argtypes = [_I] * 7
     handle.cpn_conv4d_scratch.restype = ctypes.c_longlong
     handle.cpn_gn_stats_doubles.argtypes = [_I, _I, ctypes.c_longlong]

@@ -277,6 +277,202 @@ __global__ __launch_bounds__(64 * SW) void scatter_tables_kernel(
     }
 }
 
+// ---- the same scatter with the rows BUCKETED by tile first (counting sort), default since it was measured ------------
+// The search above costs every tile a pass over all chunk boxes plus the evaluation of every chunk whose box touches it
+// (an epipolar line's 64 samples span many tiles), in barrier-separated phases with one workgroup per CU (104 KB of LDS
+// tiles).  Sorting replaces the search: (1) count the rows per (image, kind, tile), (2) exclusive scan + a work list that
+// splits tiles with more than WMAX rows, (3) write row index, the four LDS cells and the four weights of every (row, tile
+// it touches) into the tile's bucket, (4) a 13-wave workgroup per work item streams its bucket and accumulates.
+constexpr int WMAX = 2048;          // rows per work item
+constexpr int NSUB = (TP + 1) * (TPY + 1);   // a tile's bucket is ordered by the row's cell position relative to the tile (-1 .. TP-1, -1 .. TPY-1)
+constexpr int NBB = 32;             // rows per drain batch of the bucketed kernel (64 spill: 128 VGPRs + 92 B of scratch, 2.3 ms slower)
+
+struct BucketGeo {
+    int V, R, S, ray0, nrays, nimg, H, W;
+    int tiles_x[2], tiles[2], T;    // per kind; T = max(tiles) = bucket slots per (image, kind)
+};
+
+// the tiles a row's 2x2 node footprint touches: calls f(tile, cells, weights) with, for the four taps, the LDS cell of the
+// tile (byte k of `cells`; taps outside the tile or of zero weight point at the dummy cell TP*TPY with weight 0)
+template <class F>
+__device__ __forceinline__ void for_each_touched_tile(const RowRefT& rf, int kind, const NodeGridB ng, const BucketGeo& geo, F f) {
+    int xi, yi;
+    float fx, fy;
+    node_cell(rf.g, kind, ng, xi, yi, fx, fy);
+    const int txa = xi / TP, txb = (xi + 1) / TP, tya = yi / TPY, tyb = (yi + 1) / TPY;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+            if ((tx && txb == txa) || (ty && tyb == tya)) continue;
+            const int tX = tx ? txb : txa, tY = ty ? tyb : tya;
+            const int tx0 = tX * TP, ty0 = tY * TPY;
+            unsigned cells = 0;
+            f32x4 w4;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xk = xi + (k & 1), yk = yi + (k >> 1);
+                const float wk = ((k & 1) ? fx : 1.0f - fx) * ((k >> 1) ? fy : 1.0f - fy);
+                const bool hit = (xk >= tx0) && (xk < tx0 + TP) && (yk >= ty0) && (yk < ty0 + TPY) && wk != 0.0f;
+                cells |= (unsigned)(hit ? (yk - ty0) * TP + (xk - tx0) : TP * TPY) << (8 * k);
+                w4[k] = hit ? wk : 0.0f;
+                any |= hit;
+            }
+            if (any) f(tY * geo.tiles_x[kind] + tX, (yi - ty0 + 1) * (TP + 1) + (xi - tx0 + 1), cells, w4);
+        }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void bucket_rows_kernel(BucketGeo geo, const float* __restrict__ pixel_val,
+                                                          const float* __restrict__ sec_grid, int maxrows,
+                                                          int* __restrict__ counts, const int* __restrict__ offsets,
+                                                          unsigned* __restrict__ rows, unsigned* __restrict__ cellsv,
+                                                          f32x4* __restrict__ wts) {
+    const int img = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int b = img / geo.V, vi = img - b * geo.V;
+    const int rlo = max(geo.ray0, b * geo.R) - b * geo.R, rhi = min(geo.ray0 + geo.nrays, (b + 1) * geo.R) - b * geo.R;
+    const int per = max(rhi - rlo, 0) * geo.S, total = 2 * per;
+    if (idx >= total || idx >= maxrows) return;
+    const RowRefT rf = row_of_t(idx, per, geo.S, rlo, b, vi, geo.V, geo.R, geo.ray0, pixel_val, sec_grid);
+    const NodeGridB ng{geo.W >> 1, geo.H >> 1};
+    const int group = img * 2 + rf.j;
+    for_each_touched_tile(rf, rf.j, ng, geo, [&](int tile, int sub, unsigned cells, const f32x4& w4) {
+        const int slot = (group * geo.T + tile) * NSUB + sub;
+        const int pos = atomicAdd(counts + slot, 1);
+        if (FILL) {
+            const size_t at = (size_t)offsets[slot] + pos;
+            rows[at] = rf.row;
+            cellsv[at] = cells;
+            wts[at] = w4;
+        }
+    });
+}
+
+// one workgroup: exclusive scan of the bucket sizes (per tile and cell position) and the work list per TILE
+// (tile slot, first, last, shared?) in tile order
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(const int* __restrict__ counts, int ntiles, int* __restrict__ offsets,
+                                                           int* __restrict__ cursor, int4* __restrict__ work,
+                                                           int* __restrict__ nwork) {
+    __shared__ int part[1024], wpart[1024];
+    const int per = (ntiles + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, ntiles);
+    int s = 0, w = 0;
+    for (int i = lo; i < hi; ++i) {
+        int n = 0;
+        for (int k = 0; k < NSUB; ++k) n += counts[i * NSUB + k];
+        s += n;
+        w += (n + WMAX - 1) / WMAX;
+    }
+    part[threadIdx.x] = s;
+    wpart[threadIdx.x] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, c = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const int t = part[i], u = wpart[i];
+            part[i] = a; wpart[i] = c;
+            a += t; c += u;
+        }
+        offsets[ntiles * NSUB] = a;
+        *nwork = c;
+    }
+    __syncthreads();
+    int a = part[threadIdx.x], c = wpart[threadIdx.x];
+    for (int i = lo; i < hi; ++i) {
+        const int a0 = a;
+        for (int k = 0; k < NSUB; ++k) {
+            offsets[i * NSUB + k] = a;
+            cursor[i * NSUB + k] = 0;
+            a += counts[i * NSUB + k];
+        }
+        const int n = a - a0;
+        for (int st = 0; st < n; st += WMAX) work[c++] = make_int4(i, a0 + st, a0 + min(st + WMAX, n), n > WMAX);
+    }
+}
+
+// Everything about a row that is the same for the 64 lanes — its index, the four LDS cells and the four weights — is read
+// through wave-uniform indices from read-only global arrays, i.e. with SCALAR loads into SGPRs: the vector unit is left
+// with one address add per tap, one conversion and four FMAs per (row, wave).  (With the descriptors staged in LDS and
+// unpacked by the vector unit the kernel spent 29 VALU + 11 LDS instructions per row and wave and was bound by them:
+// 10 ms for 9.7 GB of reads — rocprofv3 counters of that version: VALU + LDS busy, L2 read latency only 684 clocks.)
+__global__ __launch_bounds__(64 * SW) void bucket_accumulate_kernel(const __half* __restrict__ d, int ldx, BucketGeo geo,
+                                                                    const int4* __restrict__ work, const int* __restrict__ nwork,
+                                                                    const unsigned* __restrict__ rows,
+                                                                    const unsigned* __restrict__ cellsv,
+                                                                    const f32x4* __restrict__ wts, float* __restrict__ dtab) {
+    __shared__ float tiles_lds[SW][(TP * TPY + 1) * TC];          // 32 node cells + the dummy cell, lane = channel
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* tile = tiles_lds[wave] + lane;
+    if ((int)blockIdx.x >= *nwork) return;      // (a persistent walk of the work list, one workgroup per CU, measured 2.7 ms slower)
+    {
+    const int4 item = work[blockIdx.x];
+    const int group = item.x / geo.T, tidx = item.x - group * geo.T;
+    const int img = group >> 1, kind = group & 1;
+    const NodeGridB ng{geo.W >> 1, geo.H >> 1};
+    const int nw = ng.w(kind), nh = ng.h(kind);
+    const int tx0 = (tidx % geo.tiles_x[kind]) * TP, ty0 = (tidx / geo.tiles_x[kind]) * TPY;
+    const __half* dcol = d + wave * TC + lane;
+#pragma unroll
+    for (int i = 0; i <= TP * TPY; ++i) tile[i * TC] = 0.0f;
+
+    const int first = item.y, last = item.z - 1;
+    // The bucket is ordered by the rows' cell position, so consecutive rows mostly hit the SAME four cells: their sums
+    // stay in four registers and go to the LDS tile only when the position changes (the first version did four LDS
+    // read-modify-writes per row and wave and was bound by the LDS pipe: SQ_ACTIVE_INST_LDS = 86 % of the kernel).
+    unsigned held = 0xffffffffu;                                  // cells word of the run in the registers
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    auto spill = [&]() {
+        float* t0 = tile + (held & 255u) * TC;
+        float* t1 = tile + ((held >> 8) & 255u) * TC;
+        float* t2 = tile + ((held >> 16) & 255u) * TC;
+        float* t3 = tile + (held >> 24) * TC;
+        const float v0 = *t0, v1 = *t1, v2 = *t2, v3 = *t3;      // the four cells of a position are distinct (or the dummy)
+        *t0 = v0 + a0;
+        *t1 = v1 + a1;
+        *t2 = v2 + a2;
+        *t3 = v3 + a3;
+    };
+    __half cur[NBB], nxt[NBB];
+#pragma unroll
+    for (int u = 0; u < NBB; ++u) nxt[u] = dcol[(size_t)rows[min(first + u, last)] * ldx];
+    for (int base = first; base <= last; base += NBB) {
+#pragma unroll
+        for (int u = 0; u < NBB; ++u) cur[u] = nxt[u];
+#pragma unroll
+        for (int u = 0; u < NBB; ++u) nxt[u] = dcol[(size_t)rows[min(base + NBB + u, last)] * ldx];
+#pragma unroll
+        for (int u = 0; u < NBB; ++u) {
+            if (base + u > last) break;
+            const float du = __half2float(cur[u]);
+            const unsigned cells = cellsv[base + u];
+            const f32x4 w4 = wts[base + u];
+            if (cells != held) {                                  // wave-uniform
+                if (held != 0xffffffffu) spill();
+                held = cells;
+                a0 = a1 = a2 = a3 = 0.0f;
+            }
+            a0 += du * w4[0];
+            a1 += du * w4[1];
+            a2 += du * w4[2];
+            a3 += du * w4[3];
+        }
+    }
+    if (held != 0xffffffffu) spill();
+    float* m = dtab + ((size_t)img * ng.per_image() + (kind ? ng.border_nodes() : 0)) * TLD + wave * TC + lane;
+#pragma unroll 4
+    for (int pix = 0; pix < TP * TPY; ++pix) {
+        const float v = tile[pix * TC];
+        const int gy = ty0 + (pix >> 3), gx = tx0 + (pix & 7);
+        if (v != 0.0f && gy < nh && gx < nw) {
+            if (item.w) atomicAdd(m + ((size_t)gy * nw + gx) * TLD, v);       // the tile was split over several work items
+            else m[((size_t)gy * nw + gx) * TLD] = v;                          // its only writer: dtab is zero on entry
+        }
+    }
+  }
+}
+
 // ---- adjoint of node_features_kernel as a gather: wave = one texel of one coarse level, lane = 4 channels ----------
 // dmap[img, ty, tx, c] = sum over the nodes of both tables of the image whose grid_sample footprint at this level
 // contains the texel, of weight * dfeat[node, lvl*256 + c].  The candidate nodes of texel tx are nx in
@@ -418,22 +614,76 @@ extern "C" int cpn_scale_to_f16(const float* x, long long n, float target, uint3
     return 0;
 }
 
-extern "C" long long cpn_scatter_tables_boxes(int B, int V, int R, int S) {
-    return (long long)B * V * ((2LL * R * S + 63) / 64) * 8;             // int32 entries of the chunk-box scratch
+static void bucket_geo(BucketGeo& g, int H, int W, int B, int V, int R, int S, int ray0, int nrays) {
+    const NodeGridB ng{W >> 1, H >> 1};
+    g.V = V; g.R = R; g.S = S; g.ray0 = ray0; g.nrays = nrays; g.nimg = B * V; g.H = H; g.W = W;
+    for (int k = 0; k < 2; ++k) {
+        g.tiles_x[k] = (ng.w(k) + TP - 1) / TP;
+        g.tiles[k] = g.tiles_x[k] * ((ng.h(k) + TPY - 1) / TPY);
+    }
+    g.T = std::max(g.tiles[0], g.tiles[1]);
+}
+
+// int32 entries of the scratch: [counts | cursor | offsets (+1) | nwork (4) | work items | descriptors], sized for the worst
+// case (every row in four tiles) and for the search variant's chunk boxes
+extern "C" long long cpn_scatter_tables_scratch(int H, int W, int B, int V, int R, int S) {
+    if (H < 16 || W < 16 || B <= 0 || V <= 0 || R <= 0 || S <= 0) return -1;
+    BucketGeo g;
+    bucket_geo(g, H, W, B, V, R, S, 0, B * R);
+    const long long ntiles = (long long)B * V * 2 * g.T, slots = ntiles * NSUB, rows = 2LL * B * V * R * S;
+    const long long maxdesc = 4 * rows, maxwork = ntiles + maxdesc / WMAX + 1;
+    const long long sorted = 3 * slots + 8 + 4 * maxwork + 6 * maxdesc + 16;
+    const long long boxes = (long long)B * V * ((2LL * R * S + 63) / 64) * 8;
+    return std::max(sorted, boxes);
 }
 
 extern "C" int cpn_scatter_rows_tables(const uint16_t* d, int ldx, int H, int W, const float* pixel_val,
                                        const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays, float* dtab,
-                                       int32_t* chunk_boxes, void* stream) {
-    CPN_REQUIRE(d && pixel_val && sec_grid && dtab && chunk_boxes, CPN_E_ARG, "cpn_scatter_rows_tables: null pointer");
+                                       int32_t* scratch, void* stream) {
+    CPN_REQUIRE(d && pixel_val && sec_grid && dtab && scratch, CPN_E_ARG, "cpn_scatter_rows_tables: null pointer");
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && (H % 16) == 0 && (W % 16) == 0 && ldx >= TLD, CPN_E_SHAPE,
                 "cpn_scatter_rows_tables: bad shape");
     CPN_REQUIRE(H <= 1024 && W <= 1024, CPN_E_SHAPE, "cpn_scatter_rows_tables: maps larger than 1024 pixels a side");
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_scatter_rows_tables: ray range outside B*R");
-    CPN_REQUIRE((long long)nrays * V * S * 2 < (1LL << 31), CPN_E_SHAPE, "cpn_scatter_rows_tables: chunk too large");
+    CPN_REQUIRE((long long)nrays * V * S * 2 < (1LL << 31) && ((uintptr_t)scratch % 16) == 0, CPN_E_SHAPE,
+                "cpn_scatter_rows_tables: chunk too large / scratch not 16-byte aligned");
     const hipStream_t st = (hipStream_t)stream;
-    const int maxchunks = (int)((2LL * R * S + 63) / 64), nimg = B * V;
+    const int nimg = B * V;
+    static const bool use_search = getenv("CPN_SCATTER_SEARCH") != nullptr;      // the first implementation, kept for A/B timing
+    if (!use_search) {
+        BucketGeo g;
+        bucket_geo(g, H, W, B, V, R, S, ray0, nrays);
+        const int ntiles = nimg * 2 * g.T, slots = ntiles * NSUB;
+        const long long rows = 2LL * B * V * R * S, maxdesc = 4 * rows, maxwork = ntiles + maxdesc / WMAX + 1;
+        int* counts = scratch;
+        int* cursor = counts + slots;
+        int* offsets = cursor + slots;
+        int* nwork = offsets + slots + 1;
+        nwork += (4 - ((nwork - scratch) & 3)) & 3;                                // 16-byte alignment of what follows
+        int4* work = reinterpret_cast<int4*>(nwork + 4);
+        f32x4* wts = reinterpret_cast<f32x4*>(work + maxwork);                     // [maxdesc] 16-byte aligned
+        unsigned* rows_a = reinterpret_cast<unsigned*>(wts + maxdesc);
+        unsigned* cells_a = rows_a + maxdesc;
+        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * slots, st);
+        CPN_REQUIRE(e == hipSuccess, (int)e, "cpn_scatter_rows_tables: memset failed: %s", hipGetErrorString(e));
+        const int per_img = 2 * std::min(R, nrays) * S;
+        dim3 grid(cpn_cdiv(per_img, 256), nimg);
+        hipLaunchKernelGGL((bucket_rows_kernel<false>), grid, dim3(256), 0, st, g, pixel_val, sec_grid, per_img, counts,
+                           (const int*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (f32x4*)nullptr);
+        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)counts, ntiles, offsets, cursor, work,
+                           nwork);
+        hipLaunchKernelGGL((bucket_rows_kernel<true>), grid, dim3(256), 0, st, g, pixel_val, sec_grid, per_img, cursor,
+                           (const int*)offsets, rows_a, cells_a, wts);
+        // the work-list length lives on the device: launch its upper bound, surplus workgroups return at once
+        hipLaunchKernelGGL(bucket_accumulate_kernel, dim3((unsigned)maxwork), dim3(64 * SW), 0, st,
+                           (const __half*)d, ldx, g, (const int4*)work, (const int*)nwork, (const unsigned*)rows_a,
+                           (const unsigned*)cells_a, (const f32x4*)wts, dtab);
+        CPN_LAUNCH_CHECK("cpn_scatter_rows_tables");
+        return 0;
+    }
+    int32_t* chunk_boxes = scratch;
+    const int maxchunks = (int)((2LL * R * S + 63) / 64);
     const long long nwaves = (long long)nimg * maxchunks;
     hipLaunchKernelGGL(table_bbox_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, H, W, pixel_val, sec_grid, V,
                        R, S, ray0, nrays, maxchunks, nimg, (int4*)chunk_boxes);

@@ -328,7 +328,7 @@ class EncodeFn(Function):
         gs = ctx.gs.s
         # ---- table gradient (fp32, carries the pass's scale gs)
         dT = torch.zeros(nodes, _hip.TAB_LD, dtype=torch.float32, device=dev)
-        boxes = torch.empty(int(lib.cpn_scatter_tables_boxes(B, V, R, S)), dtype=torch.int32, device=dev)
+        boxes = torch.empty(int(lib.cpn_scatter_tables_scratch(H, Wd, B, V, R, S)), dtype=torch.int32, device=dev)
         call("cpn_scatter_rows_tables", d16.data_ptr(), d16.shape[1], H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V,
              R, S, 0, B * R, dT.data_ptr(), boxes.data_ptr(), s)
         # a node sums up to thousands of rows: its own power-of-two scale for the fp16 GEMM operands (device side, no sync)

@@ -263,7 +263,8 @@ int cpn_gather_rows_bwd_level3(const uint16_t* dxin, int ldx, int col0, int H, i
  * of the pre-activation (ReLU mask applied, carrying the pass's power-of-two scale).
  *   cpn_scatter_rows_tables: dtab (N * cpn_encode_table_nodes(H,W), 832) fp32, ZERO on entry, += a_t * d[row] at the four
  *       nodes of every row (own image -> border table, other image -> zeros table; the taps of cpn_encode_hidden).
- *       chunk_boxes: scratch of cpn_scatter_tables_boxes(B,V,R,S) int32.
+ *       scratch: cpn_scatter_tables_scratch(H,W,B,V,R,S) int32, 16-byte aligned (bucket counters, work list and one
+ *       16-byte descriptor per (row, tile it touches): the rows are counting-sorted by 8x4-node tile first).
  *   cpn_node_features_bwd: adjoint of cpn_node_features: dfeat (nodes, 768) fp32 -> dmap0..2 (N,h,w,256) fp32 NHWC,
  *       OVERWRITTEN (every texel is written once: a gather over the nodes whose footprint holds it, no atomics).
  *   cpn_gather_tail: xt (rows, 128) fp16 = [bilinear gather of the full-resolution map (64) | tanh(pt/5) (3) | 1 | 0 x 60],
@@ -271,11 +272,11 @@ int cpn_gather_rows_bwd_level3(const uint16_t* dxin, int ldx, int col0, int H, i
  *   cpn_scale_to_f16: y = fp16(x * s) with s = 2^floor(log2(target / max|x|)) clamped to [2^-40, 2^40] found on the device and
  *       written to scale_out[0] (the table gradient sums up to thousands of rows per node: its own scale before the two
  *       fp16 GEMMs); amax_scratch: one uint32, ZERO on entry; n % 4 == 0.                                            */
-long long cpn_scatter_tables_boxes(int B, int V, int R, int S);
+long long cpn_scatter_tables_scratch(int H, int W, int B, int V, int R, int S);
 int cpn_scale_to_f16(const float* x, long long n, float target, uint32_t* amax_scratch, uint16_t* y, float* scale_out,
                      void* stream);
 int cpn_scatter_rows_tables(const uint16_t* d, int ldx, int H, int W, const float* pixel_val, const float* sec_grid, int B,
-                            int V, int R, int S, int ray0, int nrays, float* dtab, int32_t* chunk_boxes, void* stream);
+                            int V, int R, int S, int ray0, int nrays, float* dtab, int32_t* scratch, void* stream);
 int cpn_node_features_bwd(const float* dfeat, int H, int W, int nimg, float* dmap0, float* dmap1, float* dmap2,
                           void* stream);
 int cpn_gather_tail(const uint16_t* map3, int H, int W, const float* pixel_val, const float* sec_grid, const float* pe6,

@@ -4,7 +4,7 @@
 #   steady-state kernel lists of one get_z call and of one training step.
 #   tools/capture_profiles.sh <tag>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -12,7 +12,7 @@ export TMPDIR=/tmp PYTHONPATH=$ROOT
 cd "$ROOT"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --no-tables --cpu-rays 0 --train-steps 0 > "$OUT/bench_gather_gemm_form.json" 2>> "$OUT/bench.err"
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render_prof" -o r -- python "$ROOT/bench.py" --no-image --cpu-rays 0 --train-steps 0 --steps 5 ) > "$OUT/bench_under_rocprof.json" 2> "$OUT/render_prof.log"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render_prof" -o r -- python "$ROOT/bench.py" --no-image --no-ref-loop --cpu-rays 0 --train-steps 0 --steps 5 ) > "$OUT/bench_under_rocprof.json" 2> "$OUT/render_prof.log"
 python tools/summarize_pmc.py "$(find "$OUT/render_prof" -name '*kernel_stats.csv' | head -1)" "$OUT/render_kernel_stats.summary.csv" 40
 tools/pmc_passes.sh "$OUT/pmc_encode" encode_hidden -- python "$ROOT/tools/encode_bench.py" --only tables --iters 3 > "$OUT/pmc_encode.log" 2>&1
 python tools/make_traffic_json.py "$OUT/pmc_encode/summary.json" 4194304 "$OUT/traffic.json" >> "$OUT/pmc_encode.log" 2>&1
@@ -22,6 +22,10 @@ python tools/trace_step.py "$(find "$OUT/getz_prof" -name '*kernel_trace.csv' | 
 python tools/trace_step.py "$(find "$OUT/train_prof" -name '*kernel_trace.csv' | head -1)" project_rays 60 > "$OUT/train_step_kernels.txt" 2>&1
 grep -h train_ms_per_step "$OUT/train_prof.log" > "$OUT/train_step.json"
 python tools/encode_ablate.py > "$OUT/encode_ablation.json" 2>/dev/null
+bash tools/refloop_trace.sh "gpurun_out/$TAG/ref_loop_b1" 1 > /dev/null 2>&1
+bash tools/refloop_trace.sh "gpurun_out/$TAG/ref_loop_b2" 2 > /dev/null 2>&1
+python tools/refloop_profile.py --batch 1 --top 8 > "$OUT/ref_loop_b1_host.txt" 2>&1
+python tools/getz_graph.py > "$OUT/getz_graph.txt" 2>&1
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*.csv" -size +2M -delete
 ls "$OUT"
