@@ -67,6 +67,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_cross_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "cpn_linear_attention_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "cpn_qk_assemble": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_cost_volume_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "cpn_cross_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_conv_map7x7": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "cpn_prepare_input": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -122,6 +123,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_encode_table_nodes.restype = ctypes.c_longlong
     handle.cpn_linear_attention_scratch.argtypes = [_I, _I, _I, _I]
     handle.cpn_linear_attention_scratch.restype = ctypes.c_longlong
+    handle.cpn_cost_volume_attention_scratch.argtypes = [_I] * 5
+    handle.cpn_cost_volume_attention_scratch.restype = ctypes.c_longlong
     handle.cpn_cross_attention_bwd_scratch.argtypes = [_I, _I, _I, _I]
     handle.cpn_cross_attention_bwd_scratch.restype = ctypes.c_longlong
     handle.cpn_linear_attention_bwd_scratch.argtypes = [_I, _I, _I, _I, _I]

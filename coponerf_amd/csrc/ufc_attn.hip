@@ -683,3 +683,168 @@ extern "C" int cpn_qk_assemble(const float* lin, const float* low, const float* 
     CPN_LAUNCH_CHECK("cpn_qk_assemble");
     return 0;
 }
+
+// ---- cost-volume side of UFCLayer.forward_attention at the volume's NATIVE resolution (round 3) -------------------
+// aggregation.py:283-297: value_corr (B, H*Ht*Wt, Hs, Ws) is upsampled to fs x fs (U, bilinear, align_corners), run through
+// the linear attention with the fs*fs queries / keys, and the message is sampled back down to Hs x Ws (D).  U and D are
+// linear maps over the positions, the attention is linear in the values, so with K' = phi(k), Q' = phi(q), Z_l = 1 /
+// (Q'_l . sum_m K'_m + eps):
+//     KV   = sum_l K'_l (U v_low)_l^T  = (U^T K')^T v_low                      -> Kd = U^T K'        (P x 32 per head)
+//     msg  = D (diag(Z) Q' KV)         = (D diag(Z) Q') KV                      -> Qd = D (Z . Q')    (P x 32 per head)
+//     msg_low = Qd (Kd^T v_low)        (P x Dv), P = Hs*Ws = 256, Dv = Ht*Wt = 256: no 2 048-channel tensor at fs x fs exists
+// (exact in real arithmetic; the reference's 1/L and *L cancel).  Two launches:
+//   cva_kd       per (b, h, block of 32 positions): Kd as a gather (fixed order), the block's partial of M = Kd^T v_low
+//   cva_out      per (b, h, 8 positions): M = sum of the partials, Qd from the 4 taps of D, out = residual + Qd M
+namespace {
+constexpr int CVA_D = 32;
+
+__device__ __forceinline__ void ac_taps(int Y, int X, int n_out, int n_in, int (&idx)[4], float (&w)[4]) {
+    // the 4 source positions / weights of output pixel (Y, X) of an n_in -> n_out bilinear resize (align_corners=True),
+    // with the arithmetic of resize_bilinear_ac_kernel
+    const float s = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
+    const float fy = s * (float)Y, fx = s * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < n_in - 1), x1 = x0 + (x0 < n_in - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    idx[0] = y0 * n_in + x0; idx[1] = y0 * n_in + x1; idx[2] = y1 * n_in + x0; idx[3] = y1 * n_in + x1;
+    w[0] = (1.0f - lx) * (1.0f - ly); w[1] = lx * (1.0f - ly); w[2] = (1.0f - lx) * ly; w[3] = lx * ly;
+}
+
+// K1: workgroup = (block of 32 low-res positions, (b, h)).  Kd of its positions as a GATHER over the tokens whose bilinear
+// footprint holds the position (fixed order: no atomics, the result is bit-reproducible), then its partial of
+// M = Kd^T v_low (32 x Dv); block 0 also forms sum_l phi(k_l) with a fixed-order tree.
+constexpr int CVA_BP = 32;
+__global__ __launch_bounds__(256) void cva_kd_kernel(const float* __restrict__ k, const float* __restrict__ v_low, int L, int H,
+                                                     int fs, int hs, int Dv, int nblk, float* __restrict__ kvm_part,
+                                                     float* __restrict__ ksum_out) {
+    __shared__ float kd[CVA_BP][CVA_D];
+    __shared__ float tree[8][CVA_D];
+    const int P = hs * hs;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H, blk = blockIdx.x;
+    const int d = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const float* kb = k + ((size_t)b * L * H + h) * CVA_D + d;    // token l at kb[l * H * 32]
+    if (blk == 0) {
+        float a = 0.0f;
+        for (int l = g; l < L; l += 8) a += elu1(kb[(size_t)l * H * CVA_D]);
+        tree[g][d] = a;
+        __syncthreads();
+        if (g == 0) {
+            float t = tree[0][d];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) t += tree[i][d];
+            ksum_out[(size_t)bh * CVA_D + d] = t;
+        }
+    }
+    const float inv_s = fs > 1 && hs > 1 ? (float)(fs - 1) / (float)(hs - 1) : 1.0f;     // tokens per low-res step
+    for (int pp = g; pp < CVA_BP; pp += 8) {
+        const int p = blk * CVA_BP + pp;
+        float acc = 0.0f;
+        if (p < P) {
+            const int y = p / hs, x = p - y * hs;
+            const int Y0 = max(0, (int)floorf((float)(y - 1) * inv_s) - 1), Y1 = min(fs - 1, (int)ceilf((float)(y + 1) * inv_s) + 1);
+            const int X0 = max(0, (int)floorf((float)(x - 1) * inv_s) - 1), X1 = min(fs - 1, (int)ceilf((float)(x + 1) * inv_s) + 1);
+            for (int Y = Y0; Y <= Y1; ++Y)
+                for (int X = X0; X <= X1; ++X) {
+                    int idx[4];
+                    float w[4];
+                    ac_taps(Y, X, fs, hs, idx, w);
+                    float wsum = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) wsum += (idx[t] == p) ? w[t] : 0.0f;
+                    if (wsum != 0.0f) acc += wsum * elu1(kb[(size_t)(Y * fs + X) * H * CVA_D]);
+                }
+        }
+        kd[pp][d] = acc;
+    }
+    __syncthreads();
+    const float* vb = v_low + (size_t)bh * P * Dv;
+    float* out = kvm_part + ((size_t)bh * nblk + blk) * CVA_D * Dv;
+    for (int v = threadIdx.x; v < Dv; v += 256) {
+        float m[CVA_D];
+#pragma unroll
+        for (int dd = 0; dd < CVA_D; ++dd) m[dd] = 0.0f;
+        for (int pp = 0; pp < CVA_BP; ++pp) {
+            const int p = blk * CVA_BP + pp;
+            if (p >= P) break;
+            const float xv = vb[(size_t)p * Dv + v];
+#pragma unroll
+            for (int dd = 0; dd < CVA_D; ++dd) m[dd] += kd[pp][dd] * xv;
+        }
+#pragma unroll
+        for (int dd = 0; dd < CVA_D; ++dd) out[(size_t)dd * Dv + v] = m[dd];
+    }
+}
+
+constexpr int CVA_PB = 8;                                         // low-res positions per workgroup of cva_out
+__global__ __launch_bounds__(256) void cva_out_kernel(const float* __restrict__ q, const float* __restrict__ kvm_part,
+                                                      const float* __restrict__ ksum_in, const float* __restrict__ residual,
+                                                      int L, int H, int fs, int hs, int Dv, int nblk, float eps,
+                                                      float* __restrict__ out) {
+    __shared__ float qd[CVA_PB][CVA_D];
+    __shared__ float ksum[CVA_D];
+    const int P = hs * hs;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H, p0 = blockIdx.x * CVA_PB;
+    const float* mb = kvm_part + (size_t)bh * nblk * CVA_D * Dv;
+    if (threadIdx.x < CVA_D) ksum[threadIdx.x] = ksum_in[(size_t)bh * CVA_D + threadIdx.x];
+    __syncthreads();
+    {
+        // Qd[p][d] = sum_t w_t Z_{l_t} phi(q_{l_t})[d]: 8 positions x 32 features = 256 threads; Z through a 32-lane sum
+        const int d = threadIdx.x & 31, pp = threadIdx.x >> 5, p = p0 + pp;
+        float acc = 0.0f;
+        if (p < P) {
+            int idx[4];
+            float w[4];
+            ac_taps(p / hs, p % hs, hs, fs, idx, w);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float qv = elu1(q[(((size_t)b * L + idx[t]) * H + h) * CVA_D + d]);
+                float dot = qv * ksum[d];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o);            // over the 32 features of this position
+                acc += w[t] * qv / (dot + eps);
+            }
+        }
+        qd[pp][d] = acc;
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < Dv; v += 256) {
+        float m[CVA_D];
+#pragma unroll
+        for (int d = 0; d < CVA_D; ++d) m[d] = 0.0f;
+        for (int kb2 = 0; kb2 < nblk; ++kb2)                       // the position blocks' partials, fixed order
+#pragma unroll
+            for (int d = 0; d < CVA_D; ++d) m[d] += mb[((size_t)kb2 * CVA_D + d) * Dv + v];
+#pragma unroll
+        for (int pp = 0; pp < CVA_PB; ++pp) {
+            const int p = p0 + pp;
+            if (p >= P) break;
+            float a = 0.0f;
+#pragma unroll
+            for (int d = 0; d < CVA_D; ++d) a += qd[pp][d] * m[d];
+            const size_t o = ((size_t)bh * P + p) * Dv + v;
+            out[o] = residual ? residual[o] + a : a;
+        }
+    }
+}
+}  // namespace
+
+extern "C" long long cpn_cost_volume_attention_scratch(int B, int L, int H, int P, int Dv) {
+    const long long nblk = (P + CVA_BP - 1) / CVA_BP;
+    return (long long)B * H * (nblk * CVA_D * Dv + CVA_D);
+}
+
+extern "C" int cpn_cost_volume_attention(const float* q, const float* k, const float* v_low, const float* residual, int B,
+                                         int fs, int H, int hs, int Dv, float eps, float* scratch, float* out, void* stream) {
+    CPN_REQUIRE(q && k && v_low && scratch && out, CPN_E_ARG, "cpn_cost_volume_attention: null pointer");
+    CPN_REQUIRE(B > 0 && H > 0 && (long long)B * H < 65536 && fs >= hs && hs > 0 && Dv > 0, CPN_E_SHAPE,
+                "cpn_cost_volume_attention: bad shape (fs=%d hs=%d)", fs, hs);
+    const int L = fs * fs, P = hs * hs, nblk = (P + CVA_BP - 1) / CVA_BP;
+    float* kvm_part = scratch;
+    float* ksum = scratch + (size_t)B * H * nblk * CVA_D * Dv;
+    const hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cva_kd_kernel, dim3(nblk, B * H), dim3(256), 0, st, k, v_low, L, H, fs, hs, Dv, nblk, kvm_part, ksum);
+    hipLaunchKernelGGL(cva_out_kernel, dim3(cpn_cdiv(P, CVA_PB), B * H), dim3(256), 0, st, q, (const float*)kvm_part,
+                       (const float*)ksum, residual, L, H, fs, hs, Dv, nblk, eps, out);
+    CPN_LAUNCH_CHECK("cpn_cost_volume_attention");
+    return 0;
+}

@@ -242,14 +242,11 @@ class UFCLayer(nn.Module):
         feat = self.norm1(feat)
         q, k = self._queries_keys(corr, feat, ops)
         vf = self.v_proj(feat).view(B, -1, self.nhead, self.dim)
-        vc = ops.resize_bilinear(_corr_to_maps(self.v_proj_corr(corr, ops)), fs)      # (B, H*Ht*Wt, fs, fs)
         msg_feat = ops.linear_attention(q, k, vf).view(B, -1, self.nhead * self.dim)
-        # the cost-volume values stay channel-major (B, H, Ht*Wt, L): that IS the map layout, no permute copies
-        msg_corr = ops.linear_attention(q, k, vc.reshape(B, H, Ht * Wt, fs * fs), channel_major=True)
-        msg_corr = ops.resize_bilinear(msg_corr.reshape(B, H * Ht * Wt, fs, fs), Hs)
-        msg_corr = msg_corr.reshape(B, H, Ht, Wt, Hs, Ws).permute(0, 1, 4, 5, 2, 3)
+        # cost-volume values: corr + interp(LinearAttention(q, k, interp(v_proj_corr(corr), fs)), Hs), aggregation.py:283-301,
+        # evaluated at the volume's own resolution (ops.cost_volume_attention): no (B, 2048, fs, fs) tensor is formed
+        msg_corr = ops.cost_volume_attention(q, k, self.v_proj_corr(corr, ops), fs, residual=corr)
         msg_feat = feat_r + msg_feat
-        msg_corr = corr + msg_corr
         msg_feat = msg_feat + self._feed_forward(self.mlp, self.norm2(msg_feat))
         msg_corr = self.mlp_corr(msg_corr, ops, residual=msg_corr)
         return msg_corr, msg_feat

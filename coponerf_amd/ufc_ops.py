@@ -393,6 +393,39 @@ class _ResizeFn(Function):
                                                                  list(ctx.in_shape), True, None, None), None
 
 
+class _ResizeAdjointFn(Function):
+    """U^T: the adjoint of the bilinear (align_corners=True) upsampling size -> n, applied to x (N,C,n,n)."""
+
+    @staticmethod
+    def forward(ctx, ops, x, size):
+        ctx.ops, ctx.n = ops, x.shape[-1]
+        N, C = x.shape[:2]
+        return torch.ops.aten.upsample_bilinear2d_backward(x.contiguous(), list(x.shape[-2:]), [N, C, size, size], True, None, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, ctx.ops.resize_bilinear(g, ctx.n), None
+
+
+def cost_volume_attention_torch(ops, q, k, v_corr, fs, residual=None, eps=1e-6):
+    """HipOps.cost_volume_attention with stock differentiable ops (training), same association as the kernel."""
+    import torch.nn.functional as F_
+    B, H, Hs, Ws, Ht, Wt = v_corr.shape
+    D = q.shape[-1]
+    Q, K = F_.elu(q) + 1, F_.elu(k) + 1                                        # (B, L, H, D)
+    Z = 1.0 / (torch.einsum("blhd,bhd->blh", Q, K.sum(dim=1)) + eps)
+    as_map = lambda t: t.permute(0, 2, 3, 1).reshape(B, H * D, fs, fs)         # tokens (row-major over fs x fs) -> maps
+    if fs == Hs:
+        Qd, Kd = as_map(Q * Z[..., None]), as_map(K)
+    else:
+        Qd = ops.resize_bilinear(as_map(Q * Z[..., None]), Hs)                 # D (Z . Q')
+        Kd = ops.resize_bilinear_adjoint(as_map(K), Hs)                        # U^T K'
+    Qd, Kd = Qd.reshape(B, H, D, Hs * Ws), Kd.reshape(B, H, D, Hs * Ws)
+    M = torch.matmul(Kd, v_corr.reshape(B, H, Hs * Ws, Ht * Wt))               # (B, H, D, Dv)
+    msg = torch.matmul(Qd.transpose(-1, -2), M).reshape(B, H, Hs, Ws, Ht, Wt)
+    return msg if residual is None else residual + msg
+
+
 def _conv_map_lib(rgb, w, b):
     """Library-op statement of cpn_conv_map7x7 (only its VJP is used): CoPoNeRF.py:182-187."""
     x = (rgb.permute(0, 3, 1, 2) + 1) / 2.
@@ -520,6 +553,30 @@ class HipOps:
         call("cpn_linear_attention", q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), B, L, H, Dv, int(channel_major), float(eps),
              nsplit, scr.data_ptr(), out.data_ptr(), _stream())
         return out
+
+    def cost_volume_attention(self, q, k, v_corr, fs, residual=None, eps=1e-6):
+        """The cost-volume side of UFCLayer.forward_attention (models/aggregation.py:283-297, :301) WITHOUT the fs x fs
+        tensors: residual + interp(LinearAttention(q, k, interp(v_corr, fs)), Hs) for v_corr / residual / result
+        (B, H, Hs, Ws, Ht, Wt).  Up- and down-sampling are linear over the positions and the attention is linear in the
+        values, so  msg = (D diag(Z) phi(q)) . ((U^T phi(k))^T v_low)  — P x 32 matrices per head instead of two
+        2 048-channel resizes and a 256-wide attention over fs*fs tokens.  Inference: cpn_cost_volume_attention (two
+        launches, fixed-order sums).  Training: the same association with stock differentiable ops."""
+        self._need_gpu(q)
+        B, H, Hs, Ws, Ht, Wt = v_corr.shape
+        if _wants_grad(q, k, v_corr) or (residual is not None and _wants_grad(residual)) or Hs != Ws:
+            return cost_volume_attention_torch(self, q, k, v_corr, fs, residual, eps)
+        q_, k_, v_ = q.contiguous().float(), k.contiguous().float(), v_corr.contiguous().float()
+        r_ = None if residual is None else residual.contiguous().float()
+        P, Dv = Hs * Ws, Ht * Wt
+        scr = torch.empty(_hip.lib().cpn_cost_volume_attention_scratch(B, fs * fs, H, P, Dv), dtype=torch.float32, device=q.device)
+        out = torch.empty_like(v_)
+        call("cpn_cost_volume_attention", q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), 0 if r_ is None else r_.data_ptr(), B, fs,
+             H, Hs, Dv, float(eps), scr.data_ptr(), out.data_ptr(), _stream())
+        return out
+
+    def resize_bilinear_adjoint(self, x, size):
+        """Adjoint of resize_bilinear(., n) for x (N,C,n,n) -> (N,C,size,size): what its backward computes."""
+        return _ResizeAdjointFn.apply(self, x, size)
 
     def cross_attention(self, c, src_v, trg_v):
         """UFCLayer.forward_cross's two softmax-weighted sums (models/aggregation.py:327-328) on cpn_cross_attention.

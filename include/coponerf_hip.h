@@ -398,6 +398,16 @@ int cpn_linear_attention_bwd(const float* q, const float* k, const float* v, con
 int cpn_qk_assemble(const float* lin, const float* low, const float* pos, int B, int fs, int h, int w, int nhead, int dim,
                     float* q, float* k, void* stream);
 
+/* ---- cost-volume side of UFCLayer.forward_attention at the volume's native resolution (round 3) ----------------------
+ * replaces models/aggregation.py:283-297 (interpolate value_corr to fs x fs, LinearAttention, interpolate the message
+ * back) and the residual of :301: out = residual + D (LinearAttention(q, k, U v_low)), formed as (D diag(Z) phi(q)) .
+ * ((U^T phi(k))^T v_low) — U / D the bilinear up / down-sampling (align_corners=True), exact in real arithmetic.
+ *   q, k (B, fs*fs, H, 32)   v_low, residual (may be NULL), out (B, H, hs*hs, Dv)
+ *   scratch: cpn_cost_volume_attention_scratch(B, fs*fs, H, hs*hs, Dv) floats                                          */
+long long cpn_cost_volume_attention_scratch(int B, int L, int H, int P, int Dv);
+int cpn_cost_volume_attention(const float* q, const float* k, const float* v_low, const float* residual, int B, int fs,
+                              int H, int hs, int Dv, float eps, float* scratch, float* out, void* stream);
+
 /* ---- K10: cost-volume cross attention of UFCLayer.forward_cross (models/aggregation.py:327-328) -------------------
  * corr (B, H, S, T) fp32; src_v (B, S, H, C), trg_v (B, T, H, C), C == 32
  *   src_attn (B, S, H, C) = softmax over t of corr . trg_v ;  trg_attn (B, T, H, C) = softmax over s of corr, transposed . src_v */

@@ -94,6 +94,20 @@ class TorchOps:
         return out.permute(0, 2, 3, 1).contiguous() if channel_major else out.contiguous()
 
     @staticmethod
+    def cost_volume_attention(q, k, v_corr, fs, residual=None, eps=1e-6):
+        """The cost-volume side of UFCLayer.forward_attention AS THE REFERENCE ORDERS IT (models/aggregation.py:283-297,
+        :301): value_corr interpolated to fs x fs, LinearAttention over the fs*fs tokens, the message interpolated back."""
+        B, H, Hs, Ws, Ht, Wt = v_corr.shape
+        vc = v_corr.permute(0, 1, 4, 5, 2, 3).reshape(B, H * Ht * Wt, Hs, Ws)
+        vc = F.interpolate(vc, size=(fs, fs), mode="bilinear", align_corners=True)
+        vc = vc.reshape(B, H, Ht * Wt, fs * fs).permute(0, 3, 1, 2)                              # (B, L, H, Dv)
+        msg = TorchOps.linear_attention(q, k, vc, eps=eps)                                       # (B, L, H, Dv)
+        msg = msg.permute(0, 2, 3, 1).reshape(B, H * Ht * Wt, fs, fs)
+        msg = F.interpolate(msg, size=(Hs, Ws), mode="bilinear", align_corners=True)
+        msg = msg.reshape(B, H, Ht, Wt, Hs, Ws).permute(0, 1, 4, 5, 2, 3)
+        return msg if residual is None else residual + msg
+
+    @staticmethod
     def cross_attention(c, src_v, trg_v):
         """UFCLayer.forward_cross, models/aggregation.py:327-328: c (B,H,S,T), src_v (B,S,H,C), trg_v (B,T,H,C)."""
         src_attn = torch.einsum("bhst,bthc->bshc", c.softmax(-1), trg_v)

@@ -103,3 +103,39 @@ def test_oracle_encoder4d_gradients_match_upstream(ops_gold):
         for name, g in got.items():
             want = torch.from_numpy(ops_gold[f"enc4d_{tag}_{name}"])
             assert (g - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max())), (tag, name)
+
+
+def test_cost_volume_attention_restructuring_is_exact():
+    """ufc_ops.cost_volume_attention_torch — (D diag(Z) phi(q)) . ((U^T phi(k))^T v_low), what the HIP path evaluates —
+    against the reference's order of operations (oracle TorchOps: interpolate up, LinearAttention, interpolate down),
+    values and gradients, on the CPU."""
+    import torch.nn.functional as F
+    from coponerf_amd.ufc_ops import cost_volume_attention_torch
+    from oracle.ufc_ref import TorchOps
+
+    class Shim:
+        @staticmethod
+        def resize_bilinear(x, size):
+            return F.interpolate(x, size=(size, size), mode="bilinear", align_corners=True)
+
+        @staticmethod
+        def resize_bilinear_adjoint(x, size):
+            N, C = x.shape[:2]
+            return torch.ops.aten.upsample_bilinear2d_backward(x.contiguous(), list(x.shape[-2:]), [N, C, size, size], True, None, None)
+
+    for fs, hs in ((8, 4), (4, 4), (12, 5)):
+        B, H, D, ht = 2, 2, 32, 3
+        g = torch.Generator().manual_seed(fs * 10 + hs)
+        q = (torch.randn(B, fs * fs, H, D, generator=g) * 0.7).double().requires_grad_(True)
+        k = (torch.randn(B, fs * fs, H, D, generator=g) * 0.7).double().requires_grad_(True)
+        v = torch.randn(B, H, hs, hs, ht, ht, generator=g).double().requires_grad_(True)
+        r = torch.randn(B, H, hs, hs, ht, ht, generator=g).double()
+        want = TorchOps.cost_volume_attention(q, k, v, fs, residual=r)
+        got = cost_volume_attention_torch(Shim, q, k, v, fs, residual=r)
+        assert got.shape == want.shape
+        assert (got - want).abs().max() <= 1e-12 * max(1.0, float(want.abs().max())), (fs, hs)
+        w = torch.randn(want.shape, generator=g).double()
+        gw = torch.autograd.grad((want * w).sum(), (q, k, v))
+        gg = torch.autograd.grad((got * w).sum(), (q, k, v))
+        for a, b_ in zip(gg, gw):
+            assert (a - b_).abs().max() <= 1e-11 * max(1.0, float(b_.abs().max())), (fs, hs)

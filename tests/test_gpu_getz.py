@@ -224,3 +224,28 @@ def test_get_z_is_bit_reproducible(dev):
         for other in runs[1:]:
             for a, b in zip(runs[0], other):
                 assert torch.equal(a, b), (B, tuple(a.shape), float((a - b).abs().max()))
+
+
+def test_cost_volume_attention_kernel_against_reference_order(dev):
+    """cpn_cost_volume_attention (low-resolution form, two launches) against the reference's order of operations (oracle
+    TorchOps.cost_volume_attention: interpolate up, LinearAttention over fs*fs tokens, interpolate down) at the three
+    token counts of UFC; the differentiable stock-op form the training path uses against the same; bit-reproducible."""
+    from coponerf_amd.ufc_ops import HipOps
+    from oracle.ufc_ref import TorchOps
+    hip = HipOps()
+    for B, fs in ((1, 16), (2, 32), (1, 64)):
+        H, hs, ht = 8, 16, 16
+        q, k = syn.normal((B, fs * fs, H, 32), seed=201 + fs) * 0.7, syn.normal((B, fs * fs, H, 32), seed=202 + fs) * 0.7
+        v, r = syn.normal((B, H, hs, hs, ht, ht), seed=203 + fs), syn.normal((B, H, hs, hs, ht, ht), seed=204 + fs)
+        want = TorchOps.cost_volume_attention(q.double(), k.double(), v.double(), fs, residual=r.double()).float()
+        with torch.no_grad():
+            got = hip.cost_volume_attention(q.to(dev), k.to(dev), v.to(dev), fs, residual=r.to(dev))
+            again = hip.cost_volume_attention(q.to(dev), k.to(dev), v.to(dev), fs, residual=r.to(dev))
+        assert got.shape == want.shape and torch.equal(got, again)
+        err = float((got.cpu() - want).abs().max())
+        assert err <= 2e-5 * max(1.0, float(want.abs().max())), (B, fs, err)
+        qg, kg, vg = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        tr = hip.cost_volume_attention(qg, kg, vg, fs, residual=r.to(dev))          # training: stock ops + resize Functions
+        assert (tr.detach().cpu() - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max()))
+        tr.square().sum().backward()
+        assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in (qg, kg, vg))
