@@ -12,6 +12,8 @@
 // support axis, one scalar-broadcast weight per (out-channel, in-channel, tap).
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -384,6 +386,111 @@ __global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const doub
     const float v = (y[idx] - mean) * rstd * gamma[o] + beta[o];
     // res: the residual the caller adds to the block's output (x + Encoder4D(x), aggregation.py:306,347-355) in the same pass
     out[idx] = res ? res[idx] + fmaxf(v, 0.0f) : fmaxf(v, 0.0f);
+}
+
+// ---- the stride-1 3x3x3x3 layer on the fp32 MFMA (round 3) --------------------------------------------------------------
+// out[co, pos] = bias + sum over (branch, tap, ci) of w_branch[co, ci, tap] * x[ci, pos + tap_branch]: an implicit GEMM with
+// M = output channels, N = positions, K = 2 * 9 * Cin on v_mfma_f32_16x16x4_f32 (an fmaf chain: fp32-exact products).
+// A wave = 16 consecutive positions x ALL output channels (MT tiles of 16, padded: Cout = 8 uses half a tile); the four
+// K values of one MFMA step are four consecutive input channels of one (branch, tap): lane (n, g) loads
+// x[ci0 + g][pos_n + tap] — the 16 lanes of a group read 64 contiguous bytes — with the buffer-load out-of-range zero as
+// the padding, and the A operand w[co][ci0 + g] comes from LDS ([branch][tap][ci][co], conflict-free).  The VALU version
+// above spends 1 152 FMAs per position and 8 channels and re-reads every input once per 8 output channels; here the
+// multiplies sit on the matrix pipe and an input value is read once per tap for all channels.  DGRAD as above.
+template <int MT, bool DGRAD>
+__global__ __launch_bounds__(256) void conv4d_k3s1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                               const float* __restrict__ bq, const float* __restrict__ ws,
+                                                               const float* __restrict__ bs, int Cin, int Hq, int Wq, int Hs,
+                                                               int Ws, int cout_total, float* __restrict__ y,
+                                                               double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];        // [2][9][Cin4][MT*16], Cin4 = Cin rounded up to 4
+    const int b = blockIdx.z;
+    const int Cin4 = (Cin + 3) & ~3, CO = MT * 16;
+    for (int i = threadIdx.x; i < 18 * Cin4 * CO; i += 256) {
+        const int o = i % CO;
+        int t = i / CO;
+        const int c = t % Cin4; t /= Cin4;
+        const int tap = t % 9, br = t / 9;
+        float v = 0.0f;
+        if (o < cout_total && c < Cin)
+            v = DGRAD ? (br ? ws : wq)[((size_t)c * cout_total + o) * 9 + (8 - tap)] : (br ? ws : wq)[((size_t)o * Cin + c) * 9 + tap];
+        wl[i] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const long long npos = (long long)Hq * Wq * Hs * Ws;
+    const long long pos = ((long long)blockIdx.x * 4 + wave) * 16 + n;
+    const bool active = pos < npos;
+    const long long pc = active ? pos : npos - 1;
+    const int sx = (int)(pc % Ws);
+    long long t = pc / Ws;
+    const int sy = (int)(t % Hs); t /= Hs;
+    const int qx = (int)(t % Wq);
+    const int qy = (int)(t / Wq);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x + (size_t)b * Cin * (size_t)npos), 0, (int)((size_t)Cin * npos * 4), 0x00020000);
+    const int plane = (int)npos * 4;                               // bytes of one input channel
+    int off[18];                                                   // [branch * 9 + tap], with this lane's channel offset g
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int tp = i * 3 + j;
+            const int Y = qy + i - 1, X = qx + j - 1, U = sy + i - 1, Vv = sx + j - 1;
+            const bool okq = active && Y >= 0 && Y < Hq && X >= 0 && X < Wq;
+            const bool oks = active && U >= 0 && U < Hs && Vv >= 0 && Vv < Ws;
+            off[tp] = okq ? (((Y * Wq + X) * Hs + sy) * Ws + sx) * 4 + g * plane : 0x7ffffff0;
+            off[9 + tp] = oks ? (((qy * Wq + qx) * Hs + U) * Ws + Vv) * 4 + g * plane : 0x7ffffff0;
+        }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = mt * 16 + g * 4 + i;
+            acc[mt][i] = (DGRAD || co >= cout_total) ? 0.0f : bq[co] + bs[co];
+        }
+    for (int c0 = 0; c0 < Cin4; c0 += 4) {
+        // channels beyond Cin: the weights are zero and the load is forced out of range (0), so nothing leaks in
+        const bool cok = c0 + g < Cin;
+        float xv[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k)
+            xv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cok ? off[k] : 0x7ffffff0, c0 * plane, 0));
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            const float* wrow = wl + ((size_t)k * Cin4 + c0 + g) * CO + n;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[mt * 16], xv[k], acc[mt], 0, 0, 0);
+        }
+    }
+    double s1 = 0.0, s2 = 0.0;
+    if (active) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = mt * 16 + g * 4 + i;
+                if (co < cout_total) {
+                    const float v = acc[mt][i];
+                    y[((size_t)b * cout_total + co) * npos + pos] = v;
+                    s1 += (double)v;
+                    s2 += (double)v * v;
+                }
+            }
+    }
+    if (DGRAD) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    __shared__ double red[8];
+    if (lane == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
+    __syncthreads();
+    gn_publish(red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7], stats, b);
 }
 
 // ---- backward of GroupNorm(1 group) + ReLU, two passes over the volume ---------------------------------------
@@ -1018,9 +1125,11 @@ extern "C" int cpn_resize_bilinear_ac(const float* src, float* dst, long long pl
 }
 
 // doubles of the `stats` argument of cpn_conv4d / cpn_conv4d_gn_relu (layout: gn_publish); an upper bound over the
-// kernel variants' grids: one workgroup per 256 output positions and output channel (group)
+// kernel variants' grids
 extern "C" long long cpn_gn_stats_doubles(int B, int Cout, long long npos) {
-    return 3LL * B + 2LL * B * cpn_cdiv(npos, 256) * Cout;
+    // VALU kernels: one workgroup per 256 positions and output channel (group); MFMA kernel: one per 64 positions
+    const long long wg = std::max<long long>((long long)cpn_cdiv(npos, 256) * Cout, (long long)cpn_cdiv(npos, 64));
+    return 3LL * B + 2LL * B * wg;
 }
 
 extern "C" long long cpn_conv4d_scratch(int B, int Cin, int Hq, int Wq, int Hs, int Ws, int s) {
@@ -1044,7 +1153,23 @@ extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, cons
     const hipStream_t st = (hipStream_t)stream;
     dim3 grid(cpn_cdiv(npos, 256), Cout, B);
     const size_t wbytes = (size_t)Cin * 9 * 2 * Cout * sizeof(float);
-    if (k == 3 && s == 1 && p == 1 && (Cout == 8 || Cout == 32) && wbytes <= 64 * 1024 &&
+    // Measured (round 3, get_z at B = 1, rocprofv3): the MFMA kernel takes 40 us per Cout = 8 layer and 32 us per Cout = 32
+    // layer, the VALU kernel 24 and 34 — half of every 16-row MFMA tile is padding at 8 output channels and a wave's 16
+    // positions leave the matrix pipe waiting for 18 dependent taps per channel quad.  Opt-in (CPN_CONV4D_MFMA=1).
+    static const bool no_mfma = getenv("CPN_CONV4D_MFMA") == nullptr;
+    const int Cin4 = (Cin + 3) & ~3, mtiles = (Cout + 15) / 16;
+    const size_t wb_mfma = (size_t)18 * Cin4 * mtiles * 16 * sizeof(float);
+    if (!no_mfma && k == 3 && s == 1 && p == 1 && Cin >= 4 && mtiles <= 2 && wb_mfma <= 64 * 1024 &&
+        (long long)Cin * npos * 4 < 0x7ffffff0LL - 4LL * npos * 4) {
+        // gn_publish counts gridDim.x * gridDim.y workgroups per sample: one workgroup = 64 positions, all channels
+        dim3 g2(cpn_cdiv(npos, 64), 1, B);
+        if (mtiles == 1)
+            hipLaunchKernelGGL((conv4d_k3s1_mfma_kernel<1, false>), g2, dim3(256), wb_mfma, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs,
+                               Ws, Cout, y, stats);
+        else
+            hipLaunchKernelGGL((conv4d_k3s1_mfma_kernel<2, false>), g2, dim3(256), wb_mfma, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs,
+                               Ws, Cout, y, stats);
+    } else if (k == 3 && s == 1 && p == 1 && (Cout == 8 || Cout == 32) && wbytes <= 64 * 1024 &&
         (long long)Cin * npos * 4 < 0x7ffffff0LL) {
         // channels per thread: 8 (4 when one thread per position would leave <= 2 waves per SIMD).  All 32 channels in one
         // thread read every input once instead of four times, but the compiler cannot hold 32 accumulators + a tap's
@@ -1091,6 +1216,23 @@ extern "C" int cpn_conv4d_dgrad(const float* dy, const float* wq, const float* w
     // the data gradient is a k3 s1 p1 convolution of dy (Cout channels) producing Cin channels: channel groups of 8 (4)
     CPN_REQUIRE((Cin % 4) == 0 && (long long)Cout * npos * 4 < 0x7ffffff0LL, CPN_E_SHAPE,
                 "cpn_conv4d_dgrad: need Cin %% 4 == 0 and a batch element below 2 GiB (Cin=%d)", Cin);
+    {
+        static const bool no_mfma = getenv("CPN_CONV4D_MFMA") == nullptr;
+        const int K4 = (Cout + 3) & ~3, mtiles = (Cin + 15) / 16;           // the gradient convolves dy (Cout channels) into Cin
+        const size_t wb_mfma = (size_t)18 * K4 * mtiles * 16 * sizeof(float);
+        if (!no_mfma && Cout >= 4 && mtiles <= 2 && wb_mfma <= 64 * 1024 && (long long)Cout * npos * 4 < 0x7ffffff0LL - 4LL * npos * 4) {
+            dim3 g2(cpn_cdiv(npos, 64), 1, B);
+            const hipStream_t st2 = (hipStream_t)stream;
+            if (mtiles == 1)
+                hipLaunchKernelGGL((conv4d_k3s1_mfma_kernel<1, true>), g2, dim3(256), wb_mfma, st2, dy, wq, (const float*)nullptr, ws,
+                                   (const float*)nullptr, Cout, Hq, Wq, Hs, Ws, Cin, dx, (double*)nullptr);
+            else
+                hipLaunchKernelGGL((conv4d_k3s1_mfma_kernel<2, true>), g2, dim3(256), wb_mfma, st2, dy, wq, (const float*)nullptr, ws,
+                                   (const float*)nullptr, Cout, Hq, Wq, Hs, Ws, Cin, dx, (double*)nullptr);
+            CPN_LAUNCH_CHECK("cpn_conv4d_dgrad");
+            return 0;
+        }
+    }
     const int per = (Cin % 8) == 0 ? 8 : 4;
     const size_t wb = (size_t)Cout * 9 * 2 * per * sizeof(float);
     CPN_REQUIRE(wb <= 64 * 1024, CPN_E_SHAPE, "cpn_conv4d_dgrad: filter slice exceeds 64 KiB of LDS (Cout=%d)", Cout);

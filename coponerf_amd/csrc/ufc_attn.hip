@@ -712,8 +712,8 @@ __device__ __forceinline__ void ac_taps(int Y, int X, int n_out, int n_in, int (
 
 // K1: workgroup = (block of 32 low-res positions, (b, h)).  Kd of its positions as a GATHER over the tokens whose bilinear
 // footprint holds the position (fixed order: no atomics, the result is bit-reproducible), then its partial of
-// M = Kd^T v_low (32 x Dv); block 0 also forms sum_l phi(k_l) with a fixed-order tree.
-constexpr int CVA_BP = 32;
+// M = Kd^T v_low (32 x Dv) and its share of sum_l phi(k_l).
+constexpr int CVA_BP = 16;
 __global__ __launch_bounds__(256) void cva_kd_kernel(const float* __restrict__ k, const float* __restrict__ v_low, int L, int H,
                                                      int fs, int hs, int Dv, int nblk, float* __restrict__ kvm_part,
                                                      float* __restrict__ ksum_out) {
@@ -723,19 +723,30 @@ __global__ __launch_bounds__(256) void cva_kd_kernel(const float* __restrict__ k
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H, blk = blockIdx.x;
     const int d = threadIdx.x & 31, g = threadIdx.x >> 5;
     const float* kb = k + ((size_t)b * L * H + h) * CVA_D + d;    // token l at kb[l * H * 32]
-    if (blk == 0) {
+    {
+        // this block's share of sum_l phi(k_l) (tokens blk*Lb .. ): the nblk partials are added in block order by cva_out
+        const int Lb = (L + nblk - 1) / nblk, l0 = blk * Lb, l1 = min(L, l0 + Lb);
         float a = 0.0f;
-        for (int l = g; l < L; l += 8) a += elu1(kb[(size_t)l * H * CVA_D]);
+        for (int l = l0 + g; l < l1; l += 8) a += elu1(kb[(size_t)l * H * CVA_D]);
         tree[g][d] = a;
         __syncthreads();
         if (g == 0) {
             float t = tree[0][d];
 #pragma unroll
             for (int i = 1; i < 8; ++i) t += tree[i][d];
-            ksum_out[(size_t)bh * CVA_D + d] = t;
+            ksum_out[((size_t)bh * nblk + blk) * CVA_D + d] = t;
         }
     }
     const float inv_s = fs > 1 && hs > 1 ? (float)(fs - 1) / (float)(hs - 1) : 1.0f;     // tokens per low-res step
+    const float sc = fs > 1 ? (float)(hs - 1) / (float)(fs - 1) : 0.0f;                    // the resize kernel's scale
+    // the upsampling is separable: weight of token (Y, X) at position (y, x) = wy(Y, y) * wx(X, x), each the 1-D bilinear
+    // weight of resize_bilinear_ac_kernel (y0 = (int)(sc*Y), y1 = y0 + (y0 < hs-1), ly = sc*Y - y0)
+    auto w1d = [&](int T, int t) {
+        const float f = sc * (float)T;
+        const int t0 = (int)f, t1 = t0 + (t0 < hs - 1);
+        const float l = f - (float)t0;
+        return (t == t0 ? 1.0f - l : 0.0f) + (t == t1 ? l : 0.0f);
+    };
     for (int pp = g; pp < CVA_BP; pp += 8) {
         const int p = blk * CVA_BP + pp;
         float acc = 0.0f;
@@ -743,16 +754,16 @@ __global__ __launch_bounds__(256) void cva_kd_kernel(const float* __restrict__ k
             const int y = p / hs, x = p - y * hs;
             const int Y0 = max(0, (int)floorf((float)(y - 1) * inv_s) - 1), Y1 = min(fs - 1, (int)ceilf((float)(y + 1) * inv_s) + 1);
             const int X0 = max(0, (int)floorf((float)(x - 1) * inv_s) - 1), X1 = min(fs - 1, (int)ceilf((float)(x + 1) * inv_s) + 1);
-            for (int Y = Y0; Y <= Y1; ++Y)
+            for (int Y = Y0; Y <= Y1; ++Y) {
+                const float wy = w1d(Y, y);
+                if (wy == 0.0f) continue;
+                float row = 0.0f;
                 for (int X = X0; X <= X1; ++X) {
-                    int idx[4];
-                    float w[4];
-                    ac_taps(Y, X, fs, hs, idx, w);
-                    float wsum = 0.0f;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) wsum += (idx[t] == p) ? w[t] : 0.0f;
-                    if (wsum != 0.0f) acc += wsum * elu1(kb[(size_t)(Y * fs + X) * H * CVA_D]);
+                    const float wx = w1d(X, x);
+                    if (wx != 0.0f) row += wx * elu1(kb[(size_t)(Y * fs + X) * H * CVA_D]);
                 }
+                acc += wy * row;
+            }
         }
         kd[pp][d] = acc;
     }
@@ -785,7 +796,11 @@ __global__ __launch_bounds__(256) void cva_out_kernel(const float* __restrict__ 
     const int P = hs * hs;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H, p0 = blockIdx.x * CVA_PB;
     const float* mb = kvm_part + (size_t)bh * nblk * CVA_D * Dv;
-    if (threadIdx.x < CVA_D) ksum[threadIdx.x] = ksum_in[(size_t)bh * CVA_D + threadIdx.x];
+    if (threadIdx.x < CVA_D) {
+        float t = 0.0f;
+        for (int kb2 = 0; kb2 < nblk; ++kb2) t += ksum_in[((size_t)bh * nblk + kb2) * CVA_D + threadIdx.x];
+        ksum[threadIdx.x] = t;
+    }
     __syncthreads();
     {
         // Qd[p][d] = sum_t w_t Z_{l_t} phi(q_{l_t})[d]: 8 positions x 32 features = 256 threads; Z through a 32-lane sum
@@ -830,7 +845,7 @@ __global__ __launch_bounds__(256) void cva_out_kernel(const float* __restrict__ 
 
 extern "C" long long cpn_cost_volume_attention_scratch(int B, int L, int H, int P, int Dv) {
     const long long nblk = (P + CVA_BP - 1) / CVA_BP;
-    return (long long)B * H * (nblk * CVA_D * Dv + CVA_D);
+    return (long long)B * H * nblk * (CVA_D * Dv + CVA_D);
 }
 
 extern "C" int cpn_cost_volume_attention(const float* q, const float* k, const float* v_low, const float* residual, int B,

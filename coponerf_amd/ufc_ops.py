@@ -7,6 +7,8 @@ That restatement is never used to produce a forward value.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -426,6 +428,17 @@ def cost_volume_attention_torch(ops, q, k, v_corr, fs, residual=None, eps=1e-6):
     return msg if residual is None else residual + msg
 
 
+def cost_volume_attention_reference_order(ops, q, k, v_corr, fs, residual=None, eps=1e-6):
+    """The reference's order (interpolate up, LinearAttention over fs*fs tokens, interpolate down) on the HIP operators: what
+    rounds 1-2 ran; kept for A/B timing of the training step (CPN_CVA_REFERENCE_ORDER=1)."""
+    B, H, Hs, Ws, Ht, Wt = v_corr.shape
+    vc = ops.resize_bilinear(swap_pairs(v_corr).reshape(B, H * Ht * Wt, Hs, Ws), fs)
+    msg = ops.linear_attention(q, k, vc.reshape(B, H, Ht * Wt, fs * fs), channel_major=True, eps=eps)
+    msg = ops.resize_bilinear(msg.reshape(B, H * Ht * Wt, fs, fs), Hs)
+    msg = msg.reshape(B, H, Ht, Wt, Hs, Ws).permute(0, 1, 4, 5, 2, 3)
+    return msg if residual is None else residual + msg
+
+
 def _conv_map_lib(rgb, w, b):
     """Library-op statement of cpn_conv_map7x7 (only its VJP is used): CoPoNeRF.py:182-187."""
     x = (rgb.permute(0, 3, 1, 2) + 1) / 2.
@@ -564,6 +577,8 @@ class HipOps:
         self._need_gpu(q)
         B, H, Hs, Ws, Ht, Wt = v_corr.shape
         if _wants_grad(q, k, v_corr) or (residual is not None and _wants_grad(residual)) or Hs != Ws:
+            if os.environ.get("CPN_CVA_REFERENCE_ORDER") == "1":             # A/B: the round-2 sequence on the HIP operators
+                return cost_volume_attention_reference_order(self, q, k, v_corr, fs, residual, eps)
             return cost_volume_attention_torch(self, q, k, v_corr, fs, residual, eps)
         q_, k_, v_ = q.contiguous().float(), k.contiguous().float(), v_corr.contiguous().float()
         r_ = None if residual is None else residual.contiguous().float()
