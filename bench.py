@@ -62,6 +62,9 @@ def parse_args(argv=None):
                     help="first encoder layer as gather + 835->832 GEMM instead of the projected-table form")
     ap.add_argument("--no-image", action="store_true", help="skip the secondary image-pipeline figures (get_z + render)")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-two-stream-pass", action="store_true",
+                    help="skip the second timed pass with consecutive calls on two streams (keeps a rocprofv3 kernel "
+                         "trace of this command to the one-stream headline loop, whose kernels never overlap)")
     ap.add_argument("--no-ref-loop", action="store_true",
                     help="skip the secondary measurement of the reference callers' chunked loop (test.py:164-212)")
     ap.add_argument("--rig", choices=("narrow", "wide"), default="narrow",
@@ -236,7 +239,7 @@ def run(args):
     elapsed = _max_over_ranks(elapsed, dev, distributed)
     model._engine.call_lanes = lanes_default
     overlapped = None
-    if lanes_default > 1 and not args.pair_by_pair:
+    if lanes_default > 1 and not args.pair_by_pair and not args.no_two_stream_pass:
         for _ in range(2):
             step()
         _fence(distributed)
