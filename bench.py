@@ -308,6 +308,20 @@ def run(args):
                 pdt = time.perf_counter() - p0
             line["image_rays_per_s_pipelined"] = nimg * R / pdt
             line["image_ms_pipelined"] = 1e3 * pdt / nimg
+            # the same loop on a PARTITIONED chip: render pass on 192 CUs, get_z on the other 64 (CU-masked streams,
+            # coponerf_amd/streams.py) — ordinary streams cannot overlap the two (the line above)
+            with torch.no_grad():
+                for _ in render_images(model, pairs[:2], cu_split=(192, 64)):
+                    pass
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                nimg = 0
+                for _ in render_images(model, pairs + pairs, cu_split=(192, 64)):
+                    nimg += 1
+                torch.cuda.synchronize()
+                pdt = time.perf_counter() - p0
+            line["image_rays_per_s_cu_partition_192_64"] = nimg * R / pdt
+            line["image_ms_cu_partition_192_64"] = 1e3 * pdt / nimg
             # throughput form of the same loop: get_z batched over 4 consecutive pairs (one launch sequence for four)
             with torch.no_grad():
                 for _ in render_images(model, pairs, getz_batch=4):

@@ -18,6 +18,8 @@ _P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
 # name -> argtypes (every function returns int status except the two noted below)
 SIGNATURES: Dict[str, List] = {
+    "cpn_stream_create_cu_range": [_I, _I, ctypes.POINTER(ctypes.c_void_p)],
+    "cpn_stream_destroy": [_P],
     "cpn_project_rays": [_P, _P, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P],
     "cpn_sample_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cpn_nchw_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
@@ -119,6 +121,10 @@ def lib() -> ctypes.CDLL:
         fn.restype = ctypes.c_int
     handle.cpn_abi_version.argtypes = []
     handle.cpn_abi_version.restype = ctypes.c_int
+    handle.cpn_device_cu_count.argtypes = []
+    handle.cpn_device_cu_count.restype = ctypes.c_int
+    handle.cpn_stream_cu_count.argtypes = [_P]
+    handle.cpn_stream_cu_count.restype = ctypes.c_int
     handle.cpn_encode_table_nodes.argtypes = [_I, _I]
     handle.cpn_encode_table_nodes.restype = ctypes.c_longlong
     handle.cpn_linear_attention_scratch.argtypes = [_I, _I, _I, _I]

@@ -16,6 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 UNITS = [
     ("error.cpp", []),
+    ("streams.cpp", []),
     ("geometry.hip", ["-ffp-contract=off"]),
     ("gather.hip", []),
     ("encode.hip", []),

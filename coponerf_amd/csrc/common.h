@@ -7,6 +7,8 @@
 #include "../../include/coponerf_hip.h"
 
 void cpn_set_error(const char* fmt, ...);
+// CUs a launch on `stream` may occupy: the device's count, or the share of a CU-masked stream (streams.cpp)
+int cpn_stream_cus(void* stream);
 
 #define CPN_REQUIRE(cond, code, ...)                 \
     do {                                             \

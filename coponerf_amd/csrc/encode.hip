@@ -635,14 +635,7 @@ extern "C" int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int 
     const long long group1 = (long long)b_hi * groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
     const int nsblk = (int)cpn_cdiv(S, TSW);
     const long long nwtiles = (group1 - group0 + 1) * V * nsblk * (2 / MTN);
-    static int num_cu = 0;
-    if (num_cu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        num_cu = n;
-    }
+    const int num_cu = cpn_stream_cus((void*)stream);       // persistent grid: the CUs this stream may use
     const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nwtiles, ENC_WAVES));      // persistent: one workgroup per CU
     hipLaunchKernelGGL(encode_hidden_kernel, dim3(grid), dim3(64 * ENC_WAVES), 0, (hipStream_t)stream,
                        (const __half*)tab, (const __half*)map3, H, W, pixel_val, sec_grid, pe6, (const half8*)wfrag,

@@ -456,14 +456,7 @@ int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias
         cpn_set_error("cpn_gemm_f16: %lld output tiles exceed the 32-bit tile index", total);
         return CPN_E_SHAPE;
     }
-    static int num_cu = 0;
-    if (num_cu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        num_cu = n;
-    }
+    const int num_cu = cpn_stream_cus((void*)stream);       // persistent grid: the CUs this stream may use
     dim3 grid((unsigned)std::min<long long>(total, num_cu));       // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles, (int)total,
                        (const __half*)nullptr, 0, (const __half*)nullptr, 0, (const float*)nullptr);
@@ -488,14 +481,7 @@ int launch_rowdot(const __half* A, int lda, const __half* W, int ldw, const floa
         attr_set = true;
     }
     const long long total = cpn_cdiv(M, BM);
-    static int num_cu = 0;
-    if (num_cu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        num_cu = n;
-    }
+    const int num_cu = cpn_stream_cus((void*)stream);       // persistent grid: the CUs this stream may use
     dim3 grid((unsigned)std::min<long long>(total, num_cu));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, (void*)logits, 0, M, K32, 1, (int)total, Q,
                        ldq, W2, ldw2, bias2);

@@ -1,16 +1,20 @@
-"""Image pipeline over a sequence of stereo pairs: get_z of pair i+1 runs on a second HIP stream under the render pass
-of pair i.
+"""Image pipeline over a sequence of stereo pairs: get_z of pair i+1 runs under the render pass of pair i.
 
 The reference's evaluation loop (/root/reference test.py:164-212, wrapper.py:176-211) is strictly serial: `get_z`, then
 the chunked `forward(val=True)` calls, pair after pair.  The two halves are complementary on an MI355X — `get_z` is
-~1 100 small kernels (launch / latency bound, 15.8 ms alone), the render pass is a handful of HBM-bound kernels that
-fill the chip (34 ms) — and stereo pairs are independent, so the next pair's features can be produced while the current
-image renders.  Same kernels, same inputs as the serial order; only the schedule changes (get_z's GroupNorm statistics
-are accumulated with atomics, so two runs agree to rounding, serial or not).
+~800 small kernels (launch / latency bound, 11 ms alone), the render pass is a handful of HBM-bound kernels that fill
+the chip (25.5 ms) — and stereo pairs are independent, so the next pair's features can be produced while the current
+image renders.  Same kernels, same inputs as the serial order; only the schedule changes, and since get_z's GroupNorm
+statistics are reduced in a fixed order the results are bit-identical to the serial ones.
+
+Two ordinary streams do NOT overlap the halves (measured: 38.9 ms per image against 37.3 serial): the persistent grids
+of the render pass hold every CU, so each small kernel of get_z waits for a chip-filling launch to drain.  `cu_split`
+partitions the chip instead (coponerf_amd/streams.py): the render pass keeps `cu_split[0]` CUs, get_z the other
+`cu_split[1]`, an equal share of every XCD each.
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, Iterator, Tuple
+from typing import Dict, Iterable, Iterator, Optional, Tuple
 
 import torch
 
@@ -49,16 +53,21 @@ def _pair_slice(obj, lo: int, hi: int, per: int):
     return obj
 
 
-def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: bool = False) -> Iterator[Tuple[Dict, Dict]]:
+def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: bool = False,
+                  cu_split: Optional[Tuple[int, int]] = None) -> Iterator[Tuple[Dict, Dict]]:
     """For every model_input dict (on the device) yield (model_input, forward(model_input, z, rel_pose, val=True, flow)),
     with `get_z` of the next inputs overlapped with the render of the current ones.  Call under torch.no_grad().
 
-    getz_batch > 1 runs `get_z` ONCE for that many consecutive inputs (batched along dim 0: its ~1 100 kernels are
-    launch / latency bound, 15.8 ms for one pair, ~10 ms per pair at four) and renders them one after the other from
-    slices of the batched features; per-pair results are those of the serial order up to the rounding noise of get_z's
-    atomically accumulated GroupNorm statistics (tests/test_gpu_getz.py).
+    cu_split=(render_cus, getz_cus) runs the two halves on CU-masked streams over disjoint shares of the chip
+    (multiples of 32, sum <= the device's CU count; e.g. (192, 64)); the yielded outputs are ordered after the
+    caller's current stream as usual.  None: two ordinary streams (the get_z one at high priority).
 
-    graph=True replays `get_z` as a captured HIP graph (coponerf_amd/graphs.py: one hipGraphLaunch instead of ~1 100
+    getz_batch > 1 runs `get_z` ONCE for that many consecutive inputs (batched along dim 0: its kernels are launch /
+    latency bound, 11 ms for one pair, ~6.5 ms per pair at four) and renders them one after the other from slices of
+    the batched features; per-pair results are those of the serial order up to the rounding differences of batched
+    library GEMMs / convolutions (tests/test_gpu_getz.py).
+
+    graph=True replays `get_z` as a captured HIP graph (coponerf_amd/graphs.py: one hipGraphLaunch instead of ~800
     eager launches; same kernels, same results)."""
     it = iter(inputs)
     getz = model.get_z
@@ -83,41 +92,65 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
     cur = take()
     if not cur:
         return
-    main = torch.cuda.current_stream()
-    # high priority: the small kernels of get_z are dispatched ahead of the render's queued workgroups instead of
-    # waiting behind each of the render's chip-filling launches
-    side = torch.cuda.Stream(device=main.device, priority=-1)
-    state = features(cur)                                      # first group: nothing to hide it under
-    while cur:
-        nxt = take()
-        (z, rel_pose, flow), hint, sizes = state
-        H, W = model.H, model.W
-        if nxt:
-            side.wait_stream(main)          # BEFORE the renders are enqueued: the side stream then only waits for what
+    outer = torch.cuda.current_stream()
+    engine = model._engine
+    lanes_before = engine.call_lanes
+    if cu_split is not None:
+        from .streams import CUPartition
+        parts = model.__dict__.setdefault("_cu_partitions", {})
+        key = (int(cu_split[0]), int(cu_split[1]), outer.device.index)
+        part = parts.get(key)
+        if part is None:
+            part = parts[key] = CUPartition(key[0], key[1], outer.device)
+        main, side = part.render, part.getz
+        main.wait_stream(outer)                 # the inputs were produced on the caller's stream
+        engine.call_lanes = 1                   # consecutive calls must stay on the render share, not alternate streams
+    else:
+        main = outer
+        # high priority: the small kernels of get_z are dispatched ahead of the render's queued workgroups instead of
+        # waiting behind each of the render's chip-filling launches
+        side = torch.cuda.Stream(device=main.device, priority=-1)
+    try:
+        with torch.cuda.stream(main):
+            state = features(cur)                                  # first group: nothing to hide it under
+        while cur:
+            nxt = take()
+            (z, rel_pose, flow), hint, sizes = state
+            H, W = model.H, model.W
+            if nxt:
+                side.wait_stream(main)      # BEFORE the renders are enqueued: the side stream then only waits for what
                                             # is already on the main stream (the previous group), not for these renders
-        nstate = None
-        lo = 0
-        for i, inp in enumerate(cur):
-            hi = lo + sizes[i]
-            if len(cur) == 1:
-                zi, ri, fi = z, rel_pose, flow
-            else:
-                zi, ri, fi = _pair_slice(z, lo, hi, 2), rel_pose[lo:hi], _pair_slice(flow, lo, hi, 1)
-                if hint is not None and hint[0] is z[3]:
-                    model._engine.adopt_level3(zi[3], hint[2][2 * lo:2 * hi])
-            lo = hi
-            model.H, model.W = H, W
-            # 1. the render of this pair: a few dozen launches, asynchronous except for two short host waits
-            out = model(inp, z=zi, rel_pose=ri, val=True, flow=fi)
-            if i == 0 and nxt:
-                # 2. the ~1 100 launches of the next group's get_z on the side stream: the host issues them while the
-                #    GPU renders, the small kernels run in the gaps of / beside the HBM-bound render kernels
-                with torch.cuda.stream(side):
-                    nstate = features(nxt)
-            if i == len(cur) - 1 and nxt:
-                main.wait_stream(side)      # the NEXT renders (and whatever the caller enqueues) follow get_z(next)
-                _record(nstate[0], main)
-                if nstate[1] is not None:
-                    _record(nstate[1][2], main)
-            yield inp, out
-        cur, state = nxt, nstate
+            nstate = None
+            lo = 0
+            for i, inp in enumerate(cur):
+                hi = lo + sizes[i]
+                with torch.cuda.stream(main):                      # closed again before the yield below
+                    if len(cur) == 1:
+                        zi, ri, fi = z, rel_pose, flow
+                    else:
+                        zi, ri, fi = _pair_slice(z, lo, hi, 2), rel_pose[lo:hi], _pair_slice(flow, lo, hi, 1)
+                        if hint is not None and hint[0] is z[3]:
+                            engine.adopt_level3(zi[3], hint[2][2 * lo:2 * hi])
+                    model.H, model.W = H, W
+                    # 1. the render of this pair: a few dozen launches, asynchronous
+                    out = model(inp, z=zi, rel_pose=ri, val=True, flow=fi)
+                    if i == 0 and nxt:
+                        # 2. the ~800 launches of the next group's get_z on the side stream: the host issues them while
+                        #    the GPU renders, the small kernels run beside the HBM-bound render kernels
+                        with torch.cuda.stream(side):
+                            nstate = features(nxt)
+                    if i == len(cur) - 1 and nxt:
+                        main.wait_stream(side)  # the NEXT renders (and whatever the caller enqueues) follow get_z(next)
+                        _record(nstate[0], main)
+                        if nstate[1] is not None:
+                            _record(nstate[1][2], main)
+                if main is not outer:
+                    outer.wait_stream(main)
+                    _record(out, outer)
+                lo = hi
+                yield inp, out
+            cur, state = nxt, nstate
+    finally:
+        engine.call_lanes = lanes_before
+        if main is not outer:
+            outer.wait_stream(main)

@@ -51,6 +51,19 @@ extern "C" {
 int         cpn_abi_version(void);
 const char* cpn_last_error(void);
 
+/* ---- CU-partitioned streams -------------------------------------------------------------------------------------
+ * The reference's evaluation loop runs get_z and the chunked forward() calls strictly one after the other
+ * (test.py:164-212, wrapper.py:176-211).  On an MI355X the render pass (HBM-bound, persistent grids on every CU) and
+ * get_z (hundreds of small launches) only overlap when each has CUs of its own: a stream created here is restricted
+ * to CUs [first_cu, first_cu + num_cus) of the CU-mask order, which KFD spreads round-robin over the 8 XCDs and their
+ * 4 shader engines — both numbers must be multiples of 32, i.e. an equal share of every shader engine of every XCD.  The persistent launchers of this library
+ * (cpn_encode_hidden, cpn_gemm_f16*) size their grids by cpn_stream_cu_count(stream).  `stream_out` receives a
+ * hipStream_t; destroy it with cpn_stream_destroy once its work has completed.  (coponerf_amd/streams.py, pipeline.py) */
+int cpn_device_cu_count(void);
+int cpn_stream_cu_count(void* stream);
+int cpn_stream_create_cu_range(int first_cu, int num_cus, void** stream_out);
+int cpn_stream_destroy(void* stream);
+
 /* ---- K1: query rays -> Pluecker coords + clipped epipolar segment ------------------------------
  * replaces geometry.plucker_embedding (utils_training/geometry.py:236-245, :426-433, :409-419, :353-371),
  * epipolar.project_rays (models/epipolar.py:175-253) and the start/end scrub (models/CoPoNeRF.py:279-291).

@@ -15,7 +15,7 @@ def test_library_is_built_and_exports_header_symbols():
     assert len(declared) >= 12
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/coponerf_hip.h but not exported"
-    assert set(_hip.SIGNATURES) | {"cpn_abi_version", "cpn_last_error", "cpn_gather_bwd_chunks", "cpn_conv_wgrad_scratch", "cpn_wgrad_tall_scratch", "cpn_conv4d_scratch", "cpn_gn_stats_doubles", "cpn_scatter_tables_scratch", "cpn_encode_table_nodes", "cpn_linear_attention_scratch", "cpn_cost_volume_attention_scratch", "cpn_linear_attention_bwd_scratch", "cpn_cross_attention_bwd_scratch", "cpn_dwconv3x3_tokens_wgrad_scratch"} == set(declared)
+    assert set(_hip.SIGNATURES) | {"cpn_abi_version", "cpn_last_error", "cpn_gather_bwd_chunks", "cpn_conv_wgrad_scratch", "cpn_wgrad_tall_scratch", "cpn_conv4d_scratch", "cpn_gn_stats_doubles", "cpn_scatter_tables_scratch", "cpn_encode_table_nodes", "cpn_linear_attention_scratch", "cpn_cost_volume_attention_scratch", "cpn_linear_attention_bwd_scratch", "cpn_cross_attention_bwd_scratch", "cpn_dwconv3x3_tokens_wgrad_scratch", "cpn_device_cu_count", "cpn_stream_cu_count"} == set(declared)
     assert lib.cpn_abi_version() == _hip.ABI_VERSION
 
 
@@ -26,6 +26,13 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert b"null" in lib.cpn_last_error()
     with pytest.raises(RuntimeError, match="cpn_gemm_f16"):
         _hip.call("cpn_gemm_f16", 16, 8, 16, 8, 16, 16, 8, 4, 100, 30, 0, 0, None)   # K not a multiple of 32
+    # CU-masked streams: shares are multiples of 32 (8 XCDs x 4 shader engines); rejected before any HIP call
+    import ctypes
+    out = ctypes.c_void_p()
+    assert lib.cpn_stream_create_cu_range(0, 200, ctypes.byref(out)) == -1 and b"multiples of 32" in lib.cpn_last_error()
+    assert lib.cpn_stream_create_cu_range(0, 64, None) == -1
+    assert lib.cpn_stream_destroy(None) == -1
+    assert lib.cpn_stream_destroy(ctypes.c_void_p(1)) == -1 and b"not a stream" in lib.cpn_last_error()
 
 
 def test_missing_library_raises(monkeypatch):

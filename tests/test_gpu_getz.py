@@ -176,6 +176,8 @@ def test_pipelined_images_equal_serial(dev):
         serial = [serial_rgb(p) for p in pairs]
         piped = [out["rgb"].clone() for _, out in render_images(model, pairs)]
         batched = [out["rgb"].clone() for _, out in render_images(model, pairs, getz_batch=2)]   # groups of 2 + 1
+        parted = [out["rgb"].clone() for _, out in render_images(model, pairs, cu_split=(192, 64))]   # partitioned chip
+        lanes_after = model._engine.call_lanes
         graphed = [out["rgb"].clone() for _, out in render_images(model, pairs, graph=True)]     # get_z as a HIP graph
         graphed2 = [out["rgb"].clone() for _, out in render_images(model, pairs[::-1], graph=True)]   # replay only
         again = serial_rgb(pairs[0])
@@ -189,6 +191,11 @@ def test_pipelined_images_equal_serial(dev):
     noise = 1e-4
     assert len(piped) == 3 and len(batched) == 3
     for a, b in zip(serial, piped):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    # render pass on 192 CUs, get_z on the other 64 (CU-masked streams): the persistent grids shrink to the share, the
+    # tiles and their arithmetic do not change
+    assert len(parted) == 3 and lanes_after == 2
+    for a, b in zip(serial, parted):
         assert torch.equal(a, b), float((a - b).abs().max())
     for a, b, c in zip(serial, graphed, graphed2[::-1]):
         assert float((a - b).abs().max()) <= max(10 * noise, 2e-5), (float((a - b).abs().max()), noise)
@@ -249,3 +256,29 @@ def test_cost_volume_attention_kernel_against_reference_order(dev):
         assert (tr.detach().cpu() - want).abs().max() <= 2e-5 * max(1.0, float(want.abs().max()))
         tr.square().sum().backward()
         assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in (qg, kg, vg))
+
+
+def test_cu_partition_streams(dev):
+    """coponerf_amd.streams.CUPartition: two HIP streams over disjoint CU shares; the persistent launchers see the share."""
+    from coponerf_amd import _hip
+    from coponerf_amd.streams import CUPartition, device_cus, stream_cus
+    total = device_cus()
+    assert total == torch.cuda.get_device_properties(dev).multi_processor_count
+    assert stream_cus(torch.cuda.current_stream()) == total
+    part = CUPartition(total - 64, 64, dev)
+    assert (stream_cus(part.render), stream_cus(part.getz)) == (total - 64, 64)
+    a = torch.arange(1 << 20, device=dev, dtype=torch.float32)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(part.getz):
+        b = a * 2 + 1
+    with torch.cuda.stream(part.render):
+        c = a.sum()
+    part.close()                                            # waits for both streams
+    assert torch.equal(b, a * 2 + 1) and float(c) == float(a.sum())
+    part.close()                                            # idempotent
+    with pytest.raises(ValueError):
+        CUPartition(200, 56, dev)                           # 25 CUs per XCD: the shader engines would be unbalanced
+    with pytest.raises(ValueError):
+        CUPartition(total, 32, dev)
+    with pytest.raises(RuntimeError, match="not a stream of cpn_stream_create_cu_range"):
+        _hip.call("cpn_stream_destroy", torch.cuda.current_stream().cuda_stream or 1)
