@@ -322,6 +322,19 @@ def run(args):
                 pdt = time.perf_counter() - p0
             line["image_rays_per_s_cu_partition_192_64"] = nimg * R / pdt
             line["image_ms_cu_partition_192_64"] = 1e3 * pdt / nimg
+            # ... and with each image rendered the way the reference's callers do (18 forward() calls, test.py:176-212)
+            with torch.no_grad():
+                for _ in render_images(model, pairs[:2], cu_split=(192, 64), nchunks=18):
+                    pass
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                nimg = 0
+                for _ in render_images(model, pairs + pairs, cu_split=(192, 64), nchunks=18):
+                    nimg += 1
+                torch.cuda.synchronize()
+                pdt = time.perf_counter() - p0
+            line["image_rays_per_s_ref_loop_cu_partition_192_64"] = nimg * R / pdt
+            line["image_ms_ref_loop_cu_partition_192_64"] = 1e3 * pdt / nimg
             # throughput form of the same loop: get_z batched over 4 consecutive pairs (one launch sequence for four)
             with torch.no_grad():
                 for _ in render_images(model, pairs, getz_batch=4):

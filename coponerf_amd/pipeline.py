@@ -54,13 +54,16 @@ def _pair_slice(obj, lo: int, hi: int, per: int):
 
 
 def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: bool = False,
-                  cu_split: Optional[Tuple[int, int]] = None) -> Iterator[Tuple[Dict, Dict]]:
+                  cu_split: Optional[Tuple[int, int]] = None, nchunks: Optional[int] = None) -> Iterator[Tuple[Dict, Dict]]:
     """For every model_input dict (on the device) yield (model_input, forward(model_input, z, rel_pose, val=True, flow)),
     with `get_z` of the next inputs overlapped with the render of the current ones.  Call under torch.no_grad().
 
     cu_split=(render_cus, getz_cus) runs the two halves on CU-masked streams over disjoint shares of the chip
     (multiples of 32, sum <= the device's CU count; e.g. (192, 64)); the yielded outputs are ordered after the
     caller's current stream as usual.  None: two ordinary streams (the get_z one at high priority).
+
+    nchunks renders every input the way the reference's callers do (test.py:176-212: that many forward() calls on
+    torch.chunk(uv, nchunks), joined key by key — coponerf_amd/evalloop.render_in_chunks) instead of in one call.
 
     getz_batch > 1 runs `get_z` ONCE for that many consecutive inputs (batched along dim 0: its kernels are launch /
     latency bound, 11 ms for one pair, ~6.5 ms per pair at four) and renders them one after the other from slices of
@@ -94,17 +97,21 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
         return
     outer = torch.cuda.current_stream()
     engine = model._engine
-    lanes_before = engine.call_lanes
     if cu_split is not None:
         from .streams import CUPartition
-        parts = model.__dict__.setdefault("_cu_partitions", {})
+        # ONE partition at a time: every CU-masked stream is a hardware queue of its own, and more of them than the
+        # device has queues are time-sliced (measured: a second cached partition turned 34 ms per image into 48)
         key = (int(cu_split[0]), int(cu_split[1]), outer.device.index)
-        part = parts.get(key)
-        if part is None:
-            part = parts[key] = CUPartition(key[0], key[1], outer.device)
+        part = engine.__dict__.get("_cu_partition")
+        if part is None or part.key != key:
+            if part is not None:
+                part.close()
+            part = engine._cu_partition = CUPartition(key[0], key[1], outer.device)
+            part.key = key
         main, side = part.render, part.getz
         main.wait_stream(outer)                 # the inputs were produced on the caller's stream
-        engine.call_lanes = 1                   # consecutive calls must stay on the render share, not alternate streams
+        # consecutive calls alternate over lanes INSIDE the render share, not over the engine's own unmasked streams
+        engine.set_call_streams(part.render_lanes(engine.call_lanes) if engine.call_lanes > 1 else None)
     else:
         main = outer
         # high priority: the small kernels of get_z are dispatched ahead of the render's queued workgroups instead of
@@ -133,7 +140,11 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
                             engine.adopt_level3(zi[3], hint[2][2 * lo:2 * hi])
                     model.H, model.W = H, W
                     # 1. the render of this pair: a few dozen launches, asynchronous
-                    out = model(inp, z=zi, rel_pose=ri, val=True, flow=fi)
+                    if nchunks:
+                        from .evalloop import join_chunks, render_in_chunks
+                        chunks = render_in_chunks(model, inp, nchunks, latents=(zi, ri, fi), join=False)
+                    else:
+                        out = model(inp, z=zi, rel_pose=ri, val=True, flow=fi)
                     if i == 0 and nxt:
                         # 2. the ~800 launches of the next group's get_z on the side stream: the host issues them while
                         #    the GPU renders, the small kernels run beside the HBM-bound render kernels
@@ -144,6 +155,10 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
                         _record(nstate[0], main)
                         if nstate[1] is not None:
                             _record(nstate[1][2], main)
+                    if nchunks:
+                        # the callers' per-key concatenation waits for the host copies of `pixel_val`, i.e. for this
+                        # image's render: only now, with get_z of the next inputs already issued
+                        out = join_chunks(chunks)
                 if main is not outer:
                     outer.wait_stream(main)
                     _record(out, outer)
@@ -151,6 +166,6 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
                 yield inp, out
             cur, state = nxt, nstate
     finally:
-        engine.call_lanes = lanes_before
         if main is not outer:
-            outer.wait_stream(main)
+            outer.wait_stream(main)             # the lanes were joined into `main` by every call's completion event
+            engine.set_call_streams(None)

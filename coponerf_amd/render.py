@@ -599,10 +599,21 @@ class RenderEngine:
                 "z_local": zl, "Tq": g["Tq"], "sec_grid": g["sec_grid"], "rgb_raw": raw, "host": g["host"]}
 
     # ---- the render pass -------------------------------------------------------------------------
+    def set_call_streams(self, streams: Optional[Sequence[torch.cuda.Stream]]) -> None:
+        """Streams the consecutive render() calls alternate over instead of the engine's own (None: back to those) —
+        e.g. CU-masked lanes inside the render share of a partitioned chip (coponerf_amd/streams.py).  The caller keeps
+        them alive and orders their work before dropping them."""
+        self._call_streams = list(streams) if streams else []
+        self._call_streams_given = bool(streams)
+        self._call_idx = 0
+
     def _call_stream(self, dev) -> Optional[torch.cuda.Stream]:
         if self.call_lanes <= 1:
             return None
-        if len(self._call_streams) != self.call_lanes or self._call_streams[0].device != dev:
+        if self.__dict__.get("_call_streams_given"):
+            if len(self._call_streams) != self.call_lanes or self._call_streams[0].device != dev:
+                raise RuntimeError("set_call_streams: need call_lanes streams on the render device")
+        elif len(self._call_streams) != self.call_lanes or self._call_streams[0].device != dev:
             self._call_streams = [torch.cuda.Stream(device=dev) for _ in range(self.call_lanes)]
         self._call_idx = (self._call_idx + 1) % self.call_lanes
         return self._call_streams[self._call_idx]

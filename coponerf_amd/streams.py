@@ -42,9 +42,17 @@ class CUPartition:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.split: Tuple[int, int] = (render_cus, getz_cus)
         self._handles = []
+        self._lanes = []
         with torch.cuda.device(self.device):
             self.render = self._make(0, render_cus)
             self.getz = self._make(total - getz_cus, getz_cus)
+
+    def render_lanes(self, n: int):
+        """n more streams over the render share (RenderEngine.set_call_streams: consecutive calls alternate over them)."""
+        while len(self._lanes) < n:
+            with torch.cuda.device(self.device):
+                self._lanes.append(self._make(0, self.split[0]))
+        return self._lanes[:n]
 
     def _make(self, first: int, n: int) -> torch.cuda.Stream:
         out = ctypes.c_void_p()
@@ -56,8 +64,9 @@ class CUPartition:
         """Wait for both streams and destroy them (the torch wrappers do not own the HIP streams)."""
         handles, self._handles = self._handles, []
         if handles:
-            self.render.synchronize()
-            self.getz.synchronize()
+            for st in [self.render, self.getz] + self._lanes:
+                st.synchronize()
+        self._lanes = []
         for h in handles:
             _hip.call("cpn_stream_destroy", ctypes.c_void_p(h))
 

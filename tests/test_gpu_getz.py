@@ -178,6 +178,9 @@ def test_pipelined_images_equal_serial(dev):
         batched = [out["rgb"].clone() for _, out in render_images(model, pairs, getz_batch=2)]   # groups of 2 + 1
         parted = [out["rgb"].clone() for _, out in render_images(model, pairs, cu_split=(192, 64))]   # partitioned chip
         lanes_after = model._engine.call_lanes
+        # the callers' 5-call loop per image inside the render share, consecutive calls on two masked lanes
+        chunked = [out["rgb"].clone() for _, out in render_images(model, pairs, cu_split=(192, 64), nchunks=5)]
+        own_lanes = list(model._engine._call_streams)
         graphed = [out["rgb"].clone() for _, out in render_images(model, pairs, graph=True)]     # get_z as a HIP graph
         graphed2 = [out["rgb"].clone() for _, out in render_images(model, pairs[::-1], graph=True)]   # replay only
         again = serial_rgb(pairs[0])
@@ -195,8 +198,10 @@ def test_pipelined_images_equal_serial(dev):
     # render pass on 192 CUs, get_z on the other 64 (CU-masked streams): the persistent grids shrink to the share, the
     # tiles and their arithmetic do not change
     assert len(parted) == 3 and lanes_after == 2
-    for a, b in zip(serial, parted):
+    for a, b, c in zip(serial, parted, chunked):
         assert torch.equal(a, b), float((a - b).abs().max())
+        assert torch.equal(a, c), float((a - c).abs().max())
+    assert own_lanes == []                                  # the masked lanes were handed back
     for a, b, c in zip(serial, graphed, graphed2[::-1]):
         assert float((a - b).abs().max()) <= max(10 * noise, 2e-5), (float((a - b).abs().max()), noise)
         assert float((a - c).abs().max()) <= max(10 * noise, 2e-5), (float((a - c).abs().max()), noise)
