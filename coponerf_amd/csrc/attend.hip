@@ -111,6 +111,11 @@ __global__ __launch_bounds__(256) void attend_kernel(const __half* __restrict__ 
 // thread = 8 hidden channels (16 B), rows streamed; per ray T x 3328 B read, fully coalesced.
 // ---------------------------------------------------------------------------------------------
 constexpr int HC = 1664;
+// 1 = stream hid with non-temporal loads (the product; keeps the node tables of encode_hidden in L2 / Infinity Cache);
+// 0 = plain loads (tools/mall_probe.py: does a second pass over a cache-sized range run faster?)
+#ifndef CPN_ATTEND_NT
+#define CPN_ATTEND_NT 1
+#endif
 
 __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __restrict__ qa,
                                                             const __half* __restrict__ qb,
@@ -183,7 +188,11 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
         const __half* hp = hid + row0 * HC + tid * 8;
 #pragma unroll 4
         for (int row = 0; row < T; ++row) {
+#if CPN_ATTEND_NT
             const half8 h = __builtin_nontemporal_load(reinterpret_cast<const half8*>(hp + (size_t)row * HC));
+#else
+            const half8 h = *reinterpret_cast<const half8*>(hp + (size_t)row * HC);
+#endif
             const float w = wts[row];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += w * (float)h[e];

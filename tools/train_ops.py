@@ -17,6 +17,7 @@ ap.add_argument("--top", type=int, default=60)
 ap.add_argument("--all", action="store_true")
 ap.add_argument("--kernels", action="store_true", help="device time by kernel name")
 ap.add_argument("--fns", action="store_true", help="device time (inclusive) by autograd Function node instead of by aten op")
+ap.add_argument("--only", default="", help="comma-separated aten op names (e.g. copy_,add): only those, plus per-op totals")
 ap.add_argument("--getz", type=int, default=0, metavar="B", help="profile one inference get_z at batch B instead of a training step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -79,7 +80,10 @@ for ev in prof.events():
     if not ev.name.startswith("aten::"):
         continue
     op = ev.name[6:]
-    if not a.all and op not in SMALL:
+    if a.only:
+        if op not in a.only.split(","):
+            continue
+    elif not a.all and op not in SMALL:
         continue
     dt = getattr(ev, "self_device_time_total", None)
     if dt is None:
@@ -92,5 +96,10 @@ for ev in prof.events():
     agg[key][1] += dt
     tot += dt
 print(f"{tot / 1e3:.2f} ms of device time in the selected ops")
+per = collections.defaultdict(lambda: [0, 0.0])
+for (op, _, _), (n, t, _) in agg.items():
+    per[op][0] += n
+    per[op][1] += t
+print("  ".join(f"{op}: {t / 1e3:.2f} ms x{n}" for op, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:12]))
 for (op, shp, frame), (n, t, _) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
     print(f"{t / 1e3:8.3f} ms x{n:4d}  {op:26s} {shp}  {frame}")
