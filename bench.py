@@ -309,32 +309,24 @@ def run(args):
             line["image_rays_per_s_pipelined"] = nimg * R / pdt
             line["image_ms_pipelined"] = 1e3 * pdt / nimg
             # the same loop on a PARTITIONED chip: render pass on 192 CUs, get_z on the other 64 (CU-masked streams,
-            # coponerf_amd/streams.py) — ordinary streams cannot overlap the two (the line above)
-            with torch.no_grad():
-                for _ in render_images(model, pairs[:2], cu_split=(192, 64)):
-                    pass
-                torch.cuda.synchronize()
-                p0 = time.perf_counter()
-                nimg = 0
-                for _ in render_images(model, pairs + pairs, cu_split=(192, 64)):
-                    nimg += 1
-                torch.cuda.synchronize()
-                pdt = time.perf_counter() - p0
-            line["image_rays_per_s_cu_partition_192_64"] = nimg * R / pdt
-            line["image_ms_cu_partition_192_64"] = 1e3 * pdt / nimg
-            # ... and with each image rendered the way the reference's callers do (18 forward() calls, test.py:176-212)
-            with torch.no_grad():
-                for _ in render_images(model, pairs[:2], cu_split=(192, 64), nchunks=18):
-                    pass
-                torch.cuda.synchronize()
-                p0 = time.perf_counter()
-                nimg = 0
-                for _ in render_images(model, pairs + pairs, cu_split=(192, 64), nchunks=18):
-                    nimg += 1
-                torch.cuda.synchronize()
-                pdt = time.perf_counter() - p0
-            line["image_rays_per_s_ref_loop_cu_partition_192_64"] = nimg * R / pdt
-            line["image_ms_ref_loop_cu_partition_192_64"] = 1e3 * pdt / nimg
+            # coponerf_amd/streams.py) — ordinary streams cannot overlap the two (the line above); and with each image
+            # rendered the way the reference's callers do (18 forward() calls, test.py:176-212)
+            try:
+                for tag, kw in (("image", {}), ("image_ref_loop", {"nchunks": 18})):
+                    with torch.no_grad():
+                        for _ in render_images(model, pairs[:2], cu_split=(192, 64), **kw):
+                            pass
+                        torch.cuda.synchronize()
+                        p0 = time.perf_counter()
+                        nimg = 0
+                        for _ in render_images(model, pairs + pairs, cu_split=(192, 64), **kw):
+                            nimg += 1
+                        torch.cuda.synchronize()
+                        pdt = time.perf_counter() - p0
+                    line[f"{tag}_rays_per_s_cu_partition_192_64"] = nimg * R / pdt
+                    line[f"{tag}_ms_cu_partition_192_64"] = 1e3 * pdt / nimg
+            except Exception as e:                     # a side figure must not take the headline line down
+                line["cu_partition_error"] = f"{type(e).__name__}: {e}"[:300]
             # throughput form of the same loop: get_z batched over 4 consecutive pairs (one launch sequence for four)
             with torch.no_grad():
                 for _ in render_images(model, pairs, getz_batch=4):
