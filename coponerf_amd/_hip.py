@@ -11,7 +11,8 @@ import re
 from typing import Dict, List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoponerf_hip.so")
+# COPONERF_HIP_LIB: another build of the SAME library (kernel-variant experiments, tools/_build/); never a fallback
+LIB_PATH = os.environ.get("COPONERF_HIP_LIB") or os.path.join(_HERE, "libcoponerf_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "coponerf_hip.h")
 
 _P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
@@ -74,6 +75,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_conv_map7x7": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "cpn_prepare_input": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
+    "cpn_corr_mean3": [_P, _I, _P, _I, _P, _I, _I, _P, _P],
 }
 
 CAM_STRIDE = 96

@@ -1110,7 +1110,76 @@ __global__ __launch_bounds__(256) void resize_bilinear_ac_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// UFC.forward's last step (models/aggregation.py:549-553): the three levels' refined correlations, interpolate4d'ed to
+// n^4, averaged.  interpolate4d (aggregation.py:49-56) is two bilinear passes (align_corners=True): over the target
+// pair of dims, then over the source pair — here both passes of both coarse levels, the two adds and the division in
+// ONE pass over the fine volume: each output reads 16 values of each coarse volume (cache resident: 256 KB and 4 MB
+// per pair) and one of the fine one, in the arithmetic order of the separate kernels (resize_bilinear_ac_kernel twice,
+// then (a + b) + c, then * (1/3) as the division by a scalar is evaluated).
+// ---------------------------------------------------------------------------------------------
+struct AxisTap {
+    int i0, i1;
+    float l;
+};
+__device__ __forceinline__ AxisTap axis_tap(int I, int h, float scale) {
+    const float f = scale * (float)I;
+    AxisTap t;
+    t.i0 = (int)f;
+    t.i1 = t.i0 + (t.i0 < h - 1);
+    t.l = f - (float)t.i0;
+    return t;
+}
+__device__ __forceinline__ float blend4(float a, float b, float c, float d, float lx, float ly) {
+    const float top = a * (1.0f - lx) + b * lx;
+    const float bot = c * (1.0f - lx) + d * lx;
+    return top * (1.0f - ly) + bot * ly;
+}
+// x (h,h,h,h) of one pair -> its interpolate4d value at (I, J, i, j) of the n^4 grid
+__device__ __forceinline__ float interp4d_at(const float* __restrict__ x, int h, float sc, int I, int J, int i, int j) {
+    const AxisTap ti = axis_tap(i, h, sc), tj = axis_tap(j, h, sc), tI = axis_tap(I, h, sc), tJ = axis_tap(J, h, sc);
+    float y1[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float* p = x + ((size_t)((a ? tI.i1 : tI.i0) * h + (b ? tJ.i1 : tJ.i0))) * h * h;
+            y1[a][b] = blend4(p[ti.i0 * h + tj.i0], p[ti.i0 * h + tj.i1], p[ti.i1 * h + tj.i0], p[ti.i1 * h + tj.i1], tj.l, ti.l);
+        }
+    return blend4(y1[0][0], y1[0][1], y1[1][0], y1[1][1], tJ.l, tI.l);
+}
+__global__ __launch_bounds__(256) void corr_mean3_kernel(const float* __restrict__ c0, int h0, const float* __restrict__ c1,
+                                                         int h1, const float* __restrict__ c2, int n, int B,
+                                                         float* __restrict__ out) {
+    const long long per = (long long)n * n * n * n, total = per * B;
+    const float s0 = n > 1 ? (float)(h0 - 1) / (float)(n - 1) : 0.0f, s1 = n > 1 ? (float)(h1 - 1) / (float)(n - 1) : 0.0f;
+    const float third = 1.0f / 3.0f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int j = (int)(t % n); t /= n;
+        const int i = (int)(t % n); t /= n;
+        const int J = (int)(t % n); t /= n;
+        const int I = (int)(t % n);
+        const long long b = t / n;
+        const float u0 = interp4d_at(c0 + b * (long long)h0 * h0 * h0 * h0, h0, s0, I, J, i, j);
+        const float u1 = interp4d_at(c1 + b * (long long)h1 * h1 * h1 * h1, h1, s1, I, J, i, j);
+        out[idx] = ((u0 + u1) + c2[idx]) * third;
+    }
+}
+
 }  // namespace
+
+extern "C" int cpn_corr_mean3(const float* c0, int h0, const float* c1, int h1, const float* c2, int n, int B, float* out,
+                              void* stream) {
+    CPN_REQUIRE(c0 && c1 && c2 && out, CPN_E_ARG, "cpn_corr_mean3: null pointer");
+    CPN_REQUIRE(B > 0 && h0 > 1 && h1 > 1 && n > 1 && h0 <= n && h1 <= n && n <= 128, CPN_E_SHAPE, "cpn_corr_mean3: bad shape");
+    const long long total = (long long)B * n * n * n * n;
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(total, 256), 1 << 20);
+    hipLaunchKernelGGL(corr_mean3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c0, h0, c1, h1, c2, n, B, out);
+    CPN_LAUNCH_CHECK("cpn_corr_mean3");
+    return 0;
+}
 
 extern "C" int cpn_resize_bilinear_ac(const float* src, float* dst, long long planes, int h, int w, int H, int W,
                                       void* stream) {

@@ -362,8 +362,11 @@ class UFC(nn.Module):
                 corr, src, trg = layer(corr, src, trg, ops)
             feats.append(_tokens_to_map(torch.stack((src, trg), dim=1).flatten(0, 1), fs))
             corrs.append(ops.correlation_tokens(src, trg, fs))
-        up = [_interp4d(x, 64, ops) for x in corrs]
-        c = ((up[0] + up[1]) + up[2]) / len(corrs)                  # sum(...) / 3 without the 0 + x pass; (B,1,64,64,64,64)
+        if len(corrs) == 3 and hasattr(ops, "corr_mean3") and not (torch.is_grad_enabled() and corrs[2].requires_grad):
+            c = ops.corr_mean3(corrs)                               # both interpolate4d's, the adds and the / 3 in one pass
+        else:
+            up = [_interp4d(x, 64, ops) for x in corrs]
+            c = ((up[0] + up[1]) + up[2]) / len(corrs)              # sum(...) / 3 without the 0 + x pass; (B,1,64,64,64,64)
         t_to_s, s_to_t = ops.soft_argmax_pair(c)                                      # (B,2,64,64) each
         return feats, (_mapping_to_flow(t_to_s), _mapping_to_flow(s_to_t), t_to_s, s_to_t), c
 

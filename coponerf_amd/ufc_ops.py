@@ -626,6 +626,18 @@ class HipOps:
         self._need_gpu(a)
         return _DualSoftmaxFn.apply(a)
 
+    def corr_mean3(self, corrs):
+        """UFC.forward's final correlation (aggregation.py:549-553): sum(interpolate4d(c, n) for c in corrs) / 3 for the
+        three levels' (B,1,h,h,h,h) volumes, on cpn_corr_mean3 (inference; under autograd the caller composes it from
+        resize_bilinear)."""
+        c0, c1, c2 = (c.contiguous().float() for c in corrs)
+        self._need_gpu(c2)
+        B, n = c2.shape[0], c2.shape[-1]
+        out = torch.empty_like(c2)
+        call("cpn_corr_mean3", c0.data_ptr(), c0.shape[-1], c1.data_ptr(), c1.shape[-1], c2.data_ptr(), n, B, out.data_ptr(),
+             _stream())
+        return out
+
     def resize_bilinear(self, x, size):
         """(N,C,h,w) -> (N,C,size,size), bilinear, align_corners=True."""
         self._need_gpu(x)

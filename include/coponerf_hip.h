@@ -446,6 +446,13 @@ int cpn_conv_map7x7(const float* rgb, const float* w, const float* bias, int N, 
  * interpolate2d_token (models/aggregation.py:49-63, 285, 293, 299).                                           */
 int cpn_resize_bilinear_ac(const float* src, float* dst, long long planes, int h, int w, int H, int W, void* stream);
 
+/* ---- UFC.forward's final correlation (models/aggregation.py:549-553): mean of the three levels' correlations after
+ * interpolate4d (aggregation.py:49-56: bilinear, align_corners=True, over the target pair of dims, then the source pair)
+ * to the finest grid.  c0 (B,1,h0,h0,h0,h0), c1 (B,1,h1,h1,h1,h1), c2 and out (B,1,n,n,n,n) fp32; one pass, in the
+ * arithmetic order of the separate resize / add / divide kernels.                                                   */
+int cpn_corr_mean3(const float* c0, int h0, const float* c1, int h1, const float* c2, int n, int B, float* out,
+                   void* stream);
+
 /* ==== input pipeline: uint8 frames -> the float tensors of the input dict ========================
  * replaces the host-side square crop + `rgb.astype(np.float32) / 127.5 - 1` + query-pixel selection of
  * data/realestate10k_dataio.py:333-441 (utils_training/data_util.py:116-121).

@@ -287,3 +287,32 @@ def test_cu_partition_streams(dev):
         CUPartition(total, 32, dev)
     with pytest.raises(RuntimeError, match="not a stream of cpn_stream_create_cu_range"):
         _hip.call("cpn_stream_destroy", torch.cuda.current_stream().cuda_stream or 1)
+
+
+def test_corr_mean3_kernel_equals_composed_interpolations(dev):
+    """cpn_corr_mean3 (UFC.forward's final correlation, aggregation.py:549-553) against (1) the path it replaces — two
+    resize passes per coarse level, two adds, the division — and (2) torch's own bilinear interpolation on the CPU."""
+    import torch.nn.functional as F
+    from coponerf_amd import getz
+    from coponerf_amd.ufc_ops import HipOps
+    ops = HipOps()
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    corrs = [torch.randn(B, 1, h, h, h, h, generator=g) for h in (16, 32, 64)]
+    dc = [c.to(dev) for c in corrs]
+    got = ops.corr_mean3(dc)
+    up = [getz._interp4d(x, 64, ops) for x in dc]
+    composed = ((up[0] + up[1]) + up[2]) / 3
+    torch.cuda.synchronize()
+    assert got.shape == (B, 1, 64, 64, 64, 64)
+    # same operations in the same order; the compiler may contract a multiply-add differently in the two kernels: <= 1 ulp
+    assert float((got - composed).abs().max()) <= 2.4e-7 * float(composed.abs().max())
+
+    def interp4d_cpu(x, n):                                  # aggregation.py:49-56
+        b, c, hs, ws, ht, wt = x.shape
+        y = F.interpolate(x.reshape(b, c * hs * ws, ht, wt), size=(n, n), mode="bilinear", align_corners=True)
+        y = y.reshape(b, c, hs, ws, n, n).permute(0, 1, 4, 5, 2, 3).reshape(b, c * n * n, hs, ws)
+        y = F.interpolate(y, size=(n, n), mode="bilinear", align_corners=True)
+        return y.reshape(b, c, n, n, n, n).permute(0, 1, 4, 5, 2, 3)
+    want = sum(interp4d_cpu(c[:1], 64) for c in corrs) / 3   # one pair on the CPU is enough (1 GB of fp32 per pass)
+    assert float((got[:1].cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max())
