@@ -132,6 +132,8 @@ class _DWConv(nn.Module):
 
 
 TWO_STREAMS = os.environ.get("CPN_GETZ_TWO_STREAMS", "1") != "0"
+# source and target passes of every UFC layer as one batched pass (UFCLayer._forward_views_batched); 0 = one after the other
+BATCH_VIEWS = os.environ.get("CPN_GETZ_BATCH_VIEWS", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -269,7 +271,38 @@ class UFCLayer(nn.Module):
         trg = trg + self._feed_forward(self.mlp_cross, self.norm_cross2(trg))
         return src, trg
 
+    def _cross_views(self, corr, x2, ops):              # aggregation.py:312-340 with [src; trg] stacked along dim 0
+        B, H, Hs, Ws, Ht, Wt = corr.shape
+        fs, d = self.fs, self.nhead * self.dim
+        c = corr.reshape(B, H, Hs * Ws, Ht * Wt)
+        pooled = _map_to_tokens(F.avg_pool2d(_tokens_to_map(x2, fs), fs // Hs))
+        v = self.v_cross(self.norm_cross1(pooled)).view(2 * B, -1, self.nhead, self.dim)
+        src_attn, trg_attn = ops.cross_attention(c, v[:B], v[B:])
+        attn = torch.cat((src_attn.reshape(B, -1, d), trg_attn.reshape(B, -1, d)), 0)
+        r = fs // Hs
+        x2 = x2 + _map_to_tokens(_tokens_to_map(attn, Hs).repeat_interleave(r, 2).repeat_interleave(r, 3))
+        return x2 + self._feed_forward(self.mlp_cross, self.norm_cross2(x2))
+
+    def _forward_views_batched(self, corr, src, trg, ops):
+        """forward() with the source pass and the target pass — same weights, independent samples — as ONE pass over
+        [corr ; corr^T] and [src ; trg] stacked along the batch axis: half the launches of the token side, and the 16^4
+        volumes' kernels (a few hundred workgroups per pair) fill twice as much of the chip."""
+        t4 = lambda x: x.permute(0, 1, 4, 5, 2, 3)
+        from .ufc_ops import swap_pairs as _swap
+        B = corr.shape[0]
+        corr2 = torch.cat((corr, _swap(corr)), 0)
+        msg2, x2 = self._attention(corr2, torch.cat((src, trg), 0), ops)
+        corr_r = msg2[:B] + t4(msg2[B:])
+        corr_r = self.feat_to_corr1(ops.correlation_tokens(x2[:B], x2[B:], self.fs), ops, residual=corr_r)
+        corr_r = self.mlp_refine_corr(corr_r, ops, residual=corr_r)
+        x2 = self._cross_views(corr_r, x2, ops)
+        corr_r = self.feat_to_corr2(ops.correlation_tokens(x2[:B], x2[B:], self.fs), ops, residual=corr_r)
+        corr_r = self.mlp_refine_corr2(corr_r, ops, residual=corr_r)
+        return corr_r, x2[:B], x2[B:]
+
     def forward(self, corr, src, trg, ops):             # aggregation.py:342-356
+        if BATCH_VIEWS and corr.shape[2:4] == corr.shape[4:6] and src.shape == trg.shape:
+            return self._forward_views_batched(corr, src, trg, ops)
         t4 = lambda x: x.permute(0, 1, 4, 5, 2, 3)
         from .ufc_ops import swap_pairs as _swap              # t4(x).contiguous() as one transpose kernel
         if corr.is_cuda and TWO_STREAMS and torch.cuda.is_current_stream_capturing():
@@ -345,9 +378,11 @@ class UFC(nn.Module):
     def forward(self, feat: Sequence[torch.Tensor], nview: int, ops):
         B2 = feat[0].shape[0]
         B = B2 // nview
-        take = lambda i, v: self.proj_feat[i](_map_to_tokens(feat[i].view(B, nview, *feat[i].shape[1:])[:, v]))
-        src_f = [take(i, 0) for i in range(3)]
-        trg_f = [take(i, 1) for i in range(3)]
+        # proj_feat of both views in one call per level: (B*nview, L, 256) -> view v of every pair
+        proj = [self.proj_feat[i](_map_to_tokens(feat[i])) for i in range(3)]
+        proj = [p.view(B, nview, *p.shape[1:]) for p in proj]
+        src_f = [p[:, 0] for p in proj]
+        trg_f = [p[:, 1] for p in proj]
         feats, corrs = [], []
         corr = src = trg = None
         for lvl, fs in enumerate((16, 32, 64)):
