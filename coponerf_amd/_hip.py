@@ -73,6 +73,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_cost_volume_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "cpn_cross_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_conv_map7x7": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "cpn_bn_act": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P],
     "cpn_prepare_input": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
     "cpn_corr_mean3": [_P, _I, _P, _I, _P, _I, _I, _P, _P],

@@ -8,6 +8,8 @@
 // One thread = one pixel x 64 output channels (64 fp32 accumulators), 16 x 16 pixel tile, the 22 x 22 x 3 input
 // window and the 64 x 147 weights in LDS (weights are read as LDS broadcasts).  9408 MAC per pixel: fp32 VALU work,
 // ~0.1 ms per 256^2 stereo pair — MIOpen picked its naive kernel for this shape (0.75 ms per image).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -68,7 +70,47 @@ __global__ __launch_bounds__(256) void conv_map7x7_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Inference BatchNorm (+ residual) (+ ReLU) of the ResNet-34 trunk (models/backbone.py:10-102 via torchvision's
+// BasicBlock: bn(conv(x)), `out += identity`, relu) as ONE pass: y = act((x - mean[c]) * invstd[c] * w[c] + b[c] + res).
+// The library spends three launches on it (batch norm, add, clamp): 85 of get_z's launches -> 36.
+// Thread = 4 consecutive pixels of one (n, c) plane (HW % 4 == 0), NCHW contiguous.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* x, const float* __restrict__ res,
+                                                     const float* __restrict__ mean, const float* __restrict__ var,
+                                                     const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                     int C, int HW4, long long total4, int relu, float* y) {     // y may alias x
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW4) % C);
+        const float m = mean[c], invstd = 1.0f / sqrtf(var[c] + eps), g = w[c], beta = b[c];
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (res) r = reinterpret_cast<const f32x4*>(res)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float o = (v[e] - m) * invstd * g + beta;
+            if (res) o += r[e];
+            v[e] = (relu && o < 0.0f) ? 0.0f : o;                  // NaN stays NaN, as torch.relu keeps it
+        }
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int cpn_bn_act(const float* x, const float* res, const float* mean, const float* var, const float* w,
+                          const float* b, float eps, int N, int C, int HW, int relu, float* y, void* stream) {
+    CPN_REQUIRE(x && mean && var && w && b && y, CPN_E_ARG, "cpn_bn_act: null pointer");
+    CPN_REQUIRE(N > 0 && C > 0 && HW > 0 && (HW % 4) == 0, CPN_E_SHAPE, "cpn_bn_act: need HW %% 4 == 0 (got %d)", HW);
+    CPN_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!res || ((uintptr_t)res % 16) == 0), CPN_E_ARG,
+                "cpn_bn_act: tensors must be 16-byte aligned");
+    const long long total4 = (long long)N * C * (HW / 4);
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(total4, 256), 1 << 16);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, res, mean, var, w, b, eps, C, HW / 4,
+                       total4, relu, y);
+    CPN_LAUNCH_CHECK("cpn_bn_act");
+    return 0;
+}
 
 extern "C" int cpn_conv_map7x7(const float* rgb, const float* w, const float* bias, int N, int H, int W, float* out_nchw,
                                uint16_t* out_nhwc_f16, void* stream) {

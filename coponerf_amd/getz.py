@@ -63,6 +63,20 @@ class _ResNet34Trunk(nn.Module):
         self.fc = nn.Sequential()
 
 
+def _bn_act(x, bn, relu: bool, res=None):
+    """Inference BatchNorm (+ residual) (+ ReLU) in place on the convolution's output: cpn_bn_act (csrc/encoder.hip)."""
+    from ._hip import call
+    N, C, H, W = x.shape
+    if not x.is_contiguous() or (H * W) % 4 or (res is not None and not res.is_contiguous()):
+        y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)   # e.g. channels-last
+        y = y if res is None else y + res
+        return F.relu(y) if relu else y
+    call("cpn_bn_act", x.data_ptr(), 0 if res is None else res.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+         bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), N, C, H * W, int(relu), x.data_ptr(),
+         torch.cuda.current_stream().cuda_stream)
+    return x
+
+
 class SpatialEncoder(nn.Module):
     """backbone.py:10-102 with use_first_pool=False, num_layers=5: returns [512@H/16, 256@H/8, 128@H/4, 64@H/2, 64@H/2]."""
 
@@ -70,8 +84,27 @@ class SpatialEncoder(nn.Module):
         super().__init__()
         self.model = _ResNet34Trunk()
 
+    def _forward_infer(self, x):
+        """eval() + no_grad on the GPU: library convolutions, each followed by ONE pass for batch norm, residual and ReLU
+        (the library takes three launches: 85 -> 36 per get_z)."""
+        m = self.model
+        x = _bn_act(m.conv1(x), m.bn1, True)
+        lat = [x]
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            for blk in getattr(m, name):
+                idt = x
+                if blk.downsample is not None:
+                    idt = _bn_act(blk.downsample[0](x), blk.downsample[1], False)
+                out = _bn_act(blk.conv1(x), blk.bn1, True)
+                x = _bn_act(blk.conv2(out), blk.bn2, True, res=idt)
+            lat.append(x)
+        return lat[::-1]
+
     def forward(self, x):
         m = self.model
+        if (not torch.is_grad_enabled() and not self.training and x.is_cuda and x.dtype == torch.float32
+                and x.is_contiguous() and FUSED_TRUNK):
+            return self._forward_infer(x)
         x = m.relu(m.bn1(m.conv1(x)))
         lat = [x]
         for name in ("layer1", "layer2", "layer3", "layer4"):
@@ -134,6 +167,8 @@ class _DWConv(nn.Module):
 TWO_STREAMS = os.environ.get("CPN_GETZ_TWO_STREAMS", "1") != "0"
 # source and target passes of every UFC layer as one batched pass (UFCLayer._forward_views_batched); 0 = one after the other
 BATCH_VIEWS = os.environ.get("CPN_GETZ_BATCH_VIEWS", "1") != "0"
+# inference trunk: batch norm + residual + ReLU behind every convolution as one kernel (SpatialEncoder._forward_infer)
+FUSED_TRUNK = os.environ.get("CPN_GETZ_FUSED_TRUNK", "1") != "0"
 _SIDE_STREAMS = {}
 
 

@@ -441,6 +441,12 @@ int cpn_cross_attention_bwd(const float* corr, const float* src_v, const float* 
 int cpn_conv_map7x7(const float* rgb, const float* w, const float* bias, int N, int H, int W, float* out_nchw,
                     uint16_t* out_nhwc_f16, void* stream);
 
+/* ---- f3: inference BatchNorm (+ residual) (+ ReLU) of the ResNet-34 trunk (models/backbone.py:10-102; torchvision's
+ * BasicBlock: bn(conv(x)), `out += identity`, relu) in one pass over an NCHW fp32 map:
+ *   y = act((x - mean[c]) / sqrt(var[c] + eps) * w[c] + b[c] + res),  res (N,C,HW) or NULL, relu 0/1, HW % 4 == 0; y may be x */
+int cpn_bn_act(const float* x, const float* res, const float* mean, const float* var, const float* w, const float* b,
+               float eps, int N, int C, int HW, int relu, float* y, void* stream);
+
 /* ---- bilinear resize, align_corners=True, of `planes` independent (h,w) fp32 images -> (H,W) ----------
  * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /
  * interpolate2d_token (models/aggregation.py:49-63, 285, 293, 299).                                           */

@@ -316,3 +316,36 @@ def test_corr_mean3_kernel_equals_composed_interpolations(dev):
         return y.reshape(b, c, n, n, n, n).permute(0, 1, 4, 5, 2, 3)
     want = sum(interp4d_cpu(c[:1], 64) for c in corrs) / 3   # one pair on the CPU is enough (1 GB of fp32 per pass)
     assert float((got[:1].cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_fused_trunk_equals_stock_modules(dev):
+    """SpatialEncoder._forward_infer (library convolutions + cpn_bn_act) against the stock Conv2d / BatchNorm2d / ReLU
+    modules it replaces on the inference path (models/backbone.py:10-102), with non-trivial running statistics."""
+    from coponerf_amd import getz
+    torch.manual_seed(5)
+    enc = getz.SpatialEncoder().to(dev).eval()
+    with torch.no_grad():
+        for mod in enc.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.1)
+        x = torch.randn(2, 3, 256, 256, device=dev)
+        fused = enc(x)
+        old, getz.FUSED_TRUNK = getz.FUSED_TRUNK, False
+        try:
+            stock = enc(x)
+        finally:
+            getz.FUSED_TRUNK = old
+    assert [t.shape for t in fused] == [t.shape for t in stock]
+    for a, b in zip(fused, stock):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), float((a - b).abs().max())
+    # the kernel itself: batch norm + residual + ReLU against the three library ops, one rounding apart
+    bn = enc.model.layer2[1].bn2
+    t, r = torch.randn(2, 128, 64, 64, device=dev), torch.randn(2, 128, 64, 64, device=dev)
+    want = torch.relu(torch.nn.functional.batch_norm(t, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps) + r)
+    got = getz._bn_act(t.clone(), bn, True, res=r)
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    cl = t.clone().contiguous(memory_format=torch.channels_last)              # not NCHW-contiguous: library fallback
+    assert torch.allclose(getz._bn_act(cl, bn, True, res=r), want, atol=1e-6)
