@@ -3,7 +3,7 @@
 // The reference's evaluation loop is serial — get_z, then the chunked forward() calls, pair after pair
 // (/root/reference test.py:164-212, wrapper.py:176-211).  On an MI355X the two halves are complementary: the render
 // pass is a handful of HBM-bound launches whose persistent grids take every CU (one workgroup per CU, most of its LDS),
-// get_z is ~800 small launches that rarely fill a quarter of the chip.  Issued on two ordinary streams they alternate
+// get_z is ~550 small launches that rarely fill a quarter of the chip.  Issued on two ordinary streams they alternate
 // instead of overlapping: each small kernel waits until a chip-filling one drains.  With two CU-masked streams the
 // chip is PARTITIONED — the render pass keeps e.g. 24 CUs of every XCD, get_z the other 8 — and both run all the time.
 //

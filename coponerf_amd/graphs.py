@@ -1,7 +1,7 @@
 """get_z as a HIP graph (inference).
 
-`get_z` of one 256x256 stereo pair is ~1 100 kernel launches of 5-80 us: issued eagerly the host needs as long to launch
-them (~14 us each through PyTorch + ctypes) as the GPU needs to run them, so neither the launch gaps nor a second
+`get_z` of one 256x256 stereo pair is ~550 kernel launches of 5-80 us: issued eagerly the host needs about as long to
+launch them (~12 us each through PyTorch + ctypes) as the GPU needs to run them, so neither the launch gaps nor a second
 stream can help (tools/getz_graph.py).  Captured once per input signature and replayed, the host cost is one
 hipGraphLaunch, and the source / target attention passes of every UFC layer — forked onto a second stream inside the
 capture (coponerf_amd/getz.py) — really run side by side.  The reference has no counterpart: its evaluation loop calls

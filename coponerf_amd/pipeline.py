@@ -2,12 +2,12 @@
 
 The reference's evaluation loop (/root/reference test.py:164-212, wrapper.py:176-211) is strictly serial: `get_z`, then
 the chunked `forward(val=True)` calls, pair after pair.  The two halves are complementary on an MI355X — `get_z` is
-~800 small kernels (launch / latency bound, 11 ms alone), the render pass is a handful of HBM-bound kernels that fill
+~550 small kernels (launch / latency bound, 8 ms alone), the render pass is a handful of HBM-bound kernels that fill
 the chip (25.5 ms) — and stereo pairs are independent, so the next pair's features can be produced while the current
 image renders.  Same kernels, same inputs as the serial order; only the schedule changes, and since get_z's GroupNorm
 statistics are reduced in a fixed order the results are bit-identical to the serial ones.
 
-Two ordinary streams do NOT overlap the halves (measured: 38.9 ms per image against 37.3 serial): the persistent grids
+Two ordinary streams do NOT overlap the halves (measured: 35.3-38.9 ms per image against 35.3-38.0 serial): the persistent grids
 of the render pass hold every CU, so each small kernel of get_z waits for a chip-filling launch to drain.  `cu_split`
 partitions the chip instead (coponerf_amd/streams.py): the render pass keeps `cu_split[0]` CUs, get_z the other
 `cu_split[1]`, an equal share of every XCD each.
@@ -66,11 +66,11 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
     torch.chunk(uv, nchunks), joined key by key — coponerf_amd/evalloop.render_in_chunks) instead of in one call.
 
     getz_batch > 1 runs `get_z` ONCE for that many consecutive inputs (batched along dim 0: its kernels are launch /
-    latency bound, 11 ms for one pair, ~6.5 ms per pair at four) and renders them one after the other from slices of
+    latency bound, 8 ms for one pair, ~5.6 ms per pair at four) and renders them one after the other from slices of
     the batched features; per-pair results are those of the serial order up to the rounding differences of batched
     library GEMMs / convolutions (tests/test_gpu_getz.py).
 
-    graph=True replays `get_z` as a captured HIP graph (coponerf_amd/graphs.py: one hipGraphLaunch instead of ~800
+    graph=True replays `get_z` as a captured HIP graph (coponerf_amd/graphs.py: one hipGraphLaunch instead of ~550
     eager launches; same kernels, same results)."""
     it = iter(inputs)
     getz = model.get_z
@@ -146,7 +146,7 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
                     else:
                         out = model(inp, z=zi, rel_pose=ri, val=True, flow=fi)
                     if i == 0 and nxt:
-                        # 2. the ~800 launches of the next group's get_z on the side stream: the host issues them while
+                        # 2. the ~550 launches of the next group's get_z on the side stream: the host issues them while
                         #    the GPU renders, the small kernels run beside the HBM-bound render kernels
                         with torch.cuda.stream(side):
                             nstate = features(nxt)

@@ -2,7 +2,7 @@
 
 The reference's callers run `get_z` and the chunked `forward(val=True)` calls strictly one after the other
 (/root/reference test.py:164-212, wrapper.py:176-211).  On an MI355X the two halves want different things — the render
-pass is a few HBM-bound launches whose persistent grids take every CU, `get_z` is ~800 small launches that rarely fill a
+pass is a few HBM-bound launches whose persistent grids take every CU, `get_z` is ~550 small launches that rarely fill a
 quarter of the chip — but on ordinary streams they cannot overlap: every small kernel waits for a chip-filling one to
 drain.  A `CUPartition` gives each its own CUs: `render_cus` of the 256 for the render stream, `getz_cus` for the other,
 both an equal share of each shader engine of each of the 8 XCDs, i.e. multiples of 32 (so the XCD-aware tile orders of
