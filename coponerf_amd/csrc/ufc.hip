@@ -1671,8 +1671,13 @@ extern "C" int cpn_correlation(const float* src, const float* trg, int B, int L,
                 "cpn_correlation: C=%d must be a multiple of 16", C);
     const hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)B * L;
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, src, src_n, rows, C, eps);
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, trg, trg_n, rows, C, eps);
+    if (trg == src + rows * C && trg_n == src_n + rows * C) {
+        // [src ; trg] and [src_n ; trg_n] are halves of one buffer each (the batched views of UFCLayer): one launch
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(2 * rows, 4)), dim3(256), 0, st, src, src_n, 2 * rows, C, eps);
+    } else {
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, src, src_n, rows, C, eps);
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, trg, trg_n, rows, C, eps);
+    }
     CPN_LAUNCH_CHECK("cpn_correlation(normalise)");
     if ((long long)B * cpn_cdiv(L, 128) * cpn_cdiv(L, 64) >= 512) {
         dim3 grid(cpn_cdiv(L, 128), cpn_cdiv(L, 64), B);

@@ -529,7 +529,8 @@ class HipOps:
         s_ = src.contiguous().float()
         t_ = trg.contiguous().float()
         out = torch.empty(B, 1, fs, fs, fs, fs, device=src.device, dtype=torch.float32)
-        sn, tn = torch.empty_like(s_), torch.empty_like(t_)
+        n2 = torch.empty(2, B, L, C, device=src.device, dtype=torch.float32)     # adjacent halves: cpn_correlation normalises
+        sn, tn = n2[0], n2[1]                                                     # [src ; trg] in one launch when they are too
         call("cpn_correlation", s_.data_ptr(), t_.data_ptr(), B, L, C, 1e-5, sn.data_ptr(), tn.data_ptr(),
              out.data_ptr(), _stream())
         return out, sn, tn
