@@ -77,6 +77,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_prepare_input": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
     "cpn_corr_mean3": [_P, _I, _P, _I, _P, _I, _I, _P, _P],
+    "cpn_conv4d_strided_bwd": [_P, _P, _P, _P] + [_I] * 10 + [_P] * 6,
 }
 
 CAM_STRIDE = 96
@@ -142,6 +143,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_gather_bwd_chunks.restype = ctypes.c_longlong
     handle.cpn_scatter_tables_scratch.argtypes = [_I] * 6
     handle.cpn_scatter_tables_scratch.restype = ctypes.c_longlong
+    handle.cpn_conv4d_strided_bwd_scratch.argtypes = [_I] * 10
+    handle.cpn_conv4d_strided_bwd_scratch.restype = ctypes.c_longlong
     handle.cpn_conv4d_scratch.argtypes = [_I] * 7
     handle.cpn_conv4d_scratch.restype = ctypes.c_longlong
     handle.cpn_gn_stats_doubles.argtypes = [_I, _I, ctypes.c_longlong]

@@ -27,6 +27,7 @@ UNITS = [
     ("rayout.hip", []),
     ("ufc.hip", []),
     ("ufc_attn.hip", []),
+    ("ufc_strided_bwd.hip", []),
     ("encoder.hip", []),
     ("input.hip", []),
     ("backward.hip", []),

@@ -126,6 +126,10 @@ class _CrossAttentionFn(Function):
         return None, dc, dsv, dtv
 
 
+# strided Conv4d layers: HIP VJP (csrc/ufc_strided_bwd.hip); 0 = autograd through the library max-pool / conv2d graph
+STRIDED_HIP_VJP = os.environ.get("CPN_STRIDED_CONV4D_VJP", "1") != "0"
+
+
 def _wants_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
 
@@ -227,6 +231,23 @@ class _Conv4dGnReluFn(Function):
                 ds = dy.permute(0, 2, 3, 1, 4, 5).reshape(B * Hq * Wq, C, Hs, Ws)
                 _, gws, _ = cb(ds, xs, ws.detach(), [C], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])
                 gbs = gbq
+        elif (s > 1 and STRIDED_HIP_VJP and x.is_cuda and C == 8 and x.shape[1] in (1, 2, 8) and k <= 7 and (need_x or need_w)
+              and x.numel() < 2 ** 31):
+            # strided layers (max-pool routing): cpn_conv4d_strided_bwd instead of autograd through the library graph
+            Bx, Cin, Hq, Wq, Hs, Ws = x.shape
+            xf = x.detach().contiguous().float()
+            fw = lambda w: w.detach().contiguous().float()
+            scr = torch.empty(int(_hip.lib().cpn_conv4d_strided_bwd_scratch(Bx, Cin, C, Hq, Wq, Hs, Ws, k, s, p)),
+                              dtype=torch.float32, device=dev)
+            if need_x:
+                gx = torch.empty_like(xf)
+            if need_w:
+                gwq = torch.empty(C, Cin, k, k, dtype=torch.float32, device=dev)
+                gws = torch.empty_like(gwq)
+                gbq = gbs = torch.empty(C, dtype=torch.float32, device=dev)
+            ptr = lambda t: 0 if t is None else t.data_ptr()
+            call("cpn_conv4d_strided_bwd", xf.data_ptr(), dy.data_ptr(), fw(wq).data_ptr(), fw(ws).data_ptr(), Bx, Cin, C, Hq, Wq,
+                 Hs, Ws, k, s, p, scr.data_ptr(), ptr(gx), ptr(gwq), ptr(gws), ptr(gbq), _stream())
         else:
             need = ctx.needs_input_grad[1:6]
             with torch.enable_grad():

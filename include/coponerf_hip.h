@@ -421,6 +421,18 @@ long long cpn_cost_volume_attention_scratch(int B, int L, int H, int P, int Dv);
 int cpn_cost_volume_attention(const float* q, const float* k, const float* v_low, const float* residual, int B, int fs,
                               int H, int hs, int Dv, float eps, float* scratch, float* out, void* stream);
 
+/* ---- VJP of the strided Conv4d layers (models/conv4d.py:57-135 with stride > 1: the max-pooled branches; k3 s2 p1 on
+ * 32^4 and k5 s4 p2 on 64^4 volumes in UFC.embedding / UFCLayer.feat_to_corr1,2, aggregation.py:198-199, 369-371).
+ * Replaces autograd through two max_pool2d + two conv2d + their permute copies.  x (B,Cin,Hq,Wq,Hs,Ws), dy the gradient of
+ * the layer's output (B,Cout,Oq,Pq,Os,Ps) BEFORE GroupNorm, wq / ws (Cout,Cin,k,k).  dx (like x) or NULL; gwq, gws
+ * (Cout,Cin,k,k) and gb (Cout: the gradient of EITHER bias) or all three NULL.  Maxima are routed to the first maximum of a
+ * window in scan order, NaN wins (max_pool2d's rule).  Deterministic.  scratch: cpn_conv4d_strided_bwd_scratch(...) floats.
+ * Compiled for Cout = 8, Cin in {1, 2, 8}, k <= 7.                                                                                */
+long long cpn_conv4d_strided_bwd_scratch(int B, int Cin, int Cout, int Hq, int Wq, int Hs, int Ws, int k, int s, int p);
+int cpn_conv4d_strided_bwd(const float* x, const float* dy, const float* wq, const float* ws, int B, int Cin, int Cout,
+                           int Hq, int Wq, int Hs, int Ws, int k, int s, int p, float* scratch, float* dx, float* gwq,
+                           float* gws, float* gb, void* stream);
+
 /* ---- K10: cost-volume cross attention of UFCLayer.forward_cross (models/aggregation.py:327-328) -------------------
  * corr (B, H, S, T) fp32; src_v (B, S, H, C), trg_v (B, T, H, C), C == 32
  *   src_attn (B, S, H, C) = softmax over t of corr . trg_v ;  trg_attn (B, T, H, C) = softmax over s of corr, transposed . src_v */

@@ -412,3 +412,41 @@ def test_backward_entry_points_reject_bad_shapes():
         call("cpn_linear_attention_bwd", f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), 1, 0, 1, 8, 0, 1e-6, 1,
              f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), st)
     assert _hip.lib().cpn_wgrad_tall_scratch(100, 128) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,s,p,cin,ties", [(32, 3, 2, 1, 1, False), (64, 5, 4, 2, 1, False), (10, 5, 4, 2, 2, False),
+                                               (13, 3, 2, 1, 1, True), (16, 3, 2, 1, 1, True)])
+def test_strided_conv4d_vjp_equals_library_graph(n, k, s, p, cin, ties):
+    """cpn_conv4d_strided_bwd (csrc/ufc_strided_bwd.hip) against autograd through the library graph of the same layer
+    (two max_pool2d + two conv2d, models/conv4d.py:57-135): input, weight and bias gradients; ragged (ceil-mode) windows;
+    and — with a ReLU'd, quantised input — windows full of equal maxima, where the routing rule decides (first maximum in
+    scan order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from coponerf_amd import getz, ufc_ops
+    dev = torch.device("cuda:0")
+    ops = ufc_ops.HipOps()
+    torch.manual_seed(3)
+    enc = getz.Encoder4D((cin, 8), k, s, p).to(dev)
+    B = 2
+    x = torch.randn(B, cin, n, n, n, n, device=dev)
+    if ties:
+        x = (torch.relu(x) * 2).round() / 2                  # many exact zeros and repeated values inside every window
+    x.requires_grad_(True)
+    params = list(enc.parameters())
+    got = {}
+    for flag in (True, False):
+        old, ufc_ops.STRIDED_HIP_VJP = ufc_ops.STRIDED_HIP_VJP, flag
+        try:
+            y = enc(x, ops)
+            g = torch.cos(torch.arange(y.numel(), device=dev, dtype=torch.float32)).view_as(y)
+            got[flag] = torch.autograd.grad((y * g).sum(), [x] + params)
+        finally:
+            ufc_ops.STRIDED_HIP_VJP = old
+    for name, a, b in zip(["x"] + [f"param{i}" for i in range(len(params))], got[True], got[False]):
+        scale = float(b.abs().max()) + 1e-12
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (name, float((a - b).abs().max()), scale)
+    # the routing itself: exactly the same elements receive a gradient
+    assert torch.equal(got[True][0] != 0, got[False][0] != 0)
