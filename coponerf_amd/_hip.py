@@ -76,6 +76,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_bn_act": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P],
     "cpn_prepare_input": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
+    "cpn_resize_bilinear_ac_adjoint": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
     "cpn_corr_mean3": [_P, _I, _P, _I, _P, _I, _I, _P, _P],
     "cpn_conv4d_strided_bwd": [_P, _P, _P, _P] + [_I] * 10 + [_P] * 6,
 }

@@ -1110,6 +1110,51 @@ __global__ __launch_bounds__(256) void resize_bilinear_ac_kernel(const float* __
     }
 }
 
+// Adjoint of resize_bilinear_ac_kernel (what autograd needs behind F.interpolate(align_corners=True)): the gradient g on
+// the (H, W) grid gathered onto the (h, w) grid, out[y][x] = sum_{Y,X} wy(Y, y) wx(X, x) g[Y][X] with the forward kernel's
+// own tap / weight arithmetic.  A GATHER in a fixed order: deterministic, where the library's backward scatters with atomics.
+__global__ __launch_bounds__(256) void resize_bilinear_ac_adjoint_kernel(const float* __restrict__ g, float* __restrict__ out,
+                                                                         long long planes, int h, int w, int H, int W) {
+    const long long total = planes * h * w;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w);
+        const long long t = idx / w;
+        const int y = (int)(t % h);
+        const long long pl = t / h;
+        // fine rows / columns whose taps can touch coarse index y / x (conservative by one on each side, checked exactly below)
+        const int Ylo = sy > 0.0f ? max(0, (int)((float)(y - 1) / sy) - 1) : 0;
+        const int Yhi = sy > 0.0f ? min(H - 1, (int)((float)(y + 1) / sy) + 1) : H - 1;
+        const int Xlo = sx > 0.0f ? max(0, (int)((float)(x - 1) / sx) - 1) : 0;
+        const int Xhi = sx > 0.0f ? min(W - 1, (int)((float)(x + 1) / sx) + 1) : W - 1;
+        const float* p = g + pl * H * W;
+        float acc = 0.0f;
+        for (int Y = Ylo; Y <= Yhi; ++Y) {
+            const float fy = sy * (float)Y;
+            const int y0 = (int)fy, y1 = y0 + (y0 < h - 1);
+            const float ly = fy - (float)y0;
+            float wy = 0.0f;
+            if (y0 == y) wy += 1.0f - ly;
+            if (y1 == y) wy += ly;
+            if (wy == 0.0f) continue;
+            float row = 0.0f;
+            for (int X = Xlo; X <= Xhi; ++X) {
+                const float fx = sx * (float)X;
+                const int x0 = (int)fx, x1 = x0 + (x0 < w - 1);
+                const float lx = fx - (float)x0;
+                float wx = 0.0f;
+                if (x0 == x) wx += 1.0f - lx;
+                if (x1 == x) wx += lx;
+                row += wx * p[Y * W + X];
+            }
+            acc += wy * row;
+        }
+        out[idx] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // UFC.forward's last step (models/aggregation.py:549-553): the three levels' refined correlations, interpolate4d'ed to
 // n^4, averaged.  interpolate4d (aggregation.py:49-56) is two bilinear passes (align_corners=True): over the target
@@ -1190,6 +1235,18 @@ extern "C" int cpn_resize_bilinear_ac(const float* src, float* dst, long long pl
     hipLaunchKernelGGL(resize_bilinear_ac_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, planes,
                        h, w, H, W);
     CPN_LAUNCH_CHECK("cpn_resize_bilinear_ac");
+    return 0;
+}
+
+extern "C" int cpn_resize_bilinear_ac_adjoint(const float* g, float* out, long long planes, int h, int w, int H, int W,
+                                              void* stream) {
+    CPN_REQUIRE(g && out, CPN_E_ARG, "cpn_resize_bilinear_ac_adjoint: null pointer");
+    CPN_REQUIRE(planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, CPN_E_SHAPE, "cpn_resize_bilinear_ac_adjoint: bad shape");
+    const long long total = planes * h * w;
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(total, 256), 1 << 20);
+    hipLaunchKernelGGL(resize_bilinear_ac_adjoint_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, out, planes, h, w,
+                       H, W);
+    CPN_LAUNCH_CHECK("cpn_resize_bilinear_ac_adjoint");
     return 0;
 }
 

@@ -169,6 +169,8 @@ TWO_STREAMS = os.environ.get("CPN_GETZ_TWO_STREAMS", "1") != "0"
 BATCH_VIEWS = os.environ.get("CPN_GETZ_BATCH_VIEWS", "1") != "0"
 # inference trunk: batch norm + residual + ReLU behind every convolution as one kernel (SpatialEncoder._forward_infer)
 FUSED_TRUNK = os.environ.get("CPN_GETZ_FUSED_TRUNK", "1") != "0"
+# training: the final correlation on cpn_corr_mean3 with its own adjoint (ufc_ops._CorrMean3Fn); 0 = composed resize ops
+CORR_MEAN3_TRAIN = os.environ.get("CPN_CORR_MEAN3_TRAIN", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -432,7 +434,8 @@ class UFC(nn.Module):
                 corr, src, trg = layer(corr, src, trg, ops)
             feats.append(_tokens_to_map(torch.stack((src, trg), dim=1).flatten(0, 1), fs))
             corrs.append(ops.correlation_tokens(src, trg, fs))
-        if len(corrs) == 3 and hasattr(ops, "corr_mean3") and not (torch.is_grad_enabled() and corrs[2].requires_grad):
+        fused_ok = CORR_MEAN3_TRAIN or not (torch.is_grad_enabled() and corrs[2].requires_grad)
+        if len(corrs) == 3 and hasattr(ops, "corr_mean3") and corrs[2].shape[-1] == 64 and fused_ok:
             c = ops.corr_mean3(corrs)                               # both interpolate4d's, the adds and the / 3 in one pass
         else:
             up = [_interp4d(x, 64, ops) for x in corrs]

@@ -402,6 +402,16 @@ class DwConvTokensFn(Function):
         return dx, dw, db, None
 
 
+def _resize_adjoint_hip(g, h: int):
+    """Adjoint of resize_bilinear(., n): g (N,C,n,n) -> (N,C,h,h) on cpn_resize_bilinear_ac_adjoint (a deterministic gather;
+    the library's upsample backward scatters with atomics)."""
+    g = g.contiguous().float()
+    N, C, H, W = g.shape
+    out = torch.empty(N, C, h, h, dtype=torch.float32, device=g.device)
+    call("cpn_resize_bilinear_ac_adjoint", g.data_ptr(), out.data_ptr(), N * C, h, h, H, W, _stream())
+    return out
+
+
 class _ResizeFn(Function):
     """forward: cpn_resize_bilinear_ac.  backward: the adjoint of the (linear) interpolation, no forward re-run."""
 
@@ -412,8 +422,41 @@ class _ResizeFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.in_shape[-1] == ctx.in_shape[-2]:
+            return None, _resize_adjoint_hip(dout, ctx.in_shape[-1]), None
         return None, torch.ops.aten.upsample_bilinear2d_backward(dout.contiguous(), [ctx.size, ctx.size],
                                                                  list(ctx.in_shape), True, None, None), None
+
+
+class _CorrMean3Fn(Function):
+    """forward: cpn_corr_mean3 (sum of the three interpolate4d's / 3 in one pass).  backward: the operator is linear —
+    g / 3 for the finest level, and for each coarse level the adjoint of interpolate4d, contracted over the TARGET pair
+    of dims first: that pass reads the 64^4 gradient through a contiguous (B, n*n, n, n) view, and everything behind it
+    is h*h/n*n of the size (autograd through the composed ops ran the adjoint of the second forward pass first: two
+    full-size permute copies and two full-size adds per step)."""
+
+    @staticmethod
+    def forward(ctx, ops, c0, c1, c2):
+        ctx.hs = (c0.shape[-1], c1.shape[-1])
+        return ops._corr_mean3_hip((c0, c1, c2))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        B, n = g.shape[0], g.shape[-1]
+        third = 1.0 / 3.0
+        grads = []
+        for need, h in zip(ctx.needs_input_grad[1:3], ctx.hs):
+            if not need:
+                grads.append(None)
+                continue
+            # (I, J | i, j): contract (i, j) -> (ht, wt), then (I, J) -> (hs, ws)
+            t = _resize_adjoint_hip(g.view(B, n * n, n, n), h)                                     # (B, I*J, ht, wt)
+            t = t.view(B, n, n, h * h).permute(0, 3, 1, 2)                                         # (B, ht*wt, I, J)
+            t = _resize_adjoint_hip(t, h)                                                          # (B, ht*wt, hs, ws)
+            grads.append((t.view(B, h, h, h, h).permute(0, 3, 4, 1, 2) * third).reshape(B, 1, h, h, h, h))
+        g2 = g * third if ctx.needs_input_grad[3] else None
+        return None, grads[0], grads[1], g2
 
 
 class _ResizeAdjointFn(Function):
@@ -422,8 +465,7 @@ class _ResizeAdjointFn(Function):
     @staticmethod
     def forward(ctx, ops, x, size):
         ctx.ops, ctx.n = ops, x.shape[-1]
-        N, C = x.shape[:2]
-        return torch.ops.aten.upsample_bilinear2d_backward(x.contiguous(), list(x.shape[-2:]), [N, C, size, size], True, None, None)
+        return _resize_adjoint_hip(x, size)
 
     @staticmethod
     def backward(ctx, g):
@@ -650,9 +692,13 @@ class HipOps:
 
     def corr_mean3(self, corrs):
         """UFC.forward's final correlation (aggregation.py:549-553): sum(interpolate4d(c, n) for c in corrs) / 3 for the
-        three levels' (B,1,h,h,h,h) volumes, on cpn_corr_mean3 (inference; under autograd the caller composes it from
-        resize_bilinear)."""
-        c0, c1, c2 = (c.contiguous().float() for c in corrs)
+        three levels' (B,1,h,h,h,h) volumes, on cpn_corr_mean3; under autograd _CorrMean3Fn supplies the adjoint."""
+        if _wants_grad(*corrs):
+            return _CorrMean3Fn.apply(self, *(c.float() for c in corrs))
+        return self._corr_mean3_hip(corrs)
+
+    def _corr_mean3_hip(self, corrs):
+        c0, c1, c2 = (c.detach().contiguous().float() for c in corrs)
         self._need_gpu(c2)
         B, n = c2.shape[0], c2.shape[-1]
         out = torch.empty_like(c2)

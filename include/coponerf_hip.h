@@ -463,6 +463,8 @@ int cpn_bn_act(const float* x, const float* res, const float* mean, const float*
  * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /
  * interpolate2d_token (models/aggregation.py:49-63, 285, 293, 299).                                           */
 int cpn_resize_bilinear_ac(const float* src, float* dst, long long planes, int h, int w, int H, int W, void* stream);
+/* its adjoint (the VJP autograd needs): g on the (H,W) grid -> out on the (h,w) grid, gathered in a fixed order (deterministic) */
+int cpn_resize_bilinear_ac_adjoint(const float* g, float* out, long long planes, int h, int w, int H, int W, void* stream);
 
 /* ---- UFC.forward's final correlation (models/aggregation.py:549-553): mean of the three levels' correlations after
  * interpolate4d (aggregation.py:49-56: bilinear, align_corners=True, over the target pair of dims, then the source pair)

@@ -450,3 +450,43 @@ def test_strided_conv4d_vjp_equals_library_graph(n, k, s, p, cin, ties):
         assert float((a - b).abs().max()) <= 2e-5 * scale, (name, float((a - b).abs().max()), scale)
     # the routing itself: exactly the same elements receive a gradient
     assert torch.equal(got[True][0] != 0, got[False][0] != 0)
+
+
+@pytest.mark.gpu
+def test_corr_mean3_gradients_equal_composed_interpolations():
+    """_CorrMean3Fn's backward (adjoint of interpolate4d contracted over the target dims first) against autograd through the
+    composed resize / add / divide ops it replaces (UFC.forward, aggregation.py:549-553)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from coponerf_amd import getz, ufc_ops
+    dev = torch.device("cuda:0")
+    ops = ufc_ops.HipOps()
+    g0 = torch.Generator().manual_seed(4)
+    corrs = [torch.randn(2, 1, h, h, h, h, generator=g0).to(dev).requires_grad_(True) for h in (16, 32, 64)]
+    w = torch.cos(torch.arange(2 * 64 ** 4, device=dev, dtype=torch.float32)).view(2, 1, 64, 64, 64, 64)
+    fused = ops.corr_mean3(corrs)
+    got = torch.autograd.grad((fused * w).sum(), corrs)
+    up = [getz._interp4d(x, 64, ops) for x in corrs]
+    composed = ((up[0] + up[1]) + up[2]) / 3
+    want = torch.autograd.grad((composed * w).sum(), corrs)
+    assert float((fused - composed).abs().max()) <= 2.4e-7 * float(composed.abs().max())
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), float((a - b).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,n", [(16, 64), (32, 64), (16, 32), (16, 16), (1, 8), (5, 13), (64, 16)])
+def test_resize_adjoint_kernel_equals_library_backward(h, n):
+    """cpn_resize_bilinear_ac_adjoint (deterministic gather) against aten's upsample_bilinear2d_backward (atomic scatter),
+    the VJP of F.interpolate(mode='bilinear', align_corners=True) from (h,h) to (n,n) — up- and down-sampling."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from coponerf_amd import ufc_ops
+    dev = torch.device("cuda:0")
+    g = torch.randn(3, 7, n, n, device=dev)
+    got = ufc_ops._resize_adjoint_hip(g, h)
+    want = torch.ops.aten.upsample_bilinear2d_backward(g, [n, n], [3, 7, h, h], True, None, None)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 5e-6 * max(1.0, float(want.abs().max()))      # a few ulps over <= 100 terms
+    assert torch.equal(got, ufc_ops._resize_adjoint_hip(g, h))              # run-to-run identical
