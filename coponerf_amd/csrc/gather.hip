@@ -220,6 +220,11 @@ __global__ __launch_bounds__(256) void local_hidden_kernel(
 // off the registers against W2 fragments held in LDS (lane-linear 16-byte slots, 32 KiB).  Output rows use the
 // same channel permutation: 16-byte stores, 64 contiguous bytes per row and tile pair.
 // ---------------------------------------------------------------------------------------------
+// timing-only ablations for tools/local_mlp_bench.py (results are wrong when non-zero; the product builds with 0):
+// 1 = no first-layer MFMAs, 2 = no second-layer MFMAs, 4 = no `add` loads, 8 = no `dot_with` loads, 16 = no stores
+#ifndef CPN_LMLP_ABLATE
+#define CPN_LMLP_ABLATE 0
+#endif
 __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
     const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
         const bool live = row < (unsigned)nrows;
         const RowIn nxt = fetch(grp + nwaves < ngroups ? grp + nwaves : grp);
         half8 cv[4];
-        if (logits_out) {
+        if (logits_out && !(CPN_LMLP_ABLATE & 8)) {
             const unsigned crow = live ? row : (unsigned)nrows - 1;
 #pragma unroll
             for (int p = 0; p < 4; ++p)
@@ -289,12 +294,18 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (add) acc[t] = *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+            if (add && !(CPN_LMLP_ABLATE & 4))
+                acc[t] = *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
         }
+        if (!(CPN_LMLP_ABLATE & 1)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], cur.lv[e], acc[t], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += f32x4{cur.lv[0], cur.lv[1], cur.lv[2], cur.lv[3]} * wv[t];
+        }
         // hidden layer -> fp16 B operands: K block p = channels p*32 .. p*32+31, this lane holds fg*8 .. fg*8+7 of it
         half8 hb[4];
 #pragma unroll
@@ -308,9 +319,13 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             o2[t] = *reinterpret_cast<const f32x4*>(b2s + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+            if (!(CPN_LMLP_ABLATE & 2)) {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 o2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[(t * 4 + p) * 64 + lane], hb[p], o2[t], 0, 0, 0);
+            } else {
+                o2[t] += f32x4{(float)hb[t & 3][0], (float)hb[t & 3][1], (float)hb[t & 3][2], (float)hb[t & 3][3]};
+            }
         }
         cur = nxt;
         if (logits_out) {
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
                 }
             dsum += __shfl_xor(dsum, 16);
             dsum += __shfl_xor(dsum, 32);
-            if (live && fg == 0) logits_out[row] = dsum;
+            if (live && fg == 0 && (!(CPN_LMLP_ABLATE & 16) || dsum == 12345.678f)) logits_out[row] = dsum;
             continue;
         }
         // stage the wave's 16 x 128 tile in LDS and write whole 256-byte rows (4 rows per store instruction)
@@ -347,7 +362,8 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
             const int rr = q * 4 + (lane >> 4), slot = lane & 15;
             const unsigned orow = grp * 16 + rr;
             const half8 o = stg[rr * 17 + slot];
-            if (orow < (unsigned)nrows) *reinterpret_cast<half8*>(out + (size_t)orow * 128 + slot * 8) = o;
+            if (orow < (unsigned)nrows && (!(CPN_LMLP_ABLATE & 16) || (float)o[0] == 12345.0f))
+                *reinterpret_cast<half8*>(out + (size_t)orow * 128 + slot * 8) = o;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }

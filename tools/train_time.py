@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--detach-z", action="store_true", help="stop the gradient at z (times the render backward alone)")
     ap.add_argument("--flow-loss", action="store_true", help="add a flow / pose term to the loss (the reference's cycle, "
                                                             "ssim and pose losses send gradients through those heads)")
+    ap.add_argument("--sort-rays", choices=("none", "rowmajor", "tiles"), default="none",
+                    help="order of the query pixels inside each pair (the dataset draws them at random): locality experiment")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = CoPoNeRF.CoPoNeRF(n_view=2)
@@ -25,6 +27,13 @@ def main():
     model = model.to(dev).train()
     inp = syn.make_inputs(a.batch, 256, 256, a.rays, seed=61)
     mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (o.to(dev) if torch.is_tensor(o) else o)
+    if a.sort_rays != "none":
+        uv, rgb = inp["query"]["uv"], inp["query"]["rgb"]                      # (B,1,R,2), (B,1,R,3)
+        x, y = uv[..., 0].long(), uv[..., 1].long()
+        key = y * 256 + x if a.sort_rays == "rowmajor" else ((y // 8) * 32 + x // 8) * 64 + (y % 8) * 8 + x % 8
+        order = key.argsort(dim=-1)
+        inp["query"]["uv"] = torch.gather(uv, 2, order[..., None].expand_as(uv))
+        inp["query"]["rgb"] = torch.gather(rgb, 2, order[..., None].expand_as(rgb))
     inp = mv(inp)
     opt = torch.optim.Adam(model.parameters(), lr=1e-5)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
