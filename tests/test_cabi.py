@@ -33,6 +33,22 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert lib.cpn_stream_create_cu_range(0, 64, None) == -1
     assert lib.cpn_stream_destroy(None) == -1
     assert lib.cpn_stream_destroy(ctypes.c_void_p(1)) == -1 and b"not a stream" in lib.cpn_last_error()
+    # round-3 get_z / training entry points: shape and pointer checks come before any launch
+    assert lib.cpn_bn_act(None, None, None, None, None, None, 1e-5, 1, 8, 16, 1, None, None) == -1
+    assert lib.cpn_bn_act(16, None, 16, 16, 16, 16, 1e-5, 1, 8, 6, 1, 16, None) == -2 and b"HW % 4" in lib.cpn_last_error()
+    assert lib.cpn_bn_act(16, None, 16, 16, 16, 16, 1e-5, 1, 8, 16, 1, 20, None) == -1 and b"aligned" in lib.cpn_last_error()
+    assert lib.cpn_corr_mean3(None, 16, None, 32, None, 64, 1, None, None) == -1
+    assert lib.cpn_corr_mean3(16, 1, 16, 32, 16, 64, 1, 16, None) == -2
+    assert lib.cpn_resize_bilinear_ac_adjoint(None, None, 1, 4, 4, 8, 8, None) == -1
+    assert lib.cpn_resize_bilinear_ac_adjoint(16, 16, 0, 4, 4, 8, 8, None) == -2
+    strided = lambda cin, cout, k, s: lib.cpn_conv4d_strided_bwd(16, 16, 16, 16, 1, cin, cout, 8, 8, 8, 8, k, s, (k - 1) // 2, 16,
+                                                                 16, 16, 16, 16, None)
+    assert strided(1, 4, 3, 2) == -2 and b"Cout = 8" in lib.cpn_last_error()
+    assert strided(1, 8, 3, 1) == -2                                              # stride 1 has its own kernels
+    assert strided(3, 8, 3, 2) == -2
+    assert lib.cpn_conv4d_strided_bwd(16, 16, 16, 16, 1, 1, 8, 8, 8, 8, 8, 3, 2, 1, 16, 16, 16, None, None, None) == -1   # partial weight grads
+    assert lib.cpn_conv4d_strided_bwd_scratch(1, 1, 8, 8, 8, 8, 8, 3, 1, 1) == 0
+    assert lib.cpn_conv4d_strided_bwd_scratch(4, 1, 8, 64, 64, 64, 64, 5, 4, 2) > 4 * 2 * 64 * 64 * 16 * 16
 
 
 def test_missing_library_raises(monkeypatch):
