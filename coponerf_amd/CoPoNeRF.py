@@ -12,7 +12,7 @@ coponerf_amd.render.RenderEngine; there is no PyTorch fallback for it.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn as nn

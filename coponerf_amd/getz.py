@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import List, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import torch
 import torch.nn as nn

@@ -15,8 +15,7 @@ Shard file = 64-byte magic/header length + JSON header + arrays at 64-byte align
 from __future__ import annotations
 
 import json
-import os
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
