@@ -19,7 +19,9 @@ def main():
                                                             "ssim and pose losses send gradients through those heads)")
     ap.add_argument("--sort-rays", choices=("none", "rowmajor", "tiles"), default="none",
                     help="order of the query pixels inside each pair (the dataset draws them at random): locality experiment")
+    ap.add_argument("--cudnn-benchmark", action="store_true", help="let the convolution library time its algorithms (MIOpen find)")
     a = ap.parse_args()
+    torch.backends.cudnn.benchmark = a.cudnn_benchmark
     dev = torch.device("cuda:0")
     model = CoPoNeRF.CoPoNeRF(n_view=2)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
