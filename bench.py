@@ -54,7 +54,8 @@ def parse_args(argv=None):
                     help="render the --pairs stereo pairs one forward() call each (different pairs: the feature tables "
                          "are rebuilt for every call inside the timed region) instead of one batched call")
     ap.add_argument("--train-rays", type=int, default=4096, help="query rays per pair in a training step")
-    ap.add_argument("--chunk-rays", type=int, default=16384)
+    ap.add_argument("--chunk-rays", type=int, default=0, help="rays per chunk of the per-sample stages; 0 = the engine's automatic "
+                    "choice (a 65 536-ray image is one chunk on a 288 GB device)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="HIP streams the ray chunks are spread over (kernels of different chunks then share the GPU "
                          "and the per-kernel roofline timing is no longer clean)")
@@ -269,7 +270,7 @@ def run(args):
         "config": {"workload": f"{cfg_name}: {H}x{H} stereo pair ({args.rig} rig), full-image render {R} rays x {S} "
                                f"samples, {B} pair(s) per GPU{' rendered pair by pair' if args.pair_by_pair else ''}, "
                                f"render path only (z/rel_pose/flow given, val=True)",
-                   "chunk_rays": args.chunk_rays, "lanes": args.lanes, "pairs_per_gpu": B,
+                   "chunk_rays": args.chunk_rays or model._engine._auto_chunk(S, dev), "lanes": args.lanes, "pairs_per_gpu": B,
                    "first_layer": "projected tables + K=80 MFMA (cpn_encode_hidden)" if tables
                                   else "gather + 835->832 GEMM"},
         "rays_per_s_calls_on_two_streams": None if overlapped is None else rays_per_step * world * args.steps / overlapped,

@@ -550,10 +550,20 @@ def test_full_image_four_chunks_against_oracle(model, dev, weights):
     model._engine.chunk_rays = 16384
     try:
         with torch.no_grad():
-            out = model(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=True, flow=to_device(flow, dev))
+            dinp, dz, dflow = to_device(inp, dev), to_device(z, dev), to_device(flow, dev)
+            out = model(dinp, z=dz, rel_pose=rel.to(dev), val=True, flow=dflow)
             ref = orc.forward(sub, z, rel, flow, True, weights, npoints=S)
+            # the engine's automatic chunk size renders the image as ONE chunk on a 288 GB device: a ray's arithmetic does
+            # not depend on the chunk it is in
+            model._engine.chunk_rays = 0
+            assert model._engine._auto_chunk(S, dev) == 65536
+            one = model(dinp, z=dz, rel_pose=rel.to(dev), val=True, flow=dflow)
+            for k in ("rgb", "at_wt", "pixel_val", "valid_mask", "depth_ray"):
+                assert torch.equal(one[k], out[k]), k
+            del one
     finally:
         model._engine.chunk_rays = old
+        model._engine._ws.clear()                                  # 30 GB of one-chunk workspace: not needed by later tests
     assert torch.equal(out["pixel_val"][:, sel], ref["pixel_val"])
     assert (out["rgb"][:, :, sel].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
     assert (out["at_wt"][:, sel].cpu() - ref["at_wt"]).abs().max() <= 2e-3

@@ -14,8 +14,8 @@ python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --no-tables --cpu-rays 0 --train-steps 0 > "$OUT/bench_gather_gemm_form.json" 2>> "$OUT/bench.err"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render_prof" -o r -- python "$ROOT/bench.py" --no-image --no-ref-loop --no-two-stream-pass --cpu-rays 0 --train-steps 0 --steps 5 ) > "$OUT/bench_under_rocprof.json" 2> "$OUT/render_prof.log"
 python tools/summarize_pmc.py "$(find "$OUT/render_prof" -name '*kernel_stats.csv' | head -1)" "$OUT/render_kernel_stats.summary.csv" 40
-tools/pmc_passes.sh "$OUT/pmc_encode" encode_hidden -- python "$ROOT/tools/encode_bench.py" --only tables --iters 3 > "$OUT/pmc_encode.log" 2>&1
-python tools/make_traffic_json.py "$OUT/pmc_encode/summary.json" 4194304 "$OUT/traffic.json" >> "$OUT/pmc_encode.log" 2>&1
+tools/pmc_passes.sh "$OUT/pmc_encode" encode_hidden -- python "$ROOT/tools/encode_bench.py" --only tables --iters 3 --rays 65536 > "$OUT/pmc_encode.log" 2>&1
+python tools/make_traffic_json.py "$OUT/pmc_encode/summary.json" 16777216 "$OUT/traffic.json" >> "$OUT/pmc_encode.log" 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/getz_prof" -o g -- python "$ROOT/tools/getz_time.py" ) > "$OUT/getz_prof.log" 2>&1
 python tools/trace_step.py "$(find "$OUT/getz_prof" -name '*kernel_trace.csv' | head -1)" soft_argmax_cols 45 > "$OUT/getz_step_kernels.txt" 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/train_prof" -o t -- python "$ROOT/tools/train_time.py" --steps 3 ) > "$OUT/train_prof.log" 2>&1
