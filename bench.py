@@ -109,7 +109,10 @@ def measure_train(args, dev, rank, world, steps, warmup):
     distributed = world > 1
     B = args.pairs if (args.mode == "train" and args.pairs) else 4
     R, S = args.train_rays, args.samples
-    resident = torch.cuda.memory_allocated(dev)             # whatever earlier measurements of this process still hold
+    import gc
+    gc.collect()                                            # the render model of the earlier measurements sits in reference cycles
+    torch.cuda.empty_cache()
+    resident = torch.cuda.memory_allocated(dev)             # whatever those measurements still hold after that
     model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict(syn.make_full_weights(shapes, seed=11 + rank), strict=True)     # ranks start different ...
@@ -135,7 +138,7 @@ def measure_train(args, dev, rank, world, steps, warmup):
            "pairs_per_gpu": B, "rays_per_pair": R, "samples": S, "n_gpus": world,
            "collectives_per_step": info["collectives"], "allreduce_bytes_per_step": info["allreduce_bytes"],
            "broadcast_collectives": nbcast, "stepped": bool(info["stepped"]), "loss": float(info["loss"]),
-           "phases_ms": phases, "peak_mem_GB": (torch.cuda.max_memory_allocated(dev) - resident) / 2 ** 30,
+           "phases_ms": phases, "peak_mem_GB": max(0.0, torch.cuda.max_memory_allocated(dev) - resident) / 2 ** 30,
            # forward + backward ~ 3x the forward's algorithmic FLOPs; get_z 227.8 GFLOP per pair
            "algorithmic_tflops": rays * 3.0 * (f_ray(S) + 227.8e9 / R) / 1e12}
     del step, model
