@@ -276,7 +276,7 @@ class RenderEngine:
         # rays per chunk of the per-sample stages; 0 = automatic (`_auto_chunk`): one 65 536-ray image is ONE chunk on a
         # 288 GB MI355X (28 GB of `hid` at 64 samples) — 4 launches of each per-sample kernel instead of 16 shave the
         # ramp / tail of the persistent grids: 26.6 -> 24.7 ms per image against chunks of 16 384
-        self.chunk_rays = int(chunk_rays)
+        self.chunk_rays = int(chunk_rays) or int(os.environ.get("COPONERF_CHUNK_RAYS", "0"))
         # tables=True: first encoder layer from pre-projected feature tables (cpn_encode_hidden, csrc/encode.hip);
         # False: gather the 835-channel rows and run the 835 -> 832 GEMM on them (the form the training pass uses)
         self.tables = bool(tables)
