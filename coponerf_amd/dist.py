@@ -46,7 +46,16 @@ def grads_finite(params: Iterable[torch.nn.Parameter], group=None) -> bool:
     return bool(ok.item() > 0)
 
 
-def guard_and_clip(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, group=None):
+def _exchanging(group, force: bool) -> bool:
+    """Is there an initialised process group whose collectives should run?  `force`: also on a one-rank group — a
+    one-rank RCCL communicator still initialises, launches and completes every collective, which is how the exchange
+    path is exercised on a single MI355X (tests/test_gpu_dist.py, bench.py `exchange_probe`)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return force or dist.get_world_size(group) > 1
+
+
+def guard_and_clip(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, group=None, force: bool = False):
     """The reference's invalid-gradient guard (wrapper.py:44-58) and `clip_grad_norm_` (wrapper.py:142-146) from ONE
     pass over the gradients: per-tensor 2-norms (`torch._foreach_norm`, a handful of launches for the 570 tensors),
     combined in float64.  NaN / Inf entries make their tensor's norm non-finite, so `finite` means "no gradient holds
@@ -66,7 +75,7 @@ def guard_and_clip(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, 
         dev = plist[0].device if plist else "cpu"
         total = torch.zeros((), dtype=torch.float64, device=dev)
         ok = torch.ones((), dtype=torch.float32, device=dev)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _exchanging(group, force):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if not grads:
         return bool(ok.item() > 0), total
@@ -77,7 +86,8 @@ def guard_and_clip(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, 
     return finite, total
 
 
-def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None) -> int:
+def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
+                      force: bool = False) -> int:
     """In-place gradient averaging across ranks; returns the number of data collectives issued.
 
     Parameters without a gradient are skipped like wrapper.py:26 does.  The flat buckets need the SAME set of
@@ -85,11 +95,9 @@ def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 
     another has): one MAX all-reduce of the has-gradient mask establishes the union, and a rank missing one of those
     gradients contributes zeros for it and RECEIVES the average as its `.grad`, so the optimizers of all ranks update
     the same set of parameters and the replicas stay identical."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _exchanging(group, force):
         return 0
     world = dist.get_world_size(group)
-    if world == 1:
-        return 0
     plist = [p for p in params]
     if not plist:
         return 0
@@ -120,9 +128,10 @@ def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 
     return len(handles)
 
 
-def broadcast_parameters(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 64 << 20, group=None) -> int:
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 64 << 20, group=None,
+                         force: bool = False) -> int:
     """Initial weight sync (train.py:58-60), parameters AND floating-point buffers, in flat buckets."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _exchanging(group, force):
         return 0
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.is_floating_point()]
     n = 0

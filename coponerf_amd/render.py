@@ -180,18 +180,23 @@ class PendingHostTensor(torch.Tensor):
                           "is_floating_point", "__len__"))
 
     @staticmethod
-    def wrap(host: torch.Tensor, ready) -> "PendingHostTensor":
+    def wrap(host: torch.Tensor, ready, src: Optional[torch.Tensor] = None) -> "PendingHostTensor":
+        """`ready`: anything with .synchronize() (the copy's event); `src`: the device tensor being copied, kept alive
+        until the copy has been waited for (its block is also record_stream'ed for the copy stream by the engine)."""
         t = torch.Tensor._make_subclass(PendingHostTensor, host)
         t._cpn_ready = ready
+        t._cpn_src = src
         return t
 
     @staticmethod
-    def _cat_as_copies_arrive(tensors, dim=0, out=None):
+    def _cat_as_copies_arrive(tensors, dim=0, out=None, **other):
         """`torch.cat` of the callers' join (test.py:207: the per-chunk pixel_val along dim -3), chunk by chunk: each
         piece is copied into the result as soon as ITS device->host copy has landed, so the 67 MB host concatenation of a
         256x256x64 image runs under the GPU work of the later chunks instead of after the last one.  Same result as
         torch.cat; anything but a plain list of same-dtype PendingHostTensors falls back to it (returns None)."""
-        if out is not None or not isinstance(tensors, (list, tuple)) or len(tensors) < 2 or not all(
+        if "axis" in other and len(other) == 1 and dim == 0:      # numpy-style spelling torch.cat also accepts
+            dim, other = other["axis"], {}
+        if other or out is not None or not isinstance(tensors, (list, tuple)) or len(tensors) < 2 or not all(
                 isinstance(t, PendingHostTensor) and t.dtype == tensors[0].dtype and t.dim() == tensors[0].dim()
                 for t in tensors):
             return None
@@ -231,7 +236,48 @@ class PendingHostTensor(torch.Tensor):
         if ev is not None:
             ev.synchronize()
             self.__dict__["_cpn_ready"] = None
+            self.__dict__["_cpn_src"] = None
         return self
+
+    def plain(self) -> torch.Tensor:
+        """The wrapped pinned CPU tensor as a plain torch.Tensor, after the wait."""
+        self.wait()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor)
+
+    # Accessors to the BYTES that do not (or need not) go through __torch_function__: each waits first.  (Tensor.data_ptr,
+    # .untyped_storage, .numpy, .tolist, .item and __dlpack__ do dispatch there today — tests/test_pending_host.py checks
+    # every one of them — but the guarantee should not hang on that.)
+    def data_ptr(self):
+        return self.plain().data_ptr()
+
+    def untyped_storage(self):
+        return self.plain().untyped_storage()
+
+    def storage(self):
+        return self.plain().storage()
+
+    def numpy(self, *a, **k):
+        return self.plain().numpy(*a, **k)
+
+    def tolist(self):
+        return self.plain().tolist()
+
+    def __array__(self, *a, **k):
+        return self.plain().__array__(*a, **k)
+
+    def __dlpack__(self, *a, **k):
+        return self.plain().__dlpack__(*a, **k)
+
+    def __dlpack_device__(self):
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__dlpack_device__()
+
+    def __deepcopy__(self, memo):
+        return self.plain().clone()            # a copy of the values is a plain CPU tensor (copy.deepcopy(out) of a caller)
+
+    def __reduce_ex__(self, proto):
+        return self.plain().__reduce_ex__(proto)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -267,9 +313,10 @@ class RenderEngine:
         "query_repeat_embed_2": (128, 128, 128),
     }
 
-    # automatic ray-chunk size: the per-sample workspace (`hid`, 3.6 KB per sample and view) of a chunk may take this share
-    # of the device's memory, up to MAX_AUTO_CHUNK rays (the largest launch the GPU tests cover)
+    # automatic ray-chunk size: the per-sample workspaces (`hid`, 3.6 KB per sample and view; one per call lane) may take
+    # this share of the device's memory together, up to MAX_AUTO_CHUNK rays per chunk (the largest launch the GPU tests cover)
     WORKSPACE_SHARE = 0.25
+    FREE_SHARE = 0.5                # ... and at most this share of the memory that is free when the workspace is sized
     MAX_AUTO_CHUNK = 65536
 
     def __init__(self, chunk_rays: int = 0, fold_value: bool = True, lanes: int = 1, tables: bool = True):
@@ -535,6 +582,10 @@ class RenderEngine:
             host.copy_(t, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
+        # `t` was allocated on the caller's / call lane's stream and the copy stream reads it after the caller may have
+        # dropped it: tell the caching allocator, or the block can be handed to the next call on that lane while the
+        # copy is still reading it
+        t.record_stream(self._copy_stream)
         return host, done
 
     # ---- the differentiable render pass (training; gradients to the render weights and to z) ------------
@@ -606,16 +657,38 @@ class RenderEngine:
                 "pixel_val_cpu": pixel_val_cpu, "pt": g["pt"], "at_wt": w1, "coords": g["coords9"],
                 "z_local": zl, "Tq": g["Tq"], "sec_grid": g["sec_grid"], "rgb_raw": raw, "host": g["host"]}
 
-    def _auto_chunk(self, S: int, dev) -> int:
-        """Largest multiple of 1024 rays (<= MAX_AUTO_CHUNK) whose per-sample workspace fits WORKSPACE_SHARE of the device."""
-        per_ray = V * S * (2 * 832 * 2 + 128 * 2 + 4) * max(1, self.lanes)          # hid + coords_embed + logits, per lane
+    def _auto_chunk(self, S: int, dev, nrays: int = 0) -> int:
+        """Largest multiple of 1024 rays (<= MAX_AUTO_CHUNK) whose per-sample workspace, summed over ALL the call lanes
+        that can be in flight (each keeps its own `hid`), fits both WORKSPACE_SHARE of the device and FREE_SHARE of the
+        memory that is free right now (plus what this engine's workspace and torch's cache already hold): beside a
+        training job or captured get_z graphs in the same process the chunks shrink instead of the call running out of
+        memory.  The decision is kept per (S, device, settings) for as long as the workspace of the current call lane already
+        holds a chunk of `nrays` rays at that size (nothing would be allocated); otherwise free memory is consulted again."""
+        key = (S, str(dev), self.lanes, self.call_lanes, self.tables, self.fold_value)
+        hit = self.__dict__.get("_auto_chunk_memo")
+        if hit is not None and hit[0] == key:
+            have = self._ws.get(self._ws_prefix + "hid.0")
+            if have is not None and have.device == dev and have.numel() >= min(hit[1], max(1, nrays)) * V * S * 2 * 832:
+                return hit[1]
+        nws = max(1, self.lanes) * max(1, self.call_lanes)                              # workspaces alive at once
+        per_ray = V * S * (2 * 832 * 2 + 128 * 2 + 4) * nws                             # hid + coords_embed + logits
         if not self.tables:
-            per_ray += V * S * 2 * _hip.XIN_STRIDE * 2 * max(1, self.lanes)
+            per_ray += V * S * 2 * _hip.XIN_STRIDE * 2 * nws
         if not self.fold_value:
-            per_ray += V * S * (832 * 2 + 416 * 4 + 3 * 128 * 2) * max(1, self.lanes)
+            per_ray += V * S * (832 * 2 + 416 * 4 + 3 * 128 * 2) * nws
         total = torch.cuda.get_device_properties(dev).total_memory
-        fit = int(total * self.WORKSPACE_SHARE) // per_ray
-        return int(max(1024, min(self.MAX_AUTO_CHUNK, fit // 1024 * 1024)))
+        budget = int(total * self.WORKSPACE_SHARE)
+        try:
+            free, _ = torch.cuda.mem_get_info(dev)
+            own = sum(t.numel() * t.element_size() for t in self._ws.values() if t.device == dev)
+            cached = max(0, torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
+            budget = min(budget, int((free + own + cached) * self.FREE_SHARE))
+        except RuntimeError:
+            pass
+        fit = budget // per_ray
+        C = int(max(1024, min(self.MAX_AUTO_CHUNK, fit // 1024 * 1024)))
+        self.__dict__["_auto_chunk_memo"] = (key, C)
+        return C
 
     # ---- the render pass -------------------------------------------------------------------------
     def set_call_streams(self, streams: Optional[Sequence[torch.cuda.Stream]]) -> None:
@@ -625,6 +698,7 @@ class RenderEngine:
         self._call_streams = list(streams) if streams else []
         self._call_streams_given = bool(streams)
         self._call_idx = 0
+        self._uv_seen = None        # new streams have waited for nothing: the next call must order itself behind the caller's
 
     def _call_stream(self, dev) -> Optional[torch.cuda.Stream]:
         if self.call_lanes <= 1:
@@ -634,6 +708,7 @@ class RenderEngine:
                 raise RuntimeError("set_call_streams: need call_lanes streams on the render device")
         elif len(self._call_streams) != self.call_lanes or self._call_streams[0].device != dev:
             self._call_streams = [torch.cuda.Stream(device=dev) for _ in range(self.call_lanes)]
+            self._uv_seen = None    # (see set_call_streams)
         self._call_idx = (self._call_idx + 1) % self.call_lanes
         return self._call_streams[self._call_idx]
 
@@ -678,12 +753,12 @@ class RenderEngine:
             fp, hit = flow_products(flow, inp["context"]["rgb"].shape[-2])
             self._misses += 0 if hit else 1
         base = uv._base if uv._base is not None else uv
+        side = self._call_stream(dev)            # may install new lane streams, which resets _uv_seen (-> fresh)
         seen = self._uv_seen
         fresh = self._misses != miss0 or seen is None or seen[0] is not base or seen[1] != base._version or \
             uvc.untyped_storage().data_ptr() != uv.untyped_storage().data_ptr()
         self._uv_seen = (base, base._version)
         pre = (w, maps, tabs, up, self._interval[ikey], uvc, uvs, fp)
-        side = self._call_stream(dev)
         if side is None:
             self._ws_prefix = ""
             return self._render_body(pre, B, R, S, H, W, dev, debug, inp)
@@ -732,7 +807,7 @@ class RenderEngine:
 
         nray_total = B * R
         zl = torch.empty(nray_total, 416, dtype=f32, device=dev)
-        C = min(self.chunk_rays if self.chunk_rays > 0 else self._auto_chunk(S, dev), nray_total)
+        C = min(self.chunk_rays if self.chunk_rays > 0 else self._auto_chunk(S, dev, nray_total), nray_total)
         T = V * S                       # rows per ray for the attention stage
         GW = dict(self.GEMM_WEIGHTS, key_fold=(128, 1664, 1664), value_fold=(416, 1664, 1664))
         nchunks = (nray_total + C - 1) // C
@@ -867,7 +942,7 @@ class RenderEngine:
         call("cpn_lightfield_decode", coords9.data_ptr(), zl.data_ptr(), w["phi.pack"].data_ptr(), overlaps.data_ptr(),
              B, V, R, rgb.data_ptr(), valid.data_ptr(), _ptr(rgb_raw), s)
         if self.lazy_pixel_val:
-            pixel_val_cpu = PendingHostTensor.wrap(pixel_val_cpu, copy_done)
+            pixel_val_cpu = PendingHostTensor.wrap(pixel_val_cpu, copy_done, pixel_val)
         else:
             copy_done.synchronize()
         out = {"rgb": rgb, "valid_mask": valid, "pixel_val": pixel_val, "pixel_val_cpu": pixel_val_cpu, "pt": pt, "at_wt": at_wt, "coords": coords9, "z_local": zl, "Tq": up["Tq"],

@@ -18,7 +18,7 @@ from . import dist as cdist
 
 class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float = 5e-5 * 4, clip_grad: float = 1.0,
-                 bucket_bytes: int = 64 << 20, group=None):
+                 bucket_bytes: int = 64 << 20, group=None, force_collectives: bool = False):
         self.model = model
         self.params = [p for p in model.parameters()]
         # train.py:102-105 (both groups share lr); the fused multi-tensor form where the parameters live on the GPU
@@ -28,6 +28,9 @@ class TrainStep:
         self.clip_grad = clip_grad
         self.bucket_bytes = bucket_bytes
         self.group = group
+        # run the flag exchange and the gradient buckets even on a one-rank group (dist._exchanging): exercises RCCL on a
+        # single device; the update is unchanged (the mean over one rank is the rank's own gradient)
+        self.force_collectives = bool(force_collectives)
         self.timing: Optional[Dict[str, list]] = None                    # set to {} to collect HIP-event timings
         # fp16 activation gradients carry a static per-pass scale (train_fns.GradScale).  If they overflow the guard
         # skips the step and the next pass would pick the same scale: back the target off (x 1/4 per skipped step, down
@@ -55,11 +58,13 @@ class TrainStep:
         loss.backward()
         e2 = self._ev() if timed else None
         # guard + clip in one pass over the gradients; the flag is the same on every rank
-        stepped, _ = cdist.guard_and_clip(self.params, float(self.clip_grad or 0.0), group=self.group)
+        stepped, _ = cdist.guard_and_clip(self.params, float(self.clip_grad or 0.0), group=self.group,
+                                                force=self.force_collectives)
         ncoll, nbytes = 0, 0
         if stepped:
             e3 = self._ev() if timed else None
-            ncoll = cdist.average_gradients(self.params, bucket_bytes=self.bucket_bytes, group=self.group)
+            ncoll = cdist.average_gradients(self.params, bucket_bytes=self.bucket_bytes, group=self.group,
+                                                force=self.force_collectives)
             if ncoll:
                 nbytes = sum(p.grad.numel() * p.grad.element_size() for p in self.params if p.grad is not None)
             e4 = self._ev() if timed else None

@@ -1,0 +1,85 @@
+"""The whole-training-step gradient case of tests/golden/step.npz (made by tests/golden/make_golden_step.py from the
+upstream reference): inputs, the three losses restated on the output dict, and the comparison against the fixture.
+Shared by the CPU test (oracle composite: product get_z glue on the oracle's operators + oracle render) and the GPU test
+(the HIP training path)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from coponerf_amd import synthetic as syn
+from tests.helpers import GOLDEN
+
+CFG = dict(B=1, H=256, R=256, S=64, iseed=71)
+TAGS = ("img", "full", "aux")
+
+
+def fixture():
+    return np.load(os.path.join(GOLDEN, "step.npz"))
+
+
+def inputs():
+    c = CFG
+    inp = syn.make_inputs(c["B"], c["H"], c["H"], c["R"], seed=c["iseed"])
+    return inp, inp["query"]["rgb"].clone()
+
+
+def geodesic(m1, m2):
+    """models/loss_function.py:74-85."""
+    m = torch.bmm(m1, m2.transpose(1, 2))
+    cos = (m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - 1) / 2
+    cos = torch.max(torch.min(cos, torch.ones_like(cos)), -torch.ones_like(cos))
+    return torch.acos(cos).mean()
+
+
+def loss_terms(tag, out, gt):
+    """The loss of fixture case `tag` on a forward() output dict (models/loss_function.py:63-69,105-137 for `img` / `full`;
+    `aux` = the composition documented in make_golden_step.py)."""
+    terms = {"img_loss": (gt - out["rgb"]).abs().mean()}
+    if tag == "full":
+        d = torch.norm(out["T_to_C1_pts"] - out["C2_pts_to_C1"], dim=-1, keepdim=True)
+        m = d.detach().le(20).float() * out["mask_c2"].unsqueeze(-1).float() * out["matchability_cycle_mask"].unsqueeze(-1).float()
+        hub = F.huber_loss(out["T_to_C1_pts"], out["C2_pts_to_C1"], reduction="none")
+        terms["cycle_loss"] = 0.01 * ((hub * m).sum() / (m.sum() + 1e-6))
+        terms["pose_loss"] = geodesic(out["rel_pose"][:, :3, :3], out["gt_rel_pose"][:, :3, :3]) + \
+            torch.norm(out["rel_pose"][:, :3, 3] - out["gt_rel_pose"][:, :3, 3], dim=-1).mean()
+    if tag == "aux":
+        terms["cycle_unmasked"] = 0.01 * F.huber_loss(out["T_to_C1_pts"], out["C2_pts_to_C1"], reduction="none").mean()
+        terms["depth_mean"] = 0.1 * out["depth_ray"].mean()
+    return terms
+
+
+def compare(tag, named_grads, fx, rel_l2, rel_max, norm_floor=1e-3):
+    """named_grads: parameter name -> gradient tensor or None.  Every parameter the reference gave a gradient must have one
+    (and vice versa); per tensor: relative L2 error of the strided sample and of the norm <= rel_l2, worst entry
+    <= rel_max * max|g_ref|.  Tensors whose reference norm is below norm_floor x the largest norm of the case are
+    compared on the absolute scale of that floor (their relative error is rounding noise).  Returns the report rows."""
+    none_ref = set(fx[f"{tag}|none"].tolist())
+    none_got = {n for n, g in named_grads.items() if g is None}
+    assert none_got == none_ref, (tag, sorted(none_got ^ none_ref)[:8])
+    names = [n for n in named_grads if n not in none_ref]
+    top = max(float(fx[f"{tag}|{n}|norm"]) for n in names)
+    rows, bad = [], []
+    nsample = int(fx["nsample"])
+    for n in names:
+        g = named_grads[n].detach().reshape(-1).float().cpu()
+        ref = torch.from_numpy(fx[f"{tag}|{n}|sample"])
+        got = g[:: max(1, g.numel() // nsample)]
+        assert got.shape == ref.shape, n
+        rnorm, rmax = float(fx[f"{tag}|{n}|norm"]), float(fx[f"{tag}|{n}|max"])
+        # the sample carries numel/stride of the tensor's energy: scale the floor accordingly
+        frac = (ref.numel() / g.numel()) ** 0.5
+        den = max(float(ref.norm()), norm_floor * top * frac)
+        e_l2 = float((got - ref).norm()) / (den + 1e-30)
+        e_max = float((got - ref).abs().max()) / (max(rmax, norm_floor * top / g.numel() ** 0.5) + 1e-30)
+        e_norm = abs(float(g.double().norm()) - rnorm) / (max(rnorm, norm_floor * top) + 1e-30)
+        rows.append((max(e_l2, e_norm), e_l2, e_norm, e_max, rnorm, n))
+        if e_l2 > rel_l2 or e_norm > rel_l2 or e_max > rel_max:
+            bad.append(rows[-1])
+    rows.sort(reverse=True)
+    return rows, bad
+
+
+def report(rows, k=12):
+    return "\n".join(f"{n:72s} relL2 {a:.2e} norm {b:.2e} max {c:.2e} |g| {r:.2e}" for _, a, b, c, r, n in rows[:k])

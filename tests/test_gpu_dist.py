@@ -72,3 +72,65 @@ def test_rccl_gradient_exchange_world2():
         assert p.exitcode == 0
     for rank, ok, ncoll, synced in res:
         assert ok and synced and 1 <= ncoll <= 8
+
+
+def _worker_world1(port, q):
+    """ONE rank over backend nccl: RCCL initialises, and with `force` every collective of the step (parameter broadcast,
+    MIN-reduced guard flag, MAX-reduced gradient mask, the flat gradient buckets) is issued to it and completes on the
+    MI355X — the data path of tests on a box with a single device."""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from coponerf_amd import CoPoNeRF, dist as cd, synthetic as syn
+    from coponerf_amd.train_step import TrainStep
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev).train()
+    before = model.query_encode_latent.weight.detach().clone()
+    nb = cd.broadcast_parameters(model, force=True)
+    same_after_bcast = bool(torch.equal(before, model.query_encode_latent.weight.detach()))
+    assert cd.broadcast_parameters(model) == 0 and cd.average_gradients(list(model.parameters())) == 0   # unforced: early-outs
+    mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (o.to(dev) if torch.is_tensor(o) else o)
+    inp = mv(syn.make_inputs(1, 256, 256, 128, seed=61))
+    # the exchange on one rank is the identity, bit for bit
+    out = model(inp, val=False)
+    (out["rgb"] - inp["query"]["rgb"]).abs().mean().backward()
+    params = [p for p in model.parameters()]
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    finite, norm = cd.guard_and_clip(params, 0.0, force=True)
+    ncoll = cd.average_gradients(params, bucket_bytes=16 << 20, force=True)
+    ident = all((g is None and p.grad is None) or torch.equal(p.grad, g) for p, g in zip(params, local))
+    model.zero_grad(set_to_none=True)
+    # ... and the whole TrainStep with the forced exchange
+    step = TrainStep(model, force_collectives=True)
+    r1 = step(inp, inp["query"]["rgb"])
+    r2 = step(inp, inp["query"]["rgb"])
+    torch.cuda.synchronize()
+    q.put(dict(nb=nb, same_after_bcast=same_after_bcast, finite=finite, ncoll=ncoll, ident=ident,
+               stepped=(r1["stepped"], r2["stepped"]), collectives=r1["collectives"], nbytes=r1["allreduce_bytes"],
+               losses=(float(r1["loss"]), float(r2["loss"])),
+               moved=not torch.equal(before, model.query_encode_latent.weight.detach())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_forced_exchange_runs_on_device():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_world1, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    print("world-1 RCCL exchange:", res)
+    assert res["nb"] >= 1 and res["same_after_bcast"] and res["finite"] and res["ident"]
+    assert res["ncoll"] >= 5                             # ~143 MB of gradients in 16 MB buckets
+    assert all(res["stepped"]) and res["collectives"] >= 2 and res["nbytes"] > 100e6 and res["moved"]
+    assert all(l == l and l < 10 for l in res["losses"])

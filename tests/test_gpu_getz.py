@@ -96,9 +96,23 @@ def test_get_z_and_render_end_to_end(dev):
     assert perr <= POSE_TOL
     with torch.no_grad():
         out = model(inp, z=z, rel_pose=rel_pose, val=True, flow=flows)
-        out2 = model(inp, val=True) if False else None
     assert out["rgb"].shape == (1, 1, 64, 3) and torch.isfinite(out["rgb"]).all()
     assert out["pixel_val"].shape == (2, 64, 64, 2)
+    # ... and the render of THESE latents (what the model itself produces: |z| up to ~10 on the coarse levels, not the
+    # N(0,1) synthetic maps of the other parity cases) and THIS estimated pose against the oracle on the same tensors
+    from oracle import render_ref as orc
+    from coponerf_amd.CoPoNeRF import RENDER_PARAM_PREFIXES
+    cpu = torch.device("cpu")
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items() if k.split(".")[0] in RENDER_PARAM_PREFIXES}
+    with torch.no_grad():
+        ref = orc.forward(to_device(inp, cpu), [t.cpu() for t in z], rel_pose.cpu(), to_device(flows, cpu), True, w, npoints=64)
+    print("model-produced latents: |z|max per level", [float(t.abs().max()) for t in z],
+          "rgb max-abs HIP vs oracle", float((out["rgb"].cpu() - ref["rgb"]).abs().max()),
+          "at_wt", float((out["at_wt"].cpu() - ref["at_wt"]).abs().max()))
+    assert torch.equal(out["pixel_val"], ref["pixel_val"]), "pixel_val not bit-identical on the estimated pose"
+    assert (out["rgb"].cpu() - ref["rgb"]).abs().max() <= 1e-3
+    assert (out["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+    assert (out["depth_ray"].cpu() - ref["depth_ray"]).abs().max() <= 2e-2
 
 
 def test_attention_kernels_against_oracle(dev):

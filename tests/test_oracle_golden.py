@@ -31,9 +31,10 @@ def test_forward_matches_reference(name, weights):
 
     assert out["pixel_val"].shape == g["pixel_val"].shape
     assert (out["pixel_val"] - g["pixel_val"]).abs().max() <= 2e-6
-    # bilinear tap indices of every level: identical but for coordinates within rounding of a texel edge
+    # bilinear tap indices of every level: identical to upstream's on every sample of every case (the float coordinates
+    # differ by <= 1 ulp on ~2 % of the elements - upstream's einsum/bmm association - never across a texel edge here)
     for a, b in zip(tap_indices(out["pixel_val"], cfg["H"]), tap_indices(g["pixel_val"], cfg["H"])):
-        assert (a != b).float().mean() <= 1e-4
+        assert int((a != b).sum()) == 0
     assert (out["rgb"] - g["rgb"]).abs().max() <= 2e-5
     assert (out["at_wt"] - g["at_wt"]).abs().max() <= 1e-6
     assert torch.equal(out["valid_mask"], g["valid_mask"])
