@@ -126,7 +126,16 @@ def test_rccl_world1_forced_exchange_runs_on_device():
     q = ctx.Queue()
     p = ctx.Process(target=_worker_world1, args=(_free_port(), q))
     p.start()
-    res = q.get(timeout=900)
+    import queue
+    res = None
+    for _ in range(900):
+        try:
+            res = q.get(timeout=1)
+            break
+        except queue.Empty:
+            if not p.is_alive():
+                break
+    assert res is not None, f"worker exited with code {p.exitcode} without a result"
     p.join(timeout=120)
     assert p.exitcode == 0
     print("world-1 RCCL exchange:", res)

@@ -12,8 +12,11 @@ pytestmark = pytest.mark.gpu
 
 Z_SCALES = (1.0, 4.0, 16.0, 64.0)
 W_SCALES = (1.0, 4.0)
-# (z scale, W1 scale) points at which rgb must agree with the oracle to 1e-3 of max(1, |rgb|max)
-ENVELOPE = {(1.0, 1.0), (4.0, 1.0), (1.0, 4.0)}
+# Measured on MI355X (round 4): the error is RELATIVE - 3.2e-4 ... 4.8e-4 of max(1, |rgb|max) at every point of the sweep,
+# z_local to 2.8e-4 ... 3.4e-4 of its scale, at_wt <= 1.6e-4, nothing saturates up to z x 64 and W1 x 4 (|z_local| = 262).
+# `north_star`'s absolute 1e-3 therefore holds while |rgb| <= ~2.5, i.e. at the three points of ABS_ENVELOPE (|rgb|max
+# 1.0 / 1.15 / 1.14; at z x 16 the output itself is 4x larger and the absolute error 1.3e-3); the relative bar everywhere.
+ABS_ENVELOPE = {(1.0, 1.0), (4.0, 1.0), (1.0, 4.0)}
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +53,7 @@ def test_rgb_error_over_latent_and_weight_scale(dev):
             e_zl = float((out["_core"]["z_local"].cpu() - ref["z_local"].reshape(-1, 416)).abs().max())
             zl_scale = float(ref["z_local"].abs().max())
             rows.append((zs, ws, err, err / scale, scale, e_wt, e_zl / max(zl_scale, 1e-30), zl_scale, finite))
-            if (zs, ws) in ENVELOPE and not (finite and err <= 1e-3 * scale):
+            if not (finite and err <= 1e-3 * scale) or ((zs, ws) in ABS_ENVELOPE and err > 1e-3) or e_wt > 2e-3:
                 bad.append(rows[-1])
     print("z scale  W1 scale  rgb max-abs   / max(1,|rgb|)  |rgb|max    at_wt err   z_local rel   |z_local|max  finite")
     for r in rows:
