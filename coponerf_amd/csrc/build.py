@@ -41,7 +41,7 @@ def _newer(src, dst):
 
 def build(force=False, verbose=True):
     objs = []
-    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "taps.h"), os.path.join(HERE, "..", "..", "include", "coponerf_hip.h")]
+    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "taps.h"), os.path.join(HERE, "encode_common.h"), os.path.join(HERE, "..", "..", "include", "coponerf_hip.h")]
     for name, extra in UNITS:
         src = os.path.join(HERE, name)
         obj = os.path.join(HERE, os.path.splitext(name)[0] + ".o")

@@ -242,6 +242,30 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
         };
         __half* const hrowA = out_row(lidA);
         __half* const hrowB = out_row(lidB);
+#if CPN_ENCODE_STORE == 7
+        // The same whole-line nt stores as BUFFER stores through a per-tile descriptor, issued unconditionally: a dead row's
+        // offset lies past the descriptor's range and the hardware drops the write.  Two things follow.  (1) No branch
+        // around the store, so (2) the compiler, which does not see a store inside an `asm` (and must assume the fewest
+        // outstanding operations at the join behind a conditional one), now COUNTS the two stores of a slice in its
+        // s_waitcnt vmcnt bookkeeping: the last tap of slice n is waited for with vmcnt(2), not vmcnt(0), i.e. the stores
+        // of slice n-1 stay in flight under the blend of slice n and are only retired by the (in-order) wait for the
+        // taps of slice n+1, a whole slice later.  With the asm stores every wave drained its own 2 KB of stores once
+        // per slice: 16 waves x 2 KB in flight per CU, 8 MB on the chip = 2.5 us of store latency at the 3.3 TB/s the
+        // kernel reached - it was bound by store LATENCY, not by the write bandwidth (6.2 TB/s for this pattern).
+        const long long tile_row0 = ((((long long)b * R + (long long)rgroup * TG - ray0) * V + v) * S + (long long)sblk * TSW) * 2;
+        constexpr int kOOB = 0x7ffffff0;
+        // (the tile's base is wave-uniform; the 64-bit index arithmetic above runs on the vector unit, so say so)
+        const unsigned long long hb = (unsigned long long)(hid + tile_row0 * 832);
+        const unsigned long long hbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hb >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)hb);
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)hbu, 0, (int)(((TG - 1) * V * S + TSW) * 2 * 1664), 0x00020000);
+        auto out_off = [&](const RowId& id) {
+            const int rel = (((id.r - rgroup * TG) * V * S + (id.s - sblk * TSW)) * 2) * 1664 + (pl + 4 * qodd) * 16;
+            return id.live ? rel : kOOB;
+        };
+        const int hoffA = out_off(lidA), hoffB = out_off(lidB);
+#endif
 
         // Slice loop, software-pipelined by one slice on the store side:
         //     issue the 16 tap loads of slice n  ->  issue the stores of slice n-1  ->  compute slice n.
@@ -264,8 +288,13 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
                         sa[i] = (unsigned)__builtin_amdgcn_update_dpp((int)a0, (int)a1, 0x114, 0xF, 0xA, false);
                     }
                     const int co = (j0 + mt) * 832 + n * SLICE_CH;
+#if CPN_ENCODE_STORE == 7
+                    __builtin_amdgcn_raw_buffer_store_b128(sa, hrs, hoffA, co * 2, 2);          // aux 2 = nt
+                    __builtin_amdgcn_raw_buffer_store_b128(sb, hrs, hoffB, co * 2, 2);
+#else
                     if (lidA.live) store16(hrowA + co, __builtin_bit_cast(half8, sa));
                     if (lidB.live) store16(hrowB + co, __builtin_bit_cast(half8, sb));
+#endif
                 }
             }
         };

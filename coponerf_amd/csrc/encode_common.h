@@ -35,9 +35,11 @@ __device__ __forceinline__ float fma_mix_hi(float acc, unsigned packed, float w)
     return acc;
 }
 
-// 16-byte hid store; CPN_ENCODE_STORE selects the cache policy bits (experiment; 0 = default write-back)
+// 16-byte hid store; CPN_ENCODE_STORE selects the form: 0 = write-back, 1 = nt store inside an asm (rounds 2-3), 2..5 other
+// cache policy bits (experiments), 6 = compiler-emitted nt store behind a branch, 7 = unconditional nt BUFFER store that the
+// compiler counts in its vmcnt bookkeeping (encode.hip; the product)
 #ifndef CPN_ENCODE_STORE
-#define CPN_ENCODE_STORE 1
+#define CPN_ENCODE_STORE 7
 #endif
 __device__ __forceinline__ void store16(__half* p, half8 v) {
 #if CPN_ENCODE_STORE == 0
@@ -52,6 +54,11 @@ __device__ __forceinline__ void store16(__half* p, half8 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
 #elif CPN_ENCODE_STORE == 5
     asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+#elif CPN_ENCODE_STORE == 6
+    // the same nt store, but emitted by the compiler: it then COUNTS the store in its s_waitcnt vmcnt bookkeeping (an
+    // asm store is invisible to it, so every "vmcnt(0)" it places for the youngest tap load also waits for the stores
+    // issued behind that load)
+    __builtin_nontemporal_store(v, reinterpret_cast<half8*>(p));
 #endif
 }
 

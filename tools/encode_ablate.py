@@ -13,7 +13,9 @@ sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tools", "_build")
 # kernel configurations (CPN_ENCODE_MT images per wave tile, CPN_ENCODE_WAVES per workgroup)
 CONFIGS = ((1, 16), (2, 8))
-STORES = (0, 1)             # CPN_ENCODE_STORE cache policy: 0 = write-back, 1 = non-temporal (the product)
+# CPN_ENCODE_STORE: 0 = write-back, 1 = non-temporal inside an asm (rounds 2-3), 7 = unconditional nt buffer store the
+# compiler counts in vmcnt (round 4, the product)
+STORES = (0, 1, 7)
 FULL_ABLATION = ((1, 16),)          # the other configurations are only timed in full
 VARIANTS = {0: "full", 1: "no table taps", 2: "no hid stores", 3: "no taps, no stores (MFMA + setup)", 4: "no MFMA",
             16: "all taps -> node 0 (L1-hot)", 18: "node-0 taps, no stores",
@@ -27,6 +29,9 @@ def build():
     err_o = os.path.join(BUILD, "error.o")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
                            os.path.join(src, "error.cpp"), "-o", err_o])
+    # cpn_stream_cus() (persistent grids ask how many CUs their stream may use) lives in streams.cpp
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
+                           os.path.join(src, "streams.cpp"), "-o", os.path.join(BUILD, "streams.o")])
     for cfg in CONFIGS:
         mt, waves = cfg
         for k in VARIANTS:
@@ -39,10 +44,10 @@ def build():
                    os.path.join(src, "encode.hip"), "-o", obj]
             print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, err_o, "-o", out])
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, err_o, os.path.join(BUILD, "streams.o"), "-o", out])
 
 
-PREFETCH = ((1, 16), (1, 12), (1, 8))          # (CPN_ENCODE_PREFETCH, waves per workgroup)
+PREFETCH = ((1, 12), (1, 8))          # (CPN_ENCODE_PREFETCH, waves per workgroup)
 
 
 def build_prefetch_variants():
@@ -54,7 +59,7 @@ def build_prefetch_variants():
                                f"-DCPN_ENCODE_WAVES={waves}", "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c",
                                os.path.join(src, "encode.hip"), "-o", obj])
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, os.path.join(BUILD, "error.o"),
-                               "-o", out])
+                               os.path.join(BUILD, "streams.o"), "-o", out])
 
 
 def build_store_variants():
@@ -65,7 +70,7 @@ def build_store_variants():
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_ENCODE_STORE={st}",
                                "-x", "hip", "-c", os.path.join(src, "encode.hip"), "-o", obj])
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, os.path.join(BUILD, "error.o"),
-                               "-o", out])
+                               os.path.join(BUILD, "streams.o"), "-o", out])
 
 
 def main():
@@ -74,6 +79,7 @@ def main():
     ap.add_argument("--build-only", default="")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--ray0", type=int, default=16384, help="first ray of the timed chunk")
+    ap.add_argument("--rays", type=int, default=16384, help="rays of the timed chunk (65536 with --ray0 0 = the one-chunk launch)")
     ap.add_argument("--flush", action="store_true", help="stream 8 GB through the caches between launches (as the "
                     "key / attend kernels of the chunk loop do) and time each launch on its own")
     ap.add_argument("--flush-kind", default="rw", choices=("rw", "read", "write"), help="foreign traffic of the flush: "
@@ -93,7 +99,7 @@ def main():
     import torch
     from coponerf_amd import CoPoNeRF, synthetic as syn
     dev = torch.device("cuda:0")
-    H, S, B, V, n = 256, 64, 1, 2, 16384
+    H, S, B, V, n = 256, 64, 1, 2, a.rays
     model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
     model.load_state_dict(syn.make_render_weights(), strict=False)
     model = model.to(dev).eval()
