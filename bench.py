@@ -451,7 +451,8 @@ def roofline_block(prof, args, tables):
         tot = sum(a.elapsed_time(b) for a, b, _ in v)
         kern[k] = {"ms_per_step": tot / args.steps, "tflops": sum(f for _, _, f in v) / (tot * 1e-3) / 1e12}
     out["kernel_breakdown"] = kern
-    name = "encode_hidden" if tables else "gemm_f16:query_encode_latent"
+    fused = "encode_key" in prof                     # first layer + folded key layer in one kernel (csrc/encode_key.hip)
+    name = ("encode_key" if fused else "encode_hidden") if tables else "gemm_f16:query_encode_latent"
     evs = prof.get(name, [])
     if not evs:
         return out
@@ -460,7 +461,7 @@ def roofline_block(prof, args, tables):
     avg_ms = sum(ms) / len(ms)
     achieved = flops / (avg_ms * 1e-3) / 1e12
     rows = int(round(flops / (2.0 * 832 * 835)))
-    src = os.path.join(ROOT, "coponerf_amd", "csrc", "encode.hip" if tables else "gemm_f16.hip")
+    src = os.path.join(ROOT, "coponerf_amd", "csrc", ("encode_key.hip" if fused else "encode.hip") if tables else "gemm_f16.hip")
     with open(src, "rb") as f:
         sha = hashlib.sha256(f.read()).hexdigest()[:16]
     # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (they cannot be read
@@ -486,19 +487,26 @@ def roofline_block(prof, args, tables):
         hh = args.height                                                                  # tables + level-3 map of a pair
         nimg_bytes = 2 * ((hh // 2 + 1) ** 2 + (hh // 2 + 9) ** 2) * 1664.0 + 2 * hh * hh * 128.0
         alg_bytes = rows * 832 * 2.0 + nimg_bytes
+        key_flops = 0.0
+        if fused:                                   # + kh written (256 B per sample = per 2 rows), the folded key matrix read once
+            alg_bytes += rows / 2 * 256.0 + 128 * 1664 * 2.0
+            key_flops = 2.0 * (rows / 2) * 128 * 1664
         gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
+        achieved = (flops + key_flops) / (avg_ms * 1e-3) / 1e12
         out["roofline"] = {
-            "bound": "hbm", "kernel": "encode_hidden_kernel (query_encode_latent 835->832 + ReLU with the gathers fused)",
+            "bound": "hbm", "kernel": ("encode_key_kernel (query_encode_latent 835->832 + ReLU with the gathers fused + the folded "
+                                       "key_map 1664->128 layer on the slices of hid in registers)") if fused else
+                      "encode_hidden_kernel (query_encode_latent 835->832 + ReLU with the gathers fused)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": avg_ms, "launches": len(ms),
             "timing_source": "HIP events on the launch stream inside the timed region of THIS (unprofiled) run; the same "
                              "launches under rocprofv3 --kernel-trace run ~10 % slower (profiles/README.md)",
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_source_sha16": sha,
             "canonical_mfma_view": {"bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": achieved / F16_MFMA_PEAK_TFLOPS, "flops_per_launch": flops,
+                                    "frac": achieved / F16_MFMA_PEAK_TFLOPS, "flops_per_launch": flops + key_flops,
                                     "note": "FLOPs of the layer as the reference formulates it / launch time; the kernel "
                                             "executes 4 table taps + a K=80 MFMA product per row (DESIGN.md §4.1)"},
-            "executed_tflops": (2.0 * rows * 832 * (80 + 4)) / (avg_ms * 1e-3) / 1e12}
+            "executed_tflops": (2.0 * rows * 832 * (80 + 4) + key_flops) / (avg_ms * 1e-3) / 1e12}
     else:
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel<13> (query_encode_latent 835->832)",
                            "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

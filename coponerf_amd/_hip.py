@@ -29,6 +29,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_pack_encode_weights": [_P, _I, _P, _P, _P],
     "cpn_node_features": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cpn_encode_hidden": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
@@ -87,7 +88,7 @@ XIN_K, XIN_STRIDE = 864, 896
 TAB_LD = 832
 RAYC_STRIDE = 64
 LIGHTFIELD_PACK_FLOATS = 128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def declared_symbols() -> List[str]:

@@ -291,6 +291,9 @@ __global__ __launch_bounds__(64 * ENC_WAVES, 1) void encode_hidden_kernel(
 #if CPN_ENCODE_STORE == 7
                     __builtin_amdgcn_raw_buffer_store_b128(sa, hrs, hoffA, co * 2, 2);          // aux 2 = nt
                     __builtin_amdgcn_raw_buffer_store_b128(sb, hrs, hoffB, co * 2, 2);
+                    // two wait states before anything may write the stores' data registers: the compiler does not insert
+                    // them behind a 16-byte buffer store with an SGPR offset, and gfx950 needs them (encode_key.hip)
+                    asm volatile("s_nop 1" ::: "memory");
 #else
                     if (lidA.live) store16(hrowA + co, __builtin_bit_cast(half8, sa));
                     if (lidB.live) store16(hrowB + co, __builtin_bit_cast(half8, sb));

@@ -1,0 +1,402 @@
+// K2+K3a+K3c — the first encoder layer on the node tables (encode.hip) WITH the folded key_map contraction behind it:
+//     hid[row]  = ReLU(query_encode_latent([gather ‖ tanh(pt/5)]))                       (written once, for the two hidden sums)
+//     kh[sample] = ReLU( (Wk_a W2 | Wk_b W2) . [hid_own ; hid_other] + c' )                (128 wide, fp16)
+// i.e. /root/reference models/CoPoNeRF.py:312, 370, 384-397 and :404-407 (key_map after query_encode_latent_2, folded as
+// DESIGN.md §4.3 describes).  Round 3 ran the second line as its own kernel (cpn_gemm_f16_chain_rowdot) that read the
+// 27.9 GB of hid back from HBM: one of the four passes over hid.  Here the 64-channel slice of hid a wave has just
+// produced — still in registers — becomes the K-panel of the 1664 -> 128 MFMA contraction; `kh` (256 B per sample
+// instead of 3 328) goes to cpn_gemm_f16_rowdot for key_map_2 and the logit.
+//
+// What the fusion has to solve is the WEIGHT traffic: the folded key matrix is 128 x 1664 fp16 = 416 KiB, every 16-row
+// wave tile needs the 16 KiB that belong to its (image, slice) and LDS is full (the K = 80 fragments of the first layer
+// take 123.5 KiB).  So, unlike encode.hip, the waves of a workgroup run the slice loop IN LOCK STEP: a two-slot ring of
+// 16 KiB in LDS holds the key weights of the slice in flight; one s_barrier per slice says "everybody has finished with
+// slot (q-1) & 1 and everybody's share of slot q & 1 has landed", after which each wave DMAs its 1 KiB pieces of slice
+// q + 1 (buffer_load ... lds straight from the row-major weight matrix: an MFMA A fragment is 16 contiguous bytes per
+// lane) and runs the 16 key MFMAs of slice q against its own 16 x 64 piece of hid.  L2 -> LDS traffic: 16 KiB per
+// workgroup and slice against 96-128 KiB of table taps.  A wave owns BOTH images of its 4 rays x 4 samples (own image
+// first, then the other): the key accumulators (8 tiles x 4 = 32 VGPRs) run over K = 2 x 832.
+//   * 12 waves (3 per SIMD, <= 168 VGPRs): the accumulators do not fit the 128 of encode.hip's 16 waves.
+//   * hid is moved from the load layout to the MFMA B-operand layout with 8 ds_bpermute per slice (fp16 pairs).
+//   * every wave of a workgroup executes the same number of slice steps (dead units at the end of a range do dummy
+//     work): the barrier count must match.
+// Everything else (tap records, level-3 gather, K = 80 MFMA, 4-tap blend, whole-line nt stores) is encode.hip's.
+#include <algorithm>
+
+// timing-only ablations (results are wrong when non-zero): 1 = no table taps, 2 = no hid stores, 4 = no K = 80 MFMA,
+// 8 = no key MFMA (no LDS reads of the ring either), 64 = no ring traffic (no DMA, no barrier: weights are garbage)
+#ifndef CPN_EK_ABLATE
+#define CPN_EK_ABLATE 0
+#endif
+#ifndef CPN_EK_WAVES
+#define CPN_EK_WAVES 12
+#endif
+
+#include "encode_common.h"
+
+namespace {
+
+constexpr int WMAIN_HALF8 = NSLICE * 2 * NT * 64;              // [slice][k < 2][tile][lane] half8: 104 KiB
+constexpr int WTAIL_HALF4 = NSLICE * NT * 48;                  // [slice][tile][K group < 3][A-operand row] half4: 19.5 KiB
+constexpr int EK_WAVES = CPN_EK_WAVES;
+constexpr int KT = 8;                                          // 16-wide output tiles of the key layer (128)
+constexpr int KPIECES = KT * 2;                                // 1 KiB fragments (tile, k step) per slice
+constexpr int KSLOT_HALF8 = KPIECES * 64;                      // one ring slot: 16 KiB
+constexpr int KSTEPS = 2 * NSLICE;                             // slice steps per unit: both images
+constexpr int KLD = 2 * CPN_TAB_LD;                            // row length of the folded key matrix (1664)
+
+__global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
+    const __half* __restrict__ tab, const __half* __restrict__ map3, int H, int W,
+    const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, const float* __restrict__ pe6,
+    const half8* __restrict__ wfrag, const float* __restrict__ bias, const __half* __restrict__ kw,
+    const float* __restrict__ kbias, int V, int R, int S, int ray0, int nrays, int nsblk, int groups_per_b,
+    long long group0, long long nunits, __half* __restrict__ hid, __half* __restrict__ kh) {
+    __shared__ __attribute__((aligned(16))) half8 wmain[WMAIN_HALF8];
+    __shared__ __attribute__((aligned(16))) half4 wtail_s[WTAIL_HALF4];
+    __shared__ __attribute__((aligned(16))) half8 kring[2 * KSLOT_HALF8];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < WMAIN_HALF8; i += 64 * EK_WAVES) wmain[i] = wfrag[i];
+    {
+        const half4* tsrc = reinterpret_cast<const half4*>(wfrag + WMAIN_HALF8);          // K tail + bias: see encode.hip
+        for (int i = tid; i < WTAIL_HALF4; i += 64 * EK_WAVES) {
+            const int f = i / 48, l = i - f * 48;
+            half4 t = tsrc[f * 64 + l];
+            if (l < 32) {
+                const float bv = bias[(f / NT) * SLICE_CH + slice_channel(f % NT, l & 15)];
+                const _Float16 hi = (_Float16)bv;
+                if (l < 16) t[3] = hi;
+                else t[0] = (_Float16)(bv - (float)hi);
+            }
+            wtail_s[i] = t;
+        }
+    }
+
+    const int r = lane & 15, g = lane >> 4;                   // MFMA layout: column (row of the tile) r, K / channel group g
+    const int rl = lane >> 2, pl = lane & 3;                  // load layout: row rl, 16-byte piece pl
+    const int tail_lane = min(g, 2) * 16 + r;
+    const int to_ll = (rl + 16 * pl) * 4;                     // ds_bpermute address: this lane takes MFMA lane (r = rl, g = pl)
+    const int to_mfma = (4 * r + g) * 4;                      //                      this lane takes load-layout lane (rl = r, pl = g)
+    const NodeGrid ng{W >> 1, H >> 1};
+    const size_t img_bytes = (size_t)ng.nodes_per_image() * TAB_ROW_BYTES;
+    const char* const tbase = reinterpret_cast<const char*>(tab);
+    const char* const m3base = reinterpret_cast<const char*>(map3);
+
+    // ---- the key-weight ring.  Fragment (t, k) of slice step q = (image j, slice n): lane (a = lane & 15, g) holds
+    //      Wk[t*16 + a][j*832 + n*64 + k*32 + g*8 .. +8] = 16 contiguous bytes of the row-major matrix.
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kw, 0, 128 * KLD * 2, 0x00020000);
+    const int kvoff = (r * KLD + g * 8) * 2;
+    auto ring_fill = [&](int step_in_unit, int slot) {
+        if (CPN_EK_ABLATE & 64) return;
+        const int j = step_in_unit >= NSLICE ? 1 : 0, n = step_in_unit - j * NSLICE;
+        for (int p = wave; p < KPIECES; p += EK_WAVES) {                       // wave-uniform trip count
+            const int t = p >> 1, k = p & 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                krs, (lds_void*)(reinterpret_cast<char*>(kring) + slot * (KSLOT_HALF8 * 16) + p * 1024), 16, kvoff,
+                ((t * 16) * KLD + j * CPN_TAB_LD + n * SLICE_CH + k * 32) * 2, 0, 0);
+        }
+    };
+    ring_fill(0, 0);
+    __syncthreads();          // K = 80 fragments in place (the ring's first slot is ordered by the first slice barrier)
+
+    // XCD-aware order as in encode.hip, in UNITS = (4 rays, view, 4 samples) x both images; the waves of a workgroup take
+    // consecutive units and every wave runs the same number of iterations
+    const unsigned nbk = gridDim.x, nx = nbk < 8 ? nbk : 8;
+    const unsigned xcd = blockIdx.x % nx, wgx = blockIdx.x / nx;
+    const unsigned wg_on_xcd = nbk / nx + (xcd < nbk % nx ? 1 : 0);
+    const long long q = nunits / nx, rem = nunits % nx;
+    const long long x_begin = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    const long long x_end = x_begin + q + (xcd < rem ? 1 : 0);
+    const long long per_iter = (long long)wg_on_xcd * EK_WAVES;
+    const int iters = (int)((x_end - x_begin + per_iter - 1) / per_iter);
+    int gstep = 0;                                            // slice steps this workgroup has started (ring slot = parity)
+
+    for (int it = 0; it < iters; ++it) {
+        const long long uu_raw = x_begin + (long long)it * per_iter + (long long)wgx * EK_WAVES + wave;
+        const bool unit_live = uu_raw < x_end;
+        const long long uu = unit_live ? uu_raw : x_begin;    // a dead unit walks a live unit's addresses with every row masked
+        const int sblk = (int)(uu % nsblk);
+        const int v = (int)((uu / nsblk) % V);
+        const long long gq = group0 + uu / ((long long)nsblk * V);
+        const int b = (int)(gq / groups_per_b), rgroup = (int)(gq % groups_per_b);
+        const int img_own = b * V + v, img_oth = b * V + (V - 1 - v);
+
+        RowId lid = tile_row(rl, rgroup, sblk, S, R, b, ray0, nrays);
+        RowId mid = tile_row(r, rgroup, sblk, S, R, b, ray0, nrays);
+        lid.live = lid.live && unit_live;
+        mid.live = mid.live && unit_live;
+        const size_t sidx_l = (((size_t)(b * V + v)) * R + min(lid.r, R - 1)) * S + min(lid.s, S - 1);
+        const int qodd = (lane >> 2) & 1;
+        RowId lidA = tile_row(rl & ~1, rgroup, sblk, S, R, b, ray0, nrays);
+        RowId lidB = tile_row(rl | 1, rgroup, sblk, S, R, b, ray0, nrays);
+        lidA.live = lidA.live && unit_live;
+        lidB.live = lidB.live && unit_live;
+        // hid stores: unconditional nt buffer stores through a per-tile descriptor (encode.hip, CPN_ENCODE_STORE 7)
+        const long long tile_row0 = ((((long long)b * R + (long long)rgroup * TG - ray0) * V + v) * S + (long long)sblk * TSW) * 2;
+        constexpr int kOOB = 0x7ffffff0;
+        const unsigned long long hb = (unsigned long long)(hid + tile_row0 * 832);
+        const unsigned long long hbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hb >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)hb);
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)hbu, 0, (int)(((TG - 1) * V * S + TSW) * 2 * 1664), 0x00020000);
+        auto out_off = [&](const RowId& id) {
+            const int rel = (((id.r - rgroup * TG) * V * S + (id.s - sblk * TSW)) * 2) * 1664 + (pl + 4 * qodd) * 16;
+            return id.live ? rel : kOOB;
+        };
+        const int hoffA = out_off(lidA), hoffB = out_off(lidB);
+
+        f32x4 kacc[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) kacc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+#pragma unroll 1
+        for (int j0 = 0; j0 < 2; ++j0) {
+            // ---- per-row records of image j0 in the LOAD layout (j0 = 0: own image, border table, pixel_val;
+            //      j0 = 1: other image, zeros table, sec_grid)
+            const bool own = j0 == 0;
+            TapRec rec;
+            half8 xl[2];
+            {
+                const float2 gc = *reinterpret_cast<const float2*>((own ? pixel_val : sec_grid) + sidx_l * 2);
+                rec = node_taps(gc.x, gc.y, ng, own);
+                const Taps t3 = make_taps(gc.x, gc.y, W, H, own);
+                const char* m3 = m3base + (size_t)(own ? img_own : img_oth) * H * W * 128 + pl * 16;
+                u32x4 tv[2][4];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        tv[k][t] = *reinterpret_cast<const u32x4*>(m3 + (size_t)(unsigned)t3.off[t] * 128 + k * 64);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a8[2 * i] = fma_mix_lo(a8[2 * i], tv[k][t][i], t3.w[t]);
+                            a8[2 * i + 1] = fma_mix_hi(a8[2 * i + 1], tv[k][t][i], t3.w[t]);
+                        }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xl[k][e] = lid.live ? (_Float16)a8[e] : (_Float16)0.0f;
+                }
+                if (!lid.live) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { rec.off[t] = 0; rec.w[t] = 0.0f; }
+                }
+            }
+            half8 xa[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const u32x4 src = __builtin_bit_cast(u32x4, xl[k]);
+                u32x4 dst;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned sv = src[i];
+                    dst[i] = (unsigned)__builtin_amdgcn_ds_bpermute(to_mfma, (int)sv);
+                }
+                xa[k] = __builtin_bit_cast(half8, dst);
+            }
+            half4 xt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[e] = (_Float16)0.0f;
+            if (g == 0 && mid.live) {
+                const float* pe = pe6 + ((((size_t)(b * V + v)) * R + mid.r) * S + mid.s) * 6 + j0 * 3;
+                xt[0] = (_Float16)pe[0]; xt[1] = (_Float16)pe[1]; xt[2] = (_Float16)pe[2];
+                xt[3] = (_Float16)1.0f;                       // x bias (hi)
+            }
+            if (g == 1 && mid.live) xt[0] = (_Float16)1.0f;   // x bias (lo)
+
+            int vo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vo[k] = rec.off[k] + pl * 16;
+            const char* tb = own ? tbase + img_bytes * img_own
+                                 : tbase + img_bytes * img_oth + (size_t)ng.border_nodes() * TAB_ROW_BYTES;
+            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)tb, 0, (int)((own ? ng.border_nodes() : ng.zeros_nodes()) * TAB_ROW_BYTES), 0x00020000);
+
+            half8 res[2];                                     // fp16 results of the previous slice, waiting to be stored
+            // `drop`: the call before the first slice stores nothing (offsets out of range) — but it IS two store
+            // instructions, so every trip of the slice loop issues the same operations and the compiler's vmcnt counts stay exact
+            auto store_slice = [&](int n, bool drop) {
+                if (CPN_EK_ABLATE & 2) return;
+                const u32x4 h0 = __builtin_bit_cast(u32x4, res[0]), h1 = __builtin_bit_cast(u32x4, res[1]);
+                u32x4 sa, sb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned a0 = h0[i], a1 = h1[i];
+                    sb[i] = (unsigned)__builtin_amdgcn_update_dpp((int)a1, (int)a0, 0x104, 0xF, 0x5, false);
+                    sa[i] = (unsigned)__builtin_amdgcn_update_dpp((int)a0, (int)a1, 0x114, 0xF, 0xA, false);
+                }
+                const int co = __builtin_amdgcn_readfirstlane((j0 * 832 + n * SLICE_CH) * 2);       // scalar offset operand
+                // gfx950 hazard the compiler does not cover: a VALU write to a data VGPR of a 16-byte buffer store in the
+                // one or two issue slots behind it reaches memory in some lanes (LLVM assumes the "store > 8 bytes, then VALU
+                // write of the data" hazard away when the store has an SGPR offset; with the select of the second store's
+                // offset scheduled between the two stores, dword 0 of lanes 12-15 of every row of 16 held that offset).
+                // So: both offsets exist before the first store, and two wait states follow the second one.
+                int oa = drop ? kOOB : hoffA, ob = drop ? kOOB : hoffB;
+                asm volatile("" : "+v"(oa), "+v"(ob));
+                __builtin_amdgcn_raw_buffer_store_b128(sa, hrs, oa, co, 2);          // aux 2 = nt
+                __builtin_amdgcn_raw_buffer_store_b128(sb, hrs, ob, co, 2);
+                asm volatile("s_nop 1" ::: "memory");
+            };
+            res[0] = res[1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+
+#pragma unroll 1
+            for (int n = 0; n < NSLICE; ++n) {
+                u32x4 td[4][2];
+                if (!(CPN_EK_ABLATE & 1)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        td[k][0] = __builtin_amdgcn_raw_buffer_load_b128(trs, vo[k], n * TAB_SLICE_BYTES, 0);
+                        td[k][1] = __builtin_amdgcn_raw_buffer_load_b128(trs, vo[k] + 64, n * TAB_SLICE_BYTES, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                store_slice(n > 0 ? n - 1 : 0, n == 0);
+                __builtin_amdgcn_sched_barrier(0);
+
+                // ---- K = 80 contraction of the full-resolution level + point encoding + bias; weights from LDS
+                f32x4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (!(CPN_EK_ABLATE & 4)) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[((n * 2 + k) * NT + nt) * 64 + lane], xa[k],
+                                                                             acc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wtail_s[(n * NT + nt) * 48 + tail_lane], xt, acc[nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = acc[nt][i];
+                        acc[nt][i] = __int_as_float(__builtin_amdgcn_ds_bpermute(to_ll, __float_as_int(t)));
+                    }
+                // ---- 4 table taps per row in fp32 on top of it, ReLU, fp16
+                if (!(CPN_EK_ABLATE & 1)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float wk = rec.w[k];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const u32x4 d = td[k][h];
+                            f32x4* a2 = &acc[2 * h];
+                            a2[0][0] = fma_mix_lo(a2[0][0], d[0], wk); a2[0][1] = fma_mix_hi(a2[0][1], d[0], wk);
+                            a2[0][2] = fma_mix_lo(a2[0][2], d[1], wk); a2[0][3] = fma_mix_hi(a2[0][3], d[1], wk);
+                            a2[1][0] = fma_mix_lo(a2[1][0], d[2], wk); a2[1][1] = fma_mix_hi(a2[1][1], d[2], wk);
+                            a2[1][2] = fma_mix_lo(a2[1][2], d[3], wk); a2[1][3] = fma_mix_hi(a2[1][3], d[3], wk);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 pk;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const f32x4& src = acc[2 * h + (qq >> 1)];
+                        const f32x2v two = {src[2 * (qq & 1)], src[2 * (qq & 1) + 1]};
+                        half2v hv = __builtin_convertvector(two, half2v);
+                        hv = __builtin_elementwise_max(hv, (half2v){(_Float16)0.0f, (_Float16)0.0f});
+                        pk[qq] = __builtin_bit_cast(unsigned, hv);
+                    }
+                    res[h] = __builtin_bit_cast(half8, pk);
+                }
+                // ---- this slice of hid as the B operand of the key layer: K = 8 consecutive channels per lane and k step
+                half8 xb[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const u32x4 src = __builtin_bit_cast(u32x4, res[k]);
+                    u32x4 dst;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned sv = src[i];
+                        dst[i] = (unsigned)__builtin_amdgcn_ds_bpermute(to_mfma, (int)sv);
+                    }
+                    xb[k] = __builtin_bit_cast(half8, dst);
+                }
+                // ---- ring: slot gstep & 1 holds this step's weights once every wave's pieces have landed.  This wave's
+                //      pieces were issued one step ago, BEFORE the taps it has just consumed (in-order vmcnt), so they
+                //      are in LDS; the barrier extends that to the other waves' pieces and tells everybody that slot
+                //      (gstep + 1) & 1 — read during the previous step — is free again.
+                const int step_in_unit = j0 * NSLICE + n;
+                if (!(CPN_EK_ABLATE & 64)) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    const bool last = (it == iters - 1) && (step_in_unit == KSTEPS - 1);
+                    if (!last) ring_fill(step_in_unit == KSTEPS - 1 ? 0 : step_in_unit + 1, (gstep + 1) & 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(CPN_EK_ABLATE & 8)) {
+                    const half8* slot = kring + (gstep & 1) * KSLOT_HALF8;
+#pragma unroll
+                    for (int t = 0; t < KT; ++t)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+                            kacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(slot[(t * 2 + k) * 64 + lane], xb[k], kacc[t], 0, 0, 0);
+                }
+                ++gstep;
+            }
+            store_slice(NSLICE - 1, false);
+        }
+
+        // ---- kh = fp16(ReLU(acc + c')): lane (r, g) holds outputs t*16 + g*4 .. +4 of row r
+        if (mid.live) {
+            const size_t srow = (((size_t)b * R + mid.r - ray0) * V + v) * S + mid.s;
+            __half* dst = kh + srow * 128 + g * 4;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(kbias + t * 16 + g * 4);
+                half4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (_Float16)fmaxf(kacc[t][i] + bv[i], 0.0f);
+                *reinterpret_cast<half4*>(dst + t * 16) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                              const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
+                              const uint16_t* kw, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
+                              uint16_t* hid, uint16_t* kh, void* stream) {
+    CPN_REQUIRE(tab && map3 && pixel_val && sec_grid && pe6 && wfrag && bias && kw && kbias && hid && kh, CPN_E_ARG,
+                "cpn_encode_key: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && W >= 16 && (H % 16) == 0 && (W % 16) == 0,
+                CPN_E_SHAPE, "cpn_encode_key: need V==2 and H,W multiples of 16 (got H=%d W=%d V=%d)", H, W, V);
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_encode_key: ray range [%d,%d) outside B*R=%lld", ray0, ray0 + nrays, (long long)B * R);
+    const long long nrows = (long long)nrays * V * S * 2;
+    const NodeGrid ng{W >> 1, H >> 1};
+    CPN_REQUIRE(nrows < (1LL << 31) && ng.zeros_nodes() * TAB_ROW_BYTES < (1LL << 31) && (long long)H * W * 128 < (1LL << 31) &&
+                    (long long)TG * V * S * 2 * 1664 < (1LL << 31),
+                CPN_E_SHAPE, "cpn_encode_key: chunk / per-image table too large for 32-bit offsets (%lld rows)", nrows);
+    CPN_REQUIRE(((uintptr_t)tab % 16) == 0 && ((uintptr_t)map3 % 16) == 0 && ((uintptr_t)wfrag % 16) == 0 &&
+                    ((uintptr_t)bias % 16) == 0 && ((uintptr_t)hid % 16) == 0 && ((uintptr_t)kw % 16) == 0 &&
+                    ((uintptr_t)kbias % 16) == 0 && ((uintptr_t)kh % 8) == 0, CPN_E_ARG,
+                "cpn_encode_key: pointers must be 16-byte aligned");
+    const int groups_per_b = (int)cpn_cdiv(R, TG);
+    const int b_lo = ray0 / R, b_hi = (ray0 + nrays - 1) / R;
+    const long long group0 = (long long)b_lo * groups_per_b + (ray0 - b_lo * R) / TG;
+    const long long group1 = (long long)b_hi * groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
+    const int nsblk = (int)cpn_cdiv(S, TSW);
+    const long long nunits = (group1 - group0 + 1) * V * nsblk;
+    const int num_cu = cpn_stream_cus((void*)stream);
+    const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nunits, EK_WAVES));
+    hipLaunchKernelGGL(encode_key_kernel, dim3(grid), dim3(64 * EK_WAVES), 0, (hipStream_t)stream,
+                       (const __half*)tab, (const __half*)map3, H, W, pixel_val, sec_grid, pe6, (const half8*)wfrag,
+                       bias, (const __half*)kw, kbias, V, R, S, ray0, nrays, nsblk, groups_per_b, group0, nunits,
+                       (__half*)hid, (__half*)kh);
+    CPN_LAUNCH_CHECK("cpn_encode_key");
+    return 0;
+}

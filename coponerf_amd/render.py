@@ -319,7 +319,8 @@ class RenderEngine:
     FREE_SHARE = 0.5                # ... and at most this share of the memory that is free when the workspace is sized
     MAX_AUTO_CHUNK = 65536
 
-    def __init__(self, chunk_rays: int = 0, fold_value: bool = True, lanes: int = 1, tables: bool = True):
+    def __init__(self, chunk_rays: int = 0, fold_value: bool = True, lanes: int = 1, tables: bool = True,
+                 fuse_key: Optional[bool] = None):
         # rays per chunk of the per-sample stages; 0 = automatic (`_auto_chunk`): one 65 536-ray image is ONE chunk on a
         # 288 GB MI355X (28 GB of `hid` at 64 samples) — 4 launches of each per-sample kernel instead of 16 shave the
         # ramp / tail of the persistent grids: 26.6 -> 24.7 ms per image against chunks of 16 384
@@ -327,6 +328,11 @@ class RenderEngine:
         # tables=True: first encoder layer from pre-projected feature tables (cpn_encode_hidden, csrc/encode.hip);
         # False: gather the 835-channel rows and run the 835 -> 832 GEMM on them (the form the training pass uses)
         self.tables = bool(tables)
+        # fuse_key=True: the folded key_map layer runs inside the first-layer kernel (cpn_encode_key, csrc/encode_key.hip)
+        # on the slices of hid that are still in registers, then key_map_2 + the logit on the 128-wide result
+        # (cpn_gemm_f16_rowdot); False: cpn_encode_hidden, then cpn_gemm_f16_chain_rowdot reads hid back (round 3).
+        # Needs tables and fold_value; COPONERF_FUSE_KEY=0/1 overrides the default
+        self.fuse_key = (os.environ.get("COPONERF_FUSE_KEY", "1") != "0") if fuse_key is None else bool(fuse_key)
         # training: every fp16 activation gradient carries a power-of-two scale chosen per backward pass so that the
         # largest entry of the first fp32 -> fp16 gradient lands near this value (train_fns.GradScale)
         self.grad_scale_target = 256.0
@@ -388,7 +394,7 @@ class RenderEngine:
 
     def __deepcopy__(self, memo):
         # caches, streams and workspace are derived state: a copied model gets a fresh engine with the same settings
-        new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables)
+        new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables, self.fuse_key)
         new.grad_scale_target, new.call_lanes, new.lazy_pixel_val = self.grad_scale_target, self.call_lanes, self.lazy_pixel_val
         return new
 
@@ -816,6 +822,8 @@ class RenderEngine:
             self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(nlanes)]
         main = torch.cuda.current_stream()
 
+        fused_key = self.fuse_key and self.tables and self.fold_value
+
         def lane_buffers(lane):
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
             bufs = {"hid": t("hid", (C * T * 2, 832), f16),
@@ -824,6 +832,8 @@ class RenderEngine:
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
             if not self.tables:
                 bufs["xin"] = t("xin", (C * T * 2, _hip.XIN_STRIDE), f16)
+            if fused_key:
+                bufs["khf"] = t("khf", (C * T, 128), f16)
             if not self.fold_value:
                 bufs["enc"] = t("enc", (C * T, 832), f16)
                 bufs["value"] = t("value", (C * T, 416), f32)
@@ -856,12 +866,20 @@ class RenderEngine:
                 if prof is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(),
-                     H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
-                     w["query_encode_latent.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), s)
+                if fused_key:
+                    call("cpn_encode_key", tabs[0].data_ptr(), maps[3].data_ptr(),
+                         H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
+                         w["query_encode_latent.b"].data_ptr(), w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+                         B, V, R, S, ray0, n, hid.data_ptr(), bf["khf"].data_ptr(), s)
+                else:
+                    call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(),
+                         H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
+                         w["query_encode_latent.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), s)
                 if prof is not None:
                     e1.record()
-                    prof.setdefault("encode_hidden", []).append((e0, e1, 2.0 * rows2 * 832 * 835))
+                    # third entry: canonical FLOPs of the FIRST layer (bench.py adds the fused key layer's by kernel name)
+                    prof.setdefault("encode_key" if fused_key else "encode_hidden", []).append(
+                        (e0, e1, 2.0 * rows2 * 832 * 835))
             else:
                 call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
                      H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, ray0, n,
@@ -882,12 +900,18 @@ class RenderEngine:
                 if prof is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                call("cpn_gemm_f16_chain_rowdot", hid.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664,
-                     w["key_fold.b"].data_ptr(), w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(),
-                     ce.data_ptr(), 128, lg.data_ptr(), rows, 1664, s)
+                if fused_key:
+                    # the 1664 -> 128 layer already ran inside cpn_encode_key: key_map_2 + <key, coords_embed> on its output
+                    call("cpn_gemm_f16_rowdot", bf["khf"].data_ptr(), 128, w["key_map_2.w16"].data_ptr(), 128,
+                         w["key_map_2.b"].data_ptr(), ce.data_ptr(), 128, lg.data_ptr(), rows, 128, 128, s)
+                else:
+                    call("cpn_gemm_f16_chain_rowdot", hid.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664,
+                         w["key_fold.b"].data_ptr(), w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(),
+                         ce.data_ptr(), 128, lg.data_ptr(), rows, 1664, s)
                 if prof is not None:
                     e1.record()
-                    prof.setdefault("gemm_f16:key_fold+key_map_2", []).append((e0, e1, 2.0 * rows * 128 * (1664 + 128)))
+                    prof.setdefault("gemm_f16:key_map_2" if fused_key else "gemm_f16:key_fold+key_map_2", []).append(
+                        (e0, e1, 2.0 * rows * 128 * (128 if fused_key else 1664 + 128)))
                 call("cpn_attend_hidden", 0, 0, lg.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
                      hbar.data_ptr(), at_wt.data_ptr(), s)
                 gemm(hbar, 1664, "value_fold", z1, 416, n, 416, 1664, False, True)

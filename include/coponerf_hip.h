@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 3
+#define CPN_ABI_VERSION 4
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -157,6 +157,16 @@ int cpn_node_features(const uint16_t* map0, const uint16_t* map1, const uint16_t
 int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                       const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                       int B, int V, int R, int S, int ray0, int nrays, uint16_t* hid, void* stream);
+/* cpn_encode_key (round 4, csrc/encode_key.hip): cpn_encode_hidden with the folded key_map layer behind it
+ * (models/CoPoNeRF.py:404-407 after :387-397; folding: DESIGN.md 4.3) — the 64-channel slices of hid are the K panel
+ * of the 1664 -> 128 contraction while they are still in registers, so the key path no longer reads hid back from HBM.
+ *   kw (128, 1664) fp16 row-major = (Wk_a W2 | Wk_b W2), kbias (128) fp32 = Wk_a b2 + Wk_b b2 + bk
+ *   hid as above (still written: the two hidden sums read it); kh (rays*V*S, 128) fp16 = ReLU(kw . [hid_own ; hid_other] + kbias),
+ *   rows in the order of this header — the A operand of cpn_gemm_f16_rowdot (key_map_2 + logit).                  */
+int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                   const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
+                   const uint16_t* kw, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
+                   uint16_t* hid, uint16_t* kh, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).

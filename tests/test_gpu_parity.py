@@ -436,6 +436,32 @@ def test_table_mode_matches_gather_mode(model, dev, weights):
             assert (o["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max() <= RGB_TOL
 
 
+def test_fused_key_mode_matches_separate_key_mode(model, dev, weights):
+    """cpn_encode_key (round 4: the folded key_map contraction on the slices of hid while they are in registers, then
+    cpn_gemm_f16_rowdot) against the round-3 order (cpn_encode_hidden, then cpn_gemm_f16_chain_rowdot reading hid back):
+    same fp16 operands, same k order of the MFMA accumulation -> the attention weights and the image must agree to
+    rounding of the last bits, on every fixture case incl. the ragged one (dead rows / dead units at the end of a range)
+    and a ray count that leaves the last iteration of most workgroups without a live unit."""
+    for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
+        cfg, gold = load_case(name)
+        assert model._engine.fuse_key
+        ref, out_f = run_pair(model, dev, weights, cfg)
+        model._engine.fuse_key = False
+        try:
+            _, out_s = run_pair(model, dev, weights, cfg)
+        finally:
+            model._engine.fuse_key = True
+        assert torch.equal(out_f["pixel_val"], out_s["pixel_val"])
+        d_wt = float((out_f["at_wt"] - out_s["at_wt"]).abs().max())
+        d_rgb = float((out_f["rgb"] - out_s["rgb"]).abs().max())
+        print(name, "fused vs separate key path: at_wt", d_wt, "rgb", d_rgb,
+              "rgb vs oracle", float((out_f["rgb"].cpu() - ref["rgb"]).abs().max()))
+        assert d_wt <= 1e-5 and d_rgb <= 2e-5, (name, d_wt, d_rgb)
+        assert (out_f["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
+        assert (out_f["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max() <= RGB_TOL
+        assert (out_f["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+
+
 def test_feature_cache_is_keyed_on_identity(model, dev, weights):
     """a new pair's latents allocated at the freed addresses of the previous pair must not hit the NHWC / table
     cache.  Render pair A, free its latents, render pair B (same shapes, likely the same addresses): B's image must be
