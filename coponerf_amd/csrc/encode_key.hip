@@ -10,9 +10,9 @@
 // What the fusion has to solve is the WEIGHT traffic: the folded key matrix is 128 x 1664 fp16 = 416 KiB, every 16-row
 // wave tile needs the 16 KiB that belong to its (image, slice) and LDS is full (the K = 80 fragments of the first layer
 // take 123.5 KiB).  So, unlike encode.hip, the waves of a workgroup run the slice loop IN LOCK STEP: a two-slot ring of
-// 16 KiB in LDS holds the key weights of the slice in flight; one s_barrier per slice says "everybody has finished with
-// slot (q-1) & 1 and everybody's share of slot q & 1 has landed", after which each wave DMAs its 1 KiB pieces of slice
-// q + 1 (buffer_load ... lds straight from the row-major weight matrix: an MFMA A fragment is 16 contiguous bytes per
+// 16 KiB in LDS holds the key weights of the slice in flight; one s_barrier per slice (right behind the issue of the
+// slice's tap loads) says "everybody has finished with slot (q-1) & 1 and everybody's share of slot q & 1 has landed",
+// after which each wave DMAs its 1 KiB pieces of slice q + 1 (buffer_load ... lds straight from the row-major weight matrix: an MFMA A fragment is 16 contiguous bytes per
 // lane) and runs the 16 key MFMAs of slice q against its own 16 x 64 piece of hid.  L2 -> LDS traffic: 16 KiB per
 // workgroup and slice against 96-128 KiB of table taps.  A wave owns BOTH images of its 4 rays x 4 samples (own image
 // first, then the other): the key accumulators (8 tiles x 4 = 32 VGPRs) run over K = 2 x 832.
@@ -112,6 +112,18 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
     const long long per_iter = (long long)wg_on_xcd * EK_WAVES;
     const int iters = (int)((x_end - x_begin + per_iter - 1) / per_iter);
     int gstep = 0;                                            // slice steps this workgroup has started (ring slot = parity)
+    // Lock step costs the overlap BETWEEN waves: with one barrier site every wave is in the same phase of a slice at the
+    // same time (memory wait, then 3 waves' blends, then 3 waves' MFMAs on each SIMD, one after the other: 12.1 ms per
+    // image against 9.5 without the barrier).  The s_barrier only counts arrivals, so the waves may take it at DIFFERENT
+    // points of their slice: "early" waves right behind the issue of their tap loads, the others in front of their key
+    // MFMAs.  Both sites keep what the ring needs - a wave arrives at barrier q only after its key MFMAs of step q - 1
+    // and after its own pieces of slot q have landed, and it reads slot q / refills slot q + 1 only behind barrier q -
+    // but the two groups now run about half a slice apart: one blends while the other multiplies.
+    // CPN_EK_PHASES: 1 = every wave at the late site, 2 = waves 4-7 (one of the three waves of each SIMD) early.
+#ifndef CPN_EK_PHASES
+#define CPN_EK_PHASES 2
+#endif
+    const bool early_sync = CPN_EK_PHASES == 2 ? ((wave >> 2) & 1) != 0 : (CPN_EK_PHASES == 3);
 
     for (int it = 0; it < iters; ++it) {
         const long long uu_raw = x_begin + (long long)it * per_iter + (long long)wgx * EK_WAVES + wave;
@@ -255,6 +267,29 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // ---- ring.  The barrier sits HERE, behind the issue of the step's 8 tap loads, where every wave is about to
+                //      wait for memory anyway (in front of the key MFMAs it cost 2.6 of 12 ms per image): it says (a) every
+                //      wave has finished the key MFMAs of the previous step, so slot (gstep + 1) & 1 may be refilled, and
+                //      (b) every wave's pieces of THIS step's slot have landed - each wave issued them one step ago and
+                //      makes sure of its own with the counted wait (in-order vmcnt: all but the 2 stores and 8 taps issued
+                //      since).  The stores of the previous slice follow the refill, so that they stay the youngest
+                //      operations in flight and no wait of this step has to cover them.
+                const int step_in_unit = j0 * NSLICE + n;
+                auto ring_sync = [&](bool counted_wait) {
+                    if (CPN_EK_ABLATE & 64) return;
+                    if (counted_wait) {
+                        if (CPN_EK_ABLATE & (1 | 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    const bool last = (it == iters - 1) && (step_in_unit == KSTEPS - 1);
+                    if (!last) ring_fill(step_in_unit == KSTEPS - 1 ? 0 : step_in_unit + 1, (gstep + 1) & 1);
+                };
+                if (early_sync) ring_sync(true);
+                __builtin_amdgcn_sched_barrier(0);
                 store_slice(n > 0 ? n - 1 : 0, n == 0);
                 __builtin_amdgcn_sched_barrier(0);
 
@@ -322,18 +357,9 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                     }
                     xb[k] = __builtin_bit_cast(half8, dst);
                 }
-                // ---- ring: slot gstep & 1 holds this step's weights once every wave's pieces have landed.  This wave's
-                //      pieces were issued one step ago, BEFORE the taps it has just consumed (in-order vmcnt), so they
-                //      are in LDS; the barrier extends that to the other waves' pieces and tells everybody that slot
-                //      (gstep + 1) & 1 — read during the previous step — is free again.
-                const int step_in_unit = j0 * NSLICE + n;
-                if (!(CPN_EK_ABLATE & 64)) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    const bool last = (it == iters - 1) && (step_in_unit == KSTEPS - 1);
-                    if (!last) ring_fill(step_in_unit == KSTEPS - 1 ? 0 : step_in_unit + 1, (gstep + 1) & 1);
-                }
+                // (second site of the ring barrier: the waves that did not take it behind the tap issue.  In-order vmcnt:
+                // their pieces of this step's slot, issued one step ago before this step's taps, have landed.)
+                if (!early_sync) ring_sync(false);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(CPN_EK_ABLATE & 8)) {
                     const half8* slot = kring + (gstep & 1) * KSLOT_HALF8;
