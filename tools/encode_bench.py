@@ -1,6 +1,6 @@
 """Time the first encoder layer of one 16 384-ray chunk of the configs[1] workload in both forms:
 cpn_encode_hidden (projected tables + K=96 MFMA) and cpn_gather_rows + cpn_gemm_f16 (835 -> 832).
-Usage: python tools/encode_bench.py [--rays 16384] [--iters 20] [--only tables|gather]   (prints one JSON line)."""
+Usage: python tools/encode_bench.py [--rays 16384] [--iters 20] [--only tables|fused|gather]   (prints one JSON line)."""
 import argparse
 import json
 import os
@@ -66,6 +66,17 @@ def main():
         res["encode_hidden_ms"] = ms
         res["encode_hidden_alg_tflops"] = 2.0 * rows2 * 832 * 835 / ms / 1e9
         res["encode_hidden_hid_GBs"] = rows2 * 1664 / ms / 1e6
+    if a.only in ("both", "fused"):
+        kh = torch.empty(rows2 // 2, 128, dtype=torch.float16, device=dev)
+
+        def enck():
+            call("cpn_encode_key", tabs[0].data_ptr(), maps[3].data_ptr(), H, H,
+                 g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(), w["enc.frag"].data_ptr(),
+                 w["query_encode_latent.b"].data_ptr(), w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+                 B, V, R, S, min(16384, R - n), n, hid.data_ptr(), kh.data_ptr(), s)
+        ms = timeit(enck)
+        res["encode_key_ms"] = ms
+        res["encode_key_hid_GBs"] = rows2 * 1664 / ms / 1e6
     if a.only in ("both", "gather"):
         xin = torch.empty(rows2, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
 
