@@ -57,6 +57,16 @@ class GraphedGetZ:
         self.model = model
         self._graphs: Dict[Tuple, tuple] = {}
 
+    @staticmethod
+    def _stream_cus(stream) -> int:
+        from .streams import stream_cus
+        return stream_cus(stream)
+
+    @staticmethod
+    def _device_cus() -> int:
+        from .streams import device_cus
+        return device_cus()
+
     def _capture(self, inp):
         model = self.model
         static_in = _map(inp["context"], lambda t: t.clone())
@@ -69,7 +79,12 @@ class GraphedGetZ:
                 model.get_z(static)
         cur.wait_stream(warm)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # Under a CU partition (coponerf_amd/streams.py) the caller's stream is CU-masked, and the persistent kernels of
+        # get_z size their grids by the stream they are captured on (cpn_stream_cus): capture on THAT stream, not on
+        # torch's own unmasked side stream, or the graph bakes in whole-device grids.  The replay runs on the
+        # caller's stream again, i.e. on the masked hardware queue.
+        masked = self._stream_cus(cur) < self._device_cus()
+        with torch.cuda.graph(graph, stream=cur if masked else None):
             out = model.get_z(static)
             hint = getattr(model._engine, "_l3_hint", None)
         nhwc = hint[2] if hint is not None and hint[0] is out[0][3] else None
@@ -84,10 +99,12 @@ class GraphedGetZ:
         # projection weights of UFCLayer._qk_weights) are rebuilt as NEW tensors when their sources change
         if self.__dict__.get("_params") is None:
             self._params = list(model.parameters())
-        key = (_signature(inp["context"]), getattr(model, "_param_epoch", 0), sum(p._version for p in self._params))
+        # ... and the CU share of the stream the call runs on: a graph captured for one share has that share's grids baked in
+        key = (_signature(inp["context"]), getattr(model, "_param_epoch", 0), sum(p._version for p in self._params),
+               self._stream_cus(torch.cuda.current_stream()))
         rec = self._graphs.get(key)
         if rec is None:
-            self._graphs = {k: v for k, v in self._graphs.items() if k[1:] == key[1:]}    # stale parameter states go
+            self._graphs = {k: v for k, v in self._graphs.items() if k[1:3] == key[1:3]}    # stale parameter states go
             rec = self._graphs[key] = self._capture(inp)
         graph, static_in, out, nhwc, hw = rec
         _copy_into(static_in, inp["context"])

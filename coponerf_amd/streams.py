@@ -9,6 +9,11 @@ both an equal share of each shader engine of each of the 8 XCDs, i.e. multiples 
 the kernels keep their meaning and a one-workgroup-per-CU grid still lands one workgroup on every CU).  The
 persistent launchers of the library size their grids by the stream they are launched on (`cpn_stream_cu_count`).
 
+What is and is not confined: eager launches on the two streams are, and so is a captured `get_z` graph
+(coponerf_amd/graphs.py captures ON the masked stream when one is current and keys its graphs on the stream's share).
+The intra-call chunk lanes of `RenderEngine(lanes > 1)` are ordinary unmasked streams of their own: do not combine
+`lanes > 1` with a partition (`render_images` uses call lanes inside the render share instead, `CUPartition.render_lanes`).
+
 Both streams are ordinary HIP streams to PyTorch (`torch.cuda.ExternalStream`): MIOpen / hipBLASLt work launched under
 `torch.cuda.stream(part.getz)` is confined to that share as well.
 """

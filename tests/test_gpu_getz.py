@@ -197,6 +197,11 @@ def test_pipelined_images_equal_serial(dev):
         own_lanes = list(model._engine._call_streams)
         graphed = [out["rgb"].clone() for _, out in render_images(model, pairs, graph=True)]     # get_z as a HIP graph
         graphed2 = [out["rgb"].clone() for _, out in render_images(model, pairs[::-1], graph=True)]   # replay only
+        # graph + partition: get_z is captured ON the CU-masked stream (its persistent grids sized for the 64-CU share) and
+        # replayed there; a graph of the unpartitioned loop above must not be reused for it (key holds the stream's share)
+        ngraphs = len(model._graphed_getz._graphs)
+        graphed_parted = [out["rgb"].clone() for _, out in render_images(model, pairs, graph=True, cu_split=(192, 64))]
+        assert len(model._graphed_getz._graphs) == ngraphs + 1
         again = serial_rgb(pairs[0])
     torch.cuda.synchronize()
     # get_z is deterministic since round 3 (GroupNorm sums reduced in a fixed order): the same pair renders to the same
@@ -219,6 +224,8 @@ def test_pipelined_images_equal_serial(dev):
     for a, b, c in zip(serial, graphed, graphed2[::-1]):
         assert float((a - b).abs().max()) <= max(10 * noise, 2e-5), (float((a - b).abs().max()), noise)
         assert float((a - c).abs().max()) <= max(10 * noise, 2e-5), (float((a - c).abs().max()), noise)
+    for a, d in zip(serial, graphed_parted):
+        assert float((a - d).abs().max()) <= max(10 * noise, 2e-5), float((a - d).abs().max())
     # a parameter reload drops the captured graph (CoPoNeRF._param_epoch)
     epoch = model._param_epoch
     model.load_state_dict(model.state_dict())
