@@ -45,19 +45,33 @@ constexpr int KSLOT_HALF8 = KPIECES * 64;                      // one ring slot:
 constexpr int KSTEPS = 2 * NSLICE;                             // slice steps per unit: both images
 constexpr int KLD = 2 * CPN_TAB_LD;                            // row length of the folded key matrix (1664)
 
+// GROUP = 0 (the product): the K = 80 fragments of the first layer stay resident in LDS (123.5 KiB) and the key weights go
+// through a two-slot ring of one slice each: ONE BARRIER PER SLICE.  GROUP = G > 0 (measured, slower): nothing is resident;
+// a slice's K = 80 block (8 KiB + its tail and bias, from the pre-packed `k80blk`) travels with its key weights (26 KiB per
+// slice), the ring has two halves of G slices each and the waves meet once per G slices - with G = 3 (156 KiB) they may
+// drift up to three slices apart in between.  That was meant to give back the overlap between waves that lock step costs,
+// and the barrier count did fall 3x, but 12.4 ms per image (G = 3) / 13.6 (G = 1) against 11.7 resident say the cost sits in
+// the L2 -> LDS weight stream itself, 26 KiB instead of 16 per workgroup and slice, not in the barriers.
+constexpr int STEP_BYTES = 26 * 1024;                          // streamed form: 16 KiB key + 8 KiB K=80 main + 2 KiB tail (1.5 used)
+constexpr int K80_BLOCK_BYTES = 10 * 1024;                     // one slice of k80blk: main fragments, tail fragments with the bias, pad
+
+template <int GROUP>
 __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
     const __half* __restrict__ tab, const __half* __restrict__ map3, int H, int W,
     const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, const float* __restrict__ pe6,
-    const half8* __restrict__ wfrag, const float* __restrict__ bias, const __half* __restrict__ kw,
-    const float* __restrict__ kbias, int V, int R, int S, int ray0, int nrays, int nsblk, int groups_per_b,
-    long long group0, long long nunits, __half* __restrict__ hid, __half* __restrict__ kh) {
-    __shared__ __attribute__((aligned(16))) half8 wmain[WMAIN_HALF8];
-    __shared__ __attribute__((aligned(16))) half4 wtail_s[WTAIL_HALF4];
-    __shared__ __attribute__((aligned(16))) half8 kring[2 * KSLOT_HALF8];
+    const half8* __restrict__ wfrag, const float* __restrict__ bias, const __half* __restrict__ k80blk,
+    const __half* __restrict__ kw, const float* __restrict__ kbias, int V, int R, int S, int ray0, int nrays, int nsblk,
+    int groups_per_b, long long group0, long long nunits, __half* __restrict__ hid, __half* __restrict__ kh) {
+    constexpr bool STREAM = GROUP > 0;
+    __shared__ __attribute__((aligned(16))) half8 wmain[STREAM ? 1 : WMAIN_HALF8];
+    __shared__ __attribute__((aligned(16))) half4 wtail_s[STREAM ? 1 : WTAIL_HALF4];
+    __shared__ __attribute__((aligned(16))) half8 kring[STREAM ? 2 * GROUP * (STEP_BYTES / 16) : 2 * KSLOT_HALF8];
+    __shared__ __attribute__((aligned(16))) half8 dump[STREAM ? 64 : 1];         // target of the refill slots that carry no piece
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (!STREAM) {
     for (int i = tid; i < WMAIN_HALF8; i += 64 * EK_WAVES) wmain[i] = wfrag[i];
     {
         const half4* tsrc = reinterpret_cast<const half4*>(wfrag + WMAIN_HALF8);          // K tail + bias: see encode.hip
@@ -72,6 +86,7 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
             }
             wtail_s[i] = t;
         }
+    }
     }
 
     const int r = lane & 15, g = lane >> 4;                   // MFMA layout: column (row of the tile) r, K / channel group g
@@ -98,8 +113,25 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                 ((t * 16) * KLD + j * CPN_TAB_LD + n * SLICE_CH + k * 32) * 2, 0, 0);
         }
     };
-    ring_fill(0, 0);
-    __syncthreads();          // K = 80 fragments in place (the ring's first slot is ordered by the first slice barrier)
+    // streamed form: group gi = slice steps [gi*GROUP, gi*GROUP + GROUP) of this workgroup, into ring half gi & 1
+    const __amdgpu_buffer_rsrc_t k80rs = __builtin_amdgcn_make_buffer_rsrc((void*)k80blk, 0, NSLICE * K80_BLOCK_BYTES, 0x00020000);
+    auto group_fill = [&](int gi, int total_steps) {
+        if (CPN_EK_ABLATE & 64) return;
+        constexpr int PPS = STEP_BYTES / 1024;                                 // 1 KiB pieces per slice step
+        for (int pp = wave; pp < PPS * (STREAM ? GROUP : 1); pp += EK_WAVES) {     // wave-uniform trip count
+            const int si = pp / PPS, p = pp - si * PPS;
+            const int st = gi * GROUP + si;
+            if (st >= total_steps) break;
+            const int qq = st % KSTEPS, j = qq >= NSLICE ? 1 : 0, n = qq - j * NSLICE;
+            lds_void* dst = (lds_void*)(reinterpret_cast<char*>(kring) + ((gi & 1) * GROUP + si) * STEP_BYTES + p * 1024);
+            if (p < KPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, dst, 16, kvoff,
+                                                         (((p >> 1) * 16) * KLD + j * CPN_TAB_LD + n * SLICE_CH + (p & 1) * 32) * 2, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k80rs, dst, 16, lane * 16, n * K80_BLOCK_BYTES + (p - KPIECES) * 1024, 0, 0);
+        }
+    };
+    if constexpr (!STREAM) ring_fill(0, 0);
 
     // XCD-aware order as in encode.hip, in UNITS = (4 rays, view, 4 samples) x both images; the waves of a workgroup take
     // consecutive units and every wave runs the same number of iterations
@@ -112,6 +144,9 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
     const long long per_iter = (long long)wg_on_xcd * EK_WAVES;
     const int iters = (int)((x_end - x_begin + per_iter - 1) / per_iter);
     int gstep = 0;                                            // slice steps this workgroup has started (ring slot = parity)
+    const int total_steps = iters * KSTEPS;
+    if constexpr (STREAM) group_fill(0, total_steps);
+    __syncthreads();          // resident form: K = 80 fragments in place; streamed form: group 0 has landed (vmcnt(0) + barrier)
     // Lock step costs the overlap BETWEEN waves: with one barrier site every wave is in the same phase of a slice at the
     // same time (memory wait, then 3 waves' blends, then 3 waves' MFMAs on each SIMD, one after the other: 12.1 ms per
     // image against 9.5 without the barrier).  The s_barrier only counts arrivals, so the waves may take it at DIFFERENT
@@ -258,6 +293,22 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
 
 #pragma unroll 1
             for (int n = 0; n < NSLICE; ++n) {
+                if constexpr (STREAM) {
+                    // once per GROUP slices: everybody has finished the previous group (its ring half may be refilled with the
+                    // group after this one) and everybody's pieces of THIS group, issued a whole group ago, have landed
+                    // (in-order vmcnt; only the two stores of the previous slice may still be in flight)
+                    if (gstep % GROUP == 0 && !(CPN_EK_ABLATE & 64)) {
+                        if (CPN_EK_ABLATE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const char* const sbase = reinterpret_cast<const char*>(kring) +
+                                          (STREAM ? (((gstep / (STREAM ? GROUP : 1)) & 1) * GROUP + gstep % (STREAM ? GROUP : 1)) * STEP_BYTES : 0);
+                const half8* const wm = STREAM ? reinterpret_cast<const half8*>(sbase + KPIECES * 1024) : wmain + n * 2 * NT * 64;
+                const half4* const wt = STREAM ? reinterpret_cast<const half4*>(sbase + KPIECES * 1024 + 8192) : wtail_s + n * NT * 48;
                 u32x4 td[4][2];
                 if (!(CPN_EK_ABLATE & 1)) {
 #pragma unroll
@@ -267,6 +318,36 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STREAM) {
+                    // The refill of the other ring half (the NEXT group's 26 x GROUP pieces) is spread over this group's steps:
+                    // every wave issues exactly FPW pieces per step, BEHIND its tap loads - a fixed number of operations,
+                    // so the compiler's vmcnt counts for the taps stay exact and leave the pieces (and the stores behind
+                    // them) in flight; issued in front of the taps, as one burst per group, every wave's next tap wait also
+                    // waited for its pieces (12.9 ms per image against 12.1 for the resident form).  Slots past the group's
+                    // last piece read out of range (no memory traffic) into a 1 KiB dump.
+                    constexpr int PPS = STEP_BYTES / 1024, FPW = (PPS + EK_WAVES - 1) / EK_WAVES;
+                    const int gi = gstep / GROUP + 1, sg = gstep % GROUP;
+                    if (!(CPN_EK_ABLATE & 64)) {
+#pragma unroll
+                        for (int f = 0; f < FPW; ++f) {
+                            const int pp = (sg * FPW + f) * EK_WAVES + wave;
+                            const int si = pp / PPS, p = pp - si * PPS;
+                            const int st = gi * GROUP + si;
+                            const bool real = pp < PPS * GROUP && st < total_steps;
+                            const int qq = st % KSTEPS, j = qq >= NSLICE ? 1 : 0, nn = qq - j * NSLICE;
+                            lds_void* dst = (lds_void*)(real ? reinterpret_cast<char*>(kring) + ((gi & 1) * GROUP + si) * STEP_BYTES + p * 1024
+                                                             : reinterpret_cast<char*>(dump));
+                            const bool key = p < KPIECES;
+                            const int so = !real ? 0x7ffffff0
+                                                 : key ? (((p >> 1) * 16) * KLD + j * CPN_TAB_LD + nn * SLICE_CH + (p & 1) * 32) * 2
+                                                       : nn * K80_BLOCK_BYTES + (p - KPIECES) * 1024;
+                            // one instruction either way (the descriptor and the per-lane offset are selected, not branched on)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(key || !real ? krs : k80rs, dst, 16, key || !real ? kvoff : lane * 16,
+                                                                     so, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // ---- ring.  The barrier sits HERE, behind the issue of the step's 8 tap loads, where every wave is about to
                 //      wait for memory anyway (in front of the key MFMAs it cost 2.6 of 12 ms per image): it says (a) every
                 //      wave has finished the key MFMAs of the previous step, so slot (gstep + 1) & 1 may be refilled, and
@@ -288,7 +369,7 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                     const bool last = (it == iters - 1) && (step_in_unit == KSTEPS - 1);
                     if (!last) ring_fill(step_in_unit == KSTEPS - 1 ? 0 : step_in_unit + 1, (gstep + 1) & 1);
                 };
-                if (early_sync) ring_sync(true);
+                if (!STREAM && early_sync) ring_sync(true);
                 __builtin_amdgcn_sched_barrier(0);
                 store_slice(n > 0 ? n - 1 : 0, n == 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -302,11 +383,10 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                     for (int k = 0; k < 2; ++k)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wmain[((n * 2 + k) * NT + nt) * 64 + lane], xa[k],
-                                                                             acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[(k * NT + nt) * 64 + lane], xa[k], acc[nt], 0, 0, 0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wtail_s[(n * NT + nt) * 48 + tail_lane], xt, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wt[nt * 48 + tail_lane], xt, acc[nt], 0, 0, 0);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -359,10 +439,10 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                 }
                 // (second site of the ring barrier: the waves that did not take it behind the tap issue.  In-order vmcnt:
                 // their pieces of this step's slot, issued one step ago before this step's taps, have landed.)
-                if (!early_sync) ring_sync(false);
+                if (!STREAM && !early_sync) ring_sync(false);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(CPN_EK_ABLATE & 8)) {
-                    const half8* slot = kring + (gstep & 1) * KSLOT_HALF8;
+                    const half8* slot = STREAM ? reinterpret_cast<const half8*>(sbase) : kring + (gstep & 1) * KSLOT_HALF8;
 #pragma unroll
                     for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -394,10 +474,12 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
 
 extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                               const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
-                              const uint16_t* kw, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
-                              uint16_t* hid, uint16_t* kh, void* stream) {
+                              const uint16_t* k80blk, int group, const uint16_t* kw, const float* kbias, int B, int V, int R,
+                              int S, int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream) {
     CPN_REQUIRE(tab && map3 && pixel_val && sec_grid && pe6 && wfrag && bias && kw && kbias && hid && kh, CPN_E_ARG,
                 "cpn_encode_key: null pointer");
+    CPN_REQUIRE((group == 0 || group == 1 || group == 3) && (group == 0 || (k80blk && ((uintptr_t)k80blk % 16) == 0)), CPN_E_ARG,
+                "cpn_encode_key: group must be 0, 1 or 3 (got %d) and needs k80blk when > 0", group);
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && W >= 16 && (H % 16) == 0 && (W % 16) == 0,
                 CPN_E_SHAPE, "cpn_encode_key: need V==2 and H,W multiples of 16 (got H=%d W=%d V=%d)", H, W, V);
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
@@ -419,10 +501,11 @@ extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, 
     const long long nunits = (group1 - group0 + 1) * V * nsblk;
     const int num_cu = cpn_stream_cus((void*)stream);
     const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nunits, EK_WAVES));
-    hipLaunchKernelGGL(encode_key_kernel, dim3(grid), dim3(64 * EK_WAVES), 0, (hipStream_t)stream,
+    auto kern = group == 0 ? encode_key_kernel<0> : group == 1 ? encode_key_kernel<1> : encode_key_kernel<3>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * EK_WAVES), 0, (hipStream_t)stream,
                        (const __half*)tab, (const __half*)map3, H, W, pixel_val, sec_grid, pe6, (const half8*)wfrag,
-                       bias, (const __half*)kw, kbias, V, R, S, ray0, nrays, nsblk, groups_per_b, group0, nunits,
-                       (__half*)hid, (__half*)kh);
+                       bias, (const __half*)k80blk, (const __half*)kw, kbias, V, R, S, ray0, nrays, nsblk, groups_per_b,
+                       group0, nunits, (__half*)hid, (__half*)kh);
     CPN_LAUNCH_CHECK("cpn_encode_key");
     return 0;
 }

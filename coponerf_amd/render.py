@@ -165,6 +165,28 @@ def _flat_tensors(obj):
             yield from _flat_tensors(o)
 
 
+def pack_k80_blocks(frag: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """(13, CPN_K80_BLOCK_HALVES) fp16: per 64-channel slice of the first layer the K = 80 weight block that the streamed form
+    of cpn_encode_key DMAs into LDS next to the slice's key weights (include/coponerf_hip.h) — the slice's main MFMA
+    fragments as cpn_pack_encode_weights laid them out, then its K-tail fragments with the bias folded in as an fp16
+    (hi, lo) pair against the operand's two constant-one entries, exactly as the resident form builds them in its
+    prologue (csrc/encode.hip), then zero padding to 10 KiB."""
+    nmain = 13 * 2 * 4 * 64 * 8
+    main = frag[:nmain].view(13, 2 * 4 * 64 * 8)
+    tail = frag[nmain:nmain + 13 * 4 * 64 * 4].view(13, 4, 64, 4)[:, :, :48, :].clone()        # [slice][tile][lane < 48][4]
+    a = torch.arange(16, device=frag.device)
+    nt = torch.arange(4, device=frag.device)[:, None]
+    ch = (nt >> 1) * 32 + (a >> 2) * 8 + (nt & 1) * 4 + (a & 3)                                  # slice_channel(nt, a): (4, 16)
+    b = bias.float().view(13, 64)[:, ch]                                                          # (13, 4, 16)
+    hi = b.half()
+    tail[:, :, 0:16, 3] = hi
+    tail[:, :, 16:32, 0] = (b - hi.float()).half()
+    blk = torch.zeros(13, _hip.K80_BLOCK_HALVES, dtype=torch.float16, device=frag.device)
+    blk[:, :4096] = main
+    blk[:, 4096:4096 + 768] = tail.reshape(13, 768)
+    return blk
+
+
 class PendingHostTensor(torch.Tensor):
     """The caller contract's `pixel_val` (a CPU tensor, /root/reference models/CoPoNeRF.py:490) while its asynchronous
     device->host copy may still be running on the copy stream.  The reference's `.cpu()` blocks the host once per
@@ -333,6 +355,10 @@ class RenderEngine:
         # (cpn_gemm_f16_rowdot); False: cpn_encode_hidden, then cpn_gemm_f16_chain_rowdot reads hid back (round 3).
         # Needs tables and fold_value; COPONERF_FUSE_KEY=0/1 overrides the default
         self.fuse_key = (os.environ.get("COPONERF_FUSE_KEY", "1") != "0") if fuse_key is None else bool(fuse_key)
+        # cpn_encode_key's `group` (include/coponerf_hip.h): 0 = K = 80 fragments resident, one barrier per slice; 1..3 = all
+        # weights streamed through LDS, one barrier per that many slices (1 or 3).  Same results; 0 is the fastest (11.7 ms per
+        # 65 536-ray launch against 13.6 / 12.4).
+        self.key_group = int(os.environ.get("COPONERF_KEY_GROUP", "0"))
         # training: every fp16 activation gradient carries a power-of-two scale chosen per backward pass so that the
         # largest entry of the first fp32 -> fp16 gradient lands near this value (train_fns.GradScale)
         self.grad_scale_target = 256.0
@@ -508,6 +534,7 @@ class RenderEngine:
         w["enc.wtab"] = torch.empty(_hip.TAB_LD, 768, dtype=torch.float16, device=dev)
         call("cpn_pack_encode_weights", W1.data_ptr(), 835, w["enc.frag"].data_ptr(), w["enc.wtab"].data_ptr(), s)
         w["enc.zero_bias"] = torch.zeros(_hip.TAB_LD, dtype=torch.float32, device=dev)
+        w["enc.k80blk"] = pack_k80_blocks(w["enc.frag"], w["query_encode_latent.b"])
         self._w, self._wkey = w, key
         self._wgen += 1
         return w
@@ -869,7 +896,8 @@ class RenderEngine:
                 if fused_key:
                     call("cpn_encode_key", tabs[0].data_ptr(), maps[3].data_ptr(),
                          H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
-                         w["query_encode_latent.b"].data_ptr(), w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+                         w["query_encode_latent.b"].data_ptr(), w["enc.k80blk"].data_ptr(), self.key_group,
+                         w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
                          B, V, R, S, ray0, n, hid.data_ptr(), bf["khf"].data_ptr(), s)
                 else:
                     call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(),

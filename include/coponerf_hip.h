@@ -162,11 +162,17 @@ int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int H, int W, c
  * of the 1664 -> 128 contraction while they are still in registers, so the key path no longer reads hid back from HBM.
  *   kw (128, 1664) fp16 row-major = (Wk_a W2 | Wk_b W2), kbias (128) fp32 = Wk_a b2 + Wk_b b2 + bk
  *   hid as above (still written: the two hidden sums read it); kh (rays*V*S, 128) fp16 = ReLU(kw . [hid_own ; hid_other] + kbias),
- *   rows in the order of this header — the A operand of cpn_gemm_f16_rowdot (key_map_2 + logit).                  */
+ *   rows in the order of this header — the A operand of cpn_gemm_f16_rowdot (key_map_2 + logit).
+ *   group = 0: the K = 80 fragments (wfrag, bias) stay resident in LDS, the key weights go through a one-slice ring (one
+ *       workgroup barrier per slice; the fastest).  group = 1 or 3: nothing resident; every slice's K = 80 block comes from k80blk
+ *       (13 x CPN_K80_BLOCK_HALVES fp16: the slice's main fragments [k < 2][tile < 4][lane] half8 as in wfrag, then its tail
+ *       fragments [tile < 4][48] half4 with the bias folded in as an fp16 (hi, lo) pair, zero pad) together with its key
+ *       weights, and the waves of a workgroup meet once per `group` slices.  Results are identical for every group.     */
+#define CPN_K80_BLOCK_HALVES 5120
 int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                    const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
-                   const uint16_t* kw, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
-                   uint16_t* hid, uint16_t* kh, void* stream);
+                   const uint16_t* k80blk, int group, const uint16_t* kw, const float* kbias, int B, int V, int R, int S,
+                   int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).

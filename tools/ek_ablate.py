@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--ray0", type=int, default=0)
     ap.add_argument("--hot", action="store_true", help="back-to-back launches instead of the flushed regime")
     ap.add_argument("--only", default="")
+    ap.add_argument("--groups", type=lambda t: [int(x) for x in t.split(",")], default=[0, 3], help="cpn_encode_key group values to time")
     a = ap.parse_args()
     if a.build:
         build()
@@ -70,21 +71,23 @@ def main():
     P, I = ctypes.c_void_p, ctypes.c_int
     flush = torch.zeros(256 << 20, dtype=torch.float32, device=dev)          # 1 GB buffer: add_ = 2 GB of traffic
     res = {}
-    for w_ in WAVES:
-        for k, what, ph in [(k, v, 2) for k, v in VARIANTS.items()] + [(0, "full", 1), (0, "full", 3), (8, VARIANTS[8], 1), (2, VARIANTS[2], 1)]:
-            label = f"w{w_} phases {ph} {k}: {what}"
+    combos = [(w_, k, v, 2, grp) for w_ in WAVES for grp in a.groups for k, v in VARIANTS.items()]
+    combos += [(12, 0, "full", 1, 0), (12, 0, "full", 3, 0)]
+    for w_, k, what, ph, grp in combos:
+        if True:
+            label = f"w{w_} group {grp} phases {ph} {k}: {what}"
             path = os.path.join(BUILD, f"libek_{k}_w{w_}" + (f"p{ph}" if ph != 2 else "") + ".so")
             if (a.only and a.only not in label) or not os.path.exists(path):
                 continue
             fn = ctypes.CDLL(path).cpn_encode_key
-            fn.argtypes = [P, P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P]
+            fn.argtypes = [P, P, I, I, P, P, P, P, P, P, I, P, P, I, I, I, I, I, I, P, P, P]
             fn.restype = I
 
             def run():
                 rc = fn(tabs[0].data_ptr(), maps[3].data_ptr(), H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(),
                         g["pe6"].data_ptr(), w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(),
-                        w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, a.ray0, n, hid.data_ptr(),
-                        kh.data_ptr(), s)
+                        w["enc.k80blk"].data_ptr(), grp, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, a.ray0,
+                        n, hid.data_ptr(), kh.data_ptr(), s)
                 assert rc == 0, rc
             for _ in range(2):
                 run()

@@ -30,7 +30,7 @@ kh = torch.full((rows2 // 2, 128), -1.0, dtype=torch.float16, device=dev)
 args = (tabs[0].data_ptr(), maps[3].data_ptr(), H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(),
         w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr())
 call("cpn_encode_hidden", *args, B, V, R, S, 0, n, hid_a.data_ptr(), s)
-call("cpn_encode_key", *args, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, 0, n, hid_b.data_ptr(),
+call("cpn_encode_key", *args, w["enc.k80blk"].data_ptr(), int(os.environ.get("COPONERF_KEY_GROUP", "0")), w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, 0, n, hid_b.data_ptr(),
      kh.data_ptr(), s)
 torch.cuda.synchronize()
 kh_ref = torch.empty_like(kh)
