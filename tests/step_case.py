@@ -52,7 +52,8 @@ def loss_terms(tag, out, gt):
 
 def compare(tag, named_grads, fx, rel_l2, rel_max, norm_floor=1e-3):
     """named_grads: parameter name -> gradient tensor or None.  Every parameter the reference gave a gradient must have one
-    (and vice versa); per tensor: relative L2 error of the strided sample and of the norm <= rel_l2, worst entry
+    (and vice versa); per tensor: relative L2 error of the strided sample and of the norm <= rel_l2 (a number, or a
+    function of the parameter name), worst entry
     <= rel_max * max|g_ref|.  Tensors whose reference norm is below norm_floor x the largest norm of the case are
     compared on the absolute scale of that floor (their relative error is rounding noise).  Returns the report rows."""
     none_ref = set(fx[f"{tag}|none"].tolist())
@@ -75,7 +76,8 @@ def compare(tag, named_grads, fx, rel_l2, rel_max, norm_floor=1e-3):
         e_max = float((got - ref).abs().max()) / (max(rmax, norm_floor * top / g.numel() ** 0.5) + 1e-30)
         e_norm = abs(float(g.double().norm()) - rnorm) / (max(rnorm, norm_floor * top) + 1e-30)
         rows.append((max(e_l2, e_norm), e_l2, e_norm, e_max, rnorm, n))
-        if e_l2 > rel_l2 or e_norm > rel_l2 or e_max > rel_max:
+        lim = rel_l2(n) if callable(rel_l2) else rel_l2
+        if e_l2 > lim or e_norm > lim or e_max > rel_max:
             bad.append(rows[-1])
     rows.sort(reverse=True)
     return rows, bad

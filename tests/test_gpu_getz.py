@@ -201,7 +201,8 @@ def test_pipelined_images_equal_serial(dev):
         # replayed there; a graph of the unpartitioned loop above must not be reused for it (key holds the stream's share)
         ngraphs = len(model._graphed_getz._graphs)
         graphed_parted = [out["rgb"].clone() for _, out in render_images(model, pairs, graph=True, cu_split=(192, 64))]
-        assert len(model._graphed_getz._graphs) == ngraphs + 1
+        shares = sorted(k[3] for k in model._graphed_getz._graphs)
+        assert len(shares) > ngraphs and 64 in shares and shares[-1] == 256, shares     # (the loop's first get_z runs on the render share)
         again = serial_rgb(pairs[0])
     torch.cuda.synchronize()
     # get_z is deterministic since round 3 (GroupNorm sums reduced in a fixed order): the same pair renders to the same
