@@ -912,6 +912,37 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = xr[c] / d;
 }
 
+// VJP of the row normalisation y = x / (|x| + eps): dx = dy / (|x| + eps) - y (y . dy) / max(|x|, tiny) — one wave per row,
+// the row in registers (C <= 1024).  Ten ATen launches per call in the training step's correlation backward before.
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ dy, float* __restrict__ dx,
+                                                              long long rows, int C, float eps) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const size_t base = (size_t)row * C;
+    float xv[16], yv[16], gv[16];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+            xv[i] = x[base + c]; yv[i] = y[base + c]; gv[i] = dy[base + c];
+            ss += xv[i] * xv[i];
+            dot += yv[i] * gv[i];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); dot += __shfl_xor(dot, off); }
+    const float r = sqrtf(ss);
+    const float inv = 1.0f / (r + eps), k = dot / fmaxf(r, 1e-30f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) dx[base + c] = gv[i] * inv - yv[i] * k;
+    }
+}
+
 // C (M x N) = A (M x K) . B (N x K)^T per batch; wave = 16 rows x 16*NT cols, block = 64 rows; K % 16 == 0.
 // NT = 8 for large problems (fewer re-reads of B), NT = 2 when 128-column tiles would leave most of the chip idle
 // (a 256 x 256 correlation is 8 workgroups at NT = 8); the operands of k block kb+16 are requested before the MFMAs of kb.
@@ -1744,6 +1775,16 @@ extern "C" int cpn_correlation(const float* src, const float* trg, int B, int L,
         hipLaunchKernelGGL(gemm_nt_f32_kernel<2>, grid, dim3(256), 0, st, src_n, trg_n, out, L, L, C);
     }
     CPN_LAUNCH_CHECK("cpn_correlation(gemm)");
+    return 0;
+}
+
+extern "C" int cpn_l2norm_rows_bwd(const float* x, const float* y, const float* dy, long long rows, int C, float eps,
+                                   float* dx, void* stream) {
+    CPN_REQUIRE(x && y && dy && dx, CPN_E_ARG, "cpn_l2norm_rows_bwd: null pointer");
+    CPN_REQUIRE(rows > 0 && rows < (1LL << 33) && C > 0 && C <= 1024, CPN_E_SHAPE, "cpn_l2norm_rows_bwd: need 0 < C <= 1024 (got %d)", C);
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, dy, dx, rows,
+                       C, eps);
+    CPN_LAUNCH_CHECK("cpn_l2norm_rows_bwd");
     return 0;
 }
 

@@ -63,6 +63,12 @@ class _CorrelationFn(Function):
         dC = gout.reshape(B, L, L)
 
         def through_norm(x, xn, dxn):
+            if x.is_cuda and x.shape[-1] <= 1024:
+                x_, xn_, d_ = x.contiguous().float(), xn.contiguous(), dxn.contiguous()
+                dx = torch.empty_like(d_)
+                call("cpn_l2norm_rows_bwd", x_.data_ptr(), xn_.data_ptr(), d_.data_ptr(), x_.numel() // x_.shape[-1], x_.shape[-1],
+                     1e-5, dx.data_ptr(), _stream())
+                return dx
             r = x.norm(dim=-1, p=2, keepdim=True)
             return dxn / (r + 1e-5) - xn * ((xn * dxn).sum(-1, keepdim=True) / r.clamp_min(1e-30))
 

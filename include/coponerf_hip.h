@@ -393,6 +393,10 @@ int cpn_dual_softmax_bwd(const float* a, const float* rstat, const float* cstat,
  * src_n, trg_n (B,L,C) scratch for the normalised tokens; out (B,L,L) == (B,1,h,w,h,w).                    */
 int cpn_correlation(const float* src, const float* trg, int B, int L, int C, float eps,
                     float* src_n, float* trg_n, float* out, void* stream);
+/* VJP of the row normalisation of K7 (training): x, y = x / (|x| + eps), dy (rows, C) fp32, C <= 1024 ->
+ * dx = dy / (|x| + eps) - y (y . dy) / |x|, one launch (the stock-op form was ten per call, 26 calls per step).       */
+int cpn_l2norm_rows_bwd(const float* x, const float* y, const float* dy, long long rows, int C, float eps,
+                        float* dx, void* stream);
 
 /* ---- K8: soft-argmax with temperature over the 4-D correlation, both directions --------------------
  * replaces aggregation.soft_argmax + softmax_with_temperature (models/aggregation.py:119-144, 555-560).
