@@ -17,9 +17,16 @@ import torch
 import torch.nn.functional as F
 
 
+_GRIDS: Dict = {}
+
+
 def _grid(B: int, H: int, W: int, device) -> torch.Tensor:
-    ys, xs = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
-    return torch.stack((xs, ys), 0).float()[None].expand(B, -1, -1, -1)
+    key = (H, W, str(device))
+    g = _GRIDS.get(key)
+    if g is None:                      # a constant: built once per (size, device), not with 8 launches per use
+        ys, xs = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+        g = _GRIDS[key] = torch.stack((xs, ys), 0).float()[None]
+    return g.expand(B, -1, -1, -1)
 
 
 def _warp(x: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:

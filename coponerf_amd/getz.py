@@ -29,17 +29,37 @@ import torch.nn.functional as F
 # ----------------------------------------------------------------------------------------------
 # ResNet-34 trunk with torchvision-compatible parameter names (encoder.model.*)
 # ----------------------------------------------------------------------------------------------
+class _TrunkBatchNorm(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and training-mode arithmetic) whose `num_batches_tracked` counter is not
+    bumped layer by layer: in training each bump is a launch of its own (36 per trunk pass); the modules that ran are
+    noted on the class and `flush_counters()` advances all their counters with ONE multi-tensor add (SpatialEncoder.forward)."""
+    _pending = []
+
+    def forward(self, x):
+        if not (self.training and self.track_running_stats) or self.momentum is None:
+            return super().forward(x)
+        _TrunkBatchNorm._pending.append(self.num_batches_tracked)
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
+
+    @staticmethod
+    def flush_counters():
+        pend, _TrunkBatchNorm._pending = _TrunkBatchNorm._pending, []
+        if pend:
+            with torch.no_grad():
+                torch._foreach_add_(pend, 1)
+
+
 class _BasicBlock(nn.Module):
     def __init__(self, cin: int, cout: int, stride: int):
         super().__init__()
         self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(cout)
+        self.bn1 = _TrunkBatchNorm(cout)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(cout)
+        self.bn2 = _TrunkBatchNorm(cout)
         self.downsample = None
         if stride != 1 or cin != cout:
-            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), _TrunkBatchNorm(cout))
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
@@ -51,7 +71,7 @@ class _ResNet34Trunk(nn.Module):
     def __init__(self):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = _TrunkBatchNorm(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         cin = 64
@@ -110,6 +130,7 @@ class SpatialEncoder(nn.Module):
         for name in ("layer1", "layer2", "layer3", "layer4"):
             x = getattr(m, name)(x)
             lat.append(x)
+        _TrunkBatchNorm.flush_counters()
         return lat[::-1]
 
 
@@ -247,7 +268,9 @@ class UFCLayer(nn.Module):
         if not grad and c is not None and c[0] == key:
             return c[1]
         Wq, Wk = ps[0], ps[1]
-        out = (torch.cat((Wq[:, :ncc], Wk[:, :ncc]), 0), torch.cat((Wq[:, ncc:], Wk[:, ncc:]), 0), torch.cat((ps[2], ps[3]), 0),
+        # (one split node per weight instead of two slices: under autograd a slice's backward is a zero fill + a copy + an add)
+        (Wq_c, Wq_f), (Wk_c, Wk_f) = Wq.split((ncc, Wq.shape[1] - ncc), 1), Wk.split((ncc, Wk.shape[1] - ncc), 1)
+        out = (torch.cat((Wq_c, Wk_c), 0), torch.cat((Wq_f, Wk_f), 0), torch.cat((ps[2], ps[3]), 0),
                self.pos_embed.reshape(-1, self.dim))
         if not grad:
             out = tuple(t.detach().contiguous() for t in out)
@@ -266,7 +289,7 @@ class UFCLayer(nn.Module):
         lin = F.linear(feat_n, Wf, bqk)                                                   # (B, L, 2d)
         if torch.is_grad_enabled() and (lin.requires_grad or low.requires_grad) or not lin.is_cuda:
             qk = (lin + _map_to_tokens(ops.resize_bilinear(low, fs))).view(B, -1, 2, self.nhead, self.dim) + pos[None, :, None, None, :]
-            return qk[:, :, 0], qk[:, :, 1]
+            return qk.unbind(2)
         from ._hip import call
         q = torch.empty(B, fs * fs, self.nhead, self.dim, dtype=torch.float32, device=lin.device)
         k = torch.empty_like(q)
@@ -314,7 +337,8 @@ class UFCLayer(nn.Module):
         c = corr.reshape(B, H, Hs * Ws, Ht * Wt)
         pooled = _map_to_tokens(F.avg_pool2d(_tokens_to_map(x2, fs), fs // Hs))
         v = self.v_cross(self.norm_cross1(pooled)).view(2 * B, -1, self.nhead, self.dim)
-        src_attn, trg_attn = ops.cross_attention(c, v[:B], v[B:])
+        v_src, v_trg = v.chunk(2, 0)
+        src_attn, trg_attn = ops.cross_attention(c, v_src, v_trg)
         attn = torch.cat((src_attn.reshape(B, -1, d), trg_attn.reshape(B, -1, d)), 0)
         r = fs // Hs
         x2 = x2 + _map_to_tokens(_tokens_to_map(attn, Hs).repeat_interleave(r, 2).repeat_interleave(r, 3))
@@ -329,13 +353,19 @@ class UFCLayer(nn.Module):
         B = corr.shape[0]
         corr2 = torch.cat((corr, _swap(corr)), 0)
         msg2, x2 = self._attention(corr2, torch.cat((src, trg), 0), ops)
-        corr_r = msg2[:B] + t4(msg2[B:])
-        corr_r = self.feat_to_corr1(ops.correlation_tokens(x2[:B], x2[B:], self.fs), ops, residual=corr_r)
+        # halves taken ONCE per tensor with chunk (a view of the same storage: the correlation kernel still sees its two
+        # operands as adjacent halves of one buffer); every `x[:B]` is a slice node of its own under autograd, whose
+        # backward is a zero fill + a copy + an add into the other half's - 14 of them per layer before
+        msg_s, msg_t = msg2.chunk(2, 0)
+        xs, xt = x2.chunk(2, 0)
+        corr_r = msg_s + t4(msg_t)
+        corr_r = self.feat_to_corr1(ops.correlation_tokens(xs, xt, self.fs), ops, residual=corr_r)
         corr_r = self.mlp_refine_corr(corr_r, ops, residual=corr_r)
         x2 = self._cross_views(corr_r, x2, ops)
-        corr_r = self.feat_to_corr2(ops.correlation_tokens(x2[:B], x2[B:], self.fs), ops, residual=corr_r)
+        xs, xt = x2.chunk(2, 0)
+        corr_r = self.feat_to_corr2(ops.correlation_tokens(xs, xt, self.fs), ops, residual=corr_r)
         corr_r = self.mlp_refine_corr2(corr_r, ops, residual=corr_r)
-        return corr_r, x2[:B], x2[B:]
+        return corr_r, xs, xt
 
     def forward(self, corr, src, trg, ops):             # aggregation.py:342-356
         if BATCH_VIEWS and corr.shape[2:4] == corr.shape[4:6] and src.shape == trg.shape:

@@ -652,9 +652,8 @@ class RenderEngine:
         W2, b2 = mat("query_encode_latent_2", 416), bias("query_encode_latent_2")
 
         def fold(name, n_out):                                   # differentiable fp32 fold
-            Wx = mat(name, n_out)
-            return (torch.cat((Wx[:, :416] @ W2, Wx[:, 416:] @ W2), dim=1),
-                    Wx[:, :416] @ b2 + Wx[:, 416:] @ b2 + bias(name))
+            Wa, Wb = mat(name, n_out).chunk(2, 1)                # one split node, not four slices (each a fill + copy + add backward)
+            return torch.cat((Wa @ W2, Wb @ W2), dim=1), (Wa + Wb) @ b2 + bias(name)
 
         Wkf, ckf = fold("key_map", 128)
         Wvf, cvf = fold("latent_value", 416)
@@ -665,9 +664,9 @@ class RenderEngine:
         hbar1, w1 = AttendHiddenFn.apply(key2, ce, hid2, dims, gs, hp)
         z1 = GemmFn.apply(hbar1, Wvf, cvf, False, True, gs)
         ze = LinearF32Fn.apply(z1, mat("encode_latent", 128), bias("encode_latent"), None, False, False)
-        Wr = mat("query_repeat_embed", 128)
-        aq = LinearF32Fn.apply(ze, Wr[:, :128].contiguous(), None, None, False, False)
-        q2h = LocalHiddenFn.apply(g["loc8"], g["coords9"], Wr[:, 128:].contiguous(), bias("query_repeat_embed"), aq, dims, gs)
+        Wr_z, Wr_l = mat("query_repeat_embed", 128).split((128, 16), 1)
+        aq = LinearF32Fn.apply(ze, Wr_z.contiguous(), None, None, False, False)
+        q2h = LocalHiddenFn.apply(g["loc8"], g["coords9"], Wr_l.contiguous(), bias("query_repeat_embed"), aq, dims, gs)
         q2 = GemmFn.apply(q2h, mat("query_repeat_embed_2", 128), bias("query_repeat_embed_2"), False, False, gs)
         hbar2, _ = AttendHiddenFn.apply(q2, ce, hid2, dims, gs, hp)
         zs = GemmFn.apply(hbar2, Wvf, cvf, False, True, gs)
@@ -678,8 +677,8 @@ class RenderEngine:
         x = LinearF32Fn.apply(c18, torch.nn.functional.pad(P["phi.lin_in.weight"], (0, 14)), P["phi.lin_in.bias"], None,
                               False, False)
         for k in range(3):
-            Wz = P[f"phi.lin_z.{k}.weight"]
-            x = LinearF32Fn.apply(zl, Wz[:, :416] + Wz[:, 416:], P[f"phi.lin_z.{k}.bias"], x, False, False)
+            Wz_a, Wz_b = P[f"phi.lin_z.{k}.weight"].chunk(2, 1)
+            x = LinearF32Fn.apply(zl, Wz_a + Wz_b, P[f"phi.lin_z.{k}.bias"], x, False, False)
             net = LinearF32Fn.apply(x, P[f"phi.blocks.{k}.fc_0.weight"], P[f"phi.blocks.{k}.fc_0.bias"], None, True, False)
             x = LinearF32Fn.apply(net, P[f"phi.blocks.{k}.fc_1.weight"], P[f"phi.blocks.{k}.fc_1.bias"], x, True, False)
         raw = LinearF32Fn.apply(x, P["phi.lin_out.weight"], P["phi.lin_out.bias"], None, True, False)     # (nray, 3)
