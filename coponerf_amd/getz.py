@@ -21,6 +21,8 @@ import math
 import os
 from typing import Sequence, Tuple
 
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -31,19 +33,27 @@ import torch.nn.functional as F
 # ----------------------------------------------------------------------------------------------
 class _TrunkBatchNorm(nn.BatchNorm2d):
     """nn.BatchNorm2d (same parameters, buffers and training-mode arithmetic) whose `num_batches_tracked` counter is not
-    bumped layer by layer: in training each bump is a launch of its own (36 per trunk pass); the modules that ran are
-    noted on the class and `flush_counters()` advances all their counters with ONE multi-tensor add (SpatialEncoder.forward)."""
-    _pending = []
+    bumped layer by layer: in training each bump is a launch of its own (36 per trunk pass); inside SpatialEncoder.forward
+    the modules that ran are noted (per thread) and `flush_counters()` advances all their counters with ONE multi-tensor add."""
+    _tls = threading.local()            # per thread: replicas driven from several threads keep their own lists
 
     def forward(self, x):
         if not (self.training and self.track_running_stats) or self.momentum is None:
             return super().forward(x)
-        _TrunkBatchNorm._pending.append(self.num_batches_tracked)
+        pend = getattr(_TrunkBatchNorm._tls, "pending", None)
+        if pend is None:                # used outside SpatialEncoder.forward (nobody would flush): the stock behaviour
+            return super().forward(x)
+        pend.append(self.num_batches_tracked)
         return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum, self.eps)
 
     @staticmethod
+    def collect_counters():
+        """Start noting the counters of the modules that run on this thread (SpatialEncoder.forward, training mode)."""
+        _TrunkBatchNorm._tls.pending = []
+
+    @staticmethod
     def flush_counters():
-        pend, _TrunkBatchNorm._pending = _TrunkBatchNorm._pending, []
+        pend, _TrunkBatchNorm._tls.pending = getattr(_TrunkBatchNorm._tls, "pending", None), None
         if pend:
             with torch.no_grad():
                 torch._foreach_add_(pend, 1)
@@ -125,12 +135,15 @@ class SpatialEncoder(nn.Module):
         if (not torch.is_grad_enabled() and not self.training and x.is_cuda and x.dtype == torch.float32
                 and x.is_contiguous() and FUSED_TRUNK):
             return self._forward_infer(x)
-        x = m.relu(m.bn1(m.conv1(x)))
-        lat = [x]
-        for name in ("layer1", "layer2", "layer3", "layer4"):
-            x = getattr(m, name)(x)
-            lat.append(x)
-        _TrunkBatchNorm.flush_counters()
+        _TrunkBatchNorm.collect_counters()
+        try:
+            x = m.relu(m.bn1(m.conv1(x)))
+            lat = [x]
+            for name in ("layer1", "layer2", "layer3", "layer4"):
+                x = getattr(m, name)(x)
+                lat.append(x)
+        finally:
+            _TrunkBatchNorm.flush_counters()
         return lat[::-1]
 
 

@@ -462,6 +462,44 @@ def test_fused_key_mode_matches_separate_key_mode(model, dev, weights):
         assert (out_f["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
 
 
+def test_encode_key_entry_every_group_is_bit_identical(model, dev, weights):
+    """The C entry itself: cpn_encode_key with group 0 (K = 80 fragments resident, one barrier per slice), 1 and 3 (all weights
+    streamed, one barrier per 1 / 3 slices) writes the same bits of hid as cpn_encode_hidden and the same kh as
+    cpn_gemm_f16 on that hid — on a ragged chunk (ray0 > 0, a ray count that is no multiple of 4, dead units at the end of
+    most workgroups' ranges)."""
+    from coponerf_amd._hip import call
+    cfg, _ = load_case("wide_val")
+    inp, z, rel, flow = case_inputs(cfg)
+    B, H, R, S, V = cfg["B"], cfg["H"], cfg["R"], cfg["S"], 2
+    eng = model._engine
+    model.npoints = S
+    w = eng._weights(model._render_params())
+    maps, tabs = eng._feature_maps(to_device(z, dev), w)
+    ctx, qry = to_device(inp["context"], dev), to_device(inp["query"], dev)
+    g = eng._geometry(ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], rel.to(dev), cfg["val"], S, H, H)
+    s = torch.cuda.current_stream().cuda_stream
+    ray0, n = 7, R - 18
+    rows2 = n * V * S * 2
+    args = (tabs[0].data_ptr(), maps[3].data_ptr(), H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(),
+            w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr())
+    hid_ref = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
+    call("cpn_encode_hidden", *args, B, V, R, S, ray0, n, hid_ref.data_ptr(), s)
+    kh_ref = torch.empty(rows2 // 2, 128, dtype=torch.float16, device=dev)
+    call("cpn_gemm_f16", hid_ref.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664, w["key_fold.b"].data_ptr(), kh_ref.data_ptr(), 128,
+         rows2 // 2, 128, 1664, 1, 0, s)
+    assert int((hid_ref == -1).sum()) == 0
+    for group in (0, 1, 3):
+        hid = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
+        kh = torch.full((rows2 // 2, 128), -1.0, dtype=torch.float16, device=dev)
+        call("cpn_encode_key", *args, w["enc.k80blk"].data_ptr(), group, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+             B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
+        assert torch.equal(hid, hid_ref), (group, int((hid != hid_ref).sum()))
+        assert torch.equal(kh, kh_ref), (group, int((kh != kh_ref).sum()))
+    with pytest.raises(Exception):
+        call("cpn_encode_key", *args, w["enc.k80blk"].data_ptr(), 2, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+             B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
+
+
 def test_feature_cache_is_keyed_on_identity(model, dev, weights):
     """a new pair's latents allocated at the freed addresses of the previous pair must not hit the NHWC / table
     cache.  Render pair A, free its latents, render pair B (same shapes, likely the same addresses): B's image must be
