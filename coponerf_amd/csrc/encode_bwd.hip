@@ -396,15 +396,24 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const int* __restrict
 // with one address add per tap, one conversion and four FMAs per (row, wave).  (With the descriptors staged in LDS and
 // unpacked by the vector unit the kernel spent 29 VALU + 11 LDS instructions per row and wave and was bound by them:
 // 10 ms for 9.7 GB of reads — rocprofv3 counters of that version: VALU + LDS busy, L2 read latency only 684 clocks.)
-__global__ __launch_bounds__(64 * SW) void bucket_accumulate_kernel(const __half* __restrict__ d, int ldx, BucketGeo geo,
-                                                                    const int4* __restrict__ work, const int* __restrict__ nwork,
-                                                                    const unsigned* __restrict__ rows,
-                                                                    const unsigned* __restrict__ cellsv,
-                                                                    const f32x4* __restrict__ wts, float* __restrict__ dtab) {
-    __shared__ float tiles_lds[SW][(TP * TPY + 1) * TC];          // 32 node cells + the dummy cell, lane = channel
+// Round 4: a lane owns TWO channels (one 4-byte load per row), a wave 128, a workgroup 7 waves (the last one half
+// idle: 832 = 6.5 x 128).  With one channel per lane every row was fetched as thirteen 128-byte requests issued by
+// thirteen waves at thirteen different moments, from a row drawn at random out of 7 GB: 9.7 GB in 6.35 ms = 1.5 TB/s with
+// the L1 -> L2 latency at a modest 695 clocks, L2 hit rate 9 %, no pipe busy - the DRAM pages are what that pattern wastes.
+// 256-byte requests halve the number of pages touched per byte.
+constexpr int BTC = 128;                                       // channels per wave of bucket_accumulate_kernel
+constexpr int BSW = (TLD + BTC - 1) / BTC;                     // 7 waves
+__global__ __launch_bounds__(64 * BSW) void bucket_accumulate_kernel(const __half* __restrict__ d, int ldx, BucketGeo geo,
+                                                                     const int4* __restrict__ work, const int* __restrict__ nwork,
+                                                                     const unsigned* __restrict__ rows,
+                                                                     const unsigned* __restrict__ cellsv,
+                                                                     const f32x4* __restrict__ wts, float* __restrict__ dtab) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    __shared__ f32x2 tiles_lds[BSW][(TP * TPY + 1) * 64];        // 32 node cells + the dummy cell, lane = channel pair
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* tile = tiles_lds[wave] + lane;
+    f32x2* tile = tiles_lds[wave] + lane;
     if ((int)blockIdx.x >= *nwork) return;      // (a persistent walk of the work list, one workgroup per CU, measured 2.7 ms slower)
     {
     const int4 item = work[blockIdx.x];
@@ -413,61 +422,88 @@ __global__ __launch_bounds__(64 * SW) void bucket_accumulate_kernel(const __half
     const NodeGridB ng{geo.W >> 1, geo.H >> 1};
     const int nw = ng.w(kind), nh = ng.h(kind);
     const int tx0 = (tidx % geo.tiles_x[kind]) * TP, ty0 = (tidx / geo.tiles_x[kind]) * TPY;
-    const __half* dcol = d + wave * TC + lane;
+    const int ch0 = wave * BTC + lane * 2;
+    const bool ch_ok = ch0 < TLD;                                 // the upper half of the last wave has no channels
+    const unsigned* dcol = reinterpret_cast<const unsigned*>(d + (ch_ok ? ch0 : 0));          // one fp16 pair per row
 #pragma unroll
-    for (int i = 0; i <= TP * TPY; ++i) tile[i * TC] = 0.0f;
+    for (int i = 0; i <= TP * TPY; ++i) tile[i * 64] = f32x2{0.0f, 0.0f};
 
     const int first = item.y, last = item.z - 1;
     // The bucket is ordered by the rows' cell position, so consecutive rows mostly hit the SAME four cells: their sums
-    // stay in four registers and go to the LDS tile only when the position changes (the first version did four LDS
+    // stay in registers and go to the LDS tile only when the position changes (the first version did four LDS
     // read-modify-writes per row and wave and was bound by the LDS pipe: SQ_ACTIVE_INST_LDS = 86 % of the kernel).
     unsigned held = 0xffffffffu;                                  // cells word of the run in the registers
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    f32x2 a0 = {0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
     auto spill = [&]() {
-        float* t0 = tile + (held & 255u) * TC;
-        float* t1 = tile + ((held >> 8) & 255u) * TC;
-        float* t2 = tile + ((held >> 16) & 255u) * TC;
-        float* t3 = tile + (held >> 24) * TC;
-        const float v0 = *t0, v1 = *t1, v2 = *t2, v3 = *t3;      // the four cells of a position are distinct (or the dummy)
+        f32x2* t0 = tile + (held & 255u) * 64;
+        f32x2* t1 = tile + ((held >> 8) & 255u) * 64;
+        f32x2* t2 = tile + ((held >> 16) & 255u) * 64;
+        f32x2* t3 = tile + (held >> 24) * 64;
+        const f32x2 v0 = *t0, v1 = *t1, v2 = *t2, v3 = *t3;      // the four cells of a position are distinct (or the dummy)
         *t0 = v0 + a0;
         *t1 = v1 + a1;
         *t2 = v2 + a2;
         *t3 = v3 + a3;
     };
-    __half cur[NBB], nxt[NBB];
+    // Per-row descriptors (row index, cells word, four weights) are wave-uniform: lane u of the wave loads the descriptor
+    // of row base + u with ordinary coalesced vector loads, two batches ahead, and v_readlane hands each row's values to
+    // the scalar side when it is processed (through the scalar cache a batch of 32 rows needs 32 x 6 dwords of SGPRs).
+    static_assert(NBB <= 64, "one descriptor per lane");
+    struct Desc { unsigned row, cells; f32x4 w; };
+    auto load_desc = [&](int base) {
+        const int idx = min(base + (lane < NBB ? lane : NBB - 1), last);
+        Desc dsc;
+        dsc.row = rows[idx];
+        dsc.cells = cellsv[idx];
+        dsc.w = wts[idx];
+        return dsc;
+    };
+    auto lane_u = [](unsigned v, int u) { return (unsigned)__builtin_amdgcn_readlane((int)v, u); };
+    auto lane_f = [](float v, int u) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), u)); };
+    const size_t ldw = (size_t)ldx / 2;                           // row pitch in fp16 pairs (ldx is even)
+    unsigned cur[NBB], nxt[NBB];
+    Desc dcur = load_desc(first), dnxt = load_desc(first + NBB);
 #pragma unroll
-    for (int u = 0; u < NBB; ++u) nxt[u] = dcol[(size_t)rows[min(first + u, last)] * ldx];
+    for (int u = 0; u < NBB; ++u) nxt[u] = dcol[(size_t)lane_u(dcur.row, u) * ldw];
     for (int base = first; base <= last; base += NBB) {
+        const Desc dfar = load_desc(base + 2 * NBB);              // descriptors of the batch after next
 #pragma unroll
         for (int u = 0; u < NBB; ++u) cur[u] = nxt[u];
 #pragma unroll
-        for (int u = 0; u < NBB; ++u) nxt[u] = dcol[(size_t)rows[min(base + NBB + u, last)] * ldx];
+        for (int u = 0; u < NBB; ++u) nxt[u] = dcol[(size_t)lane_u(dnxt.row, u) * ldw];     // rows past `last` repeat the last one
 #pragma unroll
         for (int u = 0; u < NBB; ++u) {
             if (base + u > last) break;
-            const float du = __half2float(cur[u]);
-            const unsigned cells = cellsv[base + u];
-            const f32x4 w4 = wts[base + u];
+            const half2v hv = __builtin_bit_cast(half2v, cur[u]);
+            const f32x2 du = {(float)hv[0], (float)hv[1]};
+            const unsigned cells = lane_u(dcur.cells, u);
             if (cells != held) {                                  // wave-uniform
                 if (held != 0xffffffffu) spill();
                 held = cells;
-                a0 = a1 = a2 = a3 = 0.0f;
+                a0 = a1 = a2 = a3 = f32x2{0.0f, 0.0f};
             }
-            a0 += du * w4[0];
-            a1 += du * w4[1];
-            a2 += du * w4[2];
-            a3 += du * w4[3];
+            a0 += du * lane_f(dcur.w[0], u);
+            a1 += du * lane_f(dcur.w[1], u);
+            a2 += du * lane_f(dcur.w[2], u);
+            a3 += du * lane_f(dcur.w[3], u);
         }
+        dcur = dnxt;
+        dnxt = dfar;
     }
     if (held != 0xffffffffu) spill();
-    float* m = dtab + ((size_t)img * ng.per_image() + (kind ? ng.border_nodes() : 0)) * TLD + wave * TC + lane;
+    float* m = dtab + ((size_t)img * ng.per_image() + (kind ? ng.border_nodes() : 0)) * TLD + (ch_ok ? ch0 : 0);
 #pragma unroll 4
     for (int pix = 0; pix < TP * TPY; ++pix) {
-        const float v = tile[pix * TC];
+        const f32x2 v = tile[pix * 64];
         const int gy = ty0 + (pix >> 3), gx = tx0 + (pix & 7);
-        if (v != 0.0f && gy < nh && gx < nw) {
-            if (item.w) atomicAdd(m + ((size_t)gy * nw + gx) * TLD, v);       // the tile was split over several work items
-            else m[((size_t)gy * nw + gx) * TLD] = v;                          // its only writer: dtab is zero on entry
+        if (ch_ok && gy < nh && gx < nw && (v[0] != 0.0f || v[1] != 0.0f)) {
+            float* o = m + ((size_t)gy * nw + gx) * TLD;
+            if (item.w) {                                          // the tile was split over several work items
+                if (v[0] != 0.0f) atomicAdd(o, v[0]);
+                if (v[1] != 0.0f) atomicAdd(o + 1, v[1]);
+            } else {
+                *reinterpret_cast<f32x2*>(o) = v;                  // its only writer: dtab is zero on entry
+            }
         }
     }
   }
@@ -644,6 +680,8 @@ extern "C" int cpn_scatter_rows_tables(const uint16_t* d, int ldx, int H, int W,
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && (H % 16) == 0 && (W % 16) == 0 && ldx >= TLD, CPN_E_SHAPE,
                 "cpn_scatter_rows_tables: bad shape");
     CPN_REQUIRE(H <= 1024 && W <= 1024, CPN_E_SHAPE, "cpn_scatter_rows_tables: maps larger than 1024 pixels a side");
+    CPN_REQUIRE((ldx % 2) == 0 && ((uintptr_t)d % 4) == 0 && ((uintptr_t)dtab % 8) == 0, CPN_E_ARG,
+                "cpn_scatter_rows_tables: d must be 4-byte aligned with an even ldx, dtab 8-byte aligned");
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_scatter_rows_tables: ray range outside B*R");
     CPN_REQUIRE((long long)nrays * V * S * 2 < (1LL << 31) && ((uintptr_t)scratch % 16) == 0, CPN_E_SHAPE,
@@ -676,7 +714,7 @@ extern "C" int cpn_scatter_rows_tables(const uint16_t* d, int ldx, int H, int W,
         hipLaunchKernelGGL((bucket_rows_kernel<true>), grid, dim3(256), 0, st, g, pixel_val, sec_grid, per_img, cursor,
                            (const int*)offsets, rows_a, cells_a, wts);
         // the work-list length lives on the device: launch its upper bound, surplus workgroups return at once
-        hipLaunchKernelGGL(bucket_accumulate_kernel, dim3((unsigned)maxwork), dim3(64 * SW), 0, st,
+        hipLaunchKernelGGL(bucket_accumulate_kernel, dim3((unsigned)maxwork), dim3(64 * BSW), 0, st,
                            (const __half*)d, ldx, g, (const int4*)work, (const int*)nwork, (const unsigned*)rows_a,
                            (const unsigned*)cells_a, (const f32x4*)wts, dtab);
         CPN_LAUNCH_CHECK("cpn_scatter_rows_tables");
