@@ -158,7 +158,10 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
 #ifndef CPN_EK_PHASES
 #define CPN_EK_PHASES 2
 #endif
-    const bool early_sync = CPN_EK_PHASES == 2 ? ((wave >> 2) & 1) != 0 : (CPN_EK_PHASES == 3);
+    // CPN_EK_PHASES 4: a third site behind the K = 80 MFMAs for waves 8-11, so that the three waves of a SIMD are in three
+    // different phases (measured: see DESIGN.md 4.1b)
+    const bool early_sync = (CPN_EK_PHASES == 2 || CPN_EK_PHASES == 4) ? ((wave >> 2) == 1) : (CPN_EK_PHASES == 3);
+    const bool mid_sync = CPN_EK_PHASES == 4 && (wave >> 2) == 2;
 
     for (int it = 0; it < iters; ++it) {
         const long long uu_raw = x_begin + (long long)it * per_iter + (long long)wgx * EK_WAVES + wave;
@@ -388,6 +391,11 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                     for (int nt = 0; nt < NT; ++nt)
                         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wt[nt * 48 + tail_lane], xt, acc[nt], 0, 0, 0);
                 }
+                if (!STREAM && mid_sync) {                    // (taps and stores of this step are the 10 operations issued since)
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring_sync(true);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                 }
                 // (second site of the ring barrier: the waves that did not take it behind the tap issue.  In-order vmcnt:
                 // their pieces of this step's slot, issued one step ago before this step's taps, have landed.)
-                if (!STREAM && !early_sync) ring_sync(false);
+                if (!STREAM && !early_sync && !mid_sync) ring_sync(false);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(CPN_EK_ABLATE & 8)) {
                     const half8* slot = STREAM ? reinterpret_cast<const half8*>(sbase) : kring + (gstep & 1) * KSLOT_HALF8;

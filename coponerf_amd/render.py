@@ -696,7 +696,7 @@ class RenderEngine:
         training job or captured get_z graphs in the same process the chunks shrink instead of the call running out of
         memory.  The decision is kept per (S, device, settings) for as long as the workspace of the current call lane already
         holds a chunk of `nrays` rays at that size (nothing would be allocated); otherwise free memory is consulted again."""
-        key = (S, str(dev), self.lanes, self.call_lanes, self.tables, self.fold_value)
+        key = (S, str(dev), self.lanes, self.call_lanes, self.tables, self.fold_value, self.fuse_key)
         hit = self.__dict__.get("_auto_chunk_memo")
         if hit is not None and hit[0] == key:
             have = self._ws.get(self._ws_prefix + "hid.0")
@@ -704,6 +704,8 @@ class RenderEngine:
                 return hit[1]
         nws = max(1, self.lanes) * max(1, self.call_lanes)                              # workspaces alive at once
         per_ray = V * S * (2 * 832 * 2 + 128 * 2 + 4) * nws                             # hid + coords_embed + logits
+        if self.fuse_key and self.tables and self.fold_value:
+            per_ray += V * S * 128 * 2 * nws                                            # + kh of the fused key layer
         if not self.tables:
             per_ray += V * S * 2 * _hip.XIN_STRIDE * 2 * nws
         if not self.fold_value:

@@ -25,7 +25,7 @@ def build():
     for name in ("error.cpp", "streams.cpp"):
         subprocess.check_call(base + [os.path.join(src, name), "-o", os.path.join(BUILD, name.split(".")[0] + ".o")])
     for w in WAVES:
-        for k, ph in [(k, 2) for k in VARIANTS] + [(0, 1), (0, 3), (8, 1), (2, 1)]:
+        for k, ph in [(k, 2) for k in VARIANTS] + [(0, 1), (0, 3), (0, 4), (8, 1), (2, 1)]:
             tag = f"{k}_w{w}" + (f"p{ph}" if ph != 2 else "")
             obj, out = os.path.join(BUILD, f"ek_{tag}.o"), os.path.join(BUILD, f"libek_{tag}.so")
             subprocess.check_call(base + [f"-DCPN_EK_ABLATE={k}", f"-DCPN_EK_WAVES={w}", f"-DCPN_EK_PHASES={ph}",
@@ -72,7 +72,7 @@ def main():
     flush = torch.zeros(256 << 20, dtype=torch.float32, device=dev)          # 1 GB buffer: add_ = 2 GB of traffic
     res = {}
     combos = [(w_, k, v, 2, grp) for w_ in WAVES for grp in a.groups for k, v in VARIANTS.items()]
-    combos += [(12, 0, "full", 1, 0), (12, 0, "full", 3, 0)]
+    combos += [(12, 0, "full", 1, 0), (12, 0, "full", 3, 0), (12, 0, "full", 4, 0)]
     for w_, k, what, ph, grp in combos:
         if True:
             label = f"w{w_} group {grp} phases {ph} {k}: {what}"
