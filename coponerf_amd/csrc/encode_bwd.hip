@@ -285,7 +285,6 @@ __global__ __launch_bounds__(64 * SW) void scatter_tables_kernel(
 // it touches) into the tile's bucket, (4) a 13-wave workgroup per work item streams its bucket and accumulates.
 constexpr int WMAX = 2048;          // rows per work item
 constexpr int NSUB = (TP + 1) * (TPY + 1);   // a tile's bucket is ordered by the row's cell position relative to the tile (-1 .. TP-1, -1 .. TPY-1)
-constexpr int NBB = 32;             // rows per drain batch of the bucketed kernel (64 spill: 128 VGPRs + 92 B of scratch, 2.3 ms slower)
 
 struct BucketGeo {
     int V, R, S, ray0, nrays, nimg, H, W;
@@ -401,19 +400,25 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const int* __restrict
 // thirteen waves at thirteen different moments, from a row drawn at random out of 7 GB: 9.7 GB in 6.35 ms = 1.5 TB/s with
 // the L1 -> L2 latency at a modest 695 clocks, L2 hit rate 9 %, no pipe busy - the DRAM pages are what that pattern wastes.
 // 256-byte requests halve the number of pages touched per byte.
-constexpr int BTC = 128;                                       // channels per wave of bucket_accumulate_kernel
-constexpr int BSW = (TLD + BTC - 1) / BTC;                     // 7 waves
-__global__ __launch_bounds__(64 * BSW) void bucket_accumulate_kernel(const __half* __restrict__ d, int ldx, BucketGeo geo,
+#ifndef CPN_BUCKET_CPL
+#define CPN_BUCKET_CPL 2                                       // channels per lane: 2 (256-byte requests, 7 waves: 4.5 ms) or 4 (512-byte, 4 waves: 4.9 ms; 1 was 6.35)
+#endif
+constexpr int CPL = CPN_BUCKET_CPL;
+constexpr int NBK = 64 / CPL;                                   // rows in flight per wave: the same 8 KiB either way
+constexpr int BTC = 64 * CPL;                                  // channels per wave of bucket_accumulate_kernel
+constexpr int BSW = (TLD + BTC - 1) / BTC;                     // waves per workgroup
+__global__ __launch_bounds__(64 * BSW, 1) void bucket_accumulate_kernel(const __half* __restrict__ d, int ldx, BucketGeo geo,
                                                                      const int4* __restrict__ work, const int* __restrict__ nwork,
                                                                      const unsigned* __restrict__ rows,
                                                                      const unsigned* __restrict__ cellsv,
                                                                      const f32x4* __restrict__ wts, float* __restrict__ dtab) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-    __shared__ f32x2 tiles_lds[BSW][(TP * TPY + 1) * 64];        // 32 node cells + the dummy cell, lane = channel pair
+    typedef float fv __attribute__((ext_vector_type(CPL)));
+    typedef _Float16 hv_t __attribute__((ext_vector_type(CPL)));
+    typedef unsigned uv __attribute__((ext_vector_type(CPL / 2)));
+    __shared__ fv tiles_lds[BSW][(TP * TPY + 1) * 64];           // 32 node cells + the dummy cell, lane = CPL channels
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    f32x2* tile = tiles_lds[wave] + lane;
+    fv* tile = tiles_lds[wave] + lane;
     if ((int)blockIdx.x >= *nwork) return;      // (a persistent walk of the work list, one workgroup per CU, measured 2.7 ms slower)
     {
     const int4 item = work[blockIdx.x];
@@ -422,24 +427,27 @@ __global__ __launch_bounds__(64 * BSW) void bucket_accumulate_kernel(const __hal
     const NodeGridB ng{geo.W >> 1, geo.H >> 1};
     const int nw = ng.w(kind), nh = ng.h(kind);
     const int tx0 = (tidx % geo.tiles_x[kind]) * TP, ty0 = (tidx / geo.tiles_x[kind]) * TPY;
-    const int ch0 = wave * BTC + lane * 2;
-    const bool ch_ok = ch0 < TLD;                                 // the upper half of the last wave has no channels
-    const unsigned* dcol = reinterpret_cast<const unsigned*>(d + (ch_ok ? ch0 : 0));          // one fp16 pair per row
+    const int ch0 = wave * BTC + lane * CPL;
+    const bool ch_ok = ch0 < TLD;                                 // the tail of the last wave has no channels (832 = 6.5 x 128)
+    const uv* dcol = reinterpret_cast<const uv*>(d + (ch_ok ? ch0 : 0));                   // CPL fp16 values per row
+    fv zero;
 #pragma unroll
-    for (int i = 0; i <= TP * TPY; ++i) tile[i * 64] = f32x2{0.0f, 0.0f};
+    for (int c = 0; c < CPL; ++c) zero[c] = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= TP * TPY; ++i) tile[i * 64] = zero;
 
     const int first = item.y, last = item.z - 1;
     // The bucket is ordered by the rows' cell position, so consecutive rows mostly hit the SAME four cells: their sums
     // stay in registers and go to the LDS tile only when the position changes (the first version did four LDS
     // read-modify-writes per row and wave and was bound by the LDS pipe: SQ_ACTIVE_INST_LDS = 86 % of the kernel).
     unsigned held = 0xffffffffu;                                  // cells word of the run in the registers
-    f32x2 a0 = {0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+    fv a0 = zero, a1 = zero, a2 = zero, a3 = zero;
     auto spill = [&]() {
-        f32x2* t0 = tile + (held & 255u) * 64;
-        f32x2* t1 = tile + ((held >> 8) & 255u) * 64;
-        f32x2* t2 = tile + ((held >> 16) & 255u) * 64;
-        f32x2* t3 = tile + (held >> 24) * 64;
-        const f32x2 v0 = *t0, v1 = *t1, v2 = *t2, v3 = *t3;      // the four cells of a position are distinct (or the dummy)
+        fv* t0 = tile + (held & 255u) * 64;
+        fv* t1 = tile + ((held >> 8) & 255u) * 64;
+        fv* t2 = tile + ((held >> 16) & 255u) * 64;
+        fv* t3 = tile + (held >> 24) * 64;
+        const fv v0 = *t0, v1 = *t1, v2 = *t2, v3 = *t3;         // the four cells of a position are distinct (or the dummy)
         *t0 = v0 + a0;
         *t1 = v1 + a1;
         *t2 = v2 + a2;
@@ -448,10 +456,10 @@ __global__ __launch_bounds__(64 * BSW) void bucket_accumulate_kernel(const __hal
     // Per-row descriptors (row index, cells word, four weights) are wave-uniform: lane u of the wave loads the descriptor
     // of row base + u with ordinary coalesced vector loads, two batches ahead, and v_readlane hands each row's values to
     // the scalar side when it is processed (through the scalar cache a batch of 32 rows needs 32 x 6 dwords of SGPRs).
-    static_assert(NBB <= 64, "one descriptor per lane");
+    static_assert(NBK <= 64, "one descriptor per lane");
     struct Desc { unsigned row, cells; f32x4 w; };
     auto load_desc = [&](int base) {
-        const int idx = min(base + (lane < NBB ? lane : NBB - 1), last);
+        const int idx = min(base + (lane < NBK ? lane : NBK - 1), last);
         Desc dsc;
         dsc.row = rows[idx];
         dsc.cells = cellsv[idx];
@@ -460,27 +468,27 @@ __global__ __launch_bounds__(64 * BSW) void bucket_accumulate_kernel(const __hal
     };
     auto lane_u = [](unsigned v, int u) { return (unsigned)__builtin_amdgcn_readlane((int)v, u); };
     auto lane_f = [](float v, int u) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), u)); };
-    const size_t ldw = (size_t)ldx / 2;                           // row pitch in fp16 pairs (ldx is even)
-    unsigned cur[NBB], nxt[NBB];
-    Desc dcur = load_desc(first), dnxt = load_desc(first + NBB);
+    const size_t ldw = (size_t)ldx / CPL;                         // row pitch in units of CPL fp16 values
+    uv cur[NBK], nxt[NBK];
+    Desc dcur = load_desc(first), dnxt = load_desc(first + NBK);
 #pragma unroll
-    for (int u = 0; u < NBB; ++u) nxt[u] = dcol[(size_t)lane_u(dcur.row, u) * ldw];
-    for (int base = first; base <= last; base += NBB) {
-        const Desc dfar = load_desc(base + 2 * NBB);              // descriptors of the batch after next
+    for (int u = 0; u < NBK; ++u) nxt[u] = dcol[(size_t)lane_u(dcur.row, u) * ldw];
+    for (int base = first; base <= last; base += NBK) {
+        const Desc dfar = load_desc(base + 2 * NBK);              // descriptors of the batch after next
 #pragma unroll
-        for (int u = 0; u < NBB; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < NBK; ++u) cur[u] = nxt[u];
 #pragma unroll
-        for (int u = 0; u < NBB; ++u) nxt[u] = dcol[(size_t)lane_u(dnxt.row, u) * ldw];     // rows past `last` repeat the last one
+        for (int u = 0; u < NBK; ++u) nxt[u] = dcol[(size_t)lane_u(dnxt.row, u) * ldw];     // rows past `last` repeat the last one
 #pragma unroll
-        for (int u = 0; u < NBB; ++u) {
+        for (int u = 0; u < NBK; ++u) {
             if (base + u > last) break;
-            const half2v hv = __builtin_bit_cast(half2v, cur[u]);
-            const f32x2 du = {(float)hv[0], (float)hv[1]};
+            const hv_t hv = __builtin_bit_cast(hv_t, cur[u]);
+            const fv du = __builtin_convertvector(hv, fv);
             const unsigned cells = lane_u(dcur.cells, u);
             if (cells != held) {                                  // wave-uniform
                 if (held != 0xffffffffu) spill();
                 held = cells;
-                a0 = a1 = a2 = a3 = f32x2{0.0f, 0.0f};
+                a0 = a1 = a2 = a3 = zero;
             }
             a0 += du * lane_f(dcur.w[0], u);
             a1 += du * lane_f(dcur.w[1], u);
@@ -494,15 +502,19 @@ __global__ __launch_bounds__(64 * BSW) void bucket_accumulate_kernel(const __hal
     float* m = dtab + ((size_t)img * ng.per_image() + (kind ? ng.border_nodes() : 0)) * TLD + (ch_ok ? ch0 : 0);
 #pragma unroll 4
     for (int pix = 0; pix < TP * TPY; ++pix) {
-        const f32x2 v = tile[pix * 64];
+        const fv v = tile[pix * 64];
         const int gy = ty0 + (pix >> 3), gx = tx0 + (pix & 7);
-        if (ch_ok && gy < nh && gx < nw && (v[0] != 0.0f || v[1] != 0.0f)) {
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) any = any || v[c] != 0.0f;
+        if (ch_ok && gy < nh && gx < nw && any) {
             float* o = m + ((size_t)gy * nw + gx) * TLD;
             if (item.w) {                                          // the tile was split over several work items
-                if (v[0] != 0.0f) atomicAdd(o, v[0]);
-                if (v[1] != 0.0f) atomicAdd(o + 1, v[1]);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c)
+                    if (v[c] != 0.0f) atomicAdd(o + c, v[c]);
             } else {
-                *reinterpret_cast<f32x2*>(o) = v;                  // its only writer: dtab is zero on entry
+                *reinterpret_cast<fv*>(o) = v;                     // its only writer: dtab is zero on entry
             }
         }
     }
@@ -680,8 +692,8 @@ extern "C" int cpn_scatter_rows_tables(const uint16_t* d, int ldx, int H, int W,
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && (H % 16) == 0 && (W % 16) == 0 && ldx >= TLD, CPN_E_SHAPE,
                 "cpn_scatter_rows_tables: bad shape");
     CPN_REQUIRE(H <= 1024 && W <= 1024, CPN_E_SHAPE, "cpn_scatter_rows_tables: maps larger than 1024 pixels a side");
-    CPN_REQUIRE((ldx % 2) == 0 && ((uintptr_t)d % 4) == 0 && ((uintptr_t)dtab % 8) == 0, CPN_E_ARG,
-                "cpn_scatter_rows_tables: d must be 4-byte aligned with an even ldx, dtab 8-byte aligned");
+    CPN_REQUIRE((ldx % CPL) == 0 && ((uintptr_t)d % (2 * CPL)) == 0 && ((uintptr_t)dtab % (4 * CPL)) == 0, CPN_E_ARG,
+                "cpn_scatter_rows_tables: d must be %d-byte aligned with ldx a multiple of %d, dtab %d-byte aligned", 2 * CPL, CPL, 4 * CPL);
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_scatter_rows_tables: ray range outside B*R");
     CPN_REQUIRE((long long)nrays * V * S * 2 < (1LL << 31) && ((uintptr_t)scratch % 16) == 0, CPN_E_SHAPE,
