@@ -66,6 +66,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_dual_softmax_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "cpn_l2norm_rows_bwd": [_P, _P, _P, ctypes.c_longlong, _I, _F, _P, _P],
+    "cpn_wgrad_f32": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
     "cpn_soft_argmax_pair": [_P, _I, _I, _F, _P, _P, _P],
     "cpn_soft_argmax_pair_bwd": [_P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "cpn_linear_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
@@ -159,6 +160,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_conv_wgrad_scratch.restype = ctypes.c_longlong
     handle.cpn_dwconv3x3_tokens_wgrad_scratch.argtypes = [_I, _I, _I]
     handle.cpn_dwconv3x3_tokens_wgrad_scratch.restype = ctypes.c_longlong
+    handle.cpn_wgrad_f32_scratch_floats.argtypes = [ctypes.c_longlong, _I, _I]
+    handle.cpn_wgrad_f32_scratch_floats.restype = ctypes.c_longlong
     handle.cpn_last_error.argtypes = []
     handle.cpn_last_error.restype = ctypes.c_char_p
     got = handle.cpn_abi_version()

@@ -33,6 +33,7 @@ UNITS = [
     ("input.hip", []),
     ("backward.hip", []),
     ("wgrad_tall.hip", []),
+    ("wgrad_f32.hip", []),
 ]
 
 

@@ -27,6 +27,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .ufc_ops import Linear as _Linear, linear as _linear      # nn.Linear / F.linear with the training dW on cpn_wgrad_f32
+
 
 # ----------------------------------------------------------------------------------------------
 # ResNet-34 trunk with torchvision-compatible parameter names (encoder.model.*)
@@ -237,19 +239,19 @@ class UFCLayer(nn.Module):
     def __init__(self, fs: int, f2c: Tuple[int, int, int], nhead: int = 8, d: int = 256):
         super().__init__()
         self.fs, self.nhead, self.dim = fs, nhead, d // nhead
-        self.q_proj = nn.Linear(d + 256 * nhead, d)
-        self.k_proj = nn.Linear(d + 256 * nhead, d)
-        self.v_proj = nn.Linear(d, d)
+        self.q_proj = _Linear(d + 256 * nhead, d)
+        self.k_proj = _Linear(d + 256 * nhead, d)
+        self.v_proj = _Linear(d, d)
         self.v_proj_corr = Encoder4D((nhead, nhead))
-        self.mlp = nn.Sequential(nn.Linear(d, 4 * d), _DWConv(4 * d, fs), nn.GELU(), nn.Linear(4 * d, d))
+        self.mlp = nn.Sequential(_Linear(d, 4 * d), _DWConv(4 * d, fs), nn.GELU(), _Linear(4 * d, d))
         self.mlp_corr = Encoder4D((nhead, 4 * nhead, nhead))
-        self.mlp_cross = nn.Sequential(nn.Linear(d, 4 * d), _DWConv(4 * d, fs), nn.GELU(), nn.Linear(4 * d, d))
+        self.mlp_cross = nn.Sequential(_Linear(d, 4 * d), _DWConv(4 * d, fs), nn.GELU(), _Linear(4 * d, d))
         self.mlp_refine_corr = Encoder4D((nhead, 4 * nhead, nhead))
         self.mlp_refine_corr2 = Encoder4D((nhead, 4 * nhead, nhead))
         self.feat_to_corr1 = Encoder4D((1, nhead), *f2c)
         self.feat_to_corr2 = Encoder4D((1, nhead), *f2c)
         self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
-        self.v_cross = nn.Linear(d, d)
+        self.v_cross = _Linear(d, d)
         self.norm_cross1, self.norm_cross2 = nn.LayerNorm(d), nn.LayerNorm(d)
         self.pos_embed = nn.Parameter(torch.zeros(1, fs * fs, 1, self.dim))
         nn.init.trunc_normal_(self.pos_embed, std=.02)
@@ -299,7 +301,7 @@ class UFCLayer(nn.Module):
         fs, d = self.fs, self.nhead * self.dim
         Wc, Wf, bqk, pos = self._qk_weights(H * Ht * Wt)
         low = torch.matmul(Wc, _corr_to_maps(corr).flatten(2)).view(B, 2 * d, Hs, Ws)      # (B, 2d, Hs, Ws): IS the map layout
-        lin = F.linear(feat_n, Wf, bqk)                                                   # (B, L, 2d)
+        lin = _linear(feat_n, Wf, bqk)                                                    # (B, L, 2d)
         if torch.is_grad_enabled() and (lin.requires_grad or low.requires_grad) or not lin.is_cuda:
             qk = (lin + _map_to_tokens(ops.resize_bilinear(low, fs))).view(B, -1, 2, self.nhead, self.dim) + pos[None, :, None, None, :]
             return qk.unbind(2)
@@ -453,7 +455,7 @@ class UFC(nn.Module):
         cfg = [(16, (3, 1, 1), 2), (32, (3, 2, 1), 2), (64, (5, 4, 2), 1)]
         self.layers = nn.ModuleList([nn.ModuleList([UFCLayer(fs, f2c, nhead) for _ in range(n)]) for fs, f2c, n in cfg])
         self.embedding = nn.ModuleList([Encoder4D((1, nhead), *f2c) for _, f2c, _ in cfg])
-        self.proj_feat = nn.ModuleList([nn.Sequential(nn.Linear(c, 256), nn.ReLU()) for c in (512, 256, 128)])
+        self.proj_feat = nn.ModuleList([nn.Sequential(_Linear(c, 256), nn.ReLU()) for c in (512, 256, 128)])
 
     def forward(self, feat: Sequence[torch.Tensor], nview: int, ops):
         B2 = feat[0].shape[0]
@@ -518,7 +520,7 @@ def positional_encodings(fx, fy, cx, cy, n: int = 64):
 class _Mlp(nn.Module):
     def __init__(self, d: int, hidden: int):
         super().__init__()
-        self.fc1, self.act, self.fc2 = nn.Linear(d, hidden), nn.GELU(), nn.Linear(hidden, d)
+        self.fc1, self.act, self.fc2 = _Linear(d, hidden), nn.GELU(), _Linear(hidden, d)
 
     def forward(self, x):
         return self.fc2(self.act(self.fc1(x)))
@@ -527,8 +529,8 @@ class _Mlp(nn.Module):
 class _CrossAttention(nn.Module):
     def __init__(self, dim: int):
         super().__init__()
-        self.qkv = nn.Linear(dim, dim * 3, bias=False)          # unused upstream too (backbone.py:296); checkpoint key
-        self.proj_fundamental = nn.Linear(dim + 6, dim)
+        self.qkv = _Linear(dim, dim * 3, bias=False)          # unused upstream too (backbone.py:296); checkpoint key
+        self.proj_fundamental = _Linear(dim + 6, dim)
 
     def forward(self, x1, x2, corr, intr, ops):
         B = x1.shape[0]
@@ -587,9 +589,9 @@ def imagenet_normalise(x):
 
 
 def make_pose_heads():
-    mlp = lambda dims: [m for i in range(len(dims) - 1) for m in (nn.ReLU(), nn.Linear(dims[i], dims[i + 1]))]
-    pose = nn.Sequential(nn.Linear((16 * 16 + 6) * 256 * 2, 512), nn.ReLU(), nn.Linear(512, 256), nn.ReLU(),
-                         nn.Linear(256, 128 * 2), nn.ReLU())
+    mlp = lambda dims: [m for i in range(len(dims) - 1) for m in (nn.ReLU(), _Linear(dims[i], dims[i + 1]))]
+    pose = nn.Sequential(_Linear((16 * 16 + 6) * 256 * 2, 512), nn.ReLU(), _Linear(512, 256), nn.ReLU(),
+                         _Linear(256, 128 * 2), nn.ReLU())
     return pose, nn.Sequential(*mlp([128, 64, 32, 6])), nn.Sequential(*mlp([128, 64, 32, 3]))
 
 

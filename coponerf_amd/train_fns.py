@@ -189,7 +189,9 @@ class LinearF32Fn(Function):
         dX = d @ W
         if ctx.relu_in:
             dX = dX * (X > 0)
-        return dX, d.t() @ Xa, (d.sum(0) if ctx.has_b else None), (d if ctx.has_res else None), None, None
+        from .ufc_ops import wgrad_f32
+        dW, db = wgrad_f32(d, Xa, ctx.has_b)
+        return dX, dW, db, (d if ctx.has_res else None), None, None
 
 
 class LocalHiddenFn(Function):

@@ -45,6 +45,65 @@ class _HipForwardVjp(Function):
         return (None, None) + tuple(next(it) if n else None for n in need)
 
 
+WGRAD_MIN_ROWS = 256        # below this many tokens the library's TN GEMM is as good
+
+
+def wgrad_f32(dY2, X2, want_bias: bool):
+    """dW (O, I) = dY2^T . X2 and db (O) = dY2.sum(0) of a Linear layer: cpn_wgrad_f32 (row slabs on the fp32 MFMA, one
+    launch + a fixed-order reduction) where its layout rules hold, the stock products otherwise."""
+    R, O = dY2.shape
+    I = X2.shape[1]
+    ok = (dY2.is_cuda and dY2.dtype == torch.float32 and X2.dtype == torch.float32 and R >= WGRAD_MIN_ROWS
+          and O % 4 == 0 and I % 4 == 0)
+    if ok:
+        if dY2.stride(1) != 1 or dY2.stride(0) % 4 or dY2.data_ptr() % 16:
+            dY2 = dY2.contiguous()
+        if X2.stride(1) != 1 or X2.stride(0) % 4 or X2.data_ptr() % 16:
+            X2 = X2.contiguous()
+        dW = torch.empty(O, I, dtype=torch.float32, device=dY2.device)
+        db = torch.empty(O, dtype=torch.float32, device=dY2.device) if want_bias else None
+        scratch = torch.empty(_hip.lib().cpn_wgrad_f32_scratch_floats(R, O, I), dtype=torch.float32, device=dY2.device)
+        call("cpn_wgrad_f32", dY2.data_ptr(), dY2.stride(0), X2.data_ptr(), X2.stride(0), R, O, I, dW.data_ptr(),
+             0 if db is None else db.data_ptr(), scratch.data_ptr(), _stream())
+        return dW, db
+    return dY2.t() @ X2, (dY2.sum(0) if want_bias else None)
+
+
+class LinearFn(Function):
+    """y = x . W^T + b as the library computes it; backward: dx from the library, dW and db from `wgrad_f32`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dy.matmul(w) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = wgrad_f32(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]),
+                               ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, dW, db
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear; under autograd on the GPU with the weight gradient on `cpn_wgrad_f32`."""
+    if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.numel() // x.shape[-1] >= WGRAD_MIN_ROWS
+            and (weight.requires_grad or (bias is not None and bias.requires_grad))):
+        return LinearFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+class Linear(torch.nn.Linear):
+    """nn.Linear (same parameters, same checkpoint keys) whose training backward uses `linear` above."""
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)
+
+
 class _CorrelationFn(Function):
     """correlation_tokens with a closed-form backward on the normalised tokens the forward kernel already wrote:
     C = sn tn^T, sn = s / (|s| + eps)  =>  dsn = dC tn, dtn = dC^T sn, ds = dsn / (|s| + eps) - sn (sn . dsn) / |s|.

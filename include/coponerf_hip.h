@@ -398,6 +398,17 @@ int cpn_correlation(const float* src, const float* trg, int B, int L, int C, flo
 int cpn_l2norm_rows_bwd(const float* x, const float* y, const float* dy, long long rows, int C, float eps,
                         float* dx, void* stream);
 
+/* ---- weight / bias gradient of an fp32 Linear layer (training, round 4) ---------------------------------
+ * replaces the dW = dY^T . X and db = dY.sum(0) autograd performs for torch.nn.functional.linear
+ * (models/aggregation.py:200-260 projection and feed-forward layers of the cost aggregation; models/CoPoNeRF.py:468 and
+ * models/lightfield.py:52-61,131-167 per-ray layers): the tokens R are the contraction index of both row-major operands.
+ *   dY (R, O) row stride ldy   X (R, I) row stride ldx   ->   dW (O, I) contiguous, db (O) or NULL
+ *   O, I, ldy, ldx multiples of 4, operands 16-byte aligned; exact fp32 products (v_mfma_f32_16x16x4_f32), row slabs summed
+ *   in a fixed order (deterministic); scratch: cpn_wgrad_f32_scratch_floats(R, O, I) floats                              */
+long long cpn_wgrad_f32_scratch_floats(long long R, int O, int I);
+int cpn_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, long long R, int O, int I, float* dW, float* db,
+                  float* scratch, void* stream);
+
 /* ---- K8: soft-argmax with temperature over the 4-D correlation, both directions --------------------
  * replaces aggregation.soft_argmax + softmax_with_temperature (models/aggregation.py:119-144, 555-560).
  * c (B, h*h source, h*h target); t_to_s[b,:,s] = E_{t ~ softmax_t(c[b,s,:]/beta)}[(x_t, y_t)],

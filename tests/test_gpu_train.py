@@ -490,3 +490,57 @@ def test_resize_adjoint_kernel_equals_library_backward(h, n):
     assert got.shape == want.shape
     assert float((got - want).abs().max()) <= 5e-6 * max(1.0, float(want.abs().max()))      # a few ulps over <= 100 terms
     assert torch.equal(got, ufc_ops._resize_adjoint_hip(g, h))              # run-to-run identical
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,O,I,ldy,ldx", [(256, 4, 4, 4, 4), (257, 64, 64, 64, 64), (1000, 128, 144, 128, 144),
+                                           (4099, 68, 260, 72, 264), (8192, 256, 1024, 256, 1024),
+                                           (32768, 1024, 256, 1024, 256), (16384, 128, 416, 128, 416)])
+def test_linear_weight_gradient_kernel(R, O, I, ldy, ldx):
+    """cpn_wgrad_f32 (dW = dY^T . X, db = column sums, row slabs summed in a fixed order) against float64 products: exact
+    fp32 products and fp32 accumulation, so the error is that of an fp32 sum of R terms; run twice -> bit-identical;
+    strided operands (a view with a wider row) give the same bits as their contiguous copies."""
+    from coponerf_amd.ufc_ops import wgrad_f32
+    dev = torch.device("cuda:0")
+    dYw = syn.normal((R, ldy), seed=R + O).to(dev)
+    Xw = syn.normal((R, ldx), seed=R + I + 1).to(dev)
+    dY, X = dYw[:, :O], Xw[:, :I]
+    dW, db = wgrad_f32(dY, X, True)
+    ref_w = (dY.double().t() @ X.double())
+    ref_b = dY.double().sum(0)
+    scale = (R ** 0.5)
+    assert float((dW.double() - ref_w).abs().max()) <= 2e-5 * scale
+    assert float((db.double() - ref_b).abs().max()) <= 2e-5 * scale
+    dW2, db2 = wgrad_f32(dY, X, True)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    dW3, db3 = wgrad_f32(dY.contiguous(), X.contiguous(), True)
+    assert torch.equal(dW, dW3) and torch.equal(db, db3)
+    dW4, none = wgrad_f32(dY, X, False)
+    assert none is None and torch.equal(dW, dW4)
+
+
+@pytest.mark.gpu
+def test_linear_layer_backward_equals_library_backward():
+    """ufc_ops.Linear (nn.Linear whose training backward runs dW / db on cpn_wgrad_f32): same forward bits as nn.Linear,
+    gradients equal to the library's to fp32 summation order; small token counts and no-grad calls take the stock path."""
+    from coponerf_amd.ufc_ops import Linear, LinearFn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    ref = torch.nn.Linear(256, 1024).to(dev)
+    mine = Linear(256, 1024).to(dev)
+    mine.load_state_dict(ref.state_dict())
+    x = syn.normal((2, 4096, 256), seed=9).to(dev)
+    g = syn.normal((2, 4096, 1024), seed=10).to(dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = ref(xa), mine(xb)
+    assert type(yb.grad_fn).__name__ == "LinearFnBackward"
+    assert torch.equal(ya, yb)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.equal(xa.grad, xb.grad)
+    for pa, pb in zip(ref.parameters(), mine.parameters()):
+        assert float((pa.grad - pb.grad).abs().max()) <= 2e-4 * float(pa.grad.abs().max())
+    small = mine(x[:, :100].reshape(-1, 256).requires_grad_(True))
+    assert type(small.grad_fn).__name__ != "LinearFnBackward"
+    with torch.no_grad():
+        assert mine(x).grad_fn is None
