@@ -67,6 +67,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "cpn_l2norm_rows_bwd": [_P, _P, _P, ctypes.c_longlong, _I, _F, _P, _P],
     "cpn_wgrad_f32": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
+    "cpn_adam_step": [_P, _P, _I, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P],
     "cpn_soft_argmax_pair": [_P, _I, _I, _F, _P, _P, _P],
     "cpn_soft_argmax_pair_bwd": [_P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "cpn_linear_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
@@ -91,7 +92,8 @@ TAB_LD = 832
 K80_BLOCK_HALVES = 5120          # CPN_K80_BLOCK_HALVES: one slice of the streamed K = 80 weight block (cpn_encode_key)
 RAYC_STRIDE = 64
 LIGHTFIELD_PACK_FLOATS = 128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16
-ABI_VERSION = 4
+ABI_VERSION = 5
+ADAM_SEG_BYTES = 48
 
 
 def declared_symbols() -> List[str]:
@@ -162,6 +164,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_dwconv3x3_tokens_wgrad_scratch.restype = ctypes.c_longlong
     handle.cpn_wgrad_f32_scratch_floats.argtypes = [ctypes.c_longlong, _I, _I]
     handle.cpn_wgrad_f32_scratch_floats.restype = ctypes.c_longlong
+    handle.cpn_adam_chunk.argtypes = []
+    handle.cpn_adam_chunk.restype = ctypes.c_int
     handle.cpn_last_error.argtypes = []
     handle.cpn_last_error.restype = ctypes.c_char_p
     got = handle.cpn_abi_version()

@@ -34,6 +34,7 @@ UNITS = [
     ("backward.hip", []),
     ("wgrad_tall.hip", []),
     ("wgrad_f32.hip", []),
+    ("adam.hip", []),
 ]
 
 

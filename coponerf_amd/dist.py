@@ -64,6 +64,21 @@ def guard_and_clip(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, 
     MIN-all-reduced, by every rank whether or not it has gradients: every rank takes the same branch.  Clipping (per rank, BEFORE the
     exchange, like the reference) scales the gradients in place by min(1, max_norm / (norm + 1e-6)).
     Returns (finite: bool, total_norm: float64 tensor)."""
+    finite, total, grads, coef = _guard(params, max_norm, group, force)
+    if coef is not None:
+        torch._foreach_mul_(grads, coef)
+    return finite, total
+
+
+def guard_and_clip_coefficient(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, group=None, force: bool = False):
+    """`guard_and_clip` that leaves the gradients alone and hands the clip coefficient back as a device scalar (None: nothing
+    to clip) for a caller that applies it inside its update kernel — only where no exchange follows the clip.
+    Returns (finite, total_norm, coef)."""
+    finite, total, _, coef = _guard(params, max_norm, group, force)
+    return finite, total, coef
+
+
+def _guard(params, max_norm, group, force):
     plist = list(params)
     grads = [p.grad for p in plist if p.grad is not None]
     if grads:
@@ -78,12 +93,12 @@ def guard_and_clip(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0, 
     if _exchanging(group, force):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if not grads:
-        return bool(ok.item() > 0), total
+        return bool(ok.item() > 0), total, grads, None
     finite = bool(ok.item() > 0)
+    coef = None
     if finite and max_norm and max_norm > 0:
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0).float()
-        torch._foreach_mul_(grads, coef)
-    return finite, total
+    return finite, total, grads, coef
 
 
 def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,

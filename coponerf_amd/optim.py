@@ -1,0 +1,116 @@
+"""torch.optim.Adam for the training step's parameters as ONE launch (csrc/adam.hip).
+
+The reference's loop steps `torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8)` (/root/reference train.py:102-105,
+wrapper.py:149-151).  The moments of all tensors live in two flat buffers; the kernel finds parameters and gradients through
+a device table whose gradient addresses (new tensors every step) and bias corrections the host rewrites per step: 30 KB
+through a pinned buffer, under the GPU's backward pass.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import call
+
+_SEG = np.dtype([("p", "<u8"), ("g", "<u8"), ("off", "<i8"), ("n", "<i4"), ("step_size", "<f4"), ("inv_sqrt_bc2", "<f4"),
+                 ("pad", "<i4", (3,))])
+assert _SEG.itemsize == _hip.ADAM_SEG_BYTES
+
+
+class OneLaunchAdam:
+    """Adam (no weight decay, no amsgrad) over fp32 CUDA parameters.  `step(gscale)`: gscale = optional device scalar
+    multiplied into every gradient first (the clip coefficient).  A parameter without a gradient is skipped and keeps its
+    update count, like torch.optim.Adam."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.params = list(params)
+        assert self.params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in self.params), \
+            "OneLaunchAdam: fp32 contiguous CUDA parameters only"
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        dev = self.params[0].device
+        n = len(self.params)
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        chunk = _hip.lib().cpn_adam_chunk()
+        blocks = np.array([(t, s) for t, p in enumerate(self.params) for s in range(0, p.numel(), chunk)], dtype=np.int32)
+        self.nblocks = int(blocks.shape[0])
+        self._blocks = torch.from_numpy(blocks).to(dev)
+        self.steps = np.zeros(n, dtype=np.int64)
+        self._host = [torch.empty(n * _SEG.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self._host_np = [h.numpy().view(_SEG) for h in self._host]
+        for seg in self._host_np:
+            seg["p"] = [p.data_ptr() for p in self.params]
+            seg["off"] = offs
+            seg["n"] = [p.numel() for p in self.params]
+            seg["pad"] = 0
+        self._dev = [torch.empty(n * _SEG.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._sent = [None, None]
+        self._turn = 0
+
+    def moments(self, i: int):
+        """(exp_avg, exp_avg_sq) of parameter i as views shaped like it."""
+        p = self.params[i]
+        o = int(self._host_np[0]["off"][i])
+        return self.exp_avg[o:o + p.numel()].view_as(p), self.exp_avg_sq[o:o + p.numel()].view_as(p)
+
+    @torch.no_grad()
+    def prepare(self) -> None:
+        """Host half of a step: collect the gradient addresses, write the table, start its upload.  Callable as soon as the
+        backward pass is ENQUEUED (addresses exist then) — a caller that reads a device flag before it steps does this first,
+        so the ~0.8 ms of Python run under the GPU's backward pass.  The update counts move in `step`."""
+        i = self._turn & 1
+        if self._sent[i] is not None:
+            self._sent[i].synchronize()                       # the copy two steps ago read this pinned block
+        seg = self._host_np[i]
+        n = len(self.params)
+        pptr, gptr = np.empty(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        for j, p in enumerate(self.params):
+            g = p.grad
+            pptr[j] = p.data_ptr()
+            if g is None:
+                continue
+            if not (g.is_contiguous() and g.dtype == torch.float32):
+                g = p.grad = g.contiguous().float()
+            gptr[j] = g.data_ptr()
+        self._has = gptr != 0
+        k = np.maximum(self.steps + self._has, 1).astype(np.float64)
+        b1, b2 = self.betas
+        seg["p"], seg["g"] = pptr, gptr
+        seg["step_size"] = (self.lr / (1.0 - b1 ** k)).astype(np.float32)
+        seg["inv_sqrt_bc2"] = (1.0 / np.sqrt(1.0 - b2 ** k)).astype(np.float32)
+        self._dev[i].copy_(self._host[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._sent[i] = ev
+        self._prepared = True
+
+    @torch.no_grad()
+    def step(self, gscale: Optional[torch.Tensor] = None) -> None:
+        if not getattr(self, "_prepared", False):
+            self.prepare()
+        i = self._turn & 1
+        self._turn += 1
+        self._prepared = False
+        self.steps += self._has
+        b1, b2 = self.betas
+        call("cpn_adam_step", self._dev[i].data_ptr(), self._blocks.data_ptr(), self.nblocks, self.exp_avg.data_ptr(),
+             self.exp_avg_sq.data_ptr(), 0 if gscale is None else gscale.data_ptr(), b1, b2, self.eps,
+             torch.cuda.current_stream().cuda_stream)
+
+    def discard(self) -> None:
+        """Drop a prepared table (the step is skipped); its slot is written again by the next `prepare`."""
+        self._prepared = False
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 4
+#define CPN_ABI_VERSION 5
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -408,6 +408,19 @@ int cpn_l2norm_rows_bwd(const float* x, const float* y, const float* dy, long lo
 long long cpn_wgrad_f32_scratch_floats(long long R, int O, int I);
 int cpn_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, long long R, int O, int I, float* dW, float* db,
                   float* scratch, void* stream);
+
+/* ---- the Adam update of every parameter tensor, ONE launch (training, round 4) ------------------------------
+ * replaces torch.optim.Adam.step() in the reference's loop (train.py:102-105, wrapper.py:149-151): default betas / eps, no
+ * weight decay, no amsgrad; fp32, the operation order of the library's fused kernel.
+ *   segs: device array of CPN_ADAM_SEG_BYTES-byte records, one per tensor, little-endian:
+ *         { float* param; const float* grad (NULL: tensor skipped); int64 offset of its moments in exp_avg / exp_avg_sq
+ *           (multiple of 4); int32 numel; float step_size = lr / (1 - beta1^k); float 1 / sqrt(1 - beta2^k); 12 bytes pad }
+ *   blocks: device array of nblocks x { int32 tensor, int32 first element }: cpn_adam_chunk() elements per block
+ *   gscale: device scalar multiplied into every gradient first (the clip coefficient), or NULL                         */
+#define CPN_ADAM_SEG_BYTES 48
+int cpn_adam_chunk(void);
+int cpn_adam_step(const void* segs, const int* blocks, int nblocks, float* exp_avg, float* exp_avg_sq,
+                  const float* gscale, double beta1, double beta2, double eps, void* stream);
 
 /* ---- K8: soft-argmax with temperature over the 4-D correlation, both directions --------------------
  * replaces aggregation.soft_argmax + softmax_with_temperature (models/aggregation.py:119-144, 555-560).

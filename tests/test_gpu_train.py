@@ -544,3 +544,36 @@ def test_linear_layer_backward_equals_library_backward():
     assert type(small.grad_fn).__name__ != "LinearFnBackward"
     with torch.no_grad():
         assert mine(x).grad_fn is None
+
+
+@pytest.mark.gpu
+def test_one_launch_adam_equals_library_adam():
+    """optim.OneLaunchAdam (cpn_adam_step: every tensor in one launch, moments in flat buffers) against torch.optim.Adam over
+    four steps: odd sizes (vector body + scalar tail, one block and many), a tensor that has no gradient in step 2 (skipped,
+    keeps its own bias-correction count), a gradient scale applied inside the update (= scaling the gradients first)."""
+    from coponerf_amd.optim import OneLaunchAdam
+    dev = torch.device("cuda:0")
+    shapes = [(3,), (5, 1), (2049,), (4100,), (64, 33), (256, 1024), (1,)]
+    mine = [torch.nn.Parameter(syn.normal(s, seed=40 + i).to(dev)) for i, s in enumerate(shapes)]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    a, b = OneLaunchAdam(mine, lr=2e-4), torch.optim.Adam(ref, lr=2e-4)
+    for step in range(4):
+        scale = torch.tensor(0.37 if step % 2 else 1.0, device=dev)
+        for i, (p, q) in enumerate(zip(mine, ref)):
+            if step == 2 and i == 3:
+                p.grad = q.grad = None
+                continue
+            g = syn.normal(shapes[i], seed=100 * step + i).to(dev) * (10.0 ** (i - 3))
+            p.grad, q.grad = g.clone(), g * scale
+        a.step(gscale=scale)
+        b.step()
+        for i, (p, q) in enumerate(zip(mine, ref)):
+            assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-9, (step, i)
+    for i, q in enumerate(ref):
+        m, v = a.moments(i)
+        st = b.state[q]
+        assert float((m - st["exp_avg"]).abs().max()) <= 1e-6 * float(st["exp_avg"].abs().max()) + 1e-12
+        assert float((v - st["exp_avg_sq"]).abs().max()) <= 1e-6 * float(st["exp_avg_sq"].abs().max()) + 1e-12
+    assert a.steps.tolist() == [4, 4, 4, 3, 4, 4, 4]
+    a.zero_grad()
+    assert all(p.grad is None for p in mine)

@@ -82,6 +82,14 @@ def main():
     for (n, _, _), v in agg.items():
         by_op[n] += v[0]
     print("by op:", ", ".join(f"{n} {t / 1e3:.2f}" for n, t in by_op.most_common(25)))
+    by_site = collections.defaultdict(lambda: [0.0, 0])
+    for (n, _, frame), v in agg.items():
+        by_site[(n, frame)][0] += v[0]
+        by_site[(n, frame)][1] += v[1]
+    print("by op and site:")
+    for (n, frame), (t, c) in sorted(by_site.items(), key=lambda kv: -kv[1][0])[:a.top]:
+        print(f"{t / 1e3:7.3f} ms x{c:4d}  {n:32s} {frame}")
+    print("by op, shape and site:")
     for (n, shp, frame), (t, c, mx) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:a.top]:
         print(f"{t / 1e3:7.3f} ms x{c:4d} max {mx:7.1f} us  {n:32s} {shp:90s} {frame}")
 
