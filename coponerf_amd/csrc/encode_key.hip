@@ -24,7 +24,8 @@
 #include <algorithm>
 
 // timing-only ablations (results are wrong when non-zero): 1 = no table taps, 2 = no hid stores, 4 = no K = 80 MFMA,
-// 8 = no key MFMA (no LDS reads of the ring either), 64 = no ring traffic (no DMA, no barrier: weights are garbage)
+// 8 = no key MFMA (no LDS reads of the ring either), 64 = no ring traffic (no DMA, no barrier: weights are garbage),
+// 16 / 32 = every key / K = 80 MFMA of a slice on the SAME LDS fragment (the MFMAs stay, 16 -> 1 / 12 -> 2 LDS reads)
 #ifndef CPN_EK_ABLATE
 #define CPN_EK_ABLATE 0
 #endif
@@ -386,10 +387,10 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                     for (int k = 0; k < 2; ++k)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[(k * NT + nt) * 64 + lane], xa[k], acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[((CPN_EK_ABLATE & 32) ? 0 : (k * NT + nt) * 64) + lane], xa[k], acc[nt], 0, 0, 0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wt[nt * 48 + tail_lane], xt, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wt[((CPN_EK_ABLATE & 32) ? 0 : nt * 48) + tail_lane], xt, acc[nt], 0, 0, 0);
                 }
                 if (!STREAM && mid_sync) {                    // (taps and stores of this step are the 10 operations issued since)
                     __builtin_amdgcn_sched_barrier(0);
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
                     for (int t = 0; t < KT; ++t)
 #pragma unroll
                         for (int k = 0; k < 2; ++k)
-                            kacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(slot[(t * 2 + k) * 64 + lane], xb[k], kacc[t], 0, 0, 0);
+                            kacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(slot[((CPN_EK_ABLATE & 16) ? 0 : (t * 2 + k) * 64) + lane], xb[k], kacc[t], 0, 0, 0);
                 }
                 ++gstep;
             }
