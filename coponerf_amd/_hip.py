@@ -77,6 +77,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_cost_volume_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "cpn_cross_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_conv_map7x7": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "cpn_pack_conv_weight": [_P, _I, _I, _I, _P, _P],
+    "cpn_trunk_conv_bn_act": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P],
     "cpn_bn_act": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P],
     "cpn_prepare_input": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_resize_bilinear_ac": [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _P],
@@ -164,6 +166,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_dwconv3x3_tokens_wgrad_scratch.restype = ctypes.c_longlong
     handle.cpn_wgrad_f32_scratch_floats.argtypes = [ctypes.c_longlong, _I, _I]
     handle.cpn_wgrad_f32_scratch_floats.restype = ctypes.c_longlong
+    handle.cpn_trunk_conv_scratch_floats.argtypes = [_I] * 7
+    handle.cpn_trunk_conv_scratch_floats.restype = ctypes.c_longlong
     handle.cpn_adam_chunk.argtypes = []
     handle.cpn_adam_chunk.restype = ctypes.c_int
     handle.cpn_last_error.argtypes = []

@@ -35,6 +35,7 @@ UNITS = [
     ("wgrad_tall.hip", []),
     ("wgrad_f32.hip", []),
     ("adam.hip", []),
+    ("trunk_conv.hip", []),
 ]
 
 

@@ -109,6 +109,30 @@ def _bn_act(x, bn, relu: bool, res=None):
     return x
 
 
+def _trunk_conv(xh, conv, bn, relu: bool, res=None, want_nchw: bool = False):
+    """conv (3x3 / 1x1, no bias) + inference batch norm (+ residual) (+ ReLU) on an NHWC fp32 map: cpn_trunk_conv_bn_act
+    (csrc/trunk_conv.hip).  Returns the NHWC result and, if asked for, the NCHW copy the same epilogue writes."""
+    from ._hip import call, lib
+    N, H, W, Cin = xh.shape
+    Cout, k, s = conv.out_channels, conv.kernel_size[0], conv.stride[0]
+    w = conv.weight
+    pack = conv.__dict__.get("_cpn_pack")
+    if pack is None or pack[0] != (w._version, w.data_ptr()):
+        wp = torch.empty(k * k, Cin, Cout, dtype=torch.float32, device=xh.device)
+        call("cpn_pack_conv_weight", w.detach().contiguous().data_ptr(), Cout, Cin, k, wp.data_ptr(),
+             torch.cuda.current_stream().cuda_stream)
+        pack = conv.__dict__["_cpn_pack"] = ((w._version, w.data_ptr()), wp)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    out = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32, device=xh.device)
+    nchw = torch.empty(N, Cout, Ho, Wo, dtype=torch.float32, device=xh.device) if want_nchw else None
+    scratch = torch.empty(lib().cpn_trunk_conv_scratch_floats(N, H, W, Cin, Cout, k, s), dtype=torch.float32, device=xh.device)
+    call("cpn_trunk_conv_bn_act", xh.data_ptr(), pack[1].data_ptr(), N, H, W, Cin, Cout, k, s, bn.running_mean.data_ptr(),
+         bn.running_var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
+         0 if res is None else res.data_ptr(), int(relu), out.data_ptr(), 0 if nchw is None else nchw.data_ptr(),
+         scratch.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return out, nchw
+
+
 class SpatialEncoder(nn.Module):
     """backbone.py:10-102 with use_first_pool=False, num_layers=5: returns [512@H/16, 256@H/8, 128@H/4, 64@H/2, 64@H/2]."""
 
@@ -122,8 +146,24 @@ class SpatialEncoder(nn.Module):
         m = self.model
         x = _bn_act(m.conv1(x), m.bn1, True)
         lat = [x]
+        xh = None                                        # NHWC copy of x once the own kernels take over
         for name in ("layer1", "layer2", "layer3", "layer4"):
-            for blk in getattr(m, name):
+            blocks = list(getattr(m, name))
+            own = (HIP_TRUNK_TAIL and name in ("layer3", "layer4")
+                   and x.shape[0] * (x.shape[2] // 2) * (x.shape[3] // 2) <= HIP_TRUNK_MAX_POSITIONS)
+            if own and xh is None:
+                xh = x.permute(0, 2, 3, 1).contiguous()
+            for i, blk in enumerate(blocks):
+                if own:
+                    # split-K implicit GEMMs with the normalisation in their epilogue (csrc/trunk_conv.hip)
+                    idt = xh
+                    if blk.downsample is not None:
+                        idt, _ = _trunk_conv(xh, blk.downsample[0], blk.downsample[1], False)
+                    out, _ = _trunk_conv(xh, blk.conv1, blk.bn1, True)
+                    xh, xn = _trunk_conv(out, blk.conv2, blk.bn2, True, res=idt, want_nchw=i == len(blocks) - 1)
+                    x = xn if xn is not None else x
+                    continue
+                xh = None
                 idt = x
                 if blk.downsample is not None:
                     idt = _bn_act(blk.downsample[0](x), blk.downsample[1], False)
@@ -205,6 +245,11 @@ TWO_STREAMS = os.environ.get("CPN_GETZ_TWO_STREAMS", "1") != "0"
 BATCH_VIEWS = os.environ.get("CPN_GETZ_BATCH_VIEWS", "1") != "0"
 # inference trunk: batch norm + residual + ReLU behind every convolution as one kernel (SpatialEncoder._forward_infer)
 FUSED_TRUNK = os.environ.get("CPN_GETZ_FUSED_TRUNK", "1") != "0"
+# ... and layer3 / layer4 on the package's own split-K convolution (cpn_trunk_conv_bn_act) while the maps are small enough for
+# the library's kernels to leave the chip idle: output positions of the layer over all images (one 256 x 256 pair: 2 048 at
+# layer3, 512 at layer4; tools/trunk_conv_bench.py: at 4 096 positions the library's 3x3 stride-1 kernel is ahead)
+HIP_TRUNK_TAIL = os.environ.get("CPN_GETZ_HIP_TRUNK_TAIL", "1") != "0"
+HIP_TRUNK_MAX_POSITIONS = int(os.environ.get("CPN_GETZ_HIP_TRUNK_MAX_POSITIONS", "2048"))
 # training: the final correlation on cpn_corr_mean3 with its own adjoint (ufc_ops._CorrMean3Fn); 0 = composed resize ops
 CORR_MEAN3_TRAIN = os.environ.get("CPN_CORR_MEAN3_TRAIN", "1") != "0"
 _SIDE_STREAMS = {}

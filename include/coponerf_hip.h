@@ -503,6 +503,19 @@ int cpn_conv_map7x7(const float* rgb, const float* w, const float* bias, int N, 
 int cpn_bn_act(const float* x, const float* res, const float* mean, const float* var, const float* w, const float* b,
                float eps, int N, int C, int HW, int relu, float* y, void* stream);
 
+/* ---- f3: the deep trunk layers as split-K implicit GEMMs on the fp32 MFMA with the BatchNorm / residual / ReLU epilogue
+ * (inference, round 4): replaces conv + bn (+ identity) (+ relu) of torchvision's BasicBlock in layer3 / layer4 of the
+ * ResNet-34 trunk (models/backbone.py:10-102) at one or a few stereo pairs, where the library's kernels leave most CUs idle.
+ *   x (N, Hin, Win, Cin) NHWC fp32, Cin % 16 == 0;  wp = cpn_pack_conv_weight(w (Cout, Cin, k, k)) = [tap][ci][co], Cout % 4 == 0
+ *   k in {1, 3} (padding k / 2), stride in {1, 2};  mean / var / bn_w / bn_b (Cout), eps: inference batch norm
+ *   res (N, Hout, Wout, Cout) NHWC or NULL, relu 0/1;  out_nhwc and / or out_nchw (N, Cout, Hout, Wout), at least one
+ *   scratch: cpn_trunk_conv_scratch_floats(...) floats.  Exact fp32 products, fixed summation order (bit-reproducible).   */
+int cpn_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, float* wp, void* stream);
+long long cpn_trunk_conv_scratch_floats(int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride);
+int cpn_trunk_conv_bn_act(const float* x, const float* wp, int N, int Hin, int Win, int Cin, int Cout, int ksize, int stride,
+                          const float* mean, const float* var, const float* bn_w, const float* bn_b, float eps,
+                          const float* res, int relu, float* out_nhwc, float* out_nchw, float* scratch, void* stream);
+
 /* ---- bilinear resize, align_corners=True, of `planes` independent (h,w) fp32 images -> (H,W) ----------
  * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /
  * interpolate2d_token (models/aggregation.py:49-63, 285, 293, 299).                                           */

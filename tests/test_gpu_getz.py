@@ -371,3 +371,40 @@ def test_fused_trunk_equals_stock_modules(dev):
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
     cl = t.clone().contiguous(memory_format=torch.channels_last)              # not NCHW-contiguous: library fallback
     assert torch.allclose(getz._bn_act(cl, bn, True, res=r), want, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,res", [(2, 32, 32, 128, 256, 3, 2, False), (2, 16, 16, 256, 256, 3, 1, True),
+                                                    (1, 5, 7, 16, 20, 3, 1, True), (2, 8, 8, 32, 64, 1, 2, False),
+                                                    (3, 9, 6, 48, 132, 3, 2, True), (2, 16, 16, 512, 512, 3, 1, True)])
+def test_trunk_conv_kernel_matches_float64_convolution(N, H, W, Cin, Cout, k, s, res):
+    """cpn_trunk_conv_bn_act (split-K implicit GEMM on the fp32 MFMA + batch norm / residual / ReLU epilogue) against the same
+    layer in float64: partial tiles in channels and positions, image borders, both strides, 1x1; NHWC and NCHW outputs hold
+    the same values; two runs are bit-identical."""
+    import torch.nn as nn
+    from coponerf_amd.getz import _trunk_conv
+    dev = torch.device("cuda:0")
+    torch.manual_seed(N * 100 + Cin)
+    conv = nn.Conv2d(Cin, Cout, k, stride=s, padding=k // 2, bias=False).to(dev)
+    bn = nn.BatchNorm2d(Cout).to(dev).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_(1, 0.3)
+        bn.bias.normal_(0, 0.3)
+    x = torch.randn(N, Cin, H, W, device=dev)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    r = torch.randn(N, Cout, Ho, Wo, device=dev) if res else None
+    with torch.no_grad():
+        xh = x.permute(0, 2, 3, 1).contiguous()
+        rh = None if r is None else r.permute(0, 2, 3, 1).contiguous()
+        out, nchw = _trunk_conv(xh, conv, bn, True, res=rh, want_nchw=True)
+        out2, _ = _trunk_conv(xh, conv, bn, True, res=rh)
+        ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), None, s, k // 2)
+        ref = torch.nn.functional.batch_norm(ref, bn.running_mean.double(), bn.running_var.double(), bn.weight.double(),
+                                             bn.bias.double(), False, 0.0, bn.eps)
+        ref = torch.relu(ref if r is None else ref + r.double())
+    assert out.shape == (N, Ho, Wo, Cout) and nchw.shape == (N, Cout, Ho, Wo)
+    assert torch.equal(out, out2)
+    assert torch.equal(out.permute(0, 3, 1, 2), nchw)
+    assert float((nchw.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
