@@ -36,6 +36,7 @@ UNITS = [
     ("wgrad_f32.hip", []),
     ("adam.hip", []),
     ("trunk_conv.hip", []),
+    ("pose.hip", []),
 ]
 
 

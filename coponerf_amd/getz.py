@@ -249,6 +249,8 @@ FUSED_TRUNK = os.environ.get("CPN_GETZ_FUSED_TRUNK", "1") != "0"
 # the library's kernels to leave the chip idle: output positions of the layer over all images (one 256 x 256 pair: 2 048 at
 # layer3, 512 at layer4; tools/trunk_conv_bench.py: at 4 096 positions the library's 3x3 stride-1 kernel is ahead)
 HIP_TRUNK_TAIL = os.environ.get("CPN_GETZ_HIP_TRUNK_TAIL", "1") != "0"
+# inference: positional encodings of the pose head and its regressor tail as one kernel each (csrc/pose.hip)
+FUSED_POSE_ENDS = os.environ.get("CPN_GETZ_FUSED_POSE_ENDS", "1") != "0"
 HIP_TRUNK_MAX_POSITIONS = int(os.environ.get("CPN_GETZ_HIP_TRUNK_MAX_POSITIONS", "2048"))
 # training: the final correlation on cpn_corr_mean3 with its own adjoint (ufc_ops._CorrMean3Fn); 0 = composed resize ops
 CORR_MEAN3_TRAIN = os.environ.get("CPN_CORR_MEAN3_TRAIN", "1") != "0"
@@ -582,7 +584,11 @@ class _CrossAttention(nn.Module):
         a1 = corr.reshape(B, corr.shape[-4] * corr.shape[-3], -1)                       # (B, src, trg)
         f1 = ops.dual_softmax(a1)                                  # a1.softmax(-1) * a1.softmax(-2)
         f2 = f1.transpose(-2, -1)          # == a2.softmax(-1) * a2.softmax(-2) with a2 = a1^T: two softmaxes, not four
-        pos = positional_encodings(*intr, n=int(math.isqrt(x1.shape[1]))).to(x1.dtype)
+        n = int(math.isqrt(x1.shape[1]))
+        if isinstance(intr[0], str):                              # ("raw", intrinsics of the input dict, H): one kernel
+            pos = ops.pose_positional(intr[1], intr[2], n).to(x1.dtype)
+        else:
+            pos = positional_encodings(*intr, n=n).to(x1.dtype)
         v1, v2 = torch.cat([x1, pos], dim=2), torch.cat([x2, pos], dim=2)
         F1 = ((v1.transpose(-2, -1) @ f1) @ v1).transpose(-2, -1)
         F2 = ((v2.transpose(-2, -1) @ f2) @ v2).transpose(-2, -1)
@@ -677,10 +683,20 @@ def get_z(model, input, ops):
     if z_conv_nhwc16 is not None and hasattr(model, "_engine"):
         model._engine.adopt_level3(z_conv, z_conv_nhwc16)
     feats, flows, c = model.feature_cost_aggregation(z, model.n_view, ops)
-    Kn = input["context"]["intrinsics"].clone()
-    Kn[:, :, :2, :] = Kn[:, :, :2, :] / H
-    intr = (Kn[:, 0, 0, 0, None], Kn[:, 0, 1, 1, None], Kn[:, 0, 0, 2, None], Kn[:, 0, 1, 2, None])
+    fused_pose = infer and FUSED_POSE_ENDS and hasattr(ops, "pose_tail") and rgb.is_cuda
+    if fused_pose:
+        # the launch-bound ends of the pose head as two kernels (csrc/pose.hip): the K^-1 grid, and everything behind the
+        # first Linear of the regressor (~70 launches of 2-5 us kernels otherwise)
+        intr = ("raw", input["context"]["intrinsics"], H)
+    else:
+        Kn = input["context"]["intrinsics"].clone()
+        Kn[:, :, :2, :] = Kn[:, :, :2, :] / H
+        intr = (Kn[:, 0, 0, 0, None], Kn[:, 0, 1, 1, None], Kn[:, 0, 0, 2, None], Kn[:, 0, 1, 2, None])
     pose_feat = model.cross_attention(feats[-1].flatten(-2, -1).transpose(-1, -2), c, intr, ops).reshape(B, -1)
+    if fused_pose:
+        rel_pose = ops.pose_tail(model.pose_regressor[0](pose_feat), model.pose_regressor, model.rotation_regressor,
+                                 model.translation_regressor)
+        return feats + [z_conv], rel_pose, flows
     lat = model.pose_regressor(pose_feat)[:, :128]
     R = r6d_to_matrix(model.rotation_regressor(lat))[:, :3, :3]
     t = model.translation_regressor(lat)

@@ -575,6 +575,9 @@ def _conv_map_lib(rgb, w, b):
     return F.conv2d((x - mean) / std, w, b, stride=1, padding=3)
 
 
+_LINSPACE = {}
+
+
 class HipOps:
     """conv4d + GroupNorm + ReLU, cosine correlation, soft-argmax (csrc/ufc.hip) and the two attention forms of
     UFCLayer (csrc/ufc_attn.hip) on gfx950."""
@@ -749,6 +752,39 @@ class HipOps:
         s_to_t = torch.empty(B, 2, h, h, device=c.device, dtype=torch.float32)
         call("cpn_soft_argmax_pair", c.data_ptr(), B, h, 0.02, t_to_s.data_ptr(), s_to_t.data_ptr(), _stream())
         return t_to_s, s_to_t
+
+    def pose_positional(self, intrinsics, H: int, n: int):
+        """getz.positional_encodings from the input dict's raw intrinsics (B, V, 4, 4), one launch (inference)."""
+        K = intrinsics.detach().contiguous().float()
+        self._need_gpu(K)
+        key = (n, str(K.device))
+        lin = _LINSPACE.get(key)
+        if lin is None:
+            lin = _LINSPACE[key] = torch.linspace(-1, 1, steps=n, device=K.device)
+        B, V = K.shape[0], K.shape[1]
+        out = torch.empty(B, n * n, 6, dtype=torch.float32, device=K.device)
+        call("cpn_pose_positional", K.data_ptr(), B, V, float(H), lin.data_ptr(), n, out.data_ptr(), _stream())
+        return out
+
+    def pose_tail(self, h512, pose_regressor, rotation_regressor, translation_regressor):
+        """Everything behind the first Linear of the pose regressor (ReLU / Linear chains, 6-D rotation, 4 x 4 assembly) as one
+        launch (inference): h512 (B, 512) before its ReLU -> rel_pose (B, 4, 4)."""
+        import ctypes
+        h = h512.detach().contiguous().float()
+        self._need_gpu(h)
+        lins = [pose_regressor[2], pose_regressor[4]] + [m for m in rotation_regressor if isinstance(m, torch.nn.Linear)] + \
+               [m for m in translation_regressor if isinstance(m, torch.nn.Linear)]
+        shapes = [tuple(m.weight.shape) for m in lins]
+        assert shapes == [(256, 512), (256, 256), (64, 128), (32, 64), (6, 32), (64, 128), (32, 64), (3, 32)], shapes
+        ptrs = []
+        for m in lins:
+            for t in (m.weight, m.bias):
+                assert t.is_contiguous() and t.dtype == torch.float32 and t.device == h.device
+                ptrs.append(t.data_ptr())
+        arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        out = torch.empty(h.shape[0], 4, 4, dtype=torch.float32, device=h.device)
+        call("cpn_pose_tail", h.data_ptr(), arr, h.shape[0], out.data_ptr(), _stream())
+        return out
 
     def dual_softmax(self, a):
         """(B,L,M) -> softmax(a,-1) * softmax(a,-2)."""

@@ -516,6 +516,18 @@ int cpn_trunk_conv_bn_act(const float* x, const float* wp, int N, int Hin, int W
                           const float* mean, const float* var, const float* bn_w, const float* bn_b, float eps,
                           const float* res, int relu, float* out_nhwc, float* out_nchw, float* scratch, void* stream);
 
+/* ---- f1: the launch-bound ends of the pose head, one launch each (inference, round 4) -----------------------------
+ * cpn_pose_positional: (x^2, y^2, xy, x, y, 1) of the K^-1-normalised n x n grid (models/backbone.py:209-278) from the raw
+ *   intrinsics (B, V, 4, 4) of the input dict (view 0, divided by H like CoPoNeRF.py:199-201); lin = linspace(-1, 1, n);
+ *   out (B, n*n, 6), index = col * n + row.
+ * cpn_pose_tail: pose_regressor[1:] -> [:, :128] -> rotation / translation regressors -> 6-D rotation -> rel_pose (B, 4, 4)
+ *   (models/CoPoNeRF.py:106-126,190-206) from h512 = pose_regressor[0](pose_feat) (B, 512), BEFORE its ReLU.
+ *   weights: HOST array of CPN_POSE_TAIL_TENSORS device pointers, weight then bias of each Linear in the order
+ *   pose[2] (256 x 512), pose[4] (256 x 256), rotation 128->64->32->6, translation 128->64->32->3.                        */
+#define CPN_POSE_TAIL_TENSORS 16
+int cpn_pose_positional(const float* intrinsics, int B, int V, float H, const float* lin, int n, float* out, void* stream);
+int cpn_pose_tail(const float* h512, const float* const* weights, int B, float* rel_pose, void* stream);
+
 /* ---- bilinear resize, align_corners=True, of `planes` independent (h,w) fp32 images -> (H,W) ----------
  * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /
  * interpolate2d_token (models/aggregation.py:49-63, 285, 293, 299).                                           */

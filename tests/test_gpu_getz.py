@@ -408,3 +408,35 @@ def test_trunk_conv_kernel_matches_float64_convolution(N, H, W, Cin, Cout, k, s,
     assert torch.equal(out, out2)
     assert torch.equal(out.permute(0, 3, 1, 2), nchw)
     assert float((nchw.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_fused_pose_ends_equal_stock_ops(dev):
+    """get_z with the two pose-head kernels (cpn_pose_positional, cpn_pose_tail) against the same call on the stock-op
+    form they replace (~70 launches): features and flows identical (nothing upstream changes), rel_pose within the
+    summation-order noise of the small dot products; and the positional table alone against getz.positional_encodings."""
+    from coponerf_amd import CoPoNeRF, getz
+    from coponerf_amd.ufc_ops import HipOps
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev).eval()
+    for B in (1, 3):
+        inp = to_device(syn.make_inputs(B, 256, 256, 64, seed=91 + B), dev)
+        with torch.no_grad():
+            z1, rel1, flow1 = model.get_z(inp)
+            old, getz.FUSED_POSE_ENDS = getz.FUSED_POSE_ENDS, False
+            try:
+                z0, rel0, flow0 = model.get_z(inp)
+            finally:
+                getz.FUSED_POSE_ENDS = old
+        for a, b in zip(list(z1) + list(flow1), list(z0) + list(flow0)):
+            assert torch.equal(a, b)
+        assert float((rel1 - rel0).abs().max()) <= 2e-6, float((rel1 - rel0).abs().max())
+        assert torch.equal(rel1[:, 3], torch.tensor([0., 0., 0., 1.], device=dev).expand(B, 4))
+        K = inp["context"]["intrinsics"]
+        Kn = K.clone()
+        Kn[:, :, :2, :] = Kn[:, :, :2, :] / 256
+        want = getz.positional_encodings(Kn[:, 0, 0, 0, None], Kn[:, 0, 1, 1, None], Kn[:, 0, 0, 2, None], Kn[:, 0, 1, 2, None], n=64)
+        got = HipOps().pose_positional(K, 256, 64)
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
