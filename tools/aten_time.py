@@ -29,18 +29,16 @@ def main():
     inp = syn.make_inputs(1 if a.getz else a.batch, 256, 256, 4096, seed=61)
     mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (o.to(dev) if torch.is_tensor(o) else o)
     inp = mv(inp)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    if not a.getz:
+        from coponerf_amd.train_step import TrainStep
+        train = TrainStep(model, lr=1e-5)                         # the product's own step (guard, clip, one-launch Adam)
 
     def step():
         if a.getz:
             with torch.no_grad():
                 model.get_z(inp, val=True)
             return
-        opt.zero_grad(set_to_none=True)
-        z, rel, flow = model.get_z(inp, val=False)
-        out = model(inp, z=z, rel_pose=rel, val=False, flow=flow)
-        (out["rgb"] - inp["query"]["rgb"]).abs().mean().backward()
-        opt.step()
+        train(inp, inp["query"]["rgb"])
 
     for _ in range(3):
         step()

@@ -37,6 +37,10 @@ python tools/trace_step.py "$(find "$OUT/getz_prof" -name '*kernel_trace.csv' | 
 python tools/trace_step.py "$(find "$OUT/train_prof" -name '*kernel_trace.csv' | head -1)" project_rays 60 > "$OUT/train_step_kernels.txt" 2>&1
 grep -h train_ms_per_step "$OUT/train_prof.log" > "$OUT/train_step.json"
 python tools/encode_ablate.py > "$OUT/encode_ablation.json" 2>/dev/null
+python tools/aten_time.py --top 120 > "$OUT/aten_train.txt" 2>&1
+python tools/wgrad_f32_bench.py > "$OUT/wgrad_f32_bench.json" 2>/dev/null
+python tools/trunk_conv_bench.py > "$OUT/trunk_conv_bench.json" 2>/dev/null
+python tools/trace_order.py "$(find "$OUT/getz_prof" -name '*kernel_trace.csv' | head -1)" soft_argmax_cols > "$OUT/getz_order.txt" 2>&1
 bash tools/refloop_trace.sh "gpurun_out/$TAG/ref_loop_b1" 1 > /dev/null 2>&1
 bash tools/refloop_trace.sh "gpurun_out/$TAG/ref_loop_b2" 2 > /dev/null 2>&1
 python tools/refloop_profile.py --batch 1 --top 8 > "$OUT/ref_loop_b1_host.txt" 2>&1

@@ -37,6 +37,25 @@ def main():
         inp["query"]["uv"] = torch.gather(uv, 2, order[..., None].expand_as(uv))
         inp["query"]["rgb"] = torch.gather(rgb, 2, order[..., None].expand_as(rgb))
     inp = mv(inp)
+    if not (a.detach_z or a.flow_loss):
+        # the product's own step (forward, loss, backward, guard + clip, one-launch Adam): coponerf_amd.train_step.TrainStep
+        from coponerf_amd.train_step import TrainStep
+        step = TrainStep(model, lr=1e-5)
+        step.timing = {}
+        gt = inp["query"]["rgb"]
+        for it in range(a.warmup + a.steps):
+            if it == a.warmup:
+                torch.cuda.synchronize()
+                step.timing = {}
+                t0 = time.perf_counter()
+            res = step(inp, gt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        ph = step.timing_summary()
+        print(json.dumps({"train_ms_per_step": dt * 1e3, "rays_per_s": a.batch * a.rays / dt, **{k: round(v, 3) for k, v in ph.items()},
+                          "peak_mem_GB": torch.cuda.max_memory_allocated() / 2**30, "batch": a.batch, "rays_per_pair": a.rays,
+                          "stepped": bool(res["stepped"]), "loss": float(res["loss"])}))
+        return
     opt = torch.optim.Adam(model.parameters(), lr=1e-5)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     parts = []
