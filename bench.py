@@ -328,6 +328,19 @@ def run(args):
             torch.cuda.synchronize()
             getz_ms = (time.perf_counter() - g0) / 3 * 1e3
         line["get_z_ms"] = getz_ms
+        # the same call replayed as a captured HIP graph (coponerf_amd/graphs.py): no host cost per launch, what the GPU needs
+        from coponerf_amd.graphs import GraphedGetZ
+        with torch.no_grad():
+            gz = GraphedGetZ(model)
+            for _ in range(2):
+                zz = gz(inp)
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            for _ in range(3):
+                zz = gz(inp)
+            torch.cuda.synchronize()
+            line["get_z_graph_ms"] = (time.perf_counter() - g0) / 3 * 1e3
+            del gz
         line["image_rays_per_s"] = rays_per_step / (getz_ms * 1e-3 + elapsed / args.steps)
         del zz
         # the same pipeline with get_z of pair i+1 on a second HIP stream under the render of pair i

@@ -388,41 +388,36 @@ __global__ __launch_bounds__(256) void gn_relu_kernel(const float* y, const doub
     out[idx] = res ? res[idx] + fmaxf(v, 0.0f) : fmaxf(v, 0.0f);
 }
 
-// ---- the stride-1 3x3x3x3 layer on the fp32 MFMA (round 3) --------------------------------------------------------------
+// ---- the stride-1 3x3x3x3 layer on the fp32 MFMA (round 4; the round-3 form fed every MFMA with its own 4-byte load) -------
 // out[co, pos] = bias + sum over (branch, tap, ci) of w_branch[co, ci, tap] * x[ci, pos + tap_branch]: an implicit GEMM with
 // M = output channels, N = positions, K = 2 * 9 * Cin on v_mfma_f32_16x16x4_f32 (an fmaf chain: fp32-exact products).
-// A wave = 16 consecutive positions x ALL output channels (MT tiles of 16, padded: Cout = 8 uses half a tile); the four
-// K values of one MFMA step are four consecutive input channels of one (branch, tap): lane (n, g) loads
-// x[ci0 + g][pos_n + tap] — the 16 lanes of a group read 64 contiguous bytes — with the buffer-load out-of-range zero as
-// the padding, and the A operand w[co][ci0 + g] comes from LDS ([branch][tap][ci][co], conflict-free).  The VALU version
-// above spends 1 152 FMAs per position and 8 channels and re-reads every input once per 8 output channels; here the
-// multiplies sit on the matrix pipe and an input value is read once per tap for all channels.  DGRAD as above.
+//   wave      64 consecutive positions x ALL output channels (MT tiles of 16, padded: Cout = 8 uses half a tile)
+//   k step    four consecutive input channels of one (branch, tap): lane (j, g) holds a 16-byte vector of channel ci0 + g at
+//             positions p0 + 4 j .. + 3, and ELEMENT e of that vector is the B operand of the output tile of positions
+//             {p0 + 4 j + e}: one vector feeds 4 MT MFMAs
+//   loads     per 4-channel group 9 aligned vectors for the query-pair taps (whole vectors in or out of the volume: the
+//             buffer load's out-of-range zero is the padding) and 3 for the support-pair ROWS; the dx = -1 / +1 taps of a
+//             row are the same vector shifted by one element, the element that crosses a lane coming from the neighbour
+//             lane through a DPP row shift (zero at the ends of a row of Ws): 12 loads feed 72 MT MFMAs, and the loads of
+//             the next group are in flight under them
+//   A operand w[co][ci0 + g] from LDS ([branch][tap][ci][co], conflict-free 4-byte reads)
+// The VALU version above spends 1 152 FMAs per position and 8 channels and re-reads every input once per 8 output channels;
+// here the multiplies sit on the matrix pipe.  Needs Cin % 4 == 0, Ws in {4, 8, 16, 32, 64}, positions % 64 == 0.  DGRAD as above.
 template <int MT, bool DGRAD>
-__global__ __launch_bounds__(256) void conv4d_k3s1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wq,
-                                                               const float* __restrict__ bq, const float* __restrict__ ws,
-                                                               const float* __restrict__ bs, int Cin, int Hq, int Wq, int Hs,
-                                                               int Ws, int cout_total, float* __restrict__ y,
-                                                               double* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];        // [2][9][Cin4][MT*16], Cin4 = Cin rounded up to 4
+__global__ __launch_bounds__(256, 2) void conv4d_k3s1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                                  const float* __restrict__ bq, const float* __restrict__ ws,
+                                                                  const float* __restrict__ bs, int Cin, int Hq, int Wq, int Hs,
+                                                                  int Ws, int cout_total, float* __restrict__ y,
+                                                                  double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];        // [2][9][Cin][MT*16]
     const int b = blockIdx.z;
-    const int Cin4 = (Cin + 3) & ~3, CO = MT * 16;
-    for (int i = threadIdx.x; i < 18 * Cin4 * CO; i += 256) {
-        const int o = i % CO;
-        int t = i / CO;
-        const int c = t % Cin4; t /= Cin4;
-        const int tap = t % 9, br = t / 9;
-        float v = 0.0f;
-        if (o < cout_total && c < Cin)
-            v = DGRAD ? (br ? ws : wq)[((size_t)c * cout_total + o) * 9 + (8 - tap)] : (br ? ws : wq)[((size_t)o * Cin + c) * 9 + tap];
-        wl[i] = v;
-    }
-    __syncthreads();
+    constexpr int CO = MT * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = lane & 15, g = lane >> 4;
+    const int fi = lane & 15, g = lane >> 4;
     const long long npos = (long long)Hq * Wq * Hs * Ws;
-    const long long pos = ((long long)blockIdx.x * 4 + wave) * 16 + n;
-    const bool active = pos < npos;
-    const long long pc = active ? pos : npos - 1;
+    const long long pos = ((long long)blockIdx.x * 4 + wave) * 64 + 4 * fi;      // first of this lane's four positions
+    const bool active = pos < npos;                                              // whole waves: npos % 64 == 0
+    const long long pc = active ? pos : 0;
     const int sx = (int)(pc % Ws);
     long long t = pc / Ws;
     const int sy = (int)(t % Hs); t /= Hs;
@@ -431,39 +426,106 @@ __global__ __launch_bounds__(256) void conv4d_k3s1_mfma_kernel(const float* __re
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(x + (size_t)b * Cin * (size_t)npos), 0, (int)((size_t)Cin * npos * 4), 0x00020000);
     const int plane = (int)npos * 4;                               // bytes of one input channel
-    int off[18];                                                   // [branch * 9 + tap], with this lane's channel offset g
+    constexpr int kOOB = 0x7ffffff0;
+    int offq[9], offs[3];                                          // with this lane's channel offset g
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int tp = i * 3 + j;
-            const int Y = qy + i - 1, X = qx + j - 1, U = sy + i - 1, Vv = sx + j - 1;
-            const bool okq = active && Y >= 0 && Y < Hq && X >= 0 && X < Wq;
-            const bool oks = active && U >= 0 && U < Hs && Vv >= 0 && Vv < Ws;
-            off[tp] = okq ? (((Y * Wq + X) * Hs + sy) * Ws + sx) * 4 + g * plane : 0x7ffffff0;
-            off[9 + tp] = oks ? (((qy * Wq + qx) * Hs + U) * Ws + Vv) * 4 + g * plane : 0x7ffffff0;
+            const int Y = qy + i - 1, X = qx + j - 1;
+            const bool ok = active && Y >= 0 && Y < Hq && X >= 0 && X < Wq;
+            offq[i * 3 + j] = ok ? (((Y * Wq + X) * Hs + sy) * Ws + sx) * 4 + g * plane : kOOB;
         }
-    f32x4 acc[MT];
+        const int U = sy + i - 1;
+        offs[i] = (active && U >= 0 && U < Hs) ? (((qy * Wq + qx) * Hs + U) * Ws + sx) * 4 + g * plane : kOOB;
+    }
+    const bool row_first = sx == 0, row_last = sx + 4 == Ws;
+    f32x4 acc[MT][4];                                              // [channel tile][position subset e]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = mt * 16 + g * 4 + i;
-            acc[mt][i] = (DGRAD || co >= cout_total) ? 0.0f : bq[co] + bs[co];
+            const float bias = (DGRAD || co >= cout_total) ? 0.0f : bq[co] + bs[co];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mt][e][i] = bias;
         }
-    for (int c0 = 0; c0 < Cin4; c0 += 4) {
-        // channels beyond Cin: the weights are zero and the load is forced out of range (0), so nothing leaks in
-        const bool cok = c0 + g < Cin;
-        float xv[18];
+    auto load_group = [&](int c0, f32x4 (&vq)[9], f32x4 (&vs)[3]) {
+        const int so = c0 * plane;
 #pragma unroll
-        for (int k = 0; k < 18; ++k)
-            xv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cok ? off[k] : 0x7ffffff0, c0 * plane, 0));
+        for (int k = 0; k < 9; ++k) vq[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, offq[k], so, 0));
 #pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            const float* wrow = wl + ((size_t)k * Cin4 + c0 + g) * CO + n;
+        for (int k = 0; k < 3; ++k) vs[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, offs[k], so, 0));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step = [&](int c0, int k, const f32x4& v) {                // k = branch * 9 + tap
+        const float* wrow = wl + ((size_t)k * Cin + c0 + g) * CO + fi;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[mt * 16], xv[k], acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+            const float a = wrow[mt * 16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[e], acc[mt][e], 0, 0, 0);
+        }
+    };
+    auto compute_group = [&](int c0, const f32x4 (&vq)[9], const f32x4 (&vs)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 r = vs[i];
+            // neighbours' edge elements: lane j - 1's element 3 and lane j + 1's element 0 (DPP row shifts inside the 16 lanes
+            // of a channel group; a row of Ws never crosses them because Ws divides 64 or is a multiple of it)
+            // (written as asm: with the update_dpp builtin the compiler read element 0 of the vector for BOTH shifts here)
+            float left, right;
+            const float r3 = r[3], r0 = r[0];
+            asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_mov_b32_dpp %1, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                         : "=&v"(left), "=&v"(right) : "v"(r3), "v"(r0));
+            const f32x4 rm = {row_first ? 0.0f : left, r[0], r[1], r[2]};       // x - 1
+            const f32x4 rp = {r[1], r[2], r[3], row_last ? 0.0f : right};       // x + 1
+            step(c0, i * 3 + 0, vq[i * 3 + 0]);
+            step(c0, 9 + i * 3 + 0, rm);
+            step(c0, i * 3 + 1, vq[i * 3 + 1]);
+            step(c0, 9 + i * 3 + 1, r);
+            step(c0, i * 3 + 2, vq[i * 3 + 2]);
+            step(c0, 9 + i * 3 + 2, rp);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4 q0[9], s0[3], q1[9], s1v[3];
+    load_group(0, q0, s0);                                         // in flight while the filters are staged
+    // Filters into LDS: the GLOBAL index runs with the thread index (coalesced reads, four in flight per thread), the LDS
+    // index is scattered.  (Walking the LDS index instead made every thread issue up to 36 dependent 4-byte reads with a
+    // stride of 9 floats: a third of the kernel's time at 32 input channels.)
+    if (cout_total < CO)
+        for (int i = threadIdx.x; i < 18 * Cin * CO; i += 256)
+            if (i % CO >= cout_total) wl[i] = 0.0f;
+    {
+        const int per_branch = cout_total * Cin * 9, total = 2 * per_branch;
+        for (int g0 = threadIdx.x; g0 < total; g0 += 1024) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int gi = g0 + 256 * u;
+                v[u] = gi < total ? (gi < per_branch ? wq[gi] : ws[gi - per_branch]) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int gi = g0 + 256 * u;
+                if (gi >= total) continue;
+                const int br = gi >= per_branch, q = gi - br * per_branch;
+                const int tapg = q % 9, mid = (q / 9) % (DGRAD ? cout_total : Cin), top = q / (9 * (DGRAD ? cout_total : Cin));
+                // forward tensor [o][c][tap]; data gradient reads the forward layer's [c][o][8 - tap]
+                const int o = DGRAD ? mid : top, c = DGRAD ? top : mid, tap = DGRAD ? 8 - tapg : tapg;
+                wl[((size_t)(br * 9 + tap) * Cin + c) * CO + o] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < Cin; c0 += 8) {
+        if (c0 + 4 < Cin) load_group(c0 + 4, q1, s1v);
+        compute_group(c0, q0, s0);
+        if (c0 + 4 < Cin) {
+            if (c0 + 8 < Cin) load_group(c0 + 8, q0, s0);
+            compute_group(c0 + 4, q1, s1v);
         }
     }
     double s1 = 0.0, s2 = 0.0;
@@ -474,10 +536,13 @@ __global__ __launch_bounds__(256) void conv4d_k3s1_mfma_kernel(const float* __re
             for (int i = 0; i < 4; ++i) {
                 const int co = mt * 16 + g * 4 + i;
                 if (co < cout_total) {
-                    const float v = acc[mt][i];
-                    y[((size_t)b * cout_total + co) * npos + pos] = v;
-                    s1 += (double)v;
-                    s2 += (double)v * v;
+                    const f32x4 v = {acc[mt][0][i], acc[mt][1][i], acc[mt][2][i], acc[mt][3][i]};
+                    *reinterpret_cast<f32x4*>(y + ((size_t)b * cout_total + co) * npos + pos) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1 += (double)v[e];
+                        s2 += (double)v[e] * v[e];
+                    }
                 }
             }
     }
@@ -1005,6 +1070,64 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     }
 }
 
+// The same product for LARGE problems (the 4096 x 4096 x 256 correlations of the finest level): a wave owns a 64 x 64 output
+// tile — 4 row tiles x 4 column tiles, 64 MFMAs per 8 operand loads where the kernel above has 32 per 9 — and a workgroup of
+// four waves a 128 x 128 block.  Column tile t holds the columns {n0 + 4 j + t}, so a lane ends up with four CONSECUTIVE
+// columns per row and stores 16-byte vectors.  Loads of the next k block are pinned in front of the MFMAs of this one.
+// M, N multiples of 128, K of 16.  62 -> ~95 TFLOP/s on 4096 x 4096 x 256 (exact fp32 products, same k order per output).
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_tile64_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                                    float* __restrict__ Cm, int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * 128 + (wave >> 1) * 64, n0 = blockIdx.x * 128 + (wave & 1) * 64;
+    const float* Ab = A + (size_t)b * M * K;
+    const float* Bb = Bm + (size_t)b * N * K;
+    float* Cb = Cm + (size_t)b * M * N;
+    const int fi = lane & 15, fg = lane >> 4;
+    const float* ap = Ab + (size_t)(m0 + fi) * K + fg * 4;                  // row tile a: + 16 a rows
+    const float* bp = Bb + (size_t)(n0 + 4 * fi) * K + fg * 4;              // column tile t: + t rows
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int kb, f32x4 (&av)[4], f32x4 (&bv)[4]) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) av[a] = *reinterpret_cast<const f32x4*>(ap + (size_t)a * 16 * K + kb);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bp + (size_t)t * K + kb);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step = [&](const f32x4 (&av)[4], const f32x4 (&bv)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[t][e], av[a][e], acc[a][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+    load(0, a0, b0);
+    int kb = 0;
+    for (; kb + 32 <= K; kb += 32) {
+        load(kb + 16, a1, b1);
+        step(a0, b0);
+        if (kb + 32 < K) load(kb + 32, a0, b0);
+        step(a1, b1);
+    }
+    if (kb < K) step(a0, b0);
+    // operands swapped (A operand = B rows): D row index = column sub-index, D column = A row fi.  Register r of tile (a, t)
+    // in lane (fi, fg): C[m0 + 16 a + fi][n0 + 4 (4 fg + r) + t]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4*>(Cb + (size_t)(m0 + 16 * a + fi) * N + n0 + 4 * (4 * fg + r)) =
+                f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+}
+
 // ------------------------------------------------------------------------------------------------
 // soft-argmax with temperature beta over the 4-D correlation c (B, S = h*h, T = h*h)
 //   rows: for every source pixel s, softmax over t   -> expected (x, y) of the target   (t_to_s maps)
@@ -1284,7 +1407,7 @@ extern "C" int cpn_resize_bilinear_ac_adjoint(const float* g, float* out, long l
 // doubles of the `stats` argument of cpn_conv4d / cpn_conv4d_gn_relu (layout: gn_publish); an upper bound over the
 // kernel variants' grids
 extern "C" long long cpn_gn_stats_doubles(int B, int Cout, long long npos) {
-    // VALU kernels: one workgroup per 256 positions and output channel (group); MFMA kernel: one per 64 positions
+    // VALU kernels: one workgroup per 256 positions and output channel (group); MFMA kernel: one per 256 positions (64 in round 3)
     const long long wg = std::max<long long>((long long)cpn_cdiv(npos, 256) * Cout, (long long)cpn_cdiv(npos, 64));
     return 3LL * B + 2LL * B * wg;
 }
@@ -1310,16 +1433,17 @@ extern "C" int cpn_conv4d(const float* x, const float* wq, const float* bq, cons
     const hipStream_t st = (hipStream_t)stream;
     dim3 grid(cpn_cdiv(npos, 256), Cout, B);
     const size_t wbytes = (size_t)Cin * 9 * 2 * Cout * sizeof(float);
-    // Measured (round 3, get_z at B = 1, rocprofv3): the MFMA kernel takes 40 us per Cout = 8 layer and 32 us per Cout = 32
-    // layer, the VALU kernel 24 and 34 — half of every 16-row MFMA tile is padding at 8 output channels and a wave's 16
-    // positions leave the matrix pipe waiting for 18 dependent taps per channel quad.  Opt-in (CPN_CONV4D_MFMA=1).
-    static const bool no_mfma = getenv("CPN_CONV4D_MFMA") == nullptr;
-    const int Cin4 = (Cin + 3) & ~3, mtiles = (Cout + 15) / 16;
-    const size_t wb_mfma = (size_t)18 * Cin4 * mtiles * 16 * sizeof(float);
-    if (!no_mfma && k == 3 && s == 1 && p == 1 && Cin >= 4 && mtiles <= 2 && wb_mfma <= 64 * 1024 &&
-        (long long)Cin * npos * 4 < 0x7ffffff0LL - 4LL * npos * 4) {
-        // gn_publish counts gridDim.x * gridDim.y workgroups per sample: one workgroup = 64 positions, all channels
-        dim3 g2(cpn_cdiv(npos, 64), 1, B);
+    // The MFMA form (conv4d_k3s1_mfma_kernel: 64 positions per wave, 12 vector loads per 72 MT MFMAs) where its layout rules
+    // hold; CPN_CONV4D_MFMA=0 keeps the VALU kernel.  (The round-3 MFMA form — 16 positions per wave, one 4-byte load per
+    // MFMA — measured 40 / 32 us per Cout = 8 / 32 layer against 24 / 34 for the VALU kernel and was opt-in.)
+    static const bool use_mfma = !(getenv("CPN_CONV4D_MFMA") && getenv("CPN_CONV4D_MFMA")[0] == '0');
+    const int mtiles = (Cout + 15) / 16;
+    const size_t wb_mfma = (size_t)18 * Cin * mtiles * 16 * sizeof(float);
+    const bool ws_ok = Ws == 4 || Ws == 8 || Ws == 16 || Ws == 32 || Ws == 64;
+    if (use_mfma && k == 3 && s == 1 && p == 1 && Cin % 4 == 0 && mtiles <= 2 && wb_mfma <= 64 * 1024 && ws_ok && npos % 64 == 0 &&
+        (long long)Cin * npos * 4 < 0x7ffffff0LL - 4LL * npos * 4 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
+        // gn_publish counts gridDim.x * gridDim.y workgroups per sample: one workgroup = 256 positions, all channels
+        dim3 g2(cpn_cdiv(npos, 256), 1, B);
         if (mtiles == 1)
             hipLaunchKernelGGL((conv4d_k3s1_mfma_kernel<1, false>), g2, dim3(256), wb_mfma, st, x, wq, bq, ws, bs, Cin, Hq, Wq, Hs,
                                Ws, Cout, y, stats);
@@ -1374,11 +1498,13 @@ extern "C" int cpn_conv4d_dgrad(const float* dy, const float* wq, const float* w
     CPN_REQUIRE((Cin % 4) == 0 && (long long)Cout * npos * 4 < 0x7ffffff0LL, CPN_E_SHAPE,
                 "cpn_conv4d_dgrad: need Cin %% 4 == 0 and a batch element below 2 GiB (Cin=%d)", Cin);
     {
-        static const bool no_mfma = getenv("CPN_CONV4D_MFMA") == nullptr;
-        const int K4 = (Cout + 3) & ~3, mtiles = (Cin + 15) / 16;           // the gradient convolves dy (Cout channels) into Cin
-        const size_t wb_mfma = (size_t)18 * K4 * mtiles * 16 * sizeof(float);
-        if (!no_mfma && Cout >= 4 && mtiles <= 2 && wb_mfma <= 64 * 1024 && (long long)Cout * npos * 4 < 0x7ffffff0LL - 4LL * npos * 4) {
-            dim3 g2(cpn_cdiv(npos, 64), 1, B);
+        static const bool use_mfma = !(getenv("CPN_CONV4D_MFMA") && getenv("CPN_CONV4D_MFMA")[0] == '0');
+        const int mtiles = (Cin + 15) / 16;                                 // the gradient convolves dy (Cout channels) into Cin
+        const size_t wb_mfma = (size_t)18 * Cout * mtiles * 16 * sizeof(float);
+        const bool ws_ok = Ws == 4 || Ws == 8 || Ws == 16 || Ws == 32 || Ws == 64;
+        if (use_mfma && Cout % 4 == 0 && mtiles <= 2 && wb_mfma <= 64 * 1024 && ws_ok && npos % 64 == 0 &&
+            (long long)Cout * npos * 4 < 0x7ffffff0LL - 4LL * npos * 4 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0) {
+            dim3 g2(cpn_cdiv(npos, 256), 1, B);
             const hipStream_t st2 = (hipStream_t)stream;
             if (mtiles == 1)
                 hipLaunchKernelGGL((conv4d_k3s1_mfma_kernel<1, true>), g2, dim3(256), wb_mfma, st2, dy, wq, (const float*)nullptr, ws,
@@ -1767,7 +1893,10 @@ extern "C" int cpn_correlation(const float* src, const float* trg, int B, int L,
         hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cpn_cdiv(rows, 4)), dim3(256), 0, st, trg, trg_n, rows, C, eps);
     }
     CPN_LAUNCH_CHECK("cpn_correlation(normalise)");
-    if ((long long)B * cpn_cdiv(L, 128) * cpn_cdiv(L, 64) >= 512) {
+    if (L % 128 == 0 && (long long)B * (L / 128) * (L / 128) >= 512 && ((uintptr_t)out % 16) == 0) {
+        dim3 grid(L / 128, L / 128, B);
+        hipLaunchKernelGGL(gemm_nt_f32_tile64_kernel, grid, dim3(256), 0, st, src_n, trg_n, out, L, L, C);
+    } else if ((long long)B * cpn_cdiv(L, 128) * cpn_cdiv(L, 64) >= 512) {
         dim3 grid(cpn_cdiv(L, 128), cpn_cdiv(L, 64), B);
         hipLaunchKernelGGL(gemm_nt_f32_kernel<8>, grid, dim3(256), 0, st, src_n, trg_n, out, L, L, C);
     } else {

@@ -440,3 +440,48 @@ def test_fused_pose_ends_equal_stock_ops(dev):
         got = HipOps().pose_positional(K, 256, 64)
         assert got.shape == want.shape
         assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("B,cin,cout,n,grad", [(2, 8, 32, 16, False), (1, 32, 8, 16, False), (2, 8, 8, 8, True), (3, 4, 16, 4, True),
+                                               (1, 12, 20, 8, True)])
+def test_conv4d_mfma_form_against_oracle(dev, B, cin, cout, n, grad):
+    """The stride-1 Conv4d on the fp32 MFMA (64 positions per wave, support-pair taps as DPP-shifted vectors): every shape
+    class of its dispatch — one / two channel tiles, padded channel tiles, rows of 4 / 8 / 16, several samples — against
+    the CPU oracle's Conv4d + GroupNorm + ReLU; where asked, the input gradient (the same kernel on the flipped filters)
+    and the filter gradients against autograd through the oracle."""
+    from coponerf_amd.ufc_ops import HipOps
+    from oracle.ufc_ref import TorchOps
+    x = syn.normal((B, cin, n, n, n, n), seed=31 + n)
+    wq, ws = syn.normal((cout, cin, 3, 3), seed=32) * 0.2, syn.normal((cout, cin, 3, 3), seed=33) * 0.2
+    bq, bs = syn.normal((cout,), seed=34) * 0.1, syn.normal((cout,), seed=35) * 0.1
+    gw, gb = 1 + 0.1 * syn.normal((cout,), seed=36), 0.1 * syn.normal((cout,), seed=37)
+    args = [x, wq, bq, ws, bs, gw, gb]
+    a = [t.clone().requires_grad_(grad) for t in args]
+    b = [t.clone().to(dev).requires_grad_(grad) for t in args]
+    with torch.set_grad_enabled(grad):
+        want = TorchOps().conv4d_gn_relu(a[0], a[1], a[2], a[3], a[4], 3, 1, 1, a[5], a[6], 1e-5)
+        got = HipOps().conv4d_gn_relu(b[0], b[1], b[2], b[3], b[4], 3, 1, 1, b[5], b[6], 1e-5)
+    assert float((got.detach().cpu() - want.detach()).abs().max()) <= 3e-5
+    if grad:
+        coef = syn.normal(tuple(want.shape), seed=38)
+        (want * coef).sum().backward()
+        (got * coef.to(dev)).sum().backward()
+        for i, (p, q) in enumerate(zip(a, b)):
+            rel = float((q.grad.cpu() - p.grad).norm() / (p.grad.norm() + 1e-12))
+            assert rel <= 2e-3, (i, rel)
+
+
+def test_large_correlation_kernel(dev):
+    """The 64 x 64-per-wave NT GEMM behind the finest level's 4096 x 4096 correlation (taken from 512 blocks of 128 x 128
+    on) against the normalised product in float64, and against the 16 x 128-per-wave kernel it replaces there: same products,
+    same k order per output."""
+    from coponerf_amd.ufc_ops import HipOps
+    hip = HipOps()
+    a, b = syn.normal((1, 4096, 64), seed=61).to(dev), syn.normal((1, 4096, 64), seed=62).to(dev)
+    got = hip.correlation_tokens(a, b, 64).reshape(1, 4096, 4096)
+    an = a.double() / (a.double().norm(dim=-1, keepdim=True) + 1e-5)
+    bn = b.double() / (b.double().norm(dim=-1, keepdim=True) + 1e-5)
+    want = an @ bn.transpose(1, 2)
+    assert float((got.double() - want).abs().max()) <= 2e-6
+    small = hip.correlation_tokens(a[:, :256], b[:, :256], 16).reshape(1, 256, 256)        # 16 x 32-per-wave kernel
+    assert float((small - got[:, :256, :256]).abs().max()) <= 2e-7
