@@ -16,6 +16,8 @@ from typing import Dict, Sequence
 import torch
 import torch.nn.functional as F
 
+from ._hip import stream_handle as _stream_handle
+
 
 _GRIDS: Dict = {}
 
@@ -145,6 +147,6 @@ def ray_outputs(inp: Dict, flow_prods, at_wt: torch.Tensor, pt: torch.Tensor, ra
     uvc, uvs = uv_rows
     call("cpn_ray_outputs", at_wt.data_ptr(), pt.data_ptr(), uvc.data_ptr(), uvs, rayc.data_ptr(), mask2.data_ptr(),
          flow_up.data_ptr(), B, V, R, S, at_max.data_ptr(), depth.data_ptr(), t1.data_ptr(), t2.data_ptr(), mc2.data_ptr(),
-         mm.data_ptr(), c21.data_ptr(), torch.cuda.current_stream().cuda_stream)
+         mm.data_ptr(), c21.data_ptr(), _stream_handle())
     return {"matchability_cycle_mask": mm, "T_to_C1_pts": t1, "T_to_C2_pts": t2, "mask_c2": mc2, "C2_pts_to_C1": c21,
             "at_wt_max": at_max, "depth_ray": depth}

@@ -27,6 +27,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._hip import stream_handle as _stream_handle
+
 from .ufc_ops import Linear as _Linear, linear as _linear      # nn.Linear / F.linear with the training dW on cpn_wgrad_f32
 
 
@@ -105,7 +107,7 @@ def _bn_act(x, bn, relu: bool, res=None):
         return F.relu(y) if relu else y
     call("cpn_bn_act", x.data_ptr(), 0 if res is None else res.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
          bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), N, C, H * W, int(relu), x.data_ptr(),
-         torch.cuda.current_stream().cuda_stream)
+         _stream_handle())
     return x
 
 
@@ -120,7 +122,7 @@ def _trunk_conv(xh, conv, bn, relu: bool, res=None, want_nchw: bool = False):
     if pack is None or pack[0] != (w._version, w.data_ptr()):
         wp = torch.empty(k * k, Cin, Cout, dtype=torch.float32, device=xh.device)
         call("cpn_pack_conv_weight", w.detach().contiguous().data_ptr(), Cout, Cin, k, wp.data_ptr(),
-             torch.cuda.current_stream().cuda_stream)
+             _stream_handle())
         pack = conv.__dict__["_cpn_pack"] = ((w._version, w.data_ptr()), wp)
     Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
     out = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32, device=xh.device)
@@ -129,7 +131,7 @@ def _trunk_conv(xh, conv, bn, relu: bool, res=None, want_nchw: bool = False):
     call("cpn_trunk_conv_bn_act", xh.data_ptr(), pack[1].data_ptr(), N, H, W, Cin, Cout, k, s, bn.running_mean.data_ptr(),
          bn.running_var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
          0 if res is None else res.data_ptr(), int(relu), out.data_ptr(), 0 if nchw is None else nchw.data_ptr(),
-         scratch.data_ptr(), torch.cuda.current_stream().cuda_stream)
+         scratch.data_ptr(), _stream_handle())
     return out, nchw
 
 
@@ -317,7 +319,7 @@ class UFCLayer(nn.Module):
         y = torch.empty_like(h)
         call("cpn_dwconv3x3_tokens", h.data_ptr(), dw.dwconv.weight.detach().reshape(C, 9).data_ptr(),
              dw.dwconv.bias.detach().data_ptr(), B, dw.size, dw.size, C, 2, y.data_ptr(),
-             torch.cuda.current_stream().cuda_stream)
+             _stream_handle())
         return seq[3](y)
 
     def _qk_weights(self, ncc: int):
@@ -356,7 +358,7 @@ class UFCLayer(nn.Module):
         q = torch.empty(B, fs * fs, self.nhead, self.dim, dtype=torch.float32, device=lin.device)
         k = torch.empty_like(q)
         call("cpn_qk_assemble", lin.data_ptr(), low.data_ptr(), pos.data_ptr(), B, fs, Hs, Ws, self.nhead, self.dim,
-             q.data_ptr(), k.data_ptr(), torch.cuda.current_stream().cuda_stream)
+             q.data_ptr(), k.data_ptr(), _stream_handle())
         return q, k
 
     def _attention(self, corr, feat, ops):              # aggregation.py:269-310

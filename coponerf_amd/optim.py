@@ -15,6 +15,8 @@ import torch
 from . import _hip
 from ._hip import call
 
+from ._hip import stream_handle as _stream_handle
+
 _SEG = np.dtype([("p", "<u8"), ("g", "<u8"), ("off", "<i8"), ("n", "<i4"), ("step_size", "<f4"), ("inv_sqrt_bc2", "<f4"),
                  ("pad", "<i4", (3,))])
 assert _SEG.itemsize == _hip.ADAM_SEG_BYTES
@@ -102,7 +104,7 @@ class OneLaunchAdam:
         b1, b2 = self.betas
         call("cpn_adam_step", self._dev[i].data_ptr(), self._blocks.data_ptr(), self.nblocks, self.exp_avg.data_ptr(),
              self.exp_avg_sq.data_ptr(), 0 if gscale is None else gscale.data_ptr(), b1, b2, self.eps,
-             torch.cuda.current_stream().cuda_stream)
+             _stream_handle())
 
     def discard(self) -> None:
         """Drop a prepared table (the step is skipped); its slot is written again by the next `prepare`."""

@@ -25,7 +25,7 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _hip.stream_handle()
 
 
 def _to_host(*mats: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:

@@ -20,6 +20,8 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from ._hip import stream_handle as _stream_handle
+
 MAGIC = b"CPNSHARD1\n"
 
 
@@ -149,7 +151,7 @@ class BatchAssembler:
         ctx = torch.empty(B, 2, S, S, 3, dtype=torch.float32, device=self.dev)
         qrgb = torch.empty(B, 1, R, 3, dtype=torch.float32, device=self.dev)
         call("cpn_prepare_input", frames.data_ptr(), B, self.Hs, self.Ws, self.y0, self.x0, S, S, R, pix.data_ptr(),
-             ctx.data_ptr(), qrgb.data_ptr(), torch.cuda.current_stream().cuda_stream)
+             ctx.data_ptr(), qrgb.data_ptr(), _stream_handle())
         uv = torch.stack((pix % S, pix // S), dim=-1).float().view(B, 1, R, 2)               # (x = column, y = row)
         mat = lambda j, k: small[:, j, 16 * k:16 * k + 16].reshape(B, 1, 4, 4)
         query = {"rgb": qrgb, "cam2world": mat(2, 0), "intrinsics": mat(2, 1), "uv": uv}

@@ -18,7 +18,7 @@ from ._hip import call
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _hip.stream_handle()
 
 
 class _HipForwardVjp(Function):
