@@ -319,14 +319,14 @@ def run(args):
     # ---- secondary figure: the whole image pipeline (get_z once per pair + the render pass), SURVEY.md §8(d)
     if H == 256 and not args.no_image:
         with torch.no_grad():
-            for _ in range(2):
+            for _ in range(5):                               # (the library picks its convolution kernels on first use)
                 zz = model.get_z(inp)
             torch.cuda.synchronize()
             g0 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(10):
                 zz = model.get_z(inp)
             torch.cuda.synchronize()
-            getz_ms = (time.perf_counter() - g0) / 3 * 1e3
+            getz_ms = (time.perf_counter() - g0) / 10 * 1e3
         line["get_z_ms"] = getz_ms
         # the same call replayed as a captured HIP graph (coponerf_amd/graphs.py): no host cost per launch, what the GPU needs
         from coponerf_amd.graphs import GraphedGetZ
@@ -336,10 +336,10 @@ def run(args):
                 zz = gz(inp)
             torch.cuda.synchronize()
             g0 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(10):
                 zz = gz(inp)
             torch.cuda.synchronize()
-            line["get_z_graph_ms"] = (time.perf_counter() - g0) / 3 * 1e3
+            line["get_z_graph_ms"] = (time.perf_counter() - g0) / 10 * 1e3
             del gz
         line["image_rays_per_s"] = rays_per_step / (getz_ms * 1e-3 + elapsed / args.steps)
         del zz
