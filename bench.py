@@ -343,8 +343,8 @@ def run(args):
             del gz
         line["image_rays_per_s"] = rays_per_step / (getz_ms * 1e-3 + elapsed / args.steps)
         del zz
-        # the same pipeline with get_z of pair i+1 on a second HIP stream under the render of pair i
-        # (coponerf_amd/pipeline.py; pairs are independent, results identical to the serial order)
+        # the same pipeline as coponerf_amd/pipeline.render_images runs it by default: one stream, the host issuing get_z of
+        # pair i+1 while the GPU renders pair i (pairs are independent, results identical to the serial order)
         if B == 1:
             from coponerf_amd.pipeline import render_images
             pairs = [inp] + [_to(syn.make_inputs(1, H, H, 0, seed=300 + rank * 16 + i, full_image=True), dev) for i in range(3)]

@@ -54,13 +54,18 @@ def _pair_slice(obj, lo: int, hi: int, per: int):
 
 
 def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: bool = False,
-                  cu_split: Optional[Tuple[int, int]] = None, nchunks: Optional[int] = None) -> Iterator[Tuple[Dict, Dict]]:
+                  cu_split: Optional[Tuple[int, int]] = None, nchunks: Optional[int] = None,
+                  overlap: bool = False) -> Iterator[Tuple[Dict, Dict]]:
     """For every model_input dict (on the device) yield (model_input, forward(model_input, z, rel_pose, val=True, flow)),
     with `get_z` of the next inputs overlapped with the render of the current ones.  Call under torch.no_grad().
 
     cu_split=(render_cus, getz_cus) runs the two halves on CU-masked streams over disjoint shares of the chip
     (multiples of 32, sum <= the device's CU count; e.g. (192, 64)); the yielded outputs are ordered after the
-    caller's current stream as usual.  None: two ordinary streams (the get_z one at high priority).
+    caller's current stream as usual.  None: ONE stream — the GPU runs render(i), get_z(i+1), render(i+1), ... in that
+    order while the host issues get_z(i+1) under render(i) (the host half of get_z, ~6 ms of Python and launches, is what
+    this order hides); `overlap=True` puts get_z on a second, high-priority ordinary stream instead, which measured SLOWER
+    than the serial GPU order ever since the render kernels became persistent (34.9 against 31.6 ms per image in round 4:
+    each small kernel of get_z waits for a chip-filling launch to drain and the render kernels lose their cache state).
 
     nchunks renders every input the way the reference's callers do (test.py:176-212: that many forward() calls on
     torch.chunk(uv, nchunks), joined key by key — coponerf_amd/evalloop.render_in_chunks) instead of in one call.
@@ -114,9 +119,9 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
         engine.set_call_streams(part.render_lanes(engine.call_lanes) if engine.call_lanes > 1 else None)
     else:
         main = outer
-        # high priority: the small kernels of get_z are dispatched ahead of the render's queued workgroups instead of
-        # waiting behind each of the render's chip-filling launches
-        side = torch.cuda.Stream(device=main.device, priority=-1)
+        # overlap: high priority, so that the small kernels of get_z are dispatched ahead of the render's queued workgroups
+        # instead of waiting behind each of the render's chip-filling launches
+        side = torch.cuda.Stream(device=main.device, priority=-1) if overlap else main
     try:
         with torch.cuda.stream(main):
             state = features(cur)                                  # first group: nothing to hide it under

@@ -172,8 +172,8 @@ def test_encoder4d_gradients_match_upstream_fixture(dev):
 
 
 def test_pipelined_images_equal_serial(dev):
-    """coponerf_amd.pipeline.render_images (get_z of pair i+1 on a second stream under the render of pair i) returns
-    what the serial get_z -> forward order returns, pair by pair."""
+    """coponerf_amd.pipeline.render_images (the host issuing get_z of pair i+1 under the render of pair i; with overlap=True
+    on a second stream) returns what the serial get_z -> forward order returns, pair by pair."""
     from coponerf_amd import CoPoNeRF
     from coponerf_amd.pipeline import render_images
     model = CoPoNeRF.CoPoNeRF(n_view=2)
@@ -189,6 +189,7 @@ def test_pipelined_images_equal_serial(dev):
     with torch.no_grad():
         serial = [serial_rgb(p) for p in pairs]
         piped = [out["rgb"].clone() for _, out in render_images(model, pairs)]
+        overlapped = [out["rgb"].clone() for _, out in render_images(model, pairs, overlap=True)]   # get_z on a second stream
         batched = [out["rgb"].clone() for _, out in render_images(model, pairs, getz_batch=2)]   # groups of 2 + 1
         parted = [out["rgb"].clone() for _, out in render_images(model, pairs, cu_split=(192, 64))]   # partitioned chip
         lanes_after = model._engine.call_lanes
@@ -212,7 +213,9 @@ def test_pipelined_images_equal_serial(dev):
     # side) run other library kernels (GEMM / convolution choices depend on the batch size): equal to fp32 rounding in
     # get_z, which the fp16 render path turns into a few 1e-4 of rgb
     noise = 1e-4
-    assert len(piped) == 3 and len(batched) == 3
+    assert len(piped) == 3 and len(batched) == 3 and len(overlapped) == 3
+    for a, b in zip(overlapped, serial):
+        assert torch.equal(a, b)
     for a, b in zip(serial, piped):
         assert torch.equal(a, b), float((a - b).abs().max())
     # render pass on 192 CUs, get_z on the other 64 (CU-masked streams): the persistent grids shrink to the share, the
