@@ -71,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--rig", choices=("narrow", "wide"), default="narrow",
                     help="camera rig of the synthetic pairs: RealEstate10K-like (configs[1]) or ACID-like wide baseline "
                          "(configs[3])")
-    ap.add_argument("--train-steps", type=int, default=3,
+    ap.add_argument("--train-steps", type=int, default=6,
                     help="steps of the secondary training measurement in render mode (0 = skip)")
     return ap.parse_args(argv)
 
@@ -421,7 +421,7 @@ def run(args):
         del out, model, z, flow
         torch.cuda.empty_cache()
         try:
-            tr = measure_train(args, dev, rank, world, args.train_steps, 2)
+            tr = measure_train(args, dev, rank, world, args.train_steps, 3)
         except Exception as e:                         # the headline line must survive a failure of the side figure
             tr = {"error": f"{type(e).__name__}: {e}"}
         line["train"] = tr
