@@ -67,7 +67,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_correlation": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "cpn_l2norm_rows_bwd": [_P, _P, _P, ctypes.c_longlong, _I, _F, _P, _P],
     "cpn_wgrad_f32": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
-    "cpn_adam_step": [_P, _P, _I, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P],
+    "cpn_adam_step": [_P, _P, _I, _P, _P, _P, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P],
     "cpn_soft_argmax_pair": [_P, _I, _I, _F, _P, _P, _P],
     "cpn_soft_argmax_pair_bwd": [_P, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "cpn_linear_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],

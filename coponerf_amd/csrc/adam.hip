@@ -13,6 +13,9 @@
 // Arithmetic per element (fp32, the operation order of the library's fused kernel):
 //   m += (g - m) (1 - b1);   v = b2 v + (1 - b2) g g;   p -= step_size * m / (sqrt(v) * inv_sqrt_bc2 + eps)
 // `gscale` (device scalar or NULL) multiplies the gradient first: the clip coefficient can stay on the device.
+// `gate` (device scalar or NULL): 0 skips the whole update — the finite-gradient guard without a host read; the per-tensor update
+// counts then live on the device too (`counts_in` / `counts_out`, swapped by the caller every step) and the bias corrections
+// are formed from them in the kernel.
 #include "common.h"
 
 namespace {
@@ -32,11 +35,24 @@ constexpr int ADAM_CHUNK = 2048;
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamSeg* __restrict__ segs, const int2* __restrict__ blocks,
                                                         float* __restrict__ m_all, float* __restrict__ v_all,
-                                                        const float* __restrict__ gscale, float b1, float b2, float omb1, float omb2,
-                                                        float eps) {
+                                                        const float* __restrict__ gscale, const float* __restrict__ gate,
+                                                        const int* __restrict__ counts_in, int* __restrict__ counts_out,
+                                                        double lr, double b1d, double b2d, float b1, float b2, float omb1,
+                                                        float omb2, float eps) {
     const int2 blk = blocks[blockIdx.x];
-    const AdamSeg sg = segs[blk.x];
-    if (sg.g == nullptr) return;
+    AdamSeg sg = segs[blk.x];
+    const bool update = sg.g != nullptr && !(gate != nullptr && *gate == 0.0f);
+    if (counts_in != nullptr) {
+        // update counts on the device (the host never learns whether a gated step happened): this step reads counts_in and
+        // the first block of every tensor writes counts_out; bias corrections from the tensor's own count, in double
+        const int k = counts_in[blk.x] + (update ? 1 : 0);
+        if (blk.y == 0 && threadIdx.x == 0) counts_out[blk.x] = k;
+        if (!update) return;
+        sg.step_size = (float)(lr / (1.0 - pow(b1d, (double)k)));
+        sg.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(b2d, (double)k)));
+    } else if (!update) {
+        return;
+    }
     const float gs = gscale ? *gscale : 1.0f;
     float* __restrict__ p = sg.p;
     const float* __restrict__ g = sg.g;
@@ -78,12 +94,16 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamSeg* __restric
 extern "C" int cpn_adam_chunk(void) { return ADAM_CHUNK; }
 
 extern "C" int cpn_adam_step(const void* segs, const int* blocks, int nblocks, float* exp_avg, float* exp_avg_sq,
-                             const float* gscale, double beta1, double beta2, double eps, void* stream) {
+                             const float* gscale, const float* gate, const int* counts_in, int* counts_out, double lr,
+                             double beta1, double beta2, double eps, void* stream) {
     CPN_REQUIRE(nblocks > 0 && segs && blocks && exp_avg && exp_avg_sq, 1, "cpn_adam_step: empty table");
     CPN_REQUIRE(((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)segs) % 16 == 0, 1,
                 "cpn_adam_step: state buffers and the segment table must be 16-byte aligned");
+    CPN_REQUIRE((counts_in == nullptr) == (counts_out == nullptr) && (counts_in == nullptr || counts_in != counts_out), 1,
+                "cpn_adam_step: counts_in / counts_out come as a pair of DIFFERENT arrays (or both NULL)");
     hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const AdamSeg*)segs,
-                       (const int2*)blocks, exp_avg, exp_avg_sq, gscale, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                       (const int2*)blocks, exp_avg, exp_avg_sq, gscale, gate, counts_in, counts_out, lr, beta1, beta2,
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1),
                        (float)(1.0 - beta2), (float)eps);                    // 1 - beta in double: 1 - 0.999f is off by 1.3e-5
     CPN_LAUNCH_CHECK("cpn_adam_step");
     return 0;

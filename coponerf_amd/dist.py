@@ -78,6 +78,21 @@ def guard_and_clip_coefficient(params: Iterable[torch.nn.Parameter], max_norm: f
     return finite, total, coef
 
 
+def guard_on_device(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0):
+    """The same guard and clip coefficient WITHOUT a host read, for a single rank whose update kernel takes them as device
+    scalars (optim.OneLaunchAdam.step(gscale, gate)): returns (ok: fp32 device scalar 1 / 0, total_norm: float64 device
+    scalar, coef: fp32 device scalar or None).  The caller's host never waits for the backward pass here."""
+    grads = [p.grad for p in params if p.grad is not None]
+    norms = torch.stack(torch._foreach_norm(grads)).double()
+    total = norms.square().sum().sqrt()
+    ok = torch.isfinite(total).float()
+    coef = None
+    if max_norm and max_norm > 0:
+        # a non-finite norm would make the coefficient NaN: the gate already skips that step, keep the scalar finite
+        coef = torch.nan_to_num(torch.clamp(max_norm / (total + 1e-6), max=1.0), nan=0.0).float()
+    return ok, total, coef
+
+
 def _guard(params, max_norm, group, force):
     plist = list(params)
     grads = [p.grad for p in plist if p.grad is not None]

@@ -44,7 +44,10 @@ class OneLaunchAdam:
         blocks = np.array([(t, s) for t, p in enumerate(self.params) for s in range(0, p.numel(), chunk)], dtype=np.int32)
         self.nblocks = int(blocks.shape[0])
         self._blocks = torch.from_numpy(blocks).to(dev)
-        self.steps = np.zeros(n, dtype=np.int64)
+        # update counts per tensor: on the DEVICE (two arrays, read / written in turn) so that a step gated by a device flag
+        # needs no host read; `steps` reads them back
+        self._counts = torch.zeros(2, n, dtype=torch.int32, device=dev)
+        self._count_turn = 0
         self._host = [torch.empty(n * _SEG.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
         self._host_np = [h.numpy().view(_SEG) for h in self._host]
         for seg in self._host_np:
@@ -66,7 +69,7 @@ class OneLaunchAdam:
     def prepare(self) -> None:
         """Host half of a step: collect the gradient addresses, write the table, start its upload.  Callable as soon as the
         backward pass is ENQUEUED (addresses exist then) — a caller that reads a device flag before it steps does this first,
-        so the ~0.8 ms of Python run under the GPU's backward pass.  The update counts move in `step`."""
+        so the ~0.8 ms of Python run under the GPU's backward pass."""
         i = self._turn & 1
         if self._sent[i] is not None:
             self._sent[i].synchronize()                       # the copy two steps ago read this pinned block
@@ -81,12 +84,7 @@ class OneLaunchAdam:
             if not (g.is_contiguous() and g.dtype == torch.float32):
                 g = p.grad = g.contiguous().float()
             gptr[j] = g.data_ptr()
-        self._has = gptr != 0
-        k = np.maximum(self.steps + self._has, 1).astype(np.float64)
-        b1, b2 = self.betas
-        seg["p"], seg["g"] = pptr, gptr
-        seg["step_size"] = (self.lr / (1.0 - b1 ** k)).astype(np.float32)
-        seg["inv_sqrt_bc2"] = (1.0 / np.sqrt(1.0 - b2 ** k)).astype(np.float32)
+        seg["p"], seg["g"] = pptr, gptr                       # (step size / bias corrections: formed on the device from its counts)
         self._dev[i].copy_(self._host[i], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -94,17 +92,25 @@ class OneLaunchAdam:
         self._prepared = True
 
     @torch.no_grad()
-    def step(self, gscale: Optional[torch.Tensor] = None) -> None:
+    def step(self, gscale: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> None:
+        """gate: optional device scalar (fp32); 0 turns the whole step into a no-op ON THE DEVICE (no moment, count or
+        parameter changes) — the finite-gradient guard without the host reading its flag."""
         if not getattr(self, "_prepared", False):
             self.prepare()
         i = self._turn & 1
         self._turn += 1
         self._prepared = False
-        self.steps += self._has
+        cin, cout = self._counts[self._count_turn & 1], self._counts[(self._count_turn + 1) & 1]
+        self._count_turn += 1
         b1, b2 = self.betas
         call("cpn_adam_step", self._dev[i].data_ptr(), self._blocks.data_ptr(), self.nblocks, self.exp_avg.data_ptr(),
-             self.exp_avg_sq.data_ptr(), 0 if gscale is None else gscale.data_ptr(), b1, b2, self.eps,
-             _stream_handle())
+             self.exp_avg_sq.data_ptr(), 0 if gscale is None else gscale.data_ptr(), 0 if gate is None else gate.data_ptr(),
+             cin.data_ptr(), cout.data_ptr(), self.lr, b1, b2, self.eps, _stream_handle())
+
+    @property
+    def steps(self) -> np.ndarray:
+        """Updates every tensor has received (a device read: synchronises)."""
+        return self._counts[self._count_turn & 1].cpu().numpy().astype(np.int64)
 
     def discard(self) -> None:
         """Drop a prepared table (the step is skipped); its slot is written again by the next `prepare`."""

@@ -9,11 +9,27 @@ all-reduces.  One process per GPU; ranks draw independent batches (train.py:84-9
 """
 from __future__ import annotations
 
+import collections
 from typing import Dict, Optional
 
 import torch
 
 from . import dist as cdist
+
+
+class _LazyFlag:
+    """`stepped` of a step whose guard ran on the device: truth value on demand (waits for a 4-byte copy that was started
+    when the step was issued)."""
+
+    def __init__(self, host: torch.Tensor, event):
+        self._host, self._event = host, event
+
+    def __bool__(self) -> bool:
+        self._event.synchronize()
+        return bool(self._host.item() > 0)
+
+    def __repr__(self) -> str:
+        return f"_LazyFlag({bool(self)})"
 
 
 class TrainStep:
@@ -46,6 +62,9 @@ class TrainStep:
         self._good = 0
         eng = getattr(model, "_engine", None)
         self._scale_ceiling = float(eng.grad_scale_target) if eng is not None else 0.0
+        self._pending = collections.deque()                              # `stepped` flags of steps guarded on the device
+        self._flag_host = [torch.zeros(1).pin_memory() for _ in range(4)] if on_gpu else None
+        self._flag_turn = 0
 
     def _ev(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -55,6 +74,10 @@ class TrainStep:
     def __call__(self, model_input: Dict, gt_rgb: torch.Tensor) -> Dict[str, object]:
         """model_input: the reference's input dict on the device; gt_rgb (B,1,R,3).  Returns loss / bookkeeping."""
         timed = self.timing is not None and torch.cuda.is_available()
+        # steps whose guard ran on the device: their outcome reaches the scale adaptation when its 4-byte copy has landed —
+        # normally one step late, never by waiting (unless three are outstanding)
+        while self._pending and (self._pending[0]._event.query() or len(self._pending) > 2):
+            self._adapt_grad_scale(bool(self._pending.popleft()))
         e0 = self._ev() if timed else None
         out = self.model(model_input, val=False)
         zero = lambda t: torch.where(torch.isnan(t), torch.zeros_like(t), t)      # loss_function.py:66-69
@@ -63,34 +86,38 @@ class TrainStep:
         loss.backward()
         e2 = self._ev() if timed else None
         # guard + clip in one pass over the gradients; the flag is the same on every rank.  No exchange behind the clip (it
-        # may hand a rank gradients it did not have): the coefficient stays a device scalar and is applied inside the update,
-        # and the update's address table is written BEFORE the guard reads its flag — the host is still ahead of the GPU here
-        defer = self._one_launch and not cdist._exchanging(self.group, self.force_collectives)
-        coef = None
-        if defer:
+        # may hand a rank gradients it did not have): flag and coefficient STAY on the device — the update kernel is gated by
+        # the flag and multiplies the coefficient in — so the host never waits for the backward pass (behind a `.item()` it
+        # is no longer ahead of the GPU, and everything it does until the next step's first launch is GPU idle time: 0.4-0.9 ms
+        # per step depending on the host)
+        on_device = self._one_launch and not cdist._exchanging(self.group, self.force_collectives)
+        ncoll, nbytes = 0, 0
+        if on_device:
             self.opt.prepare()
-            stepped, _, coef = cdist.guard_and_clip_coefficient(self.params, float(self.clip_grad or 0.0), group=self.group,
-                                                                force=self.force_collectives)
+            ok, _, coef = cdist.guard_on_device(self.params, float(self.clip_grad or 0.0))
+            e3 = e4 = self._ev() if timed else None
+            self.opt.step(gscale=coef, gate=ok)
+            host = self._flag_host[self._flag_turn & 3]
+            self._flag_turn += 1
+            host.copy_(ok.reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            stepped = _LazyFlag(host, ev)
+            self._pending.append(stepped)
         else:
             stepped, _ = cdist.guard_and_clip(self.params, float(self.clip_grad or 0.0), group=self.group,
                                               force=self.force_collectives)
-        ncoll, nbytes = 0, 0
-        if stepped:
-            e3 = self._ev() if timed else None
-            ncoll = cdist.average_gradients(self.params, bucket_bytes=self.bucket_bytes, group=self.group,
+            if stepped:
+                e3 = self._ev() if timed else None
+                ncoll = cdist.average_gradients(self.params, bucket_bytes=self.bucket_bytes, group=self.group,
                                                 force=self.force_collectives)
-            if ncoll:
-                nbytes = sum(p.grad.numel() * p.grad.element_size() for p in self.params if p.grad is not None)
-            e4 = self._ev() if timed else None
-            if self._one_launch:
-                self.opt.step(gscale=coef)
-            else:
+                if ncoll:
+                    nbytes = sum(p.grad.numel() * p.grad.element_size() for p in self.params if p.grad is not None)
+                e4 = self._ev() if timed else None
                 self.opt.step()
-        else:
-            e3 = e4 = self._ev() if timed else None
-            if self._one_launch:
-                self.opt.discard()
-        self._adapt_grad_scale(stepped)
+            else:
+                e3 = e4 = self._ev() if timed else None
+            self._adapt_grad_scale(stepped)
         self.opt.zero_grad(set_to_none=True)
         e5 = self._ev() if timed else None
         if timed:

@@ -416,11 +416,16 @@ int cpn_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, long long R
  *         { float* param; const float* grad (NULL: tensor skipped); int64 offset of its moments in exp_avg / exp_avg_sq
  *           (multiple of 4); int32 numel; float step_size = lr / (1 - beta1^k); float 1 / sqrt(1 - beta2^k); 12 bytes pad }
  *   blocks: device array of nblocks x { int32 tensor, int32 first element }: cpn_adam_chunk() elements per block
- *   gscale: device scalar multiplied into every gradient first (the clip coefficient), or NULL                         */
+ *   gscale: device scalar multiplied into every gradient first (the clip coefficient), or NULL
+ *   gate: device scalar, 0 = skip the whole update (the finite-gradient guard of wrapper.py:44-58,147-151 without a host
+ *         read), or NULL.  counts_in / counts_out (one int32 per tensor, two DIFFERENT arrays swapped by the caller every
+ *         step; or both NULL): the tensors' update counts kept on the device — the kernel then forms step_size and
+ *         1 / sqrt(1 - beta2^k) from counts_in[t] + 1 and `lr` itself and ignores the two floats of the record             */
 #define CPN_ADAM_SEG_BYTES 48
 int cpn_adam_chunk(void);
 int cpn_adam_step(const void* segs, const int* blocks, int nblocks, float* exp_avg, float* exp_avg_sq,
-                  const float* gscale, double beta1, double beta2, double eps, void* stream);
+                  const float* gscale, const float* gate, const int* counts_in, int* counts_out, double lr,
+                  double beta1, double beta2, double eps, void* stream);
 
 /* ---- K8: soft-argmax with temperature over the 4-D correlation, both directions --------------------
  * replaces aggregation.soft_argmax + softmax_with_temperature (models/aggregation.py:119-144, 555-560).

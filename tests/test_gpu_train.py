@@ -574,6 +574,50 @@ def test_one_launch_adam_equals_library_adam():
         st = b.state[q]
         assert float((m - st["exp_avg"]).abs().max()) <= 1e-6 * float(st["exp_avg"].abs().max()) + 1e-12
         assert float((v - st["exp_avg_sq"]).abs().max()) <= 1e-6 * float(st["exp_avg_sq"].abs().max()) + 1e-12
-    assert a.steps.tolist() == [4, 4, 4, 3, 4, 4, 4]
+    assert a.steps.tolist() == [4, 4, 4, 3, 4, 4, 4]                     # kept on the device, per tensor
+    # a gated step is a no-op on the device: parameters, moments and counts stay
+    before = [p.detach().clone() for p in mine]
+    for i, p in enumerate(mine):
+        p.grad = syn.normal(shapes[i], seed=900 + i).to(dev)
+    a.step(gate=torch.zeros((), device=dev))
+    assert all(torch.equal(p, q) for p, q in zip(mine, before)) and a.steps.tolist() == [4, 4, 4, 3, 4, 4, 4]
+    a.step(gate=torch.ones((), device=dev))
+    assert not torch.equal(mine[5], before[5]) and a.steps.tolist() == [5, 5, 5, 4, 5, 5, 5]
     a.zero_grad()
     assert all(p.grad is None for p in mine)
+
+
+@pytest.mark.gpu
+def test_train_step_guards_on_the_device():
+    """TrainStep on one device (no exchange): the finite-gradient guard and the clip coefficient stay on the device, the
+    update kernel is gated by the flag.  A step whose gradients hold a NaN changes nothing (parameters, moments, counts)
+    and reports stepped == False when asked; the next clean step updates; no call of the step waits for the GPU."""
+    from coponerf_amd import CoPoNeRF
+    from coponerf_amd.train_step import TrainStep, _LazyFlag
+    dev = torch.device("cuda:0")
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev).train()
+    inp = to_device(syn.make_inputs(1, 256, 256, 128, seed=61), dev)
+    step = TrainStep(model)
+    params = [p for p in model.parameters()]
+    probe = model.query_encode_latent.weight
+    w0 = [p.detach().clone() for p in params]
+    hook = probe.register_hook(lambda g: g * float("nan"))
+    r = step(inp, inp["query"]["rgb"])
+    hook.remove()
+    assert isinstance(r["stepped"], _LazyFlag) and bool(r["stepped"]) is False
+    assert all(torch.equal(p.detach(), q) for p, q in zip(params, w0))
+    assert int(step.opt.steps.max()) == 0 and float(step.opt.exp_avg.abs().max()) == 0.0
+    assert all(p.grad is None for p in params)
+    scale_before = model._engine.grad_scale_target
+    r = step(inp, inp["query"]["rgb"])                      # the skipped step reaches the scale adaptation here
+    assert bool(r["stepped"]) is True and step.skipped_total == 1
+    assert model._engine.grad_scale_target <= scale_before
+    idx = [i for i, p in enumerate(params) if p is probe][0]
+    assert not torch.equal(probe.detach(), w0[idx])
+    got = step.opt.steps
+    assert int(got.max()) == 1 and int(got.min()) == 0      # the parameters without a gradient keep their zero
+    r = step(inp, inp["query"]["rgb"])
+    assert bool(r["stepped"]) and float(r["loss"]) == float(r["loss"])
