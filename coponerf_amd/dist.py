@@ -82,7 +82,11 @@ def guard_on_device(params: Iterable[torch.nn.Parameter], max_norm: float = 0.0)
     """The same guard and clip coefficient WITHOUT a host read, for a single rank whose update kernel takes them as device
     scalars (optim.OneLaunchAdam.step(gscale, gate)): returns (ok: fp32 device scalar 1 / 0, total_norm: float64 device
     scalar, coef: fp32 device scalar or None).  The caller's host never waits for the backward pass here."""
-    grads = [p.grad for p in params if p.grad is not None]
+    plist = list(params)
+    grads = [p.grad for p in plist if p.grad is not None]
+    if not grads:                                             # nothing to guard or clip: an update would be a no-op anyway
+        dev = plist[0].device if plist else "cpu"
+        return torch.ones((), dtype=torch.float32, device=dev), torch.zeros((), dtype=torch.float64, device=dev), None
     norms = torch.stack(torch._foreach_norm(grads)).double()
     total = norms.square().sum().sqrt()
     ok = torch.isfinite(total).float()

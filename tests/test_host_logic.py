@@ -93,3 +93,29 @@ def test_uv_rows_reads_ray_chunks_in_place():
     weird = full.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)   # (x, y) not adjacent in memory
     u2, s2 = _uv_rows(weird, 2, 10)
     assert u2.is_contiguous() and s2 == 20 and torch.equal(u2, full[:, 0])
+
+
+def test_guard_on_device_matches_the_host_guard():
+    """dist.guard_on_device (flag and clip coefficient as tensors, no host read) against dist.guard_and_clip: same flag, the
+    coefficient it would have applied; a NaN makes the flag 0 and leaves the coefficient finite; no gradients at all -> flag 1."""
+    import torch
+    from coponerf_amd import dist as cd
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2))]
+    for p in ps[:2]:
+        p.grad = torch.randn_like(p) * 3
+    ok, total, coef = cd.guard_on_device(ps, 0.5)
+    ref = [p.grad.clone() for p in ps[:2]]
+    fin, tot = cd.guard_and_clip(ps, 0.5)
+    assert fin and float(ok) == 1.0 and abs(float(total) - float(tot)) < 1e-12
+    for p, g in zip(ps[:2], ref):
+        assert torch.allclose(p.grad, g * coef)
+    ok2, _, none = cd.guard_on_device(ps, 0.0)
+    assert float(ok2) == 1.0 and none is None
+    ps[1].grad[2] = float("nan")
+    ok3, _, coef3 = cd.guard_on_device(ps, 0.5)
+    assert float(ok3) == 0.0 and bool(torch.isfinite(coef3))
+    for p in ps:
+        p.grad = None
+    ok4, tot4, c4 = cd.guard_on_device(ps, 0.5)
+    assert float(ok4) == 1.0 and float(tot4) == 0.0 and c4 is None
