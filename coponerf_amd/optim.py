@@ -85,6 +85,7 @@ class OneLaunchAdam:
                 g = p.grad = g.contiguous().float()
             gptr[j] = g.data_ptr()
         seg["p"], seg["g"] = pptr, gptr                       # (step size / bias corrections: formed on the device from its counts)
+        self._no_grad_at_prepare = [p for p, g in zip(self.params, gptr) if g == 0]
         self._dev[i].copy_(self._host[i], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -95,8 +96,8 @@ class OneLaunchAdam:
     def step(self, gscale: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> None:
         """gate: optional device scalar (fp32); 0 turns the whole step into a no-op ON THE DEVICE (no moment, count or
         parameter changes) — the finite-gradient guard without the host reading its flag."""
-        if not getattr(self, "_prepared", False):
-            self.prepare()
+        if not getattr(self, "_prepared", False) or any(p.grad is not None for p in self._no_grad_at_prepare):
+            self.prepare()                                    # (a gradient exchange may hand a rank gradients it did not have)
         i = self._turn & 1
         self._turn += 1
         self._prepared = False

@@ -105,6 +105,8 @@ class TrainStep:
             stepped = _LazyFlag(host, ev)
             self._pending.append(stepped)
         else:
+            if self._one_launch:
+                self.opt.prepare()        # under the backward pass; the exchange averages INTO the same gradient tensors
             stepped, _ = cdist.guard_and_clip(self.params, float(self.clip_grad or 0.0), group=self.group,
                                               force=self.force_collectives)
             if stepped:
@@ -117,6 +119,8 @@ class TrainStep:
                 self.opt.step()
             else:
                 e3 = e4 = self._ev() if timed else None
+                if self._one_launch:
+                    self.opt.discard()
             self._adapt_grad_scale(stepped)
         self.opt.zero_grad(set_to_none=True)
         e5 = self._ev() if timed else None
