@@ -1238,6 +1238,13 @@ __global__ __launch_bounds__(256) void transpose_pairs_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// a (1 - l) + b l as two multiplies and an add, never contracted into a multiply-add: the resize kernel and the two fused
+// forms of the final correlation then produce the same bits whatever the compiler would have chosen in each of them
+__device__ __forceinline__ float mix_nc(float a, float b, float l) {
+#pragma clang fp contract(off)
+    return a * (1.0f - l) + b * l;
+}
+
 // bilinear resize with align_corners=True of `planes` independent (h, w) images: F.interpolate as used by
 // interpolate4d / forward_attention (aggregation.py:49-56, 285, 293, 299).  thread = output pixel; HBM-bound.
 // ------------------------------------------------------------------------------------------------
@@ -1253,14 +1260,22 @@ __global__ __launch_bounds__(256) void resize_bilinear_ac_kernel(const float* __
         const long long t = idx / W;
         const int Y = (int)(t % H);
         const long long pl = t / H;
-        const float fy = sy * (float)Y, fx = sx * (float)X;
-        const int y0 = (int)fy, x0 = (int)fx;
+        float fy, fx, ly, lx;
+        int y0, x0;
+        {
+#pragma clang fp contract(off)                                // the fractions as torch forms them: a product, then a difference
+            fy = sy * (float)Y;
+            fx = sx * (float)X;
+            y0 = (int)fy;
+            x0 = (int)fx;
+            ly = fy - (float)y0;
+            lx = fx - (float)x0;
+        }
         const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
         const float* p = src + pl * h * w;
-        const float top = p[y0 * w + x0] * (1.0f - lx) + p[y0 * w + x1] * lx;
-        const float bot = p[y1 * w + x0] * (1.0f - lx) + p[y1 * w + x1] * lx;
-        dst[idx] = top * (1.0f - ly) + bot * ly;
+        const float top = mix_nc(p[y0 * w + x0], p[y0 * w + x1], lx);
+        const float bot = mix_nc(p[y1 * w + x0], p[y1 * w + x1], lx);
+        dst[idx] = mix_nc(top, bot, ly);
     }
 }
 
@@ -1322,6 +1337,7 @@ struct AxisTap {
     float l;
 };
 __device__ __forceinline__ AxisTap axis_tap(int I, int h, float scale) {
+#pragma clang fp contract(off)                                // (f - i0 must not become fma(scale, I, -i0): see mix_nc)
     const float f = scale * (float)I;
     AxisTap t;
     t.i0 = (int)f;
@@ -1330,9 +1346,7 @@ __device__ __forceinline__ AxisTap axis_tap(int I, int h, float scale) {
     return t;
 }
 __device__ __forceinline__ float blend4(float a, float b, float c, float d, float lx, float ly) {
-    const float top = a * (1.0f - lx) + b * lx;
-    const float bot = c * (1.0f - lx) + d * lx;
-    return top * (1.0f - ly) + bot * ly;
+    return mix_nc(mix_nc(a, b, lx), mix_nc(c, d, lx), ly);
 }
 // x (h,h,h,h) of one pair -> its interpolate4d value at (I, J, i, j) of the n^4 grid
 __device__ __forceinline__ float interp4d_at(const float* __restrict__ x, int h, float sc, int I, int J, int i, int j) {
@@ -1367,6 +1381,57 @@ __global__ __launch_bounds__(256) void corr_mean3_kernel(const float* __restrict
     }
 }
 
+// The same values, same arithmetic order, with the coarse planes in LDS: a workgroup owns ONE source position (I, J) of a
+// pair and all n x n target positions.  Its eight source-tap planes (2 x 2 of each coarse volume) are staged with coalesced
+// loads, every output then blends 2 x 16 LDS values instead of 2 x 16 global ones (the per-thread kernel above issues 537 M
+// 4-byte global loads for a 64^4 volume and is bound by them: 175 us where the 134 MB it must move take 30).
+__global__ __launch_bounds__(256) void corr_mean3_planes_kernel(const float* __restrict__ c0, int h0, const float* __restrict__ c1,
+                                                                int h1, const float* __restrict__ c2, int n,
+                                                                float* __restrict__ out) {
+    extern __shared__ float planes[];                            // [4][h0*h0] then [4][h1*h1]
+    const int I = blockIdx.x / n, J = blockIdx.x % n;
+    const long long b = blockIdx.y;
+    const float s0 = (float)(h0 - 1) / (float)(n - 1), s1 = (float)(h1 - 1) / (float)(n - 1);
+    const int p0 = h0 * h0, p1 = h1 * h1;
+    float* q1 = planes + 4 * p0;
+    {
+        const AxisTap tI = axis_tap(I, h0, s0), tJ = axis_tap(J, h0, s0);
+        const float* base = c0 + b * (long long)p0 * p0;
+        for (int t = threadIdx.x; t < 4 * p0; t += 256) {
+            const int ab = t / p0, e = t - ab * p0;
+            planes[t] = base[((size_t)(((ab >> 1) ? tI.i1 : tI.i0) * h0 + ((ab & 1) ? tJ.i1 : tJ.i0))) * p0 + e];
+        }
+    }
+    {
+        const AxisTap tI = axis_tap(I, h1, s1), tJ = axis_tap(J, h1, s1);
+        const float* base = c1 + b * (long long)p1 * p1;
+        for (int t = threadIdx.x; t < 4 * p1; t += 256) {
+            const int ab = t / p1, e = t - ab * p1;
+            q1[t] = base[((size_t)(((ab >> 1) ? tI.i1 : tI.i0) * h1 + ((ab & 1) ? tJ.i1 : tJ.i0))) * p1 + e];
+        }
+    }
+    __syncthreads();
+    const AxisTap uI0 = axis_tap(I, h0, s0), uJ0 = axis_tap(J, h0, s0), uI1 = axis_tap(I, h1, s1), uJ1 = axis_tap(J, h1, s1);
+    const float third = 1.0f / 3.0f;
+    const long long obase = ((b * n + I) * n + J) * (long long)n * n;
+    auto at = [&](const float* pl, int h, float sc, int pp, const AxisTap& tI, const AxisTap& tJ, int i, int j) {
+        const AxisTap ti = axis_tap(i, h, sc), tj = axis_tap(j, h, sc);
+        float y1[4];
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const float* p = pl + ab * pp;
+            y1[ab] = blend4(p[ti.i0 * h + tj.i0], p[ti.i0 * h + tj.i1], p[ti.i1 * h + tj.i0], p[ti.i1 * h + tj.i1], tj.l, ti.l);
+        }
+        return blend4(y1[0], y1[1], y1[2], y1[3], tJ.l, tI.l);
+    };
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        const float u0 = at(planes, h0, s0, p0, uI0, uJ0, i, j);
+        const float u1 = at(q1, h1, s1, p1, uI1, uJ1, i, j);
+        out[obase + e] = ((u0 + u1) + c2[obase + e]) * third;
+    }
+}
+
 }  // namespace
 
 extern "C" int cpn_corr_mean3(const float* c0, int h0, const float* c1, int h1, const float* c2, int n, int B, float* out,
@@ -1374,6 +1439,13 @@ extern "C" int cpn_corr_mean3(const float* c0, int h0, const float* c1, int h1, 
     CPN_REQUIRE(c0 && c1 && c2 && out, CPN_E_ARG, "cpn_corr_mean3: null pointer");
     CPN_REQUIRE(B > 0 && h0 > 1 && h1 > 1 && n > 1 && h0 <= n && h1 <= n && n <= 128, CPN_E_SHAPE, "cpn_corr_mean3: bad shape");
     const long long total = (long long)B * n * n * n * n;
+    const size_t lds = (size_t)4 * ((size_t)h0 * h0 + (size_t)h1 * h1) * sizeof(float);
+    if (lds <= 60 * 1024 && B < 65536) {
+        hipLaunchKernelGGL(corr_mean3_planes_kernel, dim3((unsigned)(n * n), (unsigned)B), dim3(256), lds, (hipStream_t)stream, c0, h0,
+                           c1, h1, c2, n, out);
+        CPN_LAUNCH_CHECK("cpn_corr_mean3");
+        return 0;
+    }
     const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(total, 256), 1 << 20);
     hipLaunchKernelGGL(corr_mean3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c0, h0, c1, h1, c2, n, B, out);
     CPN_LAUNCH_CHECK("cpn_corr_mean3");

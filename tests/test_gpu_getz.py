@@ -330,7 +330,9 @@ def test_corr_mean3_kernel_equals_composed_interpolations(dev):
     composed = ((up[0] + up[1]) + up[2]) / 3
     torch.cuda.synchronize()
     assert got.shape == (B, 1, 64, 64, 64, 64)
-    # same operations in the same order; the compiler may contract a multiply-add differently in the two kernels: <= 1 ulp
+    # same operations in the same order, and the blends are written so that the compiler cannot contract them differently
+    # in the resize kernel and in the fused kernel: the interpolated parts agree bit for bit, the final (a + b + c) / 3 of
+    # the composed path divides where the kernel multiplies by fl(1/3): <= 1 ulp
     assert float((got - composed).abs().max()) <= 2.4e-7 * float(composed.abs().max())
 
     def interp4d_cpu(x, n):                                  # aggregation.py:49-56
