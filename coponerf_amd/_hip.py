@@ -78,7 +78,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_cross_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_conv_map7x7": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "cpn_pose_positional": [_P, _I, _I, _F, _P, _I, _P, _P],
-    "cpn_pose_tail": [_P, _P, _I, _P, _P],
+    "cpn_pose_gemv": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "cpn_pose_tail": [_P, _I, _P, _P, _I, _P, _P],
     "cpn_pack_conv_weight": [_P, _I, _I, _I, _P, _P],
     "cpn_trunk_conv_bn_act": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P],
     "cpn_bn_act": [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P],

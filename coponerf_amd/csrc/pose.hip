@@ -59,16 +59,64 @@ __device__ __forceinline__ void dense_relu_in(const float* x, const float* __res
     }
 }
 
+// First Linear of the pose regressor at a handful of rows: y[b][o] = <W[o], x[b]> over K = 134 144 inputs, 275 MB of fp32
+// weights read ONCE for all rows (the library's kernel for this M = 1 problem streams them at 1.8 TB/s: 154 us).  A workgroup
+// takes one output row and one of `nsplit` chunks of K, 16-byte loads, and writes one partial per (row of x, output, chunk);
+// pose_tail_kernel sums the chunks in chunk order and adds the bias.
+template <int NB>
+__global__ __launch_bounds__(256) void pose_gemv_kernel(const float* __restrict__ x, const float* __restrict__ W, int K, int O,
+                                                        int nsplit, float* __restrict__ partial) {
+    const int o = blockIdx.x, c = blockIdx.y;
+    const int k4 = K / 4, per = (k4 + nsplit - 1) / nsplit;
+    const int lo = c * per, hi = lo + per < k4 ? lo + per : k4;
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + (size_t)o * K);
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const f32x4 w = w4[i];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)b * K)[i];
+            acc[b] += (w[0] * v[0] + w[1] * v[1]) + (w[2] * v[2] + w[3] * v[3]);
+        }
+    }
+    __shared__ float red[NB][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float v = acc[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[b][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        const int b = threadIdx.x;
+        partial[((size_t)b * O + o) * nsplit + c] = (red[b][0] + red[b][1]) + (red[b][2] + red[b][3]);
+    }
+}
+
 struct PoseTailW {
     const float *w2, *b2, *w3, *b3;                // pose_regressor[2] (256 x 512), [4] (256 x 256)
     const float *r1, *rb1, *r2, *rb2, *r3, *rb3;   // rotation_regressor Linear (64 x 128), (32 x 64), (6 x 32)
     const float *t1, *tb1, *t2, *tb2, *t3, *tb3;   // translation_regressor Linear (64 x 128), (32 x 64), (3 x 32)
 };
 
-__global__ __launch_bounds__(1024) void pose_tail_kernel(const float* __restrict__ h512, PoseTailW w, float* __restrict__ rel_pose) {
+__global__ __launch_bounds__(1024) void pose_tail_kernel(const float* __restrict__ h512, int nsplit, const float* __restrict__ bias0,
+                                                         PoseTailW w, float* __restrict__ rel_pose) {
     __shared__ float s0[512], s1[256], s2[256], sr[64], st[64], sr2[32], st2[32], o9[16];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 512; i += 1024) s0[i] = h512[(size_t)b * 512 + i];
+    for (int i = threadIdx.x; i < 512; i += 1024) {
+        if (nsplit > 0) {                                     // chunk partials of cpn_pose_gemv, summed in chunk order, + bias
+            const float* pp = h512 + ((size_t)b * 512 + i) * nsplit;
+            float v = pp[0];
+            for (int c = 1; c < nsplit; ++c) v += pp[c];
+            s0[i] = v + bias0[i];
+        } else {
+            s0[i] = h512[(size_t)b * 512 + i];
+        }
+    }
     __syncthreads();
     dense_relu_in<512>(s0, w.w2, w.b2, 256, s1, wave, lane, 16);
     __syncthreads();
@@ -113,15 +161,32 @@ extern "C" int cpn_pose_positional(const float* intrinsics, int B, int V, float 
     return 0;
 }
 
-extern "C" int cpn_pose_tail(const float* h512, const float* const* weights, int B, float* rel_pose, void* stream) {
-    CPN_REQUIRE(h512 && weights && rel_pose && B > 0, 1, "cpn_pose_tail: bad arguments");
+extern "C" int cpn_pose_gemv(const float* x, const float* W, int B, int K, int O, int nsplit, float* partial, void* stream) {
+    CPN_REQUIRE(x && W && partial && B >= 1 && B <= 4 && K > 0 && K % 4 == 0 && O > 0 && nsplit >= 1 && nsplit <= 64, 1,
+                "cpn_pose_gemv: 1..4 rows, K %% 4 == 0, 1..64 chunks (got B=%d K=%d nsplit=%d)", B, K, nsplit);
+    CPN_REQUIRE(((uintptr_t)x | (uintptr_t)W) % 16 == 0, 1, "cpn_pose_gemv: 16-byte alignment");
+    dim3 grid((unsigned)O, (unsigned)nsplit);
+    hipStream_t st = (hipStream_t)stream;
+    switch (B) {
+        case 1: hipLaunchKernelGGL(pose_gemv_kernel<1>, grid, dim3(256), 0, st, x, W, K, O, nsplit, partial); break;
+        case 2: hipLaunchKernelGGL(pose_gemv_kernel<2>, grid, dim3(256), 0, st, x, W, K, O, nsplit, partial); break;
+        case 3: hipLaunchKernelGGL(pose_gemv_kernel<3>, grid, dim3(256), 0, st, x, W, K, O, nsplit, partial); break;
+        default: hipLaunchKernelGGL(pose_gemv_kernel<4>, grid, dim3(256), 0, st, x, W, K, O, nsplit, partial); break;
+    }
+    CPN_LAUNCH_CHECK("cpn_pose_gemv");
+    return 0;
+}
+
+extern "C" int cpn_pose_tail(const float* h512, int nsplit, const float* bias0, const float* const* weights, int B,
+                             float* rel_pose, void* stream) {
+    CPN_REQUIRE(h512 && weights && rel_pose && B > 0 && nsplit >= 0 && (nsplit == 0 || bias0), 1, "cpn_pose_tail: bad arguments");
     PoseTailW w;
     const float** dst = reinterpret_cast<const float**>(&w);
     for (int i = 0; i < CPN_POSE_TAIL_TENSORS; ++i) {
         CPN_REQUIRE(weights[i] != nullptr, 1, "cpn_pose_tail: weight %d is null", i);
         dst[i] = weights[i];
     }
-    hipLaunchKernelGGL(pose_tail_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, h512, w, rel_pose);
+    hipLaunchKernelGGL(pose_tail_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, h512, nsplit, bias0, w, rel_pose);
     CPN_LAUNCH_CHECK("cpn_pose_tail");
     return 0;
 }

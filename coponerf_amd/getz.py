@@ -696,8 +696,7 @@ def get_z(model, input, ops):
         intr = (Kn[:, 0, 0, 0, None], Kn[:, 0, 1, 1, None], Kn[:, 0, 0, 2, None], Kn[:, 0, 1, 2, None])
     pose_feat = model.cross_attention(feats[-1].flatten(-2, -1).transpose(-1, -2), c, intr, ops).reshape(B, -1)
     if fused_pose:
-        rel_pose = ops.pose_tail(model.pose_regressor[0](pose_feat), model.pose_regressor, model.rotation_regressor,
-                                 model.translation_regressor)
+        rel_pose = ops.pose_tail(pose_feat, model.pose_regressor, model.rotation_regressor, model.translation_regressor)
         return feats + [z_conv], rel_pose, flows
     lat = model.pose_regressor(pose_feat)[:, :128]
     R = r6d_to_matrix(model.rotation_regressor(lat))[:, :3, :3]

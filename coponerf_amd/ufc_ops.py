@@ -766,12 +766,22 @@ class HipOps:
         call("cpn_pose_positional", K.data_ptr(), B, V, float(H), lin.data_ptr(), n, out.data_ptr(), _stream())
         return out
 
-    def pose_tail(self, h512, pose_regressor, rotation_regressor, translation_regressor):
-        """Everything behind the first Linear of the pose regressor (ReLU / Linear chains, 6-D rotation, 4 x 4 assembly) as one
-        launch (inference): h512 (B, 512) before its ReLU -> rel_pose (B, 4, 4)."""
+    def pose_tail(self, pose_feat, pose_regressor, rotation_regressor, translation_regressor):
+        """The pose regressor, the rotation / translation regressors, the 6-D rotation and the 4 x 4 assembly (inference):
+        pose_feat (B, (16*16+6)*256*2) -> rel_pose (B, 4, 4).  The first Linear (275 MB of weights for a handful of rows) is
+        cpn_pose_gemv's chunk partials at B <= 4 (the library's otherwise), everything behind it ONE launch."""
         import ctypes
-        h = h512.detach().contiguous().float()
-        self._need_gpu(h)
+        x = pose_feat.detach().contiguous().float()
+        self._need_gpu(x)
+        lin0 = pose_regressor[0]
+        nsplit, bias0 = 0, 0
+        if x.shape[0] <= 4 and x.shape[1] % 4 == 0 and lin0.weight.is_contiguous() and lin0.weight.shape[0] == 512:
+            nsplit = 8
+            h = torch.empty(x.shape[0], 512, nsplit, dtype=torch.float32, device=x.device)
+            call("cpn_pose_gemv", x.data_ptr(), lin0.weight.data_ptr(), x.shape[0], x.shape[1], 512, nsplit, h.data_ptr(), _stream())
+            bias0 = lin0.bias.data_ptr()
+        else:
+            h = lin0(x).contiguous()
         lins = [pose_regressor[2], pose_regressor[4]] + [m for m in rotation_regressor if isinstance(m, torch.nn.Linear)] + \
                [m for m in translation_regressor if isinstance(m, torch.nn.Linear)]
         shapes = [tuple(m.weight.shape) for m in lins]
@@ -783,7 +793,7 @@ class HipOps:
                 ptrs.append(t.data_ptr())
         arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
         out = torch.empty(h.shape[0], 4, 4, dtype=torch.float32, device=h.device)
-        call("cpn_pose_tail", h.data_ptr(), arr, h.shape[0], out.data_ptr(), _stream())
+        call("cpn_pose_tail", h.data_ptr(), nsplit, bias0, arr, h.shape[0], out.data_ptr(), _stream())
         return out
 
     def dual_softmax(self, a):

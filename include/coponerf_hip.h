@@ -528,10 +528,15 @@ int cpn_trunk_conv_bn_act(const float* x, const float* wp, int N, int Hin, int W
  * cpn_pose_tail: pose_regressor[1:] -> [:, :128] -> rotation / translation regressors -> 6-D rotation -> rel_pose (B, 4, 4)
  *   (models/CoPoNeRF.py:106-126,190-206) from h512 = pose_regressor[0](pose_feat) (B, 512), BEFORE its ReLU.
  *   weights: HOST array of CPN_POSE_TAIL_TENSORS device pointers, weight then bias of each Linear in the order
- *   pose[2] (256 x 512), pose[4] (256 x 256), rotation 128->64->32->6, translation 128->64->32->3.                        */
+ *   pose[2] (256 x 512), pose[4] (256 x 256), rotation 128->64->32->6, translation 128->64->32->3.
+ *   nsplit > 0: h512 holds the chunk partials (B, 512, nsplit) of cpn_pose_gemv instead and bias0 (512) is pose[0].bias.
+ * cpn_pose_gemv: pose_regressor[0] without its bias at B <= 4 rows — partial[b][o][c] = <W[o], x[b]> over chunk c of the
+ *   K = (16*16 + 6) * 256 * 2 inputs (W (O, K) fp32, read once for all rows; K % 4 == 0, nsplit <= 64).                    */
 #define CPN_POSE_TAIL_TENSORS 16
 int cpn_pose_positional(const float* intrinsics, int B, int V, float H, const float* lin, int n, float* out, void* stream);
-int cpn_pose_tail(const float* h512, const float* const* weights, int B, float* rel_pose, void* stream);
+int cpn_pose_gemv(const float* x, const float* W, int B, int K, int O, int nsplit, float* partial, void* stream);
+int cpn_pose_tail(const float* h512, int nsplit, const float* bias0, const float* const* weights, int B, float* rel_pose,
+                  void* stream);
 
 /* ---- bilinear resize, align_corners=True, of `planes` independent (h,w) fp32 images -> (H,W) ----------
  * replaces F.interpolate(..., mode='bilinear', align_corners=True) in interpolate4d / forward_attention /
