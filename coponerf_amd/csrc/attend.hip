@@ -116,7 +116,13 @@ constexpr int HC = 1664;
 #ifndef CPN_ATTEND_NT
 #define CPN_ATTEND_NT 1
 #endif
+// rows of hid in flight per thread (16 bytes each): 4 is enough when the kernel has the chip to itself (7 waves per SIMD);
+// beside the encoder of the next chunk (tools/coresident_probe.py) only 2 waves per SIMD fit and each must keep more in flight
+#ifndef CPN_ATTEND_UNROLL
+#define CPN_ATTEND_UNROLL 4
+#endif
 
+template <bool HAVE_LOGITS>
 __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __restrict__ qa,
                                                             const __half* __restrict__ qb,
                                                             const float* __restrict__ logits,
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
     const size_t row0 = (size_t)lray * T;
 
     float lmax = -INFINITY;
-    if (logits) {                                         // row dot products already formed by the producing kernel
+    if constexpr (HAVE_LOGITS) {                          // row dot products already formed by the producing kernel
         for (int row = tid; row < T; row += 256) {
             const float logit = logits[row0 + row] / 11.31f;
             wts[row] = logit;
@@ -186,13 +192,28 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
     if (tid < HC / 8) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const __half* hp = hid + row0 * HC + tid * 8;
-#pragma unroll 4
-        for (int row = 0; row < T; ++row) {
+        auto ld = [&](int row) {
 #if CPN_ATTEND_NT
-            const half8 h = __builtin_nontemporal_load(reinterpret_cast<const half8*>(hp + (size_t)row * HC));
+            return __builtin_nontemporal_load(reinterpret_cast<const half8*>(hp + (size_t)row * HC));
 #else
-            const half8 h = *reinterpret_cast<const half8*>(hp + (size_t)row * HC);
+            return *reinterpret_cast<const half8*>(hp + (size_t)row * HC);
 #endif
+        };
+        constexpr int U = CPN_ATTEND_UNROLL;
+        int row = 0;
+        for (; row + U <= T; row += U) {                  // U loads in flight, then their U x 8 FMAs in row order
+            half8 h[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) h[u] = ld(row + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float w = wts[row + u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * (float)h[u][e];
+            }
+        }
+        for (; row < T; ++row) {
+            const half8 h = ld(row);
             const float w = wts[row];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += w * (float)h[e];
@@ -227,7 +248,7 @@ extern "C" int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const f
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_attend_hidden: ray range outside B*R");
     const size_t lds = (size_t)(V * S + 8) * sizeof(float);
-    hipLaunchKernelGGL(attend_hidden_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
+    hipLaunchKernelGGL(logits ? attend_hidden_kernel<true> : attend_hidden_kernel<false>, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
                        (const __half*)qb, logits, (const __half*)hid, V, R, S, ray0, (__half*)hbar, at_wt);
     CPN_LAUNCH_CHECK("cpn_attend_hidden");
     return 0;

@@ -39,7 +39,8 @@ namespace {
 
 constexpr int WMAIN_HALF8 = NSLICE * 2 * NT * 64;              // [slice][k < 2][tile][lane] half8: 104 KiB
 constexpr int WTAIL_HALF4 = NSLICE * NT * 48;                  // [slice][tile][K group < 3][A-operand row] half4: 19.5 KiB
-constexpr int EK_WAVES = CPN_EK_WAVES;
+constexpr int EK_WAVES_DEFAULT = CPN_EK_WAVES;
+constexpr int EK_WAVES_BESIDE = 8;                             // the form that leaves room on its CU (cpn_encode_key_beside)
 constexpr int KT = 8;                                          // 16-wide output tiles of the key layer (128)
 constexpr int KPIECES = KT * 2;                                // 1 KiB fragments (tile, k step) per slice
 constexpr int KSLOT_HALF8 = KPIECES * 64;                      // one ring slot: 16 KiB
@@ -56,8 +57,19 @@ constexpr int KLD = 2 * CPN_TAB_LD;                            // row length of 
 constexpr int STEP_BYTES = 26 * 1024;                          // streamed form: 16 KiB key + 8 KiB K=80 main + 2 KiB tail (1.5 used)
 constexpr int K80_BLOCK_BYTES = 10 * 1024;                     // one slice of k80blk: main fragments, tail fragments with the bias, pad
 
-template <int GROUP>
-__global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
+// CPN_EK_REGS_FOR > 0: register budget of that many waves per SIMD even where the workgroup has fewer (8 waves = 2 per SIMD
+// with the 168-register budget of 3 leave a third of each SIMD's register file to the waves of ANOTHER kernel)
+#ifndef CPN_EK_REGS_FOR
+#define CPN_EK_REGS_FOR 0
+#endif
+#if CPN_EK_REGS_FOR > 0
+#define EK_OCC __attribute__((amdgpu_waves_per_eu(CPN_EK_REGS_FOR, CPN_EK_REGS_FOR)))
+#else
+#define EK_OCC
+#endif
+
+template <int GROUP, int EK_WAVES>
+__global__ __launch_bounds__(64 * EK_WAVES, 1) EK_OCC void encode_key_kernel(
     const __half* __restrict__ tab, const __half* __restrict__ map3, int H, int W,
     const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, const float* __restrict__ pe6,
     const half8* __restrict__ wfrag, const float* __restrict__ bias, const __half* __restrict__ k80blk,
@@ -481,27 +493,27 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) void encode_key_kernel(
 
 }  // namespace
 
-extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
-                              const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
-                              const uint16_t* k80blk, int group, const uint16_t* kw, const float* kbias, int B, int V, int R,
-                              int S, int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream) {
+static int encode_key_launch(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                             const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
+                             const uint16_t* k80blk, int group, int waves, const uint16_t* kw, const float* kbias, int B, int V,
+                             int R, int S, int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream, const char* who) {
     CPN_REQUIRE(tab && map3 && pixel_val && sec_grid && pe6 && wfrag && bias && kw && kbias && hid && kh, CPN_E_ARG,
-                "cpn_encode_key: null pointer");
+                "%s: null pointer", who);
     CPN_REQUIRE((group == 0 || group == 1 || group == 3) && (group == 0 || (k80blk && ((uintptr_t)k80blk % 16) == 0)), CPN_E_ARG,
-                "cpn_encode_key: group must be 0, 1 or 3 (got %d) and needs k80blk when > 0", group);
+                "%s: group must be 0, 1 or 3 (got %d) and needs k80blk when > 0", who, group);
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && W >= 16 && (H % 16) == 0 && (W % 16) == 0,
-                CPN_E_SHAPE, "cpn_encode_key: need V==2 and H,W multiples of 16 (got H=%d W=%d V=%d)", H, W, V);
+                CPN_E_SHAPE, "%s: need V==2 and H,W multiples of 16 (got H=%d W=%d V=%d)", who, H, W, V);
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
-                "cpn_encode_key: ray range [%d,%d) outside B*R=%lld", ray0, ray0 + nrays, (long long)B * R);
+                "%s: ray range [%d,%d) outside B*R=%lld", who, ray0, ray0 + nrays, (long long)B * R);
     const long long nrows = (long long)nrays * V * S * 2;
     const NodeGrid ng{W >> 1, H >> 1};
     CPN_REQUIRE(nrows < (1LL << 31) && ng.zeros_nodes() * TAB_ROW_BYTES < (1LL << 31) && (long long)H * W * 128 < (1LL << 31) &&
                     (long long)TG * V * S * 2 * 1664 < (1LL << 31),
-                CPN_E_SHAPE, "cpn_encode_key: chunk / per-image table too large for 32-bit offsets (%lld rows)", nrows);
+                CPN_E_SHAPE, "%s: chunk / per-image table too large for 32-bit offsets (%lld rows)", who, nrows);
     CPN_REQUIRE(((uintptr_t)tab % 16) == 0 && ((uintptr_t)map3 % 16) == 0 && ((uintptr_t)wfrag % 16) == 0 &&
                     ((uintptr_t)bias % 16) == 0 && ((uintptr_t)hid % 16) == 0 && ((uintptr_t)kw % 16) == 0 &&
                     ((uintptr_t)kbias % 16) == 0 && ((uintptr_t)kh % 8) == 0, CPN_E_ARG,
-                "cpn_encode_key: pointers must be 16-byte aligned");
+                "%s: pointers must be 16-byte aligned", who);
     const int groups_per_b = (int)cpn_cdiv(R, TG);
     const int b_lo = ray0 / R, b_hi = (ray0 + nrays - 1) / R;
     const long long group0 = (long long)b_lo * groups_per_b + (ray0 - b_lo * R) / TG;
@@ -509,12 +521,36 @@ extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, 
     const int nsblk = (int)cpn_cdiv(S, TSW);
     const long long nunits = (group1 - group0 + 1) * V * nsblk;
     const int num_cu = cpn_stream_cus((void*)stream);
-    const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nunits, EK_WAVES));
-    auto kern = group == 0 ? encode_key_kernel<0> : group == 1 ? encode_key_kernel<1> : encode_key_kernel<3>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * EK_WAVES), 0, (hipStream_t)stream,
+    const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nunits, waves));
+    auto kern = waves == EK_WAVES_BESIDE ? encode_key_kernel<0, EK_WAVES_BESIDE>
+                : group == 0             ? encode_key_kernel<0, EK_WAVES_DEFAULT>
+                : group == 1             ? encode_key_kernel<1, EK_WAVES_DEFAULT>
+                                         : encode_key_kernel<3, EK_WAVES_DEFAULT>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), 0, (hipStream_t)stream,
                        (const __half*)tab, (const __half*)map3, H, W, pixel_val, sec_grid, pe6, (const half8*)wfrag,
                        bias, (const __half*)k80blk, (const __half*)kw, kbias, V, R, S, ray0, nrays, nsblk, groups_per_b,
                        group0, nunits, (__half*)hid, (__half*)kh);
-    CPN_LAUNCH_CHECK("cpn_encode_key");
+    CPN_LAUNCH_CHECK(who);
     return 0;
+}
+
+extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                              const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
+                              const uint16_t* k80blk, int group, const uint16_t* kw, const float* kbias, int B, int V, int R,
+                              int S, int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream) {
+    return encode_key_launch(tab, map3, H, W, pixel_val, sec_grid, pe6, wfrag, bias, k80blk, group, EK_WAVES_DEFAULT, kw, kbias, B, V,
+                             R, S, ray0, nrays, hid, kh, stream, "cpn_encode_key");
+}
+
+// The same kernel (resident form) with 8 waves per workgroup instead of 12: 2 waves x 160 VGPRs per SIMD and 155.5 KiB of LDS
+// leave 192 registers per SIMD and 4.5 KiB of LDS on every CU to the waves of ANOTHER kernel - cpn_attend_hidden of the
+// chunks before this one (53 VGPRs, 544 B), launched on a second stream, then runs UNDER this launch instead of behind it
+// (coponerf_amd/render.py: the slot schedule; tools/coresident_probe.py).  Alone it is 5-7 % slower than the 12-wave form.
+// hid / kh are bit-identical to cpn_encode_key's.
+extern "C" int cpn_encode_key_beside(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                                     const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
+                                     const uint16_t* kw, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
+                                     uint16_t* hid, uint16_t* kh, void* stream) {
+    return encode_key_launch(tab, map3, H, W, pixel_val, sec_grid, pe6, wfrag, bias, nullptr, 0, EK_WAVES_BESIDE, kw, kbias, B, V, R, S,
+                             ray0, nrays, hid, kh, stream, "cpn_encode_key_beside");
 }

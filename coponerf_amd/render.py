@@ -340,6 +340,7 @@ class RenderEngine:
     WORKSPACE_SHARE = 0.25
     FREE_SHARE = 0.5                # ... and at most this share of the memory that is free when the workspace is sized
     MAX_AUTO_CHUNK = 65536
+    SLOT_MIN_CHUNKS = 4
 
     def __init__(self, chunk_rays: int = 0, fold_value: bool = True, lanes: int = 1, tables: bool = True,
                  fuse_key: Optional[bool] = None):
@@ -366,6 +367,12 @@ class RenderEngine:
         # that the HBM-bound stages of one chunk (gather, hidden sums) run under the MFMA-bound GEMMs of another
         self.lanes = max(1, int(lanes))
         self._lane_streams: List[torch.cuda.Stream] = []
+        # slot schedule of _render_body: rays per chunk, used when a call has at least SLOT_MIN_CHUNKS such chunks, one lane
+        # and an automatic chunk size.  0 = off (the default: measured at -2 ... +1 % of the serial loop, DESIGN.md 4.1c —
+        # beside the hidden sums the encoder slows by as much as the sums gain, and 8-wave / 8 192-ray launches cost what is left)
+        self.slot_rays = int(os.environ.get("COPONERF_SLOT_RAYS", "0"))
+        self._slot_streams: Dict[int, torch.cuda.Stream] = {}
+        self.slot_trace: Optional[list] = None     # tools/slot_probe.py: (slot, start, encoder end, sums end) events
         # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
         # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it
         self.fold_value = bool(fold_value)
@@ -422,6 +429,7 @@ class RenderEngine:
         # caches, streams and workspace are derived state: a copied model gets a fresh engine with the same settings
         new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables, self.fuse_key)
         new.grad_scale_target, new.call_lanes, new.lazy_pixel_val = self.grad_scale_target, self.call_lanes, self.lazy_pixel_val
+        new.slot_rays = self.slot_rays
         return new
 
     def _host_inputs(self, *mats):
@@ -734,6 +742,15 @@ class RenderEngine:
         self._call_idx = 0
         self._uv_seen = None        # new streams have waited for nothing: the next call must order itself behind the caller's
 
+    def _slot_stream(self, dev) -> torch.cuda.Stream:
+        """The second stream of the slot schedule, one per stream the call itself runs on (two call lanes must not share it:
+        their hidden sums would serialise behind each other)."""
+        key = torch.cuda.current_stream(dev).cuda_stream
+        st = self._slot_streams.get(key)
+        if st is None or st.device != dev:
+            st = self._slot_streams[key] = torch.cuda.Stream(device=dev)
+        return st
+
     def _call_stream(self, dev) -> Optional[torch.cuda.Stream]:
         if self.call_lanes <= 1:
             return None
@@ -841,7 +858,13 @@ class RenderEngine:
 
         nray_total = B * R
         zl = torch.empty(nray_total, 416, dtype=f32, device=dev)
-        C = min(self.chunk_rays if self.chunk_rays > 0 else self._auto_chunk(S, dev, nray_total), nray_total)
+        fused_key = self.fuse_key and self.tables and self.fold_value
+        # slot schedule (below): chunks of `slot_rays`, three of them in flight (3 x 3.8 GB at 8 192 rays x 64 samples); only
+        # where there are enough chunks to fill it
+        slots = (self.slot_rays > 0 and fused_key and self.lanes == 1 and self.chunk_rays == 0
+                 and nray_total >= self.SLOT_MIN_CHUNKS * self.slot_rays)
+        C = self.slot_rays if slots else min(
+            self.chunk_rays if self.chunk_rays > 0 else self._auto_chunk(S, dev, nray_total), nray_total)
         T = V * S                       # rows per ray for the attention stage
         GW = dict(self.GEMM_WEIGHTS, key_fold=(128, 1664, 1664), value_fold=(416, 1664, 1664))
         nchunks = (nray_total + C - 1) // C
@@ -849,8 +872,6 @@ class RenderEngine:
         if nlanes > 1 and (len(self._lane_streams) < nlanes or self._lane_streams[0].device != dev):
             self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(nlanes)]
         main = torch.cuda.current_stream()
-
-        fused_key = self.fuse_key and self.tables and self.fold_value
 
         def lane_buffers(lane):
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
@@ -870,31 +891,35 @@ class RenderEngine:
                 bufs["q2"] = t("q2", (C * T, 128), f16)
             return bufs
 
-        def run_chunk(ray0, bf, s):
-            hid, ce, lg = (bf[k] for k in ("hid", "ce", "lg"))
-            xin = bf.get("xin")
-            z1, ze, addq, hbar, zs = (bf[k] for k in ("z1", "ze", "addq", "hbar", "zs"))
-            enc, value, kh, key2, q2 = (bf.get(k) for k in ("enc", "value", "kh", "key2", "q2"))
+        # ---- the stages of one chunk.  Serial order (run_chunk): E M1 G A1 V1 M2 A2 V2; the slot schedule below interleaves the
+        #      stages of three consecutive chunks.  Every stage takes the chunk's first ray, its buffers and the raw stream.
+        def _gemm(s, a, lda, wname, out, ldc, m, n, k, relu, out_f32):
+            prof = self.profile
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            call("cpn_gemm_f16", a.data_ptr(), lda, w[wname + ".w16"].data_ptr(), w[wname + ".w16"].shape[1],
+                 w[wname + ".b"].data_ptr(), out.data_ptr(), ldc, m, n, k, int(relu), int(out_f32), s)
+            if prof is not None:
+                e1.record()
+                prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * GW[wname][1]))
 
-            def gemm(a, lda, wname, out, ldc, m, n, k, relu, out_f32):
-                prof = self.profile
-                if prof is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                call("cpn_gemm_f16", a.data_ptr(), lda, w[wname + ".w16"].data_ptr(), w[wname + ".w16"].shape[1],
-                     w[wname + ".b"].data_ptr(), out.data_ptr(), ldc, m, n, k, int(relu), int(out_f32), s)
-                if prof is not None:
-                    e1.record()
-                    prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * GW[wname][1]))
-
+        def stage_encode(ray0, bf, s, beside=False):
+            """E: first encoder layer (+ the folded key_map layer when fused) -> hid (, khf)  [CoPoNeRF.py:384-397, 404-407]"""
+            hid, xin = bf["hid"], bf.get("xin")
             n = min(C, nray_total - ray0)
-            rows, rows2 = n * T, n * T * 2
+            rows2 = n * T * 2
             if self.tables:
                 prof = self.profile
                 if prof is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                if fused_key:
+                if fused_key and beside:
+                    call("cpn_encode_key_beside", tabs[0].data_ptr(), maps[3].data_ptr(),
+                         H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
+                         w["query_encode_latent.b"].data_ptr(), w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+                         B, V, R, S, ray0, n, hid.data_ptr(), bf["khf"].data_ptr(), s)
+                elif fused_key:
                     call("cpn_encode_key", tabs[0].data_ptr(), maps[3].data_ptr(),
                          H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
                          w["query_encode_latent.b"].data_ptr(), w["enc.k80blk"].data_ptr(), self.key_group,
@@ -913,15 +938,25 @@ class RenderEngine:
                 call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
                      H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, ray0, n,
                      xin.data_ptr(), s)
-                gemm(xin, _hip.XIN_STRIDE, "query_encode_latent", hid, 832, rows2, 832, _hip.XIN_K, True, False)
+                _gemm(s, xin, _hip.XIN_STRIDE, "query_encode_latent", hid, 832, rows2, 832, _hip.XIN_K, True, False)
             if not self.fold_value:
-                gemm(hid, 832, "query_encode_latent_2", enc, 416, rows2, 416, 832, False, False)
-                gemm(enc, 832, "latent_value", value, 416, rows, 416, 832, False, True)
-                gemm(enc, 832, "key_map", kh, 128, rows, 128, 832, True, False)
+                rows = n * T
+                _gemm(s, hid, 832, "query_encode_latent_2", bf["enc"], 416, rows2, 416, 832, False, False)
+                _gemm(s, bf["enc"], 832, "latent_value", bf["value"], 416, rows, 416, 832, False, True)
+                _gemm(s, bf["enc"], 832, "key_map", bf["kh"], 128, rows, 128, 832, True, False)
+
+        def stage_embed(ray0, bf, s):
+            """M1: coords_embed = query_embed_2(ReLU(query_embed(local_coords)))  [CoPoNeRF.py:446]"""
+            n = min(C, nray_total - ray0)
             call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
                  w["query_embed.b"].data_ptr(), 0, w["query_embed_2.w16"].data_ptr(), 128,
-                 w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, ce.data_ptr(), 0, 0, s)
-            # round 1 (CoPoNeRF.py:450-461)
+                 w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, bf["ce"].data_ptr(), 0, 0, s)
+
+        def stage_logits(ray0, bf, s):
+            """G: key_map_2 (+ the folded key_map layer when it did not run inside E) and <key, coords_embed>  [:408, :450]"""
+            n = min(C, nray_total - ray0)
+            rows = n * T
+            ce, lg = bf["ce"], bf["lg"]
             if self.fold_value:
                 # folded key_map -> ReLU -> key_map_2 -> <key, coords_embed> in ONE kernel over hid viewed as (rows,1664):
                 # neither the 128-wide hidden layer nor the key reaches HBM, only 4 bytes of logit per row
@@ -934,21 +969,32 @@ class RenderEngine:
                     call("cpn_gemm_f16_rowdot", bf["khf"].data_ptr(), 128, w["key_map_2.w16"].data_ptr(), 128,
                          w["key_map_2.b"].data_ptr(), ce.data_ptr(), 128, lg.data_ptr(), rows, 128, 128, s)
                 else:
-                    call("cpn_gemm_f16_chain_rowdot", hid.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664,
+                    call("cpn_gemm_f16_chain_rowdot", bf["hid"].data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664,
                          w["key_fold.b"].data_ptr(), w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(),
                          ce.data_ptr(), 128, lg.data_ptr(), rows, 1664, s)
                 if prof is not None:
                     e1.record()
                     prof.setdefault("gemm_f16:key_map_2" if fused_key else "gemm_f16:key_fold+key_map_2", []).append(
                         (e0, e1, 2.0 * rows * 128 * (128 if fused_key else 1664 + 128)))
-                call("cpn_attend_hidden", 0, 0, lg.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n,
-                     hbar.data_ptr(), at_wt.data_ptr(), s)
-                gemm(hbar, 1664, "value_fold", z1, 416, n, 416, 1664, False, True)
             else:
-                gemm(kh, 128, "key_map_2", key2, 128, rows, 128, 128, False, False)
-                call("cpn_attend", key2.data_ptr(), ce.data_ptr(), value.data_ptr(), 0, B, V, R, S, ray0, n,
-                     z1.data_ptr(), at_wt.data_ptr(), s)
-            # round 2 (CoPoNeRF.py:467-485)
+                _gemm(s, bf["kh"], 128, "key_map_2", bf["key2"], 128, rows, 128, 128, False, False)
+
+        def stage_sum1(ray0, bf, s):
+            """A1: joint softmax over the 2 x S samples of a ray + the weighted sum, round 1  [:450-461]"""
+            n = min(C, nray_total - ray0)
+            if self.fold_value:
+                call("cpn_attend_hidden", 0, 0, bf["lg"].data_ptr(), bf["hid"].data_ptr(), B, V, R, S, ray0, n,
+                     bf["hbar"].data_ptr(), at_wt.data_ptr(), s)
+            else:
+                call("cpn_attend", bf["key2"].data_ptr(), bf["ce"].data_ptr(), bf["value"].data_ptr(), 0, B, V, R, S, ray0, n,
+                     bf["z1"].data_ptr(), at_wt.data_ptr(), s)
+
+        def stage_query2(ray0, bf, s):
+            """V1 L M2: value projection of the round-1 sum, encode_latent, the second query and its logits  [:467-475]"""
+            n = min(C, nray_total - ray0)
+            z1, ze, addq = bf["z1"], bf["ze"], bf["addq"]
+            if self.fold_value:
+                _gemm(s, bf["hbar"], 1664, "value_fold", z1, 416, n, 416, 1664, False, True)
             call("cpn_linear_f32", z1.data_ptr(), 416, w["encode_latent.w"].data_ptr(), 416,
                  w["encode_latent.b"].data_ptr(), 0, 0, ze.data_ptr(), 128, n, 128, 416, 0, 0, s)
             call("cpn_linear_f32", ze.data_ptr(), 128, w["query_repeat_embed.w_z"].data_ptr(), 128, 0, 0, 0,
@@ -957,19 +1003,77 @@ class RenderEngine:
                 # the second query only enters through <query2, coords_embed>: local_mlp writes that logit directly
                 call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
                      w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
-                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, 0, ce.data_ptr(), lg.data_ptr(), s)
-                call("cpn_attend_hidden", 0, 0, lg.data_ptr(), hid.data_ptr(), B, V, R, S, ray0, n, hbar.data_ptr(), 0, s)
-                gemm(hbar, 1664, "value_fold", zs, 416, n, 416, 1664, False, True)
-                # the round-1 vector sits in both view slots when the views are summed (CoPoNeRF.py:481-485)
-                torch.add(zs[:n], z1[:n], alpha=float(V), out=zl[ray0:ray0 + n])
+                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, 0, bf["ce"].data_ptr(), bf["lg"].data_ptr(), s)
             else:
                 call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
                      w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
-                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, q2.data_ptr(), 0, 0, s)
-                call("cpn_attend", q2.data_ptr(), ce.data_ptr(), value.data_ptr(), z1.data_ptr(), B, V, R, S, ray0, n,
-                     zl[ray0:ray0 + n].data_ptr(), 0, s)
+                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, bf["q2"].data_ptr(), 0, 0, s)
 
-        if nlanes == 1:
+        def stage_sum2(ray0, bf, s):
+            """A2: round 2 of the attention  [:475-485]"""
+            n = min(C, nray_total - ray0)
+            if self.fold_value:
+                call("cpn_attend_hidden", 0, 0, bf["lg"].data_ptr(), bf["hid"].data_ptr(), B, V, R, S, ray0, n,
+                     bf["hbar"].data_ptr(), 0, s)
+            else:
+                call("cpn_attend", bf["q2"].data_ptr(), bf["ce"].data_ptr(), bf["value"].data_ptr(), bf["z1"].data_ptr(), B, V, R, S,
+                     ray0, n, zl[ray0:ray0 + n].data_ptr(), 0, s)
+
+        def stage_out(ray0, bf, s):
+            """V2: value projection of the round-2 sum; the round-1 vector sits in both view slots when the views are summed
+            (CoPoNeRF.py:481-485)"""
+            n = min(C, nray_total - ray0)
+            if self.fold_value:
+                _gemm(s, bf["hbar"], 1664, "value_fold", bf["zs"], 416, n, 416, 1664, False, True)
+                torch.add(bf["zs"][:n], bf["z1"][:n], alpha=float(V), out=zl[ray0:ray0 + n])
+
+        def run_chunk(ray0, bf, s):
+            stage_encode(ray0, bf, s)
+            stage_embed(ray0, bf, s)
+            stage_logits(ray0, bf, s)
+            stage_sum1(ray0, bf, s)
+            stage_query2(ray0, bf, s)
+            stage_sum2(ray0, bf, s)
+            stage_out(ray0, bf, s)
+
+        if slots:
+            # ---- the slot schedule.  cpn_encode_key is bound by its L1 / LDS pipes and lock step (2.5 TB/s of stores), the
+            #      two hidden sums by HBM reads (6.5 TB/s); one after the other they take 12.2 + 8.5 ms per image.  In slot k
+            #      the 8-wave form of the encoder (cpn_encode_key_beside: it leaves a third of every CU's registers free)
+            #      works on chunk k while a second stream sums round 1 of chunk k - 1 and round 2 of chunk k - 2 ON THE
+            #      SAME CUs; the small stages between them (LDS-heavy GEMMs / MLPs that cannot co-reside with the encoder)
+            #      run on the whole chip between two slots.  Three buffer sets; results bit-identical to the serial order.
+            side = self._slot_stream(dev)
+            sets = [lane_buffers(f"s{i}") for i in range(3)]
+            starts = list(range(0, nray_total, C))
+            trace = self.slot_trace
+            for k in range(nchunks + 2):
+                go = torch.cuda.Event(enable_timing=trace is not None)
+                go.record(main)
+                if k < nchunks:
+                    stage_encode(starts[k], sets[k % 3], s, beside=True)
+                if trace is not None:
+                    enc_end = torch.cuda.Event(enable_timing=True)
+                    enc_end.record(main)
+                if k >= 1:
+                    side.wait_event(go)
+                    if k <= nchunks:
+                        stage_sum1(starts[k - 1], sets[(k - 1) % 3], side.cuda_stream)
+                    if k >= 2:
+                        stage_sum2(starts[k - 2], sets[(k - 2) % 3], side.cuda_stream)
+                    back = torch.cuda.Event(enable_timing=trace is not None)
+                    back.record(side)
+                    main.wait_event(back)
+                if trace is not None:
+                    trace.append((k, go, enc_end, back if k >= 1 else enc_end))
+                if k < nchunks:
+                    stage_embed(starts[k], sets[k % 3], s)
+                    stage_logits(starts[k], sets[k % 3], s)
+                if 1 <= k <= nchunks:
+                    stage_query2(starts[k - 1], sets[(k - 1) % 3], s)
+                if k >= 2:
+                    stage_out(starts[k - 2], sets[(k - 2) % 3], s)
+        elif nlanes == 1:
             bf = lane_buffers(0)
             for ray0 in range(0, nray_total, C):
                 run_chunk(ray0, bf, s)

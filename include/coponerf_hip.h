@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 5
+#define CPN_ABI_VERSION 6
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -173,6 +173,16 @@ int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, cons
                    const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                    const uint16_t* k80blk, int group, const uint16_t* kw, const float* kbias, int B, int V, int R, int S,
                    int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream);
+/* cpn_encode_key_beside (round 4): the resident form (group 0) of cpn_encode_key with 8 waves per workgroup instead of 12.
+ * Two waves x 160 VGPRs per SIMD and 155.5 KiB of LDS leave a third of every CU's register file and 4.5 KiB of its LDS
+ * free: cpn_attend_hidden launches of EARLIER ray chunks, issued on a second stream, run on the same CUs under this launch
+ * (the along-ray sums of models/CoPoNeRF.py:456-461 / :481-485 read hid at the HBM rate while this kernel, bound by its
+ * L1 / LDS pipes, leaves 70 % of that rate unused).  Same arguments and bit-identical hid / kh; alone 5-7 % slower than
+ * cpn_encode_key - it is for the slot schedule of coponerf_amd/render.py only.                                        */
+int cpn_encode_key_beside(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                          const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
+                          const uint16_t* kw, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
+                          uint16_t* hid, uint16_t* kh, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).

@@ -498,6 +498,39 @@ def test_encode_key_entry_every_group_is_bit_identical(model, dev, weights):
     with pytest.raises(Exception):
         call("cpn_encode_key", *args, w["enc.k80blk"].data_ptr(), 2, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
              B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
+    # the 8-wave form that leaves room on its CUs for the hidden sums of other chunks: same bits
+    hid = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
+    kh = torch.full((rows2 // 2, 128), -1.0, dtype=torch.float16, device=dev)
+    call("cpn_encode_key_beside", *args, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+         B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
+    assert torch.equal(hid, hid_ref) and torch.equal(kh, kh_ref)
+
+
+def test_slot_schedule_is_bit_identical(model, dev, weights):
+    """RenderEngine.slot_rays > 0: the encoder of chunk k (cpn_encode_key_beside) on the call's stream, the hidden sums of
+    chunks k - 1 (round 1) and k - 2 (round 2) on a second stream under it, the small stages between two slots, three buffer
+    sets — against the serial chunk loop, incl. a last chunk that is not full and a call too short for the schedule."""
+    H, S = 64, 32
+    inp = syn.make_inputs(2, H, H, 0, seed=71, full_image=True)            # 2 x 4 096 rays
+    z, rel, flow = syn.make_latents(2, H, H, seed=72)
+    model.npoints = S
+    eng = model._engine
+    old = (eng.slot_rays, eng.chunk_rays)
+    try:
+        with torch.no_grad():
+            dinp, dz, dflow = to_device(inp, dev), to_device(z, dev), to_device(flow, dev)
+            eng.slot_rays, eng.chunk_rays = 0, 0
+            ref = model(dinp, z=dz, rel_pose=rel.to(dev), val=True, flow=dflow)
+            ref = {k: ref[k].clone() for k in ("rgb", "at_wt", "valid_mask", "depth_ray")}
+            for sr in (1024, 1536, 2048, 4096):                          # 8 chunks; 5 1/3; 4; 2 (< SLOT_MIN_CHUNKS: serial)
+                eng.slot_rays = sr
+                for _ in range(2):                                       # the second call reuses the buffer sets
+                    out = model(dinp, z=dz, rel_pose=rel.to(dev), val=True, flow=dflow)
+                    for k in ref:
+                        assert torch.equal(out[k], ref[k]), (sr, k)
+    finally:
+        eng.slot_rays, eng.chunk_rays = old
+        eng._ws.clear()
 
 
 def test_feature_cache_is_keyed_on_identity(model, dev, weights):
