@@ -16,6 +16,14 @@
 
 namespace {
 
+// blockIdx.y selects a group of NT column tiles: at small M (the callers' 3 641-ray calls: 228 waves of NT = 8 on 1 024 SIMDs,
+// each walking K as a chain of L2 round trips) the launch runs as 4 x as many waves of NT = 2 - 35 -> 13-19 us at K = 416,
+// 12 -> 6-8 us at K = 128.  CPN_LIN_DEPTH k blocks are in flight per wave (2 = one block ahead of the MFMAs; 4 and 6 measured
+// the same at small M and 2-17 % slower at M = 65 536, where NT = 8 then needs 202 VGPRs).  The k order of every output element
+// is the same in every form: the results are bit-identical (test_small_call_forms_are_bit_identical).
+#ifndef CPN_LIN_DEPTH
+#define CPN_LIN_DEPTH 2
+#endif
 template <int NT>
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ X, int ldx,
                                                          const float* __restrict__ W, int ldw,
@@ -23,8 +31,10 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
                                                          const float* __restrict__ res, int ldr,
                                                          float* __restrict__ Y, int ldy, int M, int N, int K,
                                                          int relu_in, int relu_out) {
+    constexpr int D = CPN_LIN_DEPTH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = (blockIdx.x * 4 + wave) * 16;
+    const int t0 = blockIdx.y * NT;                           // first 16-column tile of this workgroup
     if (m0 >= M) return;
     const int fi = lane & 15, fg = lane >> 4;
     int xr = m0 + fi;
@@ -34,52 +44,51 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // operands of k block kb+16 are requested before the 4*NT MFMAs of block kb (L2 latency ~ the MFMA time of a block)
     const float* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int n = t * 16 + fi;
+        const int n = (t0 + t) * 16 + fi;
         wp[t] = W + (size_t)(n < N ? n : N - 1) * ldw + fg * 4;
     }
-    auto load_w = [&](int kb, f32x4 (&wv)[NT]) {
+    f32x4 xa[D], wa[D][NT];
+    auto fetch = [&](int d, int kb) {
+        xa[d] = *reinterpret_cast<const f32x4*>(xp + kb * 16);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            wv[t] = *reinterpret_cast<const f32x4*>(wp[t] + kb);
-            if (t * 16 + fi >= N) wv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wa[d][t] = *reinterpret_cast<const f32x4*>(wp[t] + kb * 16);
+            if ((t0 + t) * 16 + fi >= N) wa[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto step = [&](f32x4 xv, const f32x4 (&wv)[NT]) {
-        if (relu_in) {
+    const int nkb = K >> 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] = fmaxf(xv[e], 0.0f);
+    for (int d = 0; d < D; ++d)
+        if (d < nkb) fetch(d, d);
+    for (int kb0 = 0; kb0 < nkb; kb0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int kb = kb0 + d;
+            if (kb < nkb) {
+                f32x4 xv = xa[d];
+                if (relu_in) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = fmaxf(xv[e], 0.0f);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[d][t][e], xv[e], acc[t], 0, 0, 0);
+                if (kb + D < nkb) fetch(d, kb + D);
+            }
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], xv[e], acc[t], 0, 0, 0);
-    };
-    f32x4 xa = *reinterpret_cast<const f32x4*>(xp), wa[NT], xb, wb[NT];
-    load_w(0, wa);
-    int kb = 0;
-    for (; kb + 32 <= K; kb += 32) {
-        xb = *reinterpret_cast<const f32x4*>(xp + kb + 16);
-        load_w(kb + 16, wb);
-        step(xa, wa);
-        if (kb + 32 < K) {
-            xa = *reinterpret_cast<const f32x4*>(xp + kb + 32);
-            load_w(kb + 32, wa);
-        }
-        step(xb, wb);
     }
-    if (kb < K) step(xa, wa);                                   // K / 16 odd: the last block is already in (xa, wa)
     const int m = m0 + fi;
     if (m >= M) return;
     const bool vec = ((N | ldy | ldr) & 3) == 0 &&               // 16-byte epilogue: a lane owns 4 consecutive columns
                      (((uintptr_t)Y | (uintptr_t)bias | (uintptr_t)res) & 15) == 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int n0 = t * 16 + fg * 4;
+        const int n0 = (t0 + t) * 16 + fg * 4;
         if (vec) {
             if (n0 >= N) continue;
             f32x4 v = acc[t];
@@ -118,10 +127,15 @@ extern "C" int cpn_linear_f32(const float* X, int ldx, const float* W, int ldw, 
     CPN_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0, CPN_E_ARG, "cpn_linear_f32: X/W must be 16-B aligned");
     const hipStream_t s = (hipStream_t)stream;
     dim3 grid(cpn_cdiv(M, 64)), block(256);
+    const int ntiles = (int)cpn_cdiv(N, 16);
     if (N <= 16)
         hipLaunchKernelGGL(linear_f32_kernel<1>, grid, block, 0, s, X, ldx, W, ldw, bias, res, ldr, Y, ldy, M, N, K,
                            relu_in, relu_out);
-    else
+    else if (M <= 16384) {                                     // fewer than one wave of NT = 8 per SIMD: split the columns
+        grid.y = cpn_cdiv(ntiles, 2);
+        hipLaunchKernelGGL(linear_f32_kernel<2>, grid, block, 0, s, X, ldx, W, ldw, bias, res, ldr, Y, ldy, M, N, K,
+                           relu_in, relu_out);
+    } else
         hipLaunchKernelGGL(linear_f32_kernel<8>, grid, block, 0, s, X, ldx, W, ldw, bias, res, ldr, Y, ldy, M, N, K,
                            relu_in, relu_out);
     CPN_LAUNCH_CHECK("cpn_linear_f32");

@@ -137,6 +137,25 @@ def test_gemm_f16_against_torch(dev):
                 assert err <= (2e-4 if f32 else 4e-3) * max(1.0, want.abs().max().item()), (M, N, K, relu, f32, err)
 
 
+def test_small_call_forms_are_bit_identical(dev):
+    """A ray's value must not depend on the size of the call it is rendered in (the callers render an image as 18 calls of
+    3 641 rays): at M <= 16 384 cpn_linear_f32 runs as 4 x as many waves of 2 column tiles each (228 waves of 8 tiles leave
+    most SIMDs empty and walk K as a chain of L2 round trips: 35 -> 13-19 us at K = 416) and must reproduce the large-M form
+    bit for bit on the same rows."""
+    from coponerf_amd._hip import call
+    torch.manual_seed(5)
+    s = torch.cuda.current_stream().cuda_stream
+    for (N, K) in [(128, 416), (128, 128), (48, 32)]:
+        Mbig, Msmall = 16384 + 64, 3641
+        X = torch.randn(Mbig, K, device=dev)
+        Wt = torch.randn(N, K, device=dev) * 0.1
+        b = torch.randn(N, device=dev)
+        big, small = torch.empty(Mbig, N, device=dev), torch.empty(Msmall, N, device=dev)
+        call("cpn_linear_f32", X.data_ptr(), K, Wt.data_ptr(), K, b.data_ptr(), 0, 0, big.data_ptr(), N, Mbig, N, K, 1, 0, s)
+        call("cpn_linear_f32", X.data_ptr(), K, Wt.data_ptr(), K, b.data_ptr(), 0, 0, small.data_ptr(), N, Msmall, N, K, 1, 0, s)
+        assert torch.equal(small, big[:Msmall]), (N, K)
+
+
 def test_linear_f32_against_torch(dev):
     from coponerf_amd._hip import call
     torch.manual_seed(1)
