@@ -10,6 +10,9 @@
 //   phase 2  block max / sum-exp through LDS (fp32), weights to LDS
 //   phase 3  z[c] = sum_rows w[row] * value[row][c], c = tid and tid+256 (416 channels), coalesced row reads
 // HBM/L2-bound: per ray 2 x T x 256 B (q operands) + T x 1664 B (values) = 278 KiB at T = 128.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -122,19 +125,17 @@ constexpr int HC = 1664;
 #define CPN_ATTEND_UNROLL 4
 #endif
 
-template <bool HAVE_LOGITS>
-__global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __restrict__ qa,
-                                                            const __half* __restrict__ qb,
-                                                            const float* __restrict__ logits,
-                                                            const __half* __restrict__ hid, int V, int R, int S,
-                                                            int ray0, __half* __restrict__ hbar,
-                                                            float* __restrict__ at_wt) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* wts = reinterpret_cast<float*>(smem_raw);
-    float* red = wts + V * S;
+// U = rows of hid in flight per thread.  The grid is either one workgroup per ray (U = 4: 8 waves per SIMD cover the
+// latency) or a FIXED number of workgroups per CU that walk the rays (cpn_attend_hidden_few, U = 8): the same bytes in
+// flight from half the wave slots and a third of the registers, the rest of every CU left to the kernels of another stream.
+template <bool HAVE_LOGITS, int U>
+__device__ __forceinline__ void attend_hidden_ray(const unsigned lray, float* __restrict__ wts, float* __restrict__ red,
+                                                  const __half* __restrict__ qa, const __half* __restrict__ qb,
+                                                  const float* __restrict__ logits, const __half* __restrict__ hid, int V,
+                                                  int R, int S, int ray0, __half* __restrict__ hbar,
+                                                  float* __restrict__ at_wt) {
     const int T = V * S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned lray = blockIdx.x;
     const size_t row0 = (size_t)lray * T;
 
     float lmax = -INFINITY;
@@ -199,7 +200,6 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
             return *reinterpret_cast<const half8*>(hp + (size_t)row * HC);
 #endif
         };
-        constexpr int U = CPN_ATTEND_UNROLL;
         int row = 0;
         for (; row + U <= T; row += U) {                  // U loads in flight, then their U x 8 FMAs in row order
             half8 h[U];
@@ -222,6 +222,30 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[e];
         *reinterpret_cast<half8*>(hbar + (size_t)lray * HC + tid * 8) = o;
+    }
+}
+
+template <bool HAVE_LOGITS>
+__global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __restrict__ qa,
+                                                            const __half* __restrict__ qb,
+                                                            const float* __restrict__ logits,
+                                                            const __half* __restrict__ hid, int V, int R, int S,
+                                                            int ray0, __half* __restrict__ hbar,
+                                                            float* __restrict__ at_wt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wts = reinterpret_cast<float*>(smem_raw);
+    attend_hidden_ray<HAVE_LOGITS, CPN_ATTEND_UNROLL>(blockIdx.x, wts, wts + V * S, qa, qb, logits, hid, V, R, S, ray0, hbar, at_wt);
+}
+
+__global__ __launch_bounds__(256) void attend_hidden_few_kernel(const float* __restrict__ logits,
+                                                                const __half* __restrict__ hid, int V, int R, int S,
+                                                                int ray0, int nrays, __half* __restrict__ hbar,
+                                                                float* __restrict__ at_wt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wts = reinterpret_cast<float*>(smem_raw);
+    for (unsigned lray = blockIdx.x; lray < (unsigned)nrays; lray += gridDim.x) {
+        if (lray != blockIdx.x) __syncthreads();              // every wave is done with the previous ray's weights
+        attend_hidden_ray<true, 8>(lray, wts, wts + V * S, nullptr, nullptr, logits, hid, V, R, S, ray0, hbar, at_wt);
     }
 }
 
@@ -248,6 +272,13 @@ extern "C" int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const f
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_attend_hidden: ray range outside B*R");
     const size_t lds = (size_t)(V * S + 8) * sizeof(float);
+    // CPN_ATTEND_FEW=k (experiments): k workgroups per CU walking the rays instead of one workgroup per ray
+    static const int few = [] { const char* e = getenv("CPN_ATTEND_FEW"); return e ? atoi(e) : 0; }();
+    if (few > 0 && logits) {
+        const unsigned grid = (unsigned)std::min<long long>(nrays, (long long)few * cpn_stream_cus(stream));
+        hipLaunchKernelGGL(attend_hidden_few_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, logits, (const __half*)hid,
+                           V, R, S, ray0, nrays, (__half*)hbar, at_wt);
+    } else
     hipLaunchKernelGGL(logits ? attend_hidden_kernel<true> : attend_hidden_kernel<false>, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
                        (const __half*)qb, logits, (const __half*)hid, V, R, S, ray0, (__half*)hbar, at_wt);
     CPN_LAUNCH_CHECK("cpn_attend_hidden");

@@ -373,6 +373,11 @@ class RenderEngine:
         self.slot_rays = int(os.environ.get("COPONERF_SLOT_RAYS", "0"))
         self._slot_streams: Dict[int, torch.cuda.Stream] = {}
         self.slot_trace: Optional[list] = None     # tools/slot_probe.py: (slot, start, encoder end, sums end) events
+        # pipeline.render_images(overlap="sums"): when True, every render call leaves in `encode_done` an event recorded
+        # behind the encoder launch of its LAST chunk (from there on the call's kernels leave the LDS and most registers
+        # of the CUs free: the point where another stream's small kernels may join without starving a persistent grid)
+        self.mark_encode_done = False
+        self.encode_done: Optional[torch.cuda.Event] = None
         # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
         # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it
         self.fold_value = bool(fold_value)
@@ -906,6 +911,13 @@ class RenderEngine:
 
         def stage_encode(ray0, bf, s, beside=False):
             """E: first encoder layer (+ the folded key_map layer when fused) -> hid (, khf)  [CoPoNeRF.py:384-397, 404-407]"""
+            _stage_encode(ray0, bf, s, beside)
+            if self.mark_encode_done and ray0 + C >= nray_total:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.encode_done = ev
+
+        def _stage_encode(ray0, bf, s, beside):
             hid, xin = bf["hid"], bf.get("xin")
             n = min(C, nray_total - ray0)
             rows2 = n * T * 2

@@ -20,6 +20,6 @@ def t(**kw):
         for _ in render_images(model, seq, **kw): n += 1
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
-ALL = ({}, {"getz_batch": 4}, {"getz_batch": 4, "cu_split": (224, 32)}, {"getz_batch": 4, "cu_split": (192, 64)}, {"cu_split": (192, 64)}, {"cu_split": (192, 64), "graph": True}, {"getz_batch": 4, "cu_split": (192, 64), "graph": True})
+ALL = ({}, {"overlap": "sums"}, {"overlap": True}, {"overlap": "sums", "graph": True}, {"graph": True}, {"getz_batch": 4}, {"getz_batch": 4, "cu_split": (224, 32)}, {"getz_batch": 4, "cu_split": (192, 64)}, {"cu_split": (192, 64)}, {"cu_split": (192, 64), "graph": True}, {"getz_batch": 4, "cu_split": (192, 64), "graph": True})
 for i in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else range(len(ALL))):
     print(ALL[i], round(t(**ALL[i]), 2), round(t(**ALL[i]), 2), flush=True)
