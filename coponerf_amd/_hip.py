@@ -36,6 +36,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
     "cpn_gemm_f16_chain_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
     "cpn_gemm_f16": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "cpn_pack_gemm_frags": [_P, _I, _I, _I, _P, _P],
+    "cpn_gemm_f16_fewrows": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpn_attend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_attend_hidden": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_linear_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],

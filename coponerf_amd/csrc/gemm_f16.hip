@@ -500,7 +500,184 @@ int dispatch(const __half* A, int lda, const __half* W, int ldw, const float* bi
                 : launch<NT, false, false>(A, lda, W, ldw, bias, C, ldc, M, N, K32, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Few rows (the per-RAY GEMM of a small call: value_fold at M = 3 641 rays, 1/18 of an image).  The 256-row tiles above leave
+// 30 workgroups on 256 CUs walking K = 1664 as 26 barrier-separated stages: 35 us for 5 GFLOP.  Here a wave owns 32 rows x
+// CPN_FEW_NT column tiles, no LDS staging, no barrier, CPN_FEW_DEPTH 64-deep stages in flight (pinned with sched_barriers: left
+// alone the scheduler sinks every load to just above its use).  What it took (tools/fewrows_bench.py, us at M = 3 641):
+//   * operands read in the MFMA fragment layout from row-major matrices (lane = row + 16 * piece: 64 tag look-ups per
+//     instruction): 52-62 - the wave waits on the L1 tag pipe, not on L2;
+//   * weights pre-packed in FRAGMENT order (cpn_pack_gemm_frags: the 1 KiB of A operand (tile t, k32 step ks) contiguous,
+//     a load instruction covers 8 whole lines): 30;
+//   * the activation rows in the load layout as well (lane = 4 * row + piece: 16 look-ups), moved to the fragment layout with
+//     4 ds_bpermute per register set: 22 (7 tiles per wave, 2-3 stages in flight), **17** (4 tiles, 4 stages) - the default.
+// The accumulation order of every output element is that of gemm_f16_kernel (zero start, k32 steps in order, bias last):
+// bit-identical results, so a ray's value does not depend on the size of the call it is rendered in.  Above ~ 6 000 rows the
+// tiled kernel wins again (weights re-read per 32 rows).
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_gemm_frags_kernel(const __half* __restrict__ W, int ldw, int N, int K32, half8* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // (tile, k32 step, lane)
+    const long long total = (long long)(N >> 4) * K32 * 64;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const long long q = i >> 6;
+    const int ks = (int)(q % K32), t = (int)(q / K32);
+    out[i] = *reinterpret_cast<const half8*>(W + (size_t)(t * 16 + (lane & 15)) * ldw + ks * 32 + (lane >> 4) * 8);
+}
+
+#ifndef CPN_FEW_NT
+#define CPN_FEW_NT 4
+#endif
+#ifndef CPN_FEW_DEPTH
+#define CPN_FEW_DEPTH 4
+#endif
+#ifndef CPN_FEW_RT
+#define CPN_FEW_RT 2
+#endif
+constexpr int FEW_NT = CPN_FEW_NT, FEW_RT = CPN_FEW_RT;
+__global__ __launch_bounds__(256) void gemm_f16_fewrows_kernel(const __half* __restrict__ A, int lda,
+                                                               const half8* __restrict__ Wp, const float* __restrict__ bias,
+                                                               float* __restrict__ C, int ldc, int M, int N, int K32, int relu) {
+    constexpr int NT = FEW_NT, RT = FEW_RT, D = CPN_FEW_DEPTH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 16 * RT;
+    const int ntiles = N >> 4;
+    const int tile0 = (blockIdx.y * 4 + wave) * NT;
+    if (tile0 >= ntiles) return;
+    // activation rows in the LOAD layout (lane = 4 * row + 16-byte piece: 4 adjacent lanes read 64 contiguous bytes, 16 tag
+    // look-ups per instruction instead of the 64 of the fragment layout lane = row + 16 * piece, which made the kernel wait on
+    // the L1 tag pipe: 1.1 us per 64-deep stage), moved to the fragment layout with 4 ds_bpermute per register set
+    const int rl = lane >> 2, pl = lane & 3;
+    const int to_frag = (4 * r + g) * 4;
+    const __half* ap[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        const int row = m0 + q * 16 + rl < M ? m0 + q * 16 + rl : M - 1;
+        ap[q] = A + (size_t)row * lda + pl * 8;
+    }
+    const half8* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tt = tile0 + t < ntiles ? tile0 + t : ntiles - 1;               // dead tiles of the last wave redo its last live one
+        wp[t] = Wp + (size_t)tt * K32 * 64 + lane;
+    }
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nfull = K32 >> 1;                  // whole stages of two k32 steps
+    half8 xa[D][2][RT], wa[D][2][NT];
+    // no branch around a fetch (the compiler's vmcnt bookkeeping stays exact): a stage index past the end re-reads the last
+    // stage into a slot nobody uses any more
+    auto fetch = [&](int d, int st) {
+        st = st < nfull ? st : nfull - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < RT; ++q) xa[d][h][q] = *reinterpret_cast<const half8*>(ap[q] + (st * 2 + h) * 32);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wa[d][h][t] = wp[t][(size_t)(st * 2 + h) * 64];
+        }
+    };
+    auto frag = [&](half8 v) {
+        const u32x4 src = __builtin_bit_cast(u32x4, v);
+        u32x4 dst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = (unsigned)__builtin_amdgcn_ds_bpermute(to_frag, (int)src[i]);
+        return __builtin_bit_cast(half8, dst);
+    };
+    auto mma = [&](int d) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            half8 xf[RT];
+#pragma unroll
+            for (int q = 0; q < RT; ++q) xf[q] = frag(xa[d][h][q]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < RT; ++q)
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[d][h][t], xf[q], acc[q][t], 0, 0, 0);
+        }
+    };
+    if (nfull > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) fetch(d, d);
+        int s0 = 0;
+        for (; s0 + D <= nfull; s0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                __builtin_amdgcn_sched_barrier(0);
+                mma(d);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(d, s0 + d + D);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+            if (s0 + d < nfull) mma(d);
+    }
+    if (K32 & 1) {                               // odd trailing k32 step
+        half8 xl[RT], wl[NT];
+#pragma unroll
+        for (int q = 0; q < RT; ++q) xl[q] = *reinterpret_cast<const half8*>(ap[q] + (K32 - 1) * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wl[t] = wp[t][(size_t)(K32 - 1) * 64];
+#pragma unroll
+        for (int q = 0; q < RT; ++q) xl[q] = frag(xl[q]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < RT; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], xl[q], acc[q][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        const int m = m0 + q * 16 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (tile0 + t >= ntiles) continue;
+            const int n = (tile0 + t) * 16 + g * 4;
+            f32x4 v = acc[q][t] + *reinterpret_cast<const f32x4*>(bias + n);
+            if (relu) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+            }
+            *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int cpn_pack_gemm_frags(const uint16_t* W, int ldw, int N, int K, uint16_t* out, void* stream) {
+    CPN_REQUIRE(W && out, CPN_E_ARG, "cpn_pack_gemm_frags: null pointer");
+    CPN_REQUIRE(N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0 && ldw >= K && (ldw % 8) == 0, CPN_E_SHAPE,
+                "cpn_pack_gemm_frags: need N %% 16 == 0, K %% 32 == 0, ldw >= K (got N=%d K=%d ldw=%d)", N, K, ldw);
+    CPN_REQUIRE(((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, CPN_E_ARG, "cpn_pack_gemm_frags: pointers must be 16-byte aligned");
+    const long long total = (long long)(N / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_gemm_frags_kernel, dim3(cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)W, ldw, N,
+                       K / 32, (half8*)out);
+    CPN_LAUNCH_CHECK("cpn_pack_gemm_frags");
+    return 0;
+}
+
+extern "C" int cpn_gemm_f16_fewrows(const uint16_t* A, int lda, const uint16_t* Wp, const float* bias, float* C, int ldc, int M,
+                                    int N, int K, int relu, void* stream) {
+    CPN_REQUIRE(A && Wp && bias && C, CPN_E_ARG, "cpn_gemm_f16_fewrows: null pointer");
+    CPN_REQUIRE(M > 0 && N > 0 && (N % 16) == 0 && K > 0 && (K % 32) == 0, CPN_E_SHAPE,
+                "cpn_gemm_f16_fewrows: need N %% 16 == 0 and K %% 32 == 0 (got N=%d K=%d)", N, K);
+    CPN_REQUIRE(lda >= K && (lda % 8) == 0 && ldc >= N && (ldc % 4) == 0, CPN_E_SHAPE, "cpn_gemm_f16_fewrows: bad leading dimension");
+    CPN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)bias % 16) == 0,
+                CPN_E_ARG, "cpn_gemm_f16_fewrows: pointers must be 16-byte aligned");
+    dim3 grid(cpn_cdiv(M, 16 * FEW_RT), cpn_cdiv(N / 16, 4 * FEW_NT));
+    hipLaunchKernelGGL(gemm_f16_fewrows_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __half*)A, lda, (const half8*)Wp, bias,
+                       C, ldc, M, N, K / 32, relu);
+    CPN_LAUNCH_CHECK("cpn_gemm_f16_fewrows");
+    return 0;
+}
 
 extern "C" int cpn_gemm_f16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, void* C,
                             int ldc, int M, int N, int K, int relu, int out_f32, void* stream) {

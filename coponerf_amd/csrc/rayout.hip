@@ -33,13 +33,17 @@ constexpr int XS_LD = 132;                           // LDS row stride (floats) 
 
 // acc[t] = sum_k W[n_base + 16 t + fi][k] * x[k]   on v_mfma_f32_16x16x4_f32, operands swapped (A = weights, B = rays)
 // exactly as cpn_linear_f32 orders them: k block kb covers k = 16 kb + 4 fg + e, one MFMA step per e.
+// W is stored in FRAGMENT order (round 4; the host packs it, include/coponerf_hip.h): the 1 KiB of A operand (tile, k block)
+// contiguous, lane l's four floats at l * 16 bytes - a load instruction covers 8 whole lines.  Row-major weights read in the
+// fragment layout (lane = row + 16 * k group: 16 rows x 16 bytes) cost 64 L1 tag look-ups per instruction, and the 272
+// weight loads of a wave made the decoder wait on the tag pipe, not on the MFMA (552 us per 65 536 rays at 42 % of the fp32
+// MFMA rate; tools/fewrows_bench.py found the same limit in the few-row GEMM).
 template <int NT, class LoadX>
-__device__ __forceinline__ void mm_f32(LoadX load_x, const float* __restrict__ W, int ldw, int nkb, int n_base, int fi,
-                                       int fg, f32x4 (&acc)[NT]) {
+__device__ __forceinline__ void mm_f32(LoadX load_x, const float* __restrict__ W, int nkb, int n_base, int lane, f32x4 (&acc)[NT]) {
     const float* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        wp[t] = W + (size_t)(n_base + 16 * t + fi) * ldw + fg * 4;
+        wp[t] = W + ((size_t)((n_base >> 4) + t) * nkb * 64 + lane) * 4;
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     f32x4 xa = load_x(0), wa[NT];
@@ -52,7 +56,7 @@ __device__ __forceinline__ void mm_f32(LoadX load_x, const float* __restrict__ W
         if (kb + 1 < nkb) {                                        // next block's operands in flight under the MFMAs
             xn = load_x(kb + 1);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wn[t] = *reinterpret_cast<const f32x4*>(wp[t] + (kb + 1) * 16);
+            for (int t = 0; t < NT; ++t) wn[t] = *reinterpret_cast<const f32x4*>(wp[t] + (kb + 1) * 256);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -109,16 +113,27 @@ __global__ __launch_bounds__(256) void lightfield_decode_kernel(const float* __r
             v[e] = k < 18 ? coords9[(((size_t)b * 2 + vw) * R + r) * 9 + (k - 9 * vw)] : 0.0f;
         }
         return v;
-    }, wp + OFF_IN_W, 32, 2, n_base, fi, fg, acc);
+    }, wp + OFF_IN_W, 2, n_base, lane, acc);
 #pragma unroll
     for (int t = 0; t < 2; ++t) x[t] = acc[t] + bias4(OFF_IN_B, t);
 
-    const float* zrow = zl + (size_t)ray * 416 + fg * 4;
+    // z rows in the LOAD layout (lane = 4 * ray + 16-byte piece: 4 adjacent lanes read 64 contiguous bytes of one row, 16 tag
+    // look-ups per instruction instead of 64), moved to the B-operand layout (lane = ray + 16 * k group) with 4 ds_bpermute
+    long long ray_l = (long long)blockIdx.x * 16 + (lane >> 2);
+    ray_l = ray_l < nray ? ray_l : nray - 1;
+    const float* zrow = zl + (size_t)ray_l * 416 + (lane & 3) * 4;
+    const int to_b = (4 * fi + fg) * 4;
+    auto load_z = [&](int kb) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(zrow + kb * 16);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(to_b, __float_as_int(v[e])));
+        return o;
+    };
     for (int k = 0; k < 3; ++k) {
         const float* blk = wp + OFF_BLK + (size_t)k * BLK_SZ;
         // x = x + lin_z[k](z)                                                           (lightfield.py:150-156)
-        mm_f32<2>([&](int kb) { return *reinterpret_cast<const f32x4*>(zrow + kb * 16); }, blk + BLK_ZW, 416, 26, n_base,
-                  fi, fg, acc);
+        mm_f32<2>(load_z, blk + BLK_ZW, 26, n_base, lane, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 v = acc[t];
@@ -129,13 +144,13 @@ __global__ __launch_bounds__(256) void lightfield_decode_kernel(const float* __r
         to_lds(xs, x);
         __syncthreads();
         // net = fc_0(relu(x));  x = x + fc_1(relu(net))                                  (lightfield.py:52-61)
-        mm_f32<2>(from_lds(xs), blk + BLK_0W, 128, 8, n_base, fi, fg, acc);
+        mm_f32<2>(from_lds(xs), blk + BLK_0W, 8, n_base, lane, acc);
         f32x4 net[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) net[t] = acc[t] + bias4(OFF_BLK + k * BLK_SZ + BLK_0B, t);
         to_lds(ns, net);
         __syncthreads();
-        mm_f32<2>(from_lds(ns), blk + BLK_1W, 128, 8, n_base, fi, fg, acc);
+        mm_f32<2>(from_lds(ns), blk + BLK_1W, 8, n_base, lane, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 v = acc[t];
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(256) void lightfield_decode_kernel(const float* __r
     if (wave != 0) return;
     // lin_out(relu(x)) -> 3 channels, then white where no context view sees the ray (CoPoNeRF.py:562-566)
     f32x4 o[1];
-    mm_f32<1>(from_lds(xs), wp + OFF_OUT_W, 128, 8, 0, fi, fg, o);
+    mm_f32<1>(from_lds(xs), wp + OFF_OUT_W, 8, 0, lane, o);
     if (fg != 0 || !live) return;
     f32x4 raw = o[0] + *reinterpret_cast<const f32x4*>(wp + OFF_OUT_B);
     const bool any = overlaps[((size_t)b * 2 + 0) * R + r] || overlaps[((size_t)b * 2 + 1) * R + r];

@@ -341,6 +341,7 @@ class RenderEngine:
     FREE_SHARE = 0.5                # ... and at most this share of the memory that is free when the workspace is sized
     MAX_AUTO_CHUNK = 65536
     SLOT_MIN_CHUNKS = 4
+    FEW_ROWS = 4096                 # per-ray GEMMs of at most this many rows take the few-row kernel (cpn_gemm_f16_fewrows: 17 vs 35 us at 3 641)
 
     def __init__(self, chunk_rays: int = 0, fold_value: bool = True, lanes: int = 1, tables: bool = True,
                  fuse_key: Optional[bool] = None):
@@ -509,6 +510,9 @@ class RenderEngine:
 
         w["key_fold.w16"], w["key_fold.b"] = fold("key_map.weight", "key_map.bias", 128)
         w["value_fold.w16"], w["value_fold.b"] = fold("latent_value.weight", "latent_value.bias", 416)
+        # the same matrix in MFMA fragment order for the few-row form of the per-ray value projection (cpn_gemm_f16_fewrows)
+        w["value_fold.wpk"] = torch.empty(416 * 1664, dtype=torch.float16, device=dev)
+        call("cpn_pack_gemm_frags", w["value_fold.w16"].data_ptr(), 1664, 416, 1664, w["value_fold.wpk"].data_ptr(), s)
         w["query_embed.w"] = f32("query_embed.weight").reshape(128, 16)
         w["query_embed.b"] = f32("query_embed.bias")
         wr = f32("query_repeat_embed.weight").reshape(128, 144)
@@ -534,11 +538,15 @@ class RenderEngine:
         wout[:3] = w["phi.lin_out.w"]
         bout = torch.zeros(16, dtype=torch.float32, device=dev)
         bout[:3] = w["phi.lin_out.b"]
-        parts = [w["phi.lin_in.w"], w["phi.lin_in.b"]]
+        def fr(m):                  # (N, K) row-major -> MFMA fragment order [N/16][K/16][lane = row + 16 * k group][4]
+            n, k = m.shape
+            return m.view(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+        parts = [fr(w["phi.lin_in.w"]), w["phi.lin_in.b"]]
         for k in range(3):
-            parts += [w[f"phi.lin_z.{k}.w"], w[f"phi.lin_z.{k}.b"], w[f"phi.blocks.{k}.fc_0.w"], w[f"phi.blocks.{k}.fc_0.b"],
-                      w[f"phi.blocks.{k}.fc_1.w"], w[f"phi.blocks.{k}.fc_1.b"]]
-        w["phi.pack"] = torch.cat([t.reshape(-1) for t in parts + [wout, bout]])
+            parts += [fr(w[f"phi.lin_z.{k}.w"]), w[f"phi.lin_z.{k}.b"], fr(w[f"phi.blocks.{k}.fc_0.w"]), w[f"phi.blocks.{k}.fc_0.b"],
+                      fr(w[f"phi.blocks.{k}.fc_1.w"]), w[f"phi.blocks.{k}.fc_1.b"]]
+        w["phi.pack"] = torch.cat([t.reshape(-1) for t in parts + [fr(wout), bout]])
         assert w["phi.pack"].numel() == _hip.LIGHTFIELD_PACK_FLOATS
         # ---- "project, then interpolate" form of the first layer (csrc/encode.hip): MFMA fragments of the
         #      full-resolution / point-encoding columns and the table projection weights of the three coarse levels
@@ -903,8 +911,13 @@ class RenderEngine:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            call("cpn_gemm_f16", a.data_ptr(), lda, w[wname + ".w16"].data_ptr(), w[wname + ".w16"].shape[1],
-                 w[wname + ".b"].data_ptr(), out.data_ptr(), ldc, m, n, k, int(relu), int(out_f32), s)
+            if out_f32 and m <= self.FEW_ROWS and (wname + ".wpk") in w:
+                # a small call's per-ray GEMM: 30 of the 256-row tiles would walk K alone (37 us at 3 641 rays); bit-identical
+                call("cpn_gemm_f16_fewrows", a.data_ptr(), lda, w[wname + ".wpk"].data_ptr(), w[wname + ".b"].data_ptr(),
+                     out.data_ptr(), ldc, m, n, k, int(relu), s)
+            else:
+                call("cpn_gemm_f16", a.data_ptr(), lda, w[wname + ".w16"].data_ptr(), w[wname + ".w16"].shape[1],
+                     w[wname + ".b"].data_ptr(), out.data_ptr(), ldc, m, n, k, int(relu), int(out_f32), s)
             if prof is not None:
                 e1.record()
                 prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * GW[wname][1]))

@@ -190,6 +190,13 @@ int cpn_encode_key_beside(const uint16_t* tab, const uint16_t* map3, int H, int 
  *   out_f32 = 0: C fp16 (M, ldc) ; 1: C fp32 (M, ldc)                                                           */
 int cpn_gemm_f16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
                  void* C, int ldc, int M, int N, int K, int relu, int out_f32, void* stream);
+/* Few-row form (round 4): the per-RAY value projection of a small call (M = 3 641 rays when the callers render an image as 18
+ * forward() calls, test.py:176-190) - fp32 out, results bit-identical to cpn_gemm_f16 (same accumulation order), 13 us where
+ * the 256-row tiles take 37.  Wp = the weights in MFMA fragment order, written once per parameter version by
+ * cpn_pack_gemm_frags: (N/16, K/32, 64 lanes, 8) fp16, lane l of fragment (t, ks) = W[16 t + (l & 15)][32 ks + 8 (l >> 4) .. +8]. */
+int cpn_pack_gemm_frags(const uint16_t* W, int ldw, int N, int K, uint16_t* out, void* stream);
+int cpn_gemm_f16_fewrows(const uint16_t* A, int lda, const uint16_t* Wp, const float* bias, float* C, int ldc, int M, int N,
+                         int K, int relu, void* stream);
 
 /* ---- K4: joint softmax over (V*S) + weighted value sum, one query ray per workgroup ---------------
  * replaces einsum / softmax / broadcast-mul-sum (CoPoNeRF.py:450-461, 475-485).
@@ -224,7 +231,10 @@ int cpn_mask_rgb(const float* rgb_raw, int ld, const uint8_t* overlaps, int B, i
  * rays no context view sees (:562-566).  Exact fp32 (v_mfma_f32_16x16x4_f32), same operation order as the
  * layer-by-layer cpn_linear_f32 chain + cpn_mask_rgb it supersedes on the inference path.
  *   coords9 (N,R,9)   z_local (B*R,416)   overlaps (N,R) uint8
- *   wpack: CPN_LIGHTFIELD_PACK_FLOATS floats = lin_in W[128][32] (18 columns used, rest zero) b[128] |
+ *   wpack: every weight matrix W[N][K] in MFMA FRAGMENT order (round 4) - [N/16][K/16][64 lanes][4]: lane l of fragment
+ *          (t, kb) holds W[16 t + (l & 15)][16 kb + 4 (l >> 4) .. +4], so that a wave's load of one fragment is 1 KiB of
+ *          contiguous memory (row-major weights read in that layout cost 64 L1 tag look-ups per instruction) - biases plain:
+ *          CPN_LIGHTFIELD_PACK_FLOATS floats = lin_in W[128][32] (18 columns used, rest zero) b[128] |
  *          3 x { lin_z W[128][416] (the two 416-column halves of the reference's 832 summed) b[128] |
  *                fc_0 W[128][128] b[128] | fc_1 W[128][128] b[128] } | lin_out W[16][128] (rows 3.. zero) b[16]
  *   rgb (B,1,R,3)   valid (B,R,1) float 0/1   rgb_raw (B*R,3) or NULL: the decoder output before masking        */

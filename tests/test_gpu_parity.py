@@ -140,11 +140,31 @@ def test_gemm_f16_against_torch(dev):
 def test_small_call_forms_are_bit_identical(dev):
     """A ray's value must not depend on the size of the call it is rendered in (the callers render an image as 18 calls of
     3 641 rays): at M <= 16 384 cpn_linear_f32 runs as 4 x as many waves of 2 column tiles each (228 waves of 8 tiles leave
-    most SIMDs empty and walk K as a chain of L2 round trips: 35 -> 13-19 us at K = 416) and must reproduce the large-M form
-    bit for bit on the same rows."""
+    most SIMDs empty and walk K as a chain of L2 round trips: 35 -> 13-19 us at K = 416), at M <= 8 192 the value projection
+    takes cpn_gemm_f16_fewrows; both must reproduce the large-M forms bit for bit on the same rows."""
     from coponerf_amd._hip import call
     torch.manual_seed(5)
     s = torch.cuda.current_stream().cuda_stream
+    # cpn_gemm_f16_fewrows (weights pre-packed in MFMA fragment order) against the tiled cpn_gemm_f16 with fp32 output
+    for (N, K, ld, M) in [(416, 1664, 1664, 3641), (416, 1664, 1664, 8192), (128, 832, 896, 77), (832, 864, 896, 1000), (48, 32, 32, 5)]:
+        A = torch.zeros(M, ld, device=dev, dtype=torch.float16)
+        A[:, :K] = torch.randn(M, K, device=dev) * 0.5
+        Wt = torch.zeros(N, ld, device=dev, dtype=torch.float16)
+        Wt[:, :K] = torch.randn(N, K, device=dev) * 0.05
+        bias = torch.randn(N, device=dev)
+        Wp = torch.full((N * K,), float("nan"), device=dev, dtype=torch.float16)
+        call("cpn_pack_gemm_frags", Wt.data_ptr(), ld, N, K, Wp.data_ptr(), s)
+        assert not torch.isnan(Wp).any()
+        for relu in (0, 1):
+            few = torch.full((M, N), float("nan"), device=dev)
+            call("cpn_gemm_f16_fewrows", A.data_ptr(), ld, Wp.data_ptr(), bias.data_ptr(), few.data_ptr(), N, M, N, K, relu, s)
+            ref = A[:, :K].float() @ Wt[:, :K].float().t() + bias
+            ref = ref.clamp_min(0) if relu else ref
+            assert (few - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max())), (N, K, M, relu)
+            if N % 208 == 0 or N % 128 == 0:
+                tiled = torch.full((M, N), float("nan"), device=dev)
+                call("cpn_gemm_f16", A.data_ptr(), ld, Wt.data_ptr(), ld, bias.data_ptr(), tiled.data_ptr(), N, M, N, K, relu, 1, s)
+                assert torch.equal(few, tiled), (N, K, M, relu, int((few != tiled).sum()))
     for (N, K) in [(128, 416), (128, 128), (48, 32)]:
         Mbig, Msmall = 16384 + 64, 3641
         X = torch.randn(Mbig, K, device=dev)
