@@ -225,6 +225,12 @@ __global__ __launch_bounds__(256) void local_hidden_kernel(
 #ifndef CPN_LMLP_ABLATE
 #define CPN_LMLP_ABLATE 0
 #endif
+// 1 = the dot_with rows in the load layout (lane = 4 * row + piece, 16 L1 tag look-ups per instruction instead of 64) and 16
+// ds_bpermute per group to the accumulator layout: measured SLOWER here (0.293 against 0.235 ms per 16 384-ray call, tools/
+// local_mlp_bench.py variant 100 = this macro at 0) - the kernel's LDS pipe already carries the W2 fragments; the product builds 0
+#ifndef CPN_LMLP_DOT_LOAD_LAYOUT
+#define CPN_LMLP_DOT_LOAD_LAYOUT 0
+#endif
 __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
     const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
@@ -285,10 +291,20 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
         const RowIn nxt = fetch(grp + nwaves < ngroups ? grp + nwaves : grp);
         half8 cv[4];
         if (logits_out && !(CPN_LMLP_ABLATE & 8)) {
+#if CPN_LMLP_DOT_LOAD_LAYOUT
+            // load layout: lane = 4 * row + piece, 4 adjacent lanes read 64 contiguous bytes of one row (16 L1 tag look-ups per
+            // instruction; in the fragment layout lane = row + 16 * piece every lane is a look-up of its own: 64)
+            const unsigned lrow = grp * 16 + (lane >> 2);
+            const unsigned crow = lrow < (unsigned)nrows ? lrow : (unsigned)nrows - 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(dot_with + (size_t)crow * 128 + p * 32 + (lane & 3) * 8));
+#else
             const unsigned crow = live ? row : (unsigned)nrows - 1;
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(dot_with + (size_t)crow * 128 + p * 32 + fg * 8));
+#endif
         }
         f32x4 acc[8];
 #pragma unroll
@@ -332,6 +348,16 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
             // the consumer only needs <out[row], dot_with[row]>: form it here from the fp16-rounded outputs (the values
             // a stored row would have had) and write 4 bytes per row instead of 256
             float dsum = 0.0f;
+#if CPN_LMLP_DOT_LOAD_LAYOUT
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {                      // to the accumulator layout (lane = row + 16 * piece)
+                const u32x4 src = __builtin_bit_cast(u32x4, cv[p]);
+                u32x4 dst;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[i] = (unsigned)__builtin_amdgcn_ds_bpermute((4 * a + fg) * 4, (int)src[i]);
+                cv[p] = __builtin_bit_cast(half8, dst);
+            }
+#endif
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tools", "_build")
 VARIANTS = {0: "full", 1: "no layer-1 MFMA", 2: "no layer-2 MFMA", 3: "no MFMA", 4: "no add loads", 8: "no dot_with loads",
-            12: "no add / dot_with loads", 16: "no stores", 31: "loop + input loads only"}
+            12: "no add / dot_with loads", 16: "no stores", 31: "loop + input loads only",
+            100: "full, dot_with rows in the load layout + 16 ds_bpermute (CPN_LMLP_DOT_LOAD_LAYOUT=1)"}
 if "--build" in sys.argv:
     os.makedirs(BUILD, exist_ok=True)
     src = os.path.join(ROOT, "coponerf_amd", "csrc")
@@ -20,7 +21,7 @@ if "--build" in sys.argv:
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", os.path.join(src, "error.cpp"), "-o", err_o])
     for k in VARIANTS:
         obj, out = os.path.join(BUILD, f"gather_lmlp{k}.o"), os.path.join(BUILD, f"libgather_lmlp{k}.so")
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_LMLP_ABLATE={k}", "-x", "hip", "-c",
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DCPN_LMLP_ABLATE={k % 100}", f"-DCPN_LMLP_DOT_LOAD_LAYOUT={1 if k >= 100 else 0}", "-x", "hip", "-c",
                                os.path.join(src, "gather.hip"), "-o", obj])
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj, err_o, "-o", out])
     sys.exit(0)
