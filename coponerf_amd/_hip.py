@@ -32,7 +32,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_encode_key_beside": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
     "cpn_gemm_f16_chain_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
     "cpn_gemm_f16": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
     const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
     const float* __restrict__ b2, int V, int R, int S, int ray0, long long nrows, __half* __restrict__ out,
-    const __half* __restrict__ dot_with, float* __restrict__ logits_out) {
+    const __half* __restrict__ dot_with, float* __restrict__ logits_out, int frag) {
     // 8 waves share the W2 fragments; 2 workgroups per CU = 4 waves per SIMD (<= 128 VGPRs): the first layer's bias
     // rides on the unused K = 3 input slot (x = 1, exact in the fp32 MFMA), the second layer's sits in LDS, and the
     // inputs of the NEXT 16-row group are requested before the MFMAs of the current one.
@@ -300,10 +300,17 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
             for (int p = 0; p < 4; ++p)
                 cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(dot_with + (size_t)crow * 128 + p * 32 + (lane & 3) * 8));
 #else
-            const unsigned crow = live ? row : (unsigned)nrows - 1;
+            if (frag) {
+                // fragment order (CPN_ROWS_FRAG): the 1 KiB a wave needs of (16-row group, 32-channel block p) is contiguous
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(dot_with + (size_t)crow * 128 + p * 32 + fg * 8));
+                for (int p = 0; p < 4; ++p)
+                    cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(dot_with) + ((size_t)grp * 4 + p) * 64 + lane);
+            } else {
+                const unsigned crow = live ? row : (unsigned)nrows - 1;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(dot_with + (size_t)crow * 128 + p * 32 + fg * 8));
+            }
 #endif
         }
         f32x4 acc[8];
@@ -368,6 +375,22 @@ __global__ __launch_bounds__(512, 4) void local_mlp_kernel(
             dsum += __shfl_xor(dsum, 16);
             dsum += __shfl_xor(dsum, 32);
             if (live && fg == 0 && (!(CPN_LMLP_ABLATE & 16) || dsum == 12345.678f)) logits_out[row] = dsum;
+            continue;
+        }
+        if (frag) {
+            // fragment order: the registers leave as they are, 4 stores of 1 KiB of contiguous memory each (dead rows of the
+            // last group land in the buffer's padding: the caller sizes it to whole groups)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                half8 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = (_Float16)o2[2 * p][i];
+                    o[4 + i] = (_Float16)o2[2 * p + 1][i];
+                }
+                if (!(CPN_LMLP_ABLATE & 16) || (float)o[0] == 12345.0f)
+                    reinterpret_cast<half8*>(out)[((size_t)grp * 4 + p) * 64 + lane] = o;
+            }
             continue;
         }
         // stage the wave's 16 x 128 tile in LDS and write whole 256-byte rows (4 rows per store instruction)
@@ -459,7 +482,7 @@ extern "C" int cpn_local_hidden(const float* loc8, const float* coords9, const f
 extern "C" int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
                              const float* add, const uint16_t* w2, int ldw2, const float* b2, int B, int V, int R, int S,
                              int ray0, int nrays, uint16_t* out, const uint16_t* dot_with, float* logits_out,
-                             void* stream) {
+                             int rows_frag, void* stream) {
     CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && (out || (dot_with && logits_out)), CPN_E_ARG,
                 "cpn_local_mlp: null pointer");
     CPN_REQUIRE(!logits_out || dot_with, CPN_E_ARG, "cpn_local_mlp: logits_out needs dot_with");
@@ -472,7 +495,8 @@ extern "C" int cpn_local_mlp(const float* loc8, const float* coords9, const floa
     const long long groups = cpn_cdiv(nrows, 16);
     const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(groups, 8), 1024);
     hipLaunchKernelGGL(local_mlp_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
-                       (const __half*)w2, ldw2, b2, V, R, S, ray0, nrows, (__half*)out, (const __half*)dot_with, logits_out);
+                       (const __half*)w2, ldw2, b2, V, R, S, ray0, nrows, (__half*)out, (const __half*)dot_with, logits_out,
+                       rows_frag);
     CPN_LAUNCH_CHECK("cpn_local_mlp");
     return 0;
 }

@@ -373,6 +373,7 @@ class RenderEngine:
         # beside the hidden sums the encoder slows by as much as the sums gain, and 8-wave / 8 192-ray launches cost what is left)
         self.slot_rays = int(os.environ.get("COPONERF_SLOT_RAYS", "0"))
         self._slot_streams: Dict[int, torch.cuda.Stream] = {}
+        self.ce_frag = os.environ.get("COPONERF_CE_FRAG", "1") != "0"
         self.slot_trace: Optional[list] = None     # tools/slot_probe.py: (slot, start, encoder end, sums end) events
         # pipeline.render_images(overlap="sums"): when True, every render call leaves in `encode_done` an event recorded
         # behind the encoder launch of its LAST chunk (from there on the call's kernels leave the LDS and most registers
@@ -872,6 +873,9 @@ class RenderEngine:
         nray_total = B * R
         zl = torch.empty(nray_total, 416, dtype=f32, device=dev)
         fused_key = self.fuse_key and self.tables and self.fold_value
+        # coords_embed in fragment order (include/coponerf_hip.h, cpn_local_mlp rows_frag): its writer and both readers are then
+        # whole-line accesses.  Only where every user of the buffer understands it: the folded path (cpn_attend reads rows)
+        ce_frag = self.fold_value and self.ce_frag
         # slot schedule (below): chunks of `slot_rays`, three of them in flight (3 x 3.8 GB at 8 192 rays x 64 samples); only
         # where there are enough chunks to fill it
         slots = (self.slot_rays > 0 and fused_key and self.lanes == 1 and self.chunk_rays == 0
@@ -975,7 +979,7 @@ class RenderEngine:
             n = min(C, nray_total - ray0)
             call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
                  w["query_embed.b"].data_ptr(), 0, w["query_embed_2.w16"].data_ptr(), 128,
-                 w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, bf["ce"].data_ptr(), 0, 0, s)
+                 w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, bf["ce"].data_ptr(), 0, 0, int(ce_frag), s)
 
         def stage_logits(ray0, bf, s):
             """G: key_map_2 (+ the folded key_map layer when it did not run inside E) and <key, coords_embed>  [:408, :450]"""
@@ -992,11 +996,11 @@ class RenderEngine:
                 if fused_key:
                     # the 1664 -> 128 layer already ran inside cpn_encode_key: key_map_2 + <key, coords_embed> on its output
                     call("cpn_gemm_f16_rowdot", bf["khf"].data_ptr(), 128, w["key_map_2.w16"].data_ptr(), 128,
-                         w["key_map_2.b"].data_ptr(), ce.data_ptr(), 128, lg.data_ptr(), rows, 128, 128, s)
+                         w["key_map_2.b"].data_ptr(), ce.data_ptr(), 0 if ce_frag else 128, lg.data_ptr(), rows, 128, 128, s)
                 else:
                     call("cpn_gemm_f16_chain_rowdot", bf["hid"].data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664,
                          w["key_fold.b"].data_ptr(), w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(),
-                         ce.data_ptr(), 128, lg.data_ptr(), rows, 1664, s)
+                         ce.data_ptr(), 0 if ce_frag else 128, lg.data_ptr(), rows, 1664, s)
                 if prof is not None:
                     e1.record()
                     prof.setdefault("gemm_f16:key_map_2" if fused_key else "gemm_f16:key_fold+key_map_2", []).append(
@@ -1028,11 +1032,12 @@ class RenderEngine:
                 # the second query only enters through <query2, coords_embed>: local_mlp writes that logit directly
                 call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
                      w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
-                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, 0, bf["ce"].data_ptr(), bf["lg"].data_ptr(), s)
+                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, 0, bf["ce"].data_ptr(), bf["lg"].data_ptr(),
+                     int(ce_frag), s)
             else:
                 call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
                      w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
-                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, bf["q2"].data_ptr(), 0, 0, s)
+                     w["query_repeat_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, bf["q2"].data_ptr(), 0, 0, 0, s)
 
         def stage_sum2(ray0, bf, s):
             """A2: round 2 of the attention  [:475-485]"""

@@ -125,9 +125,14 @@ int cpn_gemm_f16_chain_rowdot(const uint16_t* A, int lda, const uint16_t* W, int
 /* both layers of query_embed / query_repeat_embed in one pass (CoPoNeRF.py:446, 472-473):
  * out[row, 0:128] = fp16( W2 . fp16(relu(W1[:, 0:16] . L(row) + b1 + add[ray])) + b2 ), W2 (128, ldw2) fp16 packed   */
 /* dot_with (rows,128) fp16 + logits_out (rows) fp32, both or neither: write <out[row], dot_with[row]> instead of out */
+/* rows_frag = 1 (round 4): `out` / `dot_with` are (rows, 128) fp16 matrices in FRAGMENT order - [16-row group][32-column block]
+ * [lane = row + 16 * 8-column group][8 halves], the layout of this kernel's accumulators: every access of a wave is 1 KiB of
+ * contiguous memory (row-major rows in that layout: 64 L1 tag look-ups per instruction).  The buffer holds whole groups of 16
+ * rows.  cpn_gemm_f16_rowdot / _chain_rowdot read such a matrix as Q when ldq == 0.  0 = row-major (ld 128).                 */
 int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
                   const float* add, const uint16_t* w2, int ldw2, const float* b2, int B, int V, int R, int S,
-                  int ray0, int nrays, uint16_t* out, const uint16_t* dot_with, float* logits_out, void* stream);
+                  int ray0, int nrays, uint16_t* out, const uint16_t* dot_with, float* logits_out, int rows_frag,
+                  void* stream);
 
 /* ---- K2+K3a: first encoder layer straight from the feature maps ("project, then interpolate") -------------------
  * hid = ReLU(query_encode_latent([primary/secondary gather (832) | tanh(pt/5) (3)])) without the gathered rows ever

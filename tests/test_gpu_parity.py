@@ -114,6 +114,55 @@ def test_stage_intermediates(model, dev, weights):
     assert ((core["pt"].cpu() - gpt).abs() / (1 + gpt.abs())).max() <= 2e-4
 
 
+def test_rows_in_fragment_order_are_the_same_numbers(model, dev, weights):
+    """coords_embed in fragment order (cpn_local_mlp rows_frag = 1; cpn_gemm_f16_rowdot with ldq = 0): the writer's output is the
+    row-major output permuted, both readers' logits are bit-identical to the row-major ones, and the render call gives the same
+    image with COPONERF_CE_FRAG on and off."""
+    from coponerf_amd._hip import call
+    cfg, _ = load_case("wide_val")
+    inp, z, rel, flow = case_inputs(cfg)
+    B, H, R, S, V = cfg["B"], cfg["H"], cfg["R"], cfg["S"], 2
+    eng = model._engine
+    model.npoints = S
+    w = eng._weights(model._render_params())
+    ctx, qry = to_device(inp["context"], dev), to_device(inp["query"], dev)
+    g = eng._geometry(ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], rel.to(dev), cfg["val"], S, H, H)
+    s = torch.cuda.current_stream().cuda_stream
+    n = B * R
+    rows = n * V * S
+    assert rows % 16 == 0
+    dp = lambda t: t.data_ptr()
+    ce = {f: torch.full((rows, 128), float("nan"), dtype=torch.float16, device=dev) for f in (0, 1)}
+    for f in (0, 1):
+        call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
+             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), B, V, R, S, 0, n, dp(ce[f]), 0, 0, f, s)
+    # [16-row group][32-column block][lane = row + 16 * 8-column group][8]  ->  rows x 128
+    unpacked = ce[1].view(rows // 16, 4, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(rows, 128)
+    assert torch.equal(unpacked, ce[0])
+    addq = torch.randn(n, 128, device=dev)
+    kh = (torch.randn(rows, 128, device=dev) * 0.5).half()
+    lg = {}
+    for f in (0, 1):
+        a, b = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+        call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]), dp(addq),
+             dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), B, V, R, S, 0, n, 0, dp(ce[f]), dp(a), f, s)
+        call("cpn_gemm_f16_rowdot", dp(kh), 128, dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), dp(ce[f]), 0 if f else 128, dp(b),
+             rows, 128, 128, s)
+        lg[f] = (a, b)
+    assert torch.equal(lg[0][0], lg[1][0]) and torch.equal(lg[0][1], lg[1][1])
+    old = eng.ce_frag
+    try:
+        outs = {}
+        for f in (True, False):
+            eng.ce_frag = f
+            with torch.no_grad():
+                outs[f] = model(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=cfg["val"], flow=to_device(flow, dev))
+        for k in ("rgb", "at_wt"):
+            assert torch.equal(outs[True][k], outs[False][k]), k
+    finally:
+        eng.ce_frag = old
+
+
 def test_gemm_f16_against_torch(dev):
     """cpn_gemm_f16 vs an fp32 torch matmul on the same fp16-rounded operands; ragged M, K tail of 32, both tiles."""
     from coponerf_amd._hip import call

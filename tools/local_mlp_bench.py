@@ -51,17 +51,18 @@ junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 P, I = ctypes.c_void_p, ctypes.c_int
 st = torch.cuda.current_stream().cuda_stream
 res = {}
+FRAG = int(os.environ.get("LMLP_FRAG", "1"))           # coords_embed in fragment order (the product) or row-major
 for k, name in VARIANTS.items():
     lib = ctypes.CDLL(os.path.join(BUILD, f"libgather_lmlp{k}.so"))
     fn = lib.cpn_local_mlp
-    fn.argtypes = [P, P, P, I, P, P, P, I, P, I, I, I, I, I, I, P, P, P, P]
+    fn.argtypes = [P, P, P, I, P, P, P, I, P, I, I, I, I, I, I, P, P, P, I, P]
     dp = lambda t: t.data_ptr()
     def first():
         return fn(dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), None, dp(w["query_embed_2.w16"]), 128,
-                  dp(w["query_embed_2.b"]), B, V, R, S, 0, n, dp(ce), None, None, st)
+                  dp(w["query_embed_2.b"]), B, V, R, S, 0, n, dp(ce), None, None, FRAG, st)
     def second():
         return fn(dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]), dp(addq),
-                  dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), B, V, R, S, 0, n, None, dp(ce), dp(lg), st)
+                  dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), B, V, R, S, 0, n, None, dp(ce), dp(lg), FRAG, st)
     out = []
     for call_ in (first, second):
         ts = []
