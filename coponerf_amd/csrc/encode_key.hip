@@ -25,7 +25,8 @@
 
 // timing-only ablations (results are wrong when non-zero): 1 = no table taps, 2 = no hid stores, 4 = no K = 80 MFMA,
 // 8 = no key MFMA (no LDS reads of the ring either), 64 = no ring traffic (no DMA, no barrier: weights are garbage),
-// 16 / 32 = every key / K = 80 MFMA of a slice on the SAME LDS fragment (the MFMAs stay, 16 -> 1 / 12 -> 2 LDS reads)
+// 16 / 32 = every key / K = 80 MFMA of a slice on the SAME LDS fragment (the MFMAs stay, 16 -> 1 / 12 -> 2 LDS reads),
+// 128 = no kh stores
 #ifndef CPN_EK_ABLATE
 #define CPN_EK_ABLATE 0
 #endif
@@ -475,17 +476,32 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) EK_OCC void encode_key_kernel(
             store_slice(NSLICE - 1, false);
         }
 
-        // ---- kh = fp16(ReLU(acc + c')): lane (r, g) holds outputs t*16 + g*4 .. +4 of row r
-        if (mid.live) {
-            const size_t srow = (((size_t)b * R + mid.r - ray0) * V + v) * S + mid.s;
-            __half* dst = kh + srow * 128 + g * 4;
+        // ---- kh = fp16(ReLU(acc + c')): lane (r, g) holds outputs t*16 + g*4 .. +4 of row r.  Stored as they are (8 stores of
+        //      8 bytes per lane, 16 rows x 4 pieces per instruction) the 2.1 GB of kh cost 0.38 of the kernel's 11.5 ms (ablation
+        //      128).  v_permlane16_swap (gfx950) trades the odd 16-lane rows of tile t with the even rows of tile t + 1: lane
+        //      (r, g) then holds 8 consecutive outputs of tile t + (g & 1) - 4 stores of 16 bytes, 64 contiguous bytes per row.
+        {
+            unsigned hw[KT][2];
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(kbias + t * 16 + g * 4);
                 half4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (_Float16)fmaxf(kacc[t][i] + bv[i], 0.0f);
-                *reinterpret_cast<half4*>(dst + t * 16) = o;
+                const u32x2 w2 = __builtin_bit_cast(u32x2, o);
+                hw[t][0] = w2[0];
+                hw[t][1] = w2[1];
+            }
+            const size_t srow = (((size_t)b * R + mid.r - ray0) * V + v) * S + mid.s;
+            __half* dst = kh + srow * 128 + (g & 1) * 16 + (g >> 1) * 8;
+            // (ablation 128: a condition that never holds at run time keeps the accumulators - and the key MFMAs - alive)
+            const bool store = mid.live && (!(CPN_EK_ABLATE & 128) || kacc[0][0] == 12345.678f);
+#pragma unroll
+            for (int q = 0; q < KT / 2; ++q) {
+                const u32x2 lo = __builtin_amdgcn_permlane16_swap(hw[2 * q][0], hw[2 * q + 1][0], false, false);
+                const u32x2 hi = __builtin_amdgcn_permlane16_swap(hw[2 * q][1], hw[2 * q + 1][1], false, false);
+                const u32x4 piece = {lo[0], hi[0], lo[1], hi[1]};
+                if (store) *reinterpret_cast<u32x4*>(dst + q * 32) = piece;
             }
         }
     }

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tools", "_build")
 VARIANTS = {0: "full", 8: "no key MFMA / ring reads", 64: "no ring DMA, no barrier", 72: "no ring, no key MFMA (= encode + 8 bpermute)",
             16: "key MFMAs on ONE LDS fragment (16 -> 1 ds_read_b128 per slice)", 32: "K = 80 MFMAs on one LDS fragment (12 -> 2 reads)",
-            48: "both: 28 -> 3 LDS reads per slice", 2: "no hid stores", 10: "no stores, no key MFMA", 1: "no table taps", 66: "no ring/barrier, no stores"}
+            48: "both: 28 -> 3 LDS reads per slice", 2: "no hid stores", 10: "no stores, no key MFMA", 1: "no table taps", 66: "no ring/barrier, no stores", 128: "no kh stores"}
 WAVES = (12,)
 PHASES = (1, 2, 3)          # CPN_EK_PHASES: barrier site per wave (1 = all late, 2 = waves 4-7 early, 3 = all early)
 
