@@ -69,7 +69,11 @@ constexpr int K80_BLOCK_BYTES = 10 * 1024;                     // one slice of k
 #define EK_OCC
 #endif
 
-template <int GROUP, int EK_WAVES>
+// KPACKED: the key matrix comes pre-packed in ring-piece order ([slice step][piece = tile * 2 + k][lane][8 halves], group 4 of
+// cpn_encode_key): a DMA piece is 1 KiB of contiguous memory.  From the row-major matrix a piece is 16 rows x 64 bytes - 64 L1
+// tag look-ups per instruction, and the 16 pieces per slice added two thirds to the look-ups of the 96 tap loads of a workgroup
+// in a kernel that sits on that pipe.
+template <int GROUP, int EK_WAVES, bool KPACKED = false>
 __global__ __launch_bounds__(64 * EK_WAVES, 1) EK_OCC void encode_key_kernel(
     const __half* __restrict__ tab, const __half* __restrict__ map3, int H, int W,
     const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, const float* __restrict__ pe6,
@@ -122,9 +126,14 @@ __global__ __launch_bounds__(64 * EK_WAVES, 1) EK_OCC void encode_key_kernel(
         const int j = step_in_unit >= NSLICE ? 1 : 0, n = step_in_unit - j * NSLICE;
         for (int p = wave; p < KPIECES; p += EK_WAVES) {                       // wave-uniform trip count
             const int t = p >> 1, k = p & 1;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                krs, (lds_void*)(reinterpret_cast<char*>(kring) + slot * (KSLOT_HALF8 * 16) + p * 1024), 16, kvoff,
-                ((t * 16) * KLD + j * CPN_TAB_LD + n * SLICE_CH + k * 32) * 2, 0, 0);
+            if constexpr (KPACKED)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    krs, (lds_void*)(reinterpret_cast<char*>(kring) + slot * (KSLOT_HALF8 * 16) + p * 1024), 16, lane * 16,
+                    (step_in_unit * KPIECES + p) * 1024, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    krs, (lds_void*)(reinterpret_cast<char*>(kring) + slot * (KSLOT_HALF8 * 16) + p * 1024), 16, kvoff,
+                    ((t * 16) * KLD + j * CPN_TAB_LD + n * SLICE_CH + k * 32) * 2, 0, 0);
         }
     };
     // streamed form: group gi = slice steps [gi*GROUP, gi*GROUP + GROUP) of this workgroup, into ring half gi & 1
@@ -515,8 +524,9 @@ static int encode_key_launch(const uint16_t* tab, const uint16_t* map3, int H, i
                              int R, int S, int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream, const char* who) {
     CPN_REQUIRE(tab && map3 && pixel_val && sec_grid && pe6 && wfrag && bias && kw && kbias && hid && kh, CPN_E_ARG,
                 "%s: null pointer", who);
-    CPN_REQUIRE((group == 0 || group == 1 || group == 3) && (group == 0 || (k80blk && ((uintptr_t)k80blk % 16) == 0)), CPN_E_ARG,
-                "%s: group must be 0, 1 or 3 (got %d) and needs k80blk when > 0", who, group);
+    CPN_REQUIRE((group == 0 || group == 1 || group == 3 || group == 4) &&
+                    (group == 0 || group == 4 || (k80blk && ((uintptr_t)k80blk % 16) == 0)), CPN_E_ARG,
+                "%s: group must be 0, 1, 3 or 4 (got %d) and needs k80blk for 1 and 3", who, group);
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && W >= 16 && (H % 16) == 0 && (W % 16) == 0,
                 CPN_E_SHAPE, "%s: need V==2 and H,W multiples of 16 (got H=%d W=%d V=%d)", who, H, W, V);
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
@@ -539,6 +549,7 @@ static int encode_key_launch(const uint16_t* tab, const uint16_t* map3, int H, i
     const int num_cu = cpn_stream_cus((void*)stream);
     const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nunits, waves));
     auto kern = waves == EK_WAVES_BESIDE ? encode_key_kernel<0, EK_WAVES_BESIDE>
+                : group == 4             ? encode_key_kernel<0, EK_WAVES_DEFAULT, true>
                 : group == 0             ? encode_key_kernel<0, EK_WAVES_DEFAULT>
                 : group == 1             ? encode_key_kernel<1, EK_WAVES_DEFAULT>
                                          : encode_key_kernel<3, EK_WAVES_DEFAULT>;

@@ -358,8 +358,9 @@ class RenderEngine:
         # Needs tables and fold_value; COPONERF_FUSE_KEY=0/1 overrides the default
         self.fuse_key = (os.environ.get("COPONERF_FUSE_KEY", "1") != "0") if fuse_key is None else bool(fuse_key)
         # cpn_encode_key's `group` (include/coponerf_hip.h): 0 = K = 80 fragments resident, one barrier per slice; 1..3 = all
-        # weights streamed through LDS, one barrier per that many slices (1 or 3).  Same results; 0 is the fastest (11.7 ms per
-        # 65 536-ray launch against 13.6 / 12.4).
+        # weights streamed through LDS, one barrier per that many slices (1 or 3); 4 = 0 with the key matrix pre-packed in the order
+        # the ring streams it (every DMA piece 1 KiB of contiguous memory).  Same results; 0 / 4 are the fastest (11.4-11.5 ms per
+        # 65 536-ray launch both - the row-major pieces' 64 tag look-ups do not show in the LDS-DMA path - against 13.6 / 12.4).
         self.key_group = int(os.environ.get("COPONERF_KEY_GROUP", "0"))
         # training: every fp16 activation gradient carries a power-of-two scale chosen per backward pass so that the
         # largest entry of the first fp32 -> fp16 gradient lands near this value (train_fns.GradScale)
@@ -510,6 +511,9 @@ class RenderEngine:
             return dst, cf.float().contiguous()
 
         w["key_fold.w16"], w["key_fold.b"] = fold("key_map.weight", "key_map.bias", 128)
+        # the same matrix in the order cpn_encode_key (group 4) streams it through its LDS ring: [image j][slice n][tile t][k][lane =
+        # row + 16 * 8-column group][8] - every 1 KiB DMA piece contiguous
+        w["key_fold.wpk"] = w["key_fold.w16"].view(8, 16, 2, 13, 2, 4, 8).permute(2, 3, 0, 4, 5, 1, 6).contiguous()
         w["value_fold.w16"], w["value_fold.b"] = fold("latent_value.weight", "latent_value.bias", 416)
         # the same matrix in MFMA fragment order for the few-row form of the per-ray value projection (cpn_gemm_f16_fewrows)
         w["value_fold.wpk"] = torch.empty(416 * 1664, dtype=torch.float16, device=dev)
@@ -952,7 +956,7 @@ class RenderEngine:
                     call("cpn_encode_key", tabs[0].data_ptr(), maps[3].data_ptr(),
                          H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
                          w["query_encode_latent.b"].data_ptr(), w["enc.k80blk"].data_ptr(), self.key_group,
-                         w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+                         w["key_fold.wpk" if self.key_group == 4 else "key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
                          B, V, R, S, ray0, n, hid.data_ptr(), bf["khf"].data_ptr(), s)
                 else:
                     call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(),

@@ -576,10 +576,10 @@ def test_encode_key_entry_every_group_is_bit_identical(model, dev, weights):
     call("cpn_gemm_f16", hid_ref.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664, w["key_fold.b"].data_ptr(), kh_ref.data_ptr(), 128,
          rows2 // 2, 128, 1664, 1, 0, s)
     assert int((hid_ref == -1).sum()) == 0
-    for group in (0, 1, 3):
+    for group in (0, 1, 3, 4):                      # 4 = group 0 with the key matrix pre-packed in ring-piece order
         hid = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
         kh = torch.full((rows2 // 2, 128), -1.0, dtype=torch.float16, device=dev)
-        call("cpn_encode_key", *args, w["enc.k80blk"].data_ptr(), group, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+        call("cpn_encode_key", *args, w["enc.k80blk"].data_ptr(), group, w["key_fold.wpk" if group == 4 else "key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
              B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
         assert torch.equal(hid, hid_ref), (group, int((hid != hid_ref).sum()))
         assert torch.equal(kh, kh_ref), (group, int((kh != kh_ref).sum()))

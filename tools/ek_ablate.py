@@ -87,7 +87,7 @@ def main():
             def run():
                 rc = fn(tabs[0].data_ptr(), maps[3].data_ptr(), H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(),
                         g["pe6"].data_ptr(), w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(),
-                        w["enc.k80blk"].data_ptr(), grp, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, a.ray0,
+                        w["enc.k80blk"].data_ptr(), grp, w["key_fold.wpk" if grp == 4 else "key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, a.ray0,
                         n, hid.data_ptr(), kh.data_ptr(), s)
                 assert rc == 0, rc
             for _ in range(2):
