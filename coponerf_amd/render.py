@@ -897,7 +897,8 @@ class RenderEngine:
         def lane_buffers(lane):
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
             bufs = {"hid": t("hid", (C * T * 2, 832), f16),
-                    "ce": t("ce", ((C * T + 15) // 16 * 16, 128), f16),     # whole 16-row groups (fragment order writes them whole) "lg": t("lg", (C * T,), f32),
+                    # coords_embed: whole 16-row groups (the fragment-order stores write them whole)
+                    "ce": t("ce", ((C * T + 15) // 16 * 16, 128), f16), "lg": t("lg", (C * T,), f32),
                     "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
             if not self.tables:
