@@ -359,9 +359,10 @@ class RenderEngine:
         self.fuse_key = (os.environ.get("COPONERF_FUSE_KEY", "1") != "0") if fuse_key is None else bool(fuse_key)
         # cpn_encode_key's `group` (include/coponerf_hip.h): 0 = K = 80 fragments resident, one barrier per slice; 1..3 = all
         # weights streamed through LDS, one barrier per that many slices (1 or 3); 4 = 0 with the key matrix pre-packed in the order
-        # the ring streams it (every DMA piece 1 KiB of contiguous memory).  Same results; 0 / 4 are the fastest (11.4-11.5 ms per
-        # 65 536-ray launch both - the row-major pieces' 64 tag look-ups do not show in the LDS-DMA path - against 13.6 / 12.4).
-        self.key_group = int(os.environ.get("COPONERF_KEY_GROUP", "0"))
+        # the ring streams it (every DMA piece 1 KiB of contiguous memory): the default.  Same results; the row-major pieces of 0 are
+        # a third of the kernel's L1 accesses and all of its tag-conflict stalls (353 M cycles per launch -> 5 M, TA address stalls
+        # 583 M -> 82 M), worth 0.1 ms of its 12.0 (profiles/r04_pmc_tag_conflicts.json); 13.6 / 12.4 ms for groups 1 / 3.
+        self.key_group = int(os.environ.get("COPONERF_KEY_GROUP", "4"))
         # training: every fp16 activation gradient carries a power-of-two scale chosen per backward pass so that the
         # largest entry of the first fp32 -> fp16 gradient lands near this value (train_fns.GradScale)
         self.grad_scale_target = 256.0

