@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--ray0", type=int, default=0)
     ap.add_argument("--hot", action="store_true", help="back-to-back launches instead of the flushed regime")
     ap.add_argument("--only", default="")
-    ap.add_argument("--groups", type=lambda t: [int(x) for x in t.split(",")], default=[0, 3], help="cpn_encode_key group values to time")
+    ap.add_argument("--groups", type=lambda t: [int(x) for x in t.split(",")], default=[4, 0, 3], help="cpn_encode_key group values to time")
     a = ap.parse_args()
     if a.build:
         build()

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--rig", default="narrow")
-    ap.add_argument("--group", type=int, default=int(os.environ.get("COPONERF_KEY_GROUP", "0")), help="cpn_encode_key group (0, 1, 3, 4)")
+    ap.add_argument("--group", type=int, default=int(os.environ.get("COPONERF_KEY_GROUP", "4")), help="cpn_encode_key group (0, 1, 3, 4)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     H = S = None
