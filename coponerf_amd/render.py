@@ -154,6 +154,27 @@ def build_camera_block(ctx_c2w: torch.Tensor, ctx_K: torch.Tensor, qry_c2w: torc
 
 
 # ----------------------------------------------------------------------------------------------
+def frag_order_f32(m: torch.Tensor) -> torch.Tensor:
+    """(N, K) fp32 row-major -> MFMA fragment order of v_mfma_f32_16x16x4_f32 as cpn_lightfield_decode reads it
+    (include/coponerf_hip.h): [N/16][K/16][lane = row + 16 * k group][4] - lane l of fragment (t, kb) holds
+    m[16 t + (l & 15)][16 kb + 4 (l >> 4) .. +4], so a wave's load of one fragment is 1 KiB of contiguous memory."""
+    n, k = m.shape
+    return m.reshape(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def pack_key_ring(wk: torch.Tensor) -> torch.Tensor:
+    """The folded key matrix (128, 2 * 832) fp16 in the order cpn_encode_key (group 4) streams it through its LDS ring:
+    [image j][slice n][tile t][k step][lane = row + 16 * 8-column group][8] - piece (t, k) of slice step (j, n) holds, in lane
+    (a, g), wk[16 t + a][832 j + 64 n + 32 k + 8 g .. +8]: every 1 KiB DMA piece contiguous."""
+    return wk.reshape(8, 16, 2, 13, 2, 4, 8).permute(2, 3, 0, 4, 5, 1, 6).contiguous()
+
+
+def rows_from_frag_order(x: torch.Tensor, rows: int) -> torch.Tensor:
+    """A (rows, 128) fp16 matrix stored in the fragment order of cpn_local_mlp (rows_frag = 1) / cpn_gemm_f16_rowdot
+    (ldq = 0) - [16-row group][32-column block][lane = row + 16 * 8-column group][8] - back as row-major rows."""
+    return x.reshape(-1)[:((rows + 15) // 16) * 16 * 128].reshape(-1, 4, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(-1, 128)[:rows]
+
+
 def _flat_tensors(obj):
     if isinstance(obj, torch.Tensor):
         yield obj
@@ -514,7 +535,7 @@ class RenderEngine:
         w["key_fold.w16"], w["key_fold.b"] = fold("key_map.weight", "key_map.bias", 128)
         # the same matrix in the order cpn_encode_key (group 4) streams it through its LDS ring: [image j][slice n][tile t][k][lane =
         # row + 16 * 8-column group][8] - every 1 KiB DMA piece contiguous
-        w["key_fold.wpk"] = w["key_fold.w16"].view(8, 16, 2, 13, 2, 4, 8).permute(2, 3, 0, 4, 5, 1, 6).contiguous()
+        w["key_fold.wpk"] = pack_key_ring(w["key_fold.w16"])
         w["value_fold.w16"], w["value_fold.b"] = fold("latent_value.weight", "latent_value.bias", 416)
         # the same matrix in MFMA fragment order for the few-row form of the per-ray value projection (cpn_gemm_f16_fewrows)
         w["value_fold.wpk"] = torch.empty(416 * 1664, dtype=torch.float16, device=dev)
@@ -544,10 +565,7 @@ class RenderEngine:
         wout[:3] = w["phi.lin_out.w"]
         bout = torch.zeros(16, dtype=torch.float32, device=dev)
         bout[:3] = w["phi.lin_out.b"]
-        def fr(m):                  # (N, K) row-major -> MFMA fragment order [N/16][K/16][lane = row + 16 * k group][4]
-            n, k = m.shape
-            return m.view(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
-
+        fr = frag_order_f32
         parts = [fr(w["phi.lin_in.w"]), w["phi.lin_in.b"]]
         for k in range(3):
             parts += [fr(w[f"phi.lin_z.{k}.w"]), w[f"phi.lin_z.{k}.b"], fr(w[f"phi.blocks.{k}.fc_0.w"]), w[f"phi.blocks.{k}.fc_0.b"],

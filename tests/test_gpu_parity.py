@@ -137,7 +137,8 @@ def test_rows_in_fragment_order_are_the_same_numbers(model, dev, weights):
         call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
              dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), B, V, R, S, 0, n, dp(ce[f]), 0, 0, f, s)
     # [16-row group][32-column block][lane = row + 16 * 8-column group][8]  ->  rows x 128
-    unpacked = ce[1].view(rows // 16, 4, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(rows, 128)
+    from coponerf_amd.render import rows_from_frag_order
+    unpacked = rows_from_frag_order(ce[1], rows)
     assert torch.equal(unpacked, ce[0])
     addq = torch.randn(n, 128, device=dev)
     kh = (torch.randn(rows, 128, device=dev) * 0.5).half()
