@@ -146,22 +146,24 @@ __device__ __forceinline__ void attend_hidden_ray(const unsigned lray, float* __
             lmax = fmaxf(lmax, logit);
         }
     } else
-    for (int base = 0; base < T; base += 128) {
-        const int row = base + (tid >> 1);
+    // 16 lanes per row, 16 bytes each: a load instruction covers 4 whole 256-byte rows of each operand (two lanes per row with 8
+    // loads of 16 bytes each, 128 bytes apart, touched 64 different lines per instruction: the training step's two launches of
+    // this kernel spent 42 % of their cycles with the address path stalled by the cache - TA_ADDR_STALLED_BY_TC 289 M per launch)
+    for (int base = 0; base < T; base += 16) {
+        const int row = base + (tid >> 4);
+        const int rr = row < T ? row : T - 1;
+        const half8 a = *reinterpret_cast<const half8*>(qa + (row0 + rr) * 128 + (tid & 15) * 8);
+        const half8 b = *reinterpret_cast<const half8*>(qb + (row0 + rr) * 128 + (tid & 15) * 8);
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)b[e];
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 8);
         if (row < T) {
-            const int hsel = tid & 1;
-            const half8* pa = reinterpret_cast<const half8*>(qa + (row0 + row) * 128 + hsel * 64);
-            const half8* pb = reinterpret_cast<const half8*>(qb + (row0 + row) * 128 + hsel * 64);
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const half8 a = pa[k], b = pb[k];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)b[e];
-            }
-            acc += __shfl_xor(acc, 1);
             const float logit = acc / 11.31f;
-            if (hsel == 0) wts[row] = logit;
+            if ((tid & 15) == 0) wts[row] = logit;
             lmax = fmaxf(lmax, logit);
         }
     }
