@@ -523,7 +523,7 @@ def roofline_block(prof, args, tables):
         tot = sum(a.elapsed_time(b) for a, b, _ in v)
         kern[k] = {"ms_per_step": tot / args.steps, "tflops": sum(f for _, _, f in v) / (tot * 1e-3) / 1e12}
     out["kernel_breakdown"] = kern
-    fused = "encode_key" in prof                     # first layer + folded key layer in one kernel (csrc/encode_key.hip)
+    fused = "encode_key" in prof                     # first layer + folded key layer in one kernel (csrc/encode_fused.hip)
     name = ("encode_key" if fused else "encode_hidden") if tables else "gemm_f16:query_encode_latent"
     evs = prof.get(name, [])
     if not evs:
@@ -533,7 +533,7 @@ def roofline_block(prof, args, tables):
     avg_ms = sum(ms) / len(ms)
     achieved = flops / (avg_ms * 1e-3) / 1e12
     rows = int(round(flops / (2.0 * 832 * 835)))
-    src = os.path.join(ROOT, "coponerf_amd", "csrc", ("encode_key.hip" if fused else "encode.hip") if tables else "gemm_f16.hip")
+    src = os.path.join(ROOT, "coponerf_amd", "csrc", ("encode_fused.hip" if fused else "encode.hip") if tables else "gemm_f16.hip")
     with open(src, "rb") as f:
         sha = hashlib.sha256(f.read()).hexdigest()[:16]
     # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (they cannot be read
@@ -566,7 +566,7 @@ def roofline_block(prof, args, tables):
         gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
         achieved = (flops + key_flops) / (avg_ms * 1e-3) / 1e12
         out["roofline"] = {
-            "bound": "hbm", "kernel": ("encode_key_kernel (query_encode_latent 835->832 + ReLU with the gathers fused + the folded "
+            "bound": "hbm", "kernel": ("encode_fused_kernel (cpn_encode_key: query_encode_latent 835->832 + ReLU with the gathers fused + the folded "
                                        "key_map 1664->128 layer on the slices of hid in registers)") if fused else
                       "encode_hidden_kernel (query_encode_latent 835->832 + ReLU with the gathers fused)",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -574,7 +574,7 @@ def roofline_block(prof, args, tables):
             "timing_source": "HIP events on the launch stream inside the timed region of THIS (unprofiled) run; the same "
                              "launches under rocprofv3 --kernel-trace run ~10 % slower (profiles/README.md)",
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_source_sha16": sha,
-            **rocprof_view(sha, "encode_key_kernel" if fused else "encode_hidden_kernel", rows, alg_bytes),
+            **rocprof_view(sha, "encode_fused_kernel" if fused else "encode_hidden_kernel", rows, alg_bytes),
             "canonical_mfma_view": {"bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": achieved / F16_MFMA_PEAK_TFLOPS, "flops_per_launch": flops + key_flops,
                                     "note": "FLOPs of the layer as the reference formulates it / launch time; the kernel "

@@ -29,8 +29,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_pack_encode_weights": [_P, _I, _P, _P, _P],
     "cpn_node_features": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cpn_encode_hidden": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "cpn_encode_key_beside": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_encode_project": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
@@ -40,6 +40,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_gemm_f16_fewrows": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpn_attend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_attend_hidden": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_attend_value": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_linear_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "cpn_lightfield_decode": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
@@ -97,10 +98,10 @@ CAM_STRIDE = 96
 CAM_TQ, CAM_M, CAM_AOWN, CAM_AOTH, CAM_KQ, CAM_KC, CAM_KO, CAM_KN = 0, 16, 32, 48, 64, 68, 72, 76
 XIN_K, XIN_STRIDE = 864, 896
 TAB_LD = 832
-K80_BLOCK_HALVES = 5120          # CPN_K80_BLOCK_HALVES: one slice of the streamed K = 80 weight block (cpn_encode_key)
+K80_BLOCK_HALVES = 5120          # CPN_K80_BLOCK_HALVES: one slice of the streamed K = 80 weight block (cpn_encode_project)
 RAYC_STRIDE = 64
 LIGHTFIELD_PACK_FLOATS = 128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 ADAM_SEG_BYTES = 48
 
 

@@ -11,7 +11,6 @@
 //   phase 3  z[c] = sum_rows w[row] * value[row][c], c = tid and tid+256 (416 channels), coalesced row reads
 // HBM/L2-bound: per ray 2 x T x 256 B (q operands) + T x 1664 B (values) = 278 KiB at T = 128.
 #include <algorithm>
-#include <cstdlib>
 
 #include "common.h"
 
@@ -119,15 +118,12 @@ constexpr int HC = 1664;
 #ifndef CPN_ATTEND_NT
 #define CPN_ATTEND_NT 1
 #endif
-// rows of hid in flight per thread (16 bytes each): 4 is enough when the kernel has the chip to itself (7 waves per SIMD);
-// beside the encoder of the next chunk (tools/coresident_probe.py) only 2 waves per SIMD fit and each must keep more in flight
+// rows of hid in flight per thread (16 bytes each): 4 is enough when the kernel has the chip to itself (7 waves per SIMD)
 #ifndef CPN_ATTEND_UNROLL
 #define CPN_ATTEND_UNROLL 4
 #endif
 
-// U = rows of hid in flight per thread.  The grid is either one workgroup per ray (U = 4: 8 waves per SIMD cover the
-// latency) or a FIXED number of workgroups per CU that walk the rays (cpn_attend_hidden_few, U = 8): the same bytes in
-// flight from half the wave slots and a third of the registers, the rest of every CU left to the kernels of another stream.
+// U = rows of hid in flight per thread; one workgroup per ray (U = 4: 8 waves per SIMD cover the latency).
 template <bool HAVE_LOGITS, int U>
 __device__ __forceinline__ void attend_hidden_ray(const unsigned lray, float* __restrict__ wts, float* __restrict__ red,
                                                   const __half* __restrict__ qa, const __half* __restrict__ qb,
@@ -239,19 +235,107 @@ __global__ __launch_bounds__(256) void attend_hidden_kernel(const __half* __rest
     attend_hidden_ray<HAVE_LOGITS, CPN_ATTEND_UNROLL>(blockIdx.x, wts, wts + V * S, qa, qb, logits, hid, V, R, S, ray0, hbar, at_wt);
 }
 
-__global__ __launch_bounds__(256) void attend_hidden_few_kernel(const float* __restrict__ logits,
-                                                                const __half* __restrict__ hid, int V, int R, int S,
-                                                                int ray0, int nrays, __half* __restrict__ hbar,
-                                                                float* __restrict__ at_wt) {
+// ---------------------------------------------------------------------------------------------
+// "Project before you store" variant (round 5, csrc/encode_fused.hip): the folded value projection already ran per SAMPLE
+// inside the encoder - val (rows, 416) fp16 = (Wv_a W2 | Wv_b W2) . [h_own ; h_other] - so a round of the attention is
+//     z[c] = sum_rows w[row] * val[row][c] + c'[c]  (+ V * zprev[c] in round 2: CoPoNeRF.py:481-485)
+// (the softmax weights of a ray sum to 1, so the folded constant c' enters once).  Per ray T x 832 B read instead of T x 3 328.
+// A wave takes every 4th row, lanes 0..51 one 16-byte piece (8 channels) each; the four partial sums meet in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int VC = 416;
+__global__ __launch_bounds__(256) void attend_value_kernel(const float* __restrict__ logits, const __half* __restrict__ val,
+                                                           const float* __restrict__ vbias, const float* __restrict__ zprev,
+                                                           float zprev_scale, int V, int R, int S, int ray0,
+                                                           float* __restrict__ zout, float* __restrict__ at_wt) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* wts = reinterpret_cast<float*>(smem_raw);
-    for (unsigned lray = blockIdx.x; lray < (unsigned)nrays; lray += gridDim.x) {
-        if (lray != blockIdx.x) __syncthreads();              // every wave is done with the previous ray's weights
-        attend_hidden_ray<true, 8>(lray, wts, wts + V * S, nullptr, nullptr, logits, hid, V, R, S, ray0, hbar, at_wt);
+    float* wts = reinterpret_cast<float*>(smem_raw);          // T weights
+    float* red = wts + V * S;                                 // 8 floats of reduction scratch
+    float* part = red + 8;                                    // 4 x 416 partial sums
+    const int T = V * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned lray = blockIdx.x;
+    const size_t row0 = (size_t)lray * T;
+
+    float lmax = -INFINITY;
+    for (int row = tid; row < T; row += 256) {
+        const float logit = logits[row0 + row] / 11.31f;
+        wts[row] = logit;
+        lmax = fmaxf(lmax, logit);
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+    for (int row = tid; row < T; row += 256) {
+        const float e = __expf(wts[row] - gmax);
+        wts[row] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    for (int row = tid; row < T; row += 256) {
+        const float w = wts[row] * inv;
+        wts[row] = w;
+        if (at_wt) {
+            const unsigned ray = (unsigned)ray0 + lray;
+            const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
+            const int v = row / S, s = row - v * S;
+            at_wt[(((size_t)(b * V + v)) * R + r) * S + s] = w;
+        }
+    }
+    __syncthreads();
+    if (lane < VC / 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const __half* vp = val + row0 * VC + lane * 8;
+        constexpr int UR = 8;                                  // rows in flight per lane
+        int row = wave;
+        for (; row + 4 * (UR - 1) < T; row += 4 * UR) {
+            half8 h[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) h[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(vp + (size_t)(row + 4 * u) * VC));
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const float w = wts[row + 4 * u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * (float)h[u][e];
+            }
+        }
+        for (; row < T; row += 4) {
+            const half8 h = __builtin_nontemporal_load(reinterpret_cast<const half8*>(vp + (size_t)row * VC));
+            const float w = wts[row];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += w * (float)h[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[wave * VC + lane * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < VC; c += 256) {
+        float z = ((part[c] + part[VC + c]) + (part[2 * VC + c] + part[3 * VC + c])) + vbias[c];
+        if (zprev) z += zprev_scale * zprev[(size_t)lray * VC + c];
+        zout[(size_t)lray * VC + c] = z;
     }
 }
 
 }  // namespace
+
+extern "C" int cpn_attend_value(const float* logits, const uint16_t* val, const float* vbias, const float* zprev,
+                                float zprev_scale, int B, int V, int R, int S, int ray0, int nrays, float* zout, float* at_wt,
+                                void* stream) {
+    CPN_REQUIRE(logits && val && vbias && zout, CPN_E_ARG, "cpn_attend_value: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && V * S <= 4096, CPN_E_SHAPE, "cpn_attend_value: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_attend_value: ray range outside B*R");
+    CPN_REQUIRE(((uintptr_t)val % 16) == 0, CPN_E_ARG, "cpn_attend_value: val must be 16-byte aligned");
+    const size_t lds = (size_t)(V * S + 8 + 4 * VC) * sizeof(float);
+    hipLaunchKernelGGL(attend_value_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream, logits, (const __half*)val, vbias,
+                       zprev, zprev_scale, V, R, S, ray0, zout, at_wt);
+    CPN_LAUNCH_CHECK("cpn_attend_value");
+    return 0;
+}
 
 extern "C" int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const float* zprev,
                           int B, int V, int R, int S, int ray0, int nrays, float* zout,
@@ -274,13 +358,6 @@ extern "C" int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const f
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_attend_hidden: ray range outside B*R");
     const size_t lds = (size_t)(V * S + 8) * sizeof(float);
-    // CPN_ATTEND_FEW=k (experiments): k workgroups per CU walking the rays instead of one workgroup per ray
-    static const int few = [] { const char* e = getenv("CPN_ATTEND_FEW"); return e ? atoi(e) : 0; }();
-    if (few > 0 && logits) {
-        const unsigned grid = (unsigned)std::min<long long>(nrays, (long long)few * cpn_stream_cus(stream));
-        hipLaunchKernelGGL(attend_hidden_few_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, logits, (const __half*)hid,
-                           V, R, S, ray0, nrays, (__half*)hbar, at_wt);
-    } else
     hipLaunchKernelGGL(logits ? attend_hidden_kernel<true> : attend_hidden_kernel<false>, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
                        (const __half*)qb, logits, (const __half*)hid, V, R, S, ray0, (__half*)hbar, at_wt);
     CPN_LAUNCH_CHECK("cpn_attend_hidden");

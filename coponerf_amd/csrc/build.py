@@ -20,7 +20,7 @@ UNITS = [
     ("geometry.hip", ["-ffp-contract=off"]),
     ("gather.hip", []),
     ("encode.hip", []),
-    ("encode_key.hip", []),
+    ("encode_fused.hip", []),
     ("encode_bwd.hip", []),
     ("gemm_f16.hip", []),
     ("attend.hip", []),

@@ -63,9 +63,7 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
     (multiples of 32, sum <= the device's CU count; e.g. (192, 64)); the yielded outputs are ordered after the
     caller's current stream as usual.  None: ONE stream — the GPU runs render(i), get_z(i+1), render(i+1), ... in that
     order while the host issues get_z(i+1) under render(i) (the host half of get_z, ~6 ms of Python and launches, is what
-    this order hides); `overlap="sums"` puts get_z(i+1) on a second, high-priority stream that waits for the ENCODER launch of
-    render(i) and so runs beside its hidden sums only (tools/pipeline_combos.py); `overlap=True` puts get_z on that stream
-    without the gate, which measured SLOWER
+    this order hides); `overlap=True` puts get_z(i+1) on a second, high-priority stream, which measured SLOWER
     than the serial GPU order ever since the render kernels became persistent (34.9 against 31.6 ms per image in round 4:
     each small kernel of get_z waits for a chip-filling launch to drain and the render kernels lose their cache state).
 
@@ -124,8 +122,6 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
         # overlap: high priority, so that the small kernels of get_z are dispatched ahead of the render's queued workgroups
         # instead of waiting behind each of the render's chip-filling launches
         side = torch.cuda.Stream(device=main.device, priority=-1) if overlap else main
-    gated = overlap == "sums" and cu_split is None and not nchunks
-    engine.mark_encode_done = gated
     try:
         with torch.cuda.stream(main):
             state = features(cur)                                  # first group: nothing to hide it under
@@ -157,11 +153,6 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
                     if i == 0 and nxt:
                         # 2. the ~550 launches of the next group's get_z on the side stream: the host issues them while
                         #    the GPU renders, the small kernels run beside the HBM-bound render kernels
-                        if gated and engine.encode_done is not None:
-                            # ... but only behind this render's encoder: its persistent grid (one workgroup per CU, all of
-                            # the LDS) and get_z's small kernels starve each other, the hidden sums behind it leave the
-                            # LDS and most wave slots free
-                            side.wait_event(engine.encode_done)
                         with torch.cuda.stream(side):
                             nstate = features(nxt)
                     if i == len(cur) - 1 and nxt:
@@ -180,7 +171,6 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
                 yield inp, out
             cur, state = nxt, nstate
     finally:
-        engine.mark_encode_done = False
         if main is not outer:
             outer.wait_stream(main)             # the lanes were joined into `main` by every call's completion event
             engine.set_call_streams(None)

@@ -163,10 +163,21 @@ def frag_order_f32(m: torch.Tensor) -> torch.Tensor:
 
 
 def pack_key_ring(wk: torch.Tensor) -> torch.Tensor:
-    """The folded key matrix (128, 2 * 832) fp16 in the order cpn_encode_key (group 4) streams it through its LDS ring:
+    """The folded key matrix (128, 2 * 832) fp16 in the order cpn_encode_key streams it through its LDS ring:
     [image j][slice n][tile t][k step][lane = row + 16 * 8-column group][8] - piece (t, k) of slice step (j, n) holds, in lane
     (a, g), wk[16 t + a][832 j + 64 n + 32 k + 8 g .. +8]: every 1 KiB DMA piece contiguous."""
     return wk.reshape(8, 16, 2, 13, 2, 4, 8).permute(2, 3, 0, 4, 5, 1, 6).contiguous()
+
+
+def pack_project_ring(wk: torch.Tensor, wv: torch.Tensor, k80blk: torch.Tensor) -> torch.Tensor:
+    """The slot images cpn_encode_project streams through its LDS ring, one per slice step (image j, slice n): (2, 13, 78 KiB) fp16 =
+    the step's 34 x 2 weight fragments of the folded key (tiles 0-7) and value (tiles 8-33) matrices in pack_key_ring's piece
+    order - piece (t, k), lane (a, g): W'[16 t + a][832 j + 64 n + 32 k + 8 g .. +8] - then the slice's K = 80 block of the
+    first layer (pack_k80_blocks, 10 KiB).  Every DMA piece of the kernel is 1 KiB of contiguous memory."""
+    wkv = torch.cat((wk, wv), dim=0)                                                       # (544, 1664)
+    frags = wkv.reshape(34, 16, 2, 13, 2, 4, 8).permute(2, 3, 0, 4, 5, 1, 6).reshape(2, 13, 34 * 2 * 64 * 8)
+    blk = k80blk.view(1, 13, -1).expand(2, 13, k80blk.shape[1])
+    return torch.cat((frags, blk), dim=2).contiguous()
 
 
 def rows_from_frag_order(x: torch.Tensor, rows: int) -> torch.Tensor:
@@ -187,11 +198,11 @@ def _flat_tensors(obj):
 
 
 def pack_k80_blocks(frag: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """(13, CPN_K80_BLOCK_HALVES) fp16: per 64-channel slice of the first layer the K = 80 weight block that the streamed form
-    of cpn_encode_key DMAs into LDS next to the slice's key weights (include/coponerf_hip.h) — the slice's main MFMA
+    """(13, CPN_K80_BLOCK_HALVES) fp16: per 64-channel slice of the first layer the K = 80 weight block that cpn_encode_project
+    DMAs into LDS next to the slice's key / value weights (include/coponerf_hip.h) — the slice's main MFMA
     fragments as cpn_pack_encode_weights laid them out, then its K-tail fragments with the bias folded in as an fp16
-    (hi, lo) pair against the operand's two constant-one entries, exactly as the resident form builds them in its
-    prologue (csrc/encode.hip), then zero padding to 10 KiB."""
+    (hi, lo) pair against the operand's two constant-one entries, exactly as cpn_encode_key builds them in its
+    prologue (csrc/encode_fused.hip), then zero padding to 10 KiB."""
     nmain = 13 * 2 * 4 * 64 * 8
     main = frag[:nmain].view(13, 2 * 4 * 64 * 8)
     tail = frag[nmain:nmain + 13 * 4 * 64 * 4].view(13, 4, 64, 4)[:, :, :48, :].clone()        # [slice][tile][lane < 48][4]
@@ -361,11 +372,10 @@ class RenderEngine:
     WORKSPACE_SHARE = 0.25
     FREE_SHARE = 0.5                # ... and at most this share of the memory that is free when the workspace is sized
     MAX_AUTO_CHUNK = 65536
-    SLOT_MIN_CHUNKS = 4
     FEW_ROWS = 4096                 # per-ray GEMMs of at most this many rows take the few-row kernel (cpn_gemm_f16_fewrows: 17 vs 35 us at 3 641)
 
     def __init__(self, chunk_rays: int = 0, fold_value: bool = True, lanes: int = 1, tables: bool = True,
-                 fuse_key: Optional[bool] = None):
+                 fuse_key: Optional[bool] = None, project: Optional[bool] = None):
         # rays per chunk of the per-sample stages; 0 = automatic (`_auto_chunk`): one 65 536-ray image is ONE chunk on a
         # 288 GB MI355X (28 GB of `hid` at 64 samples) — 4 launches of each per-sample kernel instead of 16 shave the
         # ramp / tail of the persistent grids: 26.6 -> 24.7 ms per image against chunks of 16 384
@@ -373,17 +383,17 @@ class RenderEngine:
         # tables=True: first encoder layer from pre-projected feature tables (cpn_encode_hidden, csrc/encode.hip);
         # False: gather the 835-channel rows and run the 835 -> 832 GEMM on them (the form the training pass uses)
         self.tables = bool(tables)
-        # fuse_key=True: the folded key_map layer runs inside the first-layer kernel (cpn_encode_key, csrc/encode_key.hip)
+        # fuse_key=True: the folded key_map layer runs inside the first-layer kernel (cpn_encode_key, csrc/encode_fused.hip)
         # on the slices of hid that are still in registers, then key_map_2 + the logit on the 128-wide result
         # (cpn_gemm_f16_rowdot); False: cpn_encode_hidden, then cpn_gemm_f16_chain_rowdot reads hid back (round 3).
         # Needs tables and fold_value; COPONERF_FUSE_KEY=0/1 overrides the default
         self.fuse_key = (os.environ.get("COPONERF_FUSE_KEY", "1") != "0") if fuse_key is None else bool(fuse_key)
-        # cpn_encode_key's `group` (include/coponerf_hip.h): 0 = K = 80 fragments resident, one barrier per slice; 1..3 = all
-        # weights streamed through LDS, one barrier per that many slices (1 or 3); 4 = 0 with the key matrix pre-packed in the order
-        # the ring streams it (every DMA piece 1 KiB of contiguous memory): the default.  Same results; the row-major pieces of 0 are
-        # a third of the kernel's L1 accesses and all of its tag-conflict stalls (353 M cycles per launch -> 5 M, TA address stalls
-        # 583 M -> 82 M), worth 0.1 ms of its 12.0 (profiles/r04_pmc_tag_conflicts.json); 13.6 / 12.4 ms for groups 1 / 3.
-        self.key_group = int(os.environ.get("COPONERF_KEY_GROUP", "4"))
+        # project=True ("project before you store", csrc/encode_fused.hip): the folded value projection runs per SAMPLE inside the
+        # encoder on the slices of hid that are still in registers; hid never reaches HBM (832 + 256 bytes per sample leave
+        # instead of 3 328 + 256) and both attention rounds read the 416-wide values (cpn_attend_value).  Measured slower than the
+        # default on configs[1] (profiles/r05_project_before_store.json: the 68 KiB of weight fragments per slice step do not
+        # stream through LDS fast enough), so it is opt-in: it divides the per-sample workspace by 3.3.  COPONERF_PROJECT=1
+        self.project = (os.environ.get("COPONERF_PROJECT", "0") == "1") if project is None else bool(project)
         # training: every fp16 activation gradient carries a power-of-two scale chosen per backward pass so that the
         # largest entry of the first fp32 -> fp16 gradient lands near this value (train_fns.GradScale)
         self.grad_scale_target = 256.0
@@ -391,18 +401,7 @@ class RenderEngine:
         # that the HBM-bound stages of one chunk (gather, hidden sums) run under the MFMA-bound GEMMs of another
         self.lanes = max(1, int(lanes))
         self._lane_streams: List[torch.cuda.Stream] = []
-        # slot schedule of _render_body: rays per chunk, used when a call has at least SLOT_MIN_CHUNKS such chunks, one lane
-        # and an automatic chunk size.  0 = off (the default: measured at -2 ... +1 % of the serial loop, DESIGN.md 4.1c —
-        # beside the hidden sums the encoder slows by as much as the sums gain, and 8-wave / 8 192-ray launches cost what is left)
-        self.slot_rays = int(os.environ.get("COPONERF_SLOT_RAYS", "0"))
-        self._slot_streams: Dict[int, torch.cuda.Stream] = {}
         self.ce_frag = os.environ.get("COPONERF_CE_FRAG", "1") != "0"
-        self.slot_trace: Optional[list] = None     # tools/slot_probe.py: (slot, start, encoder end, sums end) events
-        # pipeline.render_images(overlap="sums"): when True, every render call leaves in `encode_done` an event recorded
-        # behind the encoder launch of its LAST chunk (from there on the call's kernels leave the LDS and most registers
-        # of the CUs free: the point where another stream's small kernels may join without starving a persistent grid)
-        self.mark_encode_done = False
-        self.encode_done: Optional[torch.cuda.Event] = None
         # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
         # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it
         self.fold_value = bool(fold_value)
@@ -457,9 +456,8 @@ class RenderEngine:
 
     def __deepcopy__(self, memo):
         # caches, streams and workspace are derived state: a copied model gets a fresh engine with the same settings
-        new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables, self.fuse_key)
+        new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables, self.fuse_key, self.project)
         new.grad_scale_target, new.call_lanes, new.lazy_pixel_val = self.grad_scale_target, self.call_lanes, self.lazy_pixel_val
-        new.slot_rays = self.slot_rays
         return new
 
     def _host_inputs(self, *mats):
@@ -503,7 +501,7 @@ class RenderEngine:
         self._l3_hint = (z3, z3._version, nhwc16)
 
     def _weights(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        key = tuple((id(p), p.data_ptr(), p._version) for p in params.values())
+        key = tuple((id(p), p.data_ptr(), p._version) for p in params.values()) + (self.project,)
         if key == self._wkey:
             return self._w
         self._misses += 1
@@ -533,7 +531,7 @@ class RenderEngine:
             return dst, cf.float().contiguous()
 
         w["key_fold.w16"], w["key_fold.b"] = fold("key_map.weight", "key_map.bias", 128)
-        # the same matrix in the order cpn_encode_key (group 4) streams it through its LDS ring: [image j][slice n][tile t][k][lane =
+        # the same matrix in the order cpn_encode_key streams it through its LDS ring: [image j][slice n][tile t][k][lane =
         # row + 16 * 8-column group][8] - every 1 KiB DMA piece contiguous
         w["key_fold.wpk"] = pack_key_ring(w["key_fold.w16"])
         w["value_fold.w16"], w["value_fold.b"] = fold("latent_value.weight", "latent_value.bias", 416)
@@ -579,7 +577,9 @@ class RenderEngine:
         w["enc.wtab"] = torch.empty(_hip.TAB_LD, 768, dtype=torch.float16, device=dev)
         call("cpn_pack_encode_weights", W1.data_ptr(), 835, w["enc.frag"].data_ptr(), w["enc.wtab"].data_ptr(), s)
         w["enc.zero_bias"] = torch.zeros(_hip.TAB_LD, dtype=torch.float32, device=dev)
-        w["enc.k80blk"] = pack_k80_blocks(w["enc.frag"], w["query_encode_latent.b"])
+        if self.project:
+            w["proj.ring"] = pack_project_ring(w["key_fold.w16"], w["value_fold.w16"],
+                                               pack_k80_blocks(w["enc.frag"], w["query_encode_latent.b"]))
         self._w, self._wkey = w, key
         self._wgen += 1
         return w
@@ -741,14 +741,15 @@ class RenderEngine:
         training job or captured get_z graphs in the same process the chunks shrink instead of the call running out of
         memory.  The decision is kept per (S, device, settings) for as long as the workspace of the current call lane already
         holds a chunk of `nrays` rays at that size (nothing would be allocated); otherwise free memory is consulted again."""
-        key = (S, str(dev), self.lanes, self.call_lanes, self.tables, self.fold_value, self.fuse_key)
+        project = self.project and self.fuse_key and self.tables and self.fold_value
+        key = (S, str(dev), self.lanes, self.call_lanes, self.tables, self.fold_value, self.fuse_key, project)
         hit = self.__dict__.get("_auto_chunk_memo")
         if hit is not None and hit[0] == key:
-            have = self._ws.get(self._ws_prefix + "hid.0")
-            if have is not None and have.device == dev and have.numel() >= min(hit[1], max(1, nrays)) * V * S * 2 * 832:
+            have = self._ws.get(self._ws_prefix + ("val.0" if project else "hid.0"))
+            if have is not None and have.device == dev and have.numel() >= min(hit[1], max(1, nrays)) * V * S * (416 if project else 2 * 832):
                 return hit[1]
         nws = max(1, self.lanes) * max(1, self.call_lanes)                              # workspaces alive at once
-        per_ray = V * S * (2 * 832 * 2 + 128 * 2 + 4) * nws                             # hid + coords_embed + logits
+        per_ray = V * S * ((416 if project else 2 * 832) * 2 + 128 * 2 + 4) * nws       # hid (or val) + coords_embed + logits
         if self.fuse_key and self.tables and self.fold_value:
             per_ray += V * S * 128 * 2 * nws                                            # + kh of the fused key layer
         if not self.tables:
@@ -778,15 +779,6 @@ class RenderEngine:
         self._call_streams_given = bool(streams)
         self._call_idx = 0
         self._uv_seen = None        # new streams have waited for nothing: the next call must order itself behind the caller's
-
-    def _slot_stream(self, dev) -> torch.cuda.Stream:
-        """The second stream of the slot schedule, one per stream the call itself runs on (two call lanes must not share it:
-        their hidden sums would serialise behind each other)."""
-        key = torch.cuda.current_stream(dev).cuda_stream
-        st = self._slot_streams.get(key)
-        if st is None or st.device != dev:
-            st = self._slot_streams[key] = torch.cuda.Stream(device=dev)
-        return st
 
     def _call_stream(self, dev) -> Optional[torch.cuda.Stream]:
         if self.call_lanes <= 1:
@@ -899,12 +891,8 @@ class RenderEngine:
         # coords_embed in fragment order (include/coponerf_hip.h, cpn_local_mlp rows_frag): its writer and both readers are then
         # whole-line accesses.  Only where every user of the buffer understands it: the folded path (cpn_attend reads rows)
         ce_frag = self.fold_value and self.ce_frag
-        # slot schedule (below): chunks of `slot_rays`, three of them in flight (3 x 3.8 GB at 8 192 rays x 64 samples); only
-        # where there are enough chunks to fill it
-        slots = (self.slot_rays > 0 and fused_key and self.lanes == 1 and self.chunk_rays == 0
-                 and nray_total >= self.SLOT_MIN_CHUNKS * self.slot_rays)
-        C = self.slot_rays if slots else min(
-            self.chunk_rays if self.chunk_rays > 0 else self._auto_chunk(S, dev, nray_total), nray_total)
+        project = self.project and fused_key
+        C = min(self.chunk_rays if self.chunk_rays > 0 else self._auto_chunk(S, dev, nray_total), nray_total)
         T = V * S                       # rows per ray for the attention stage
         GW = dict(self.GEMM_WEIGHTS, key_fold=(128, 1664, 1664), value_fold=(416, 1664, 1664))
         nchunks = (nray_total + C - 1) // C
@@ -915,13 +903,16 @@ class RenderEngine:
 
         def lane_buffers(lane):
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
-            bufs = {"hid": t("hid", (C * T * 2, 832), f16),
-                    # coords_embed: whole 16-row groups (the fragment-order stores write them whole)
+            bufs = {  # coords_embed: whole 16-row groups (the fragment-order stores write them whole)
                     "ce": t("ce", ((C * T + 15) // 16 * 16, 128), f16), "lg": t("lg", (C * T,), f32),
                     "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
             if not self.tables:
                 bufs["xin"] = t("xin", (C * T * 2, _hip.XIN_STRIDE), f16)
+            if project:
+                bufs["val"] = t("val", (C * T, 416), f16)          # the per-sample values instead of hid
+            else:
+                bufs["hid"] = t("hid", (C * T * 2, 832), f16)
             if fused_key:
                 bufs["khf"] = t("khf", (C * T, 128), f16)
             if not self.fold_value:
@@ -932,8 +923,8 @@ class RenderEngine:
                 bufs["q2"] = t("q2", (C * T, 128), f16)
             return bufs
 
-        # ---- the stages of one chunk.  Serial order (run_chunk): E M1 G A1 V1 M2 A2 V2; the slot schedule below interleaves the
-        #      stages of three consecutive chunks.  Every stage takes the chunk's first ray, its buffers and the raw stream.
+        # ---- the stages of one chunk, in serial order (run_chunk): E M1 G A1 V1 M2 A2 V2.  Every stage takes the chunk's first
+        #      ray, its buffers and the raw stream.
         def _gemm(s, a, lda, wname, out, ldc, m, n, k, relu, out_f32):
             prof = self.profile
             if prof is not None:
@@ -950,16 +941,10 @@ class RenderEngine:
                 e1.record()
                 prof.setdefault("gemm_f16:" + wname, []).append((e0, e1, 2.0 * m * n * GW[wname][1]))
 
-        def stage_encode(ray0, bf, s, beside=False):
-            """E: first encoder layer (+ the folded key_map layer when fused) -> hid (, khf)  [CoPoNeRF.py:384-397, 404-407]"""
-            _stage_encode(ray0, bf, s, beside)
-            if self.mark_encode_done and ray0 + C >= nray_total:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                self.encode_done = ev
-
-        def _stage_encode(ray0, bf, s, beside):
-            hid, xin = bf["hid"], bf.get("xin")
+        def stage_encode(ray0, bf, s):
+            """E: first encoder layer (+ the folded key_map layer when fused; + the folded value projection in `project` mode)
+            -> hid (, khf) or khf, val  [CoPoNeRF.py:384-397, 404-407]"""
+            hid, xin = bf.get("hid"), bf.get("xin")
             n = min(C, nray_total - ray0)
             rows2 = n * T * 2
             if self.tables:
@@ -967,16 +952,14 @@ class RenderEngine:
                 if prof is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                if fused_key and beside:
-                    call("cpn_encode_key_beside", tabs[0].data_ptr(), maps[3].data_ptr(),
-                         H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
-                         w["query_encode_latent.b"].data_ptr(), w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
-                         B, V, R, S, ray0, n, hid.data_ptr(), bf["khf"].data_ptr(), s)
+                if project:
+                    call("cpn_encode_project", tabs[0].data_ptr(), maps[3].data_ptr(), H, W, pixel_val.data_ptr(),
+                         sec_grid.data_ptr(), pe6.data_ptr(), w["proj.ring"].data_ptr(), w["key_fold.b"].data_ptr(),
+                         B, V, R, S, ray0, n, bf["khf"].data_ptr(), bf["val"].data_ptr(), s)
                 elif fused_key:
                     call("cpn_encode_key", tabs[0].data_ptr(), maps[3].data_ptr(),
                          H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
-                         w["query_encode_latent.b"].data_ptr(), w["enc.k80blk"].data_ptr(), self.key_group,
-                         w["key_fold.wpk" if self.key_group == 4 else "key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
+                         w["query_encode_latent.b"].data_ptr(), w["key_fold.wpk"].data_ptr(), w["key_fold.b"].data_ptr(),
                          B, V, R, S, ray0, n, hid.data_ptr(), bf["khf"].data_ptr(), s)
                 else:
                     call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(),
@@ -985,7 +968,7 @@ class RenderEngine:
                 if prof is not None:
                     e1.record()
                     # third entry: canonical FLOPs of the FIRST layer (bench.py adds the fused key layer's by kernel name)
-                    prof.setdefault("encode_key" if fused_key else "encode_hidden", []).append(
+                    prof.setdefault("encode_project" if project else "encode_key" if fused_key else "encode_hidden", []).append(
                         (e0, e1, 2.0 * rows2 * 832 * 835))
             else:
                 call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
@@ -1035,7 +1018,10 @@ class RenderEngine:
         def stage_sum1(ray0, bf, s):
             """A1: joint softmax over the 2 x S samples of a ray + the weighted sum, round 1  [:450-461]"""
             n = min(C, nray_total - ray0)
-            if self.fold_value:
+            if project:
+                call("cpn_attend_value", bf["lg"].data_ptr(), bf["val"].data_ptr(), w["value_fold.b"].data_ptr(), 0, 0.0,
+                     B, V, R, S, ray0, n, bf["z1"].data_ptr(), at_wt.data_ptr(), s)
+            elif self.fold_value:
                 call("cpn_attend_hidden", 0, 0, bf["lg"].data_ptr(), bf["hid"].data_ptr(), B, V, R, S, ray0, n,
                      bf["hbar"].data_ptr(), at_wt.data_ptr(), s)
             else:
@@ -1046,7 +1032,7 @@ class RenderEngine:
             """V1 L M2: value projection of the round-1 sum, encode_latent, the second query and its logits  [:467-475]"""
             n = min(C, nray_total - ray0)
             z1, ze, addq = bf["z1"], bf["ze"], bf["addq"]
-            if self.fold_value:
+            if self.fold_value and not project:
                 _gemm(s, bf["hbar"], 1664, "value_fold", z1, 416, n, 416, 1664, False, True)
             call("cpn_linear_f32", z1.data_ptr(), 416, w["encode_latent.w"].data_ptr(), 416,
                  w["encode_latent.b"].data_ptr(), 0, 0, ze.data_ptr(), 128, n, 128, 416, 0, 0, s)
@@ -1066,7 +1052,11 @@ class RenderEngine:
         def stage_sum2(ray0, bf, s):
             """A2: round 2 of the attention  [:475-485]"""
             n = min(C, nray_total - ray0)
-            if self.fold_value:
+            if project:
+                # the round-1 vector sits in both view slots when the views are summed (CoPoNeRF.py:481-485): + V * z1
+                call("cpn_attend_value", bf["lg"].data_ptr(), bf["val"].data_ptr(), w["value_fold.b"].data_ptr(),
+                     bf["z1"].data_ptr(), float(V), B, V, R, S, ray0, n, zl[ray0:ray0 + n].data_ptr(), 0, s)
+            elif self.fold_value:
                 call("cpn_attend_hidden", 0, 0, bf["lg"].data_ptr(), bf["hid"].data_ptr(), B, V, R, S, ray0, n,
                      bf["hbar"].data_ptr(), 0, s)
             else:
@@ -1077,7 +1067,7 @@ class RenderEngine:
             """V2: value projection of the round-2 sum; the round-1 vector sits in both view slots when the views are summed
             (CoPoNeRF.py:481-485)"""
             n = min(C, nray_total - ray0)
-            if self.fold_value:
+            if self.fold_value and not project:
                 _gemm(s, bf["hbar"], 1664, "value_fold", bf["zs"], 416, n, 416, 1664, False, True)
                 torch.add(bf["zs"][:n], bf["z1"][:n], alpha=float(V), out=zl[ray0:ray0 + n])
 
@@ -1090,44 +1080,7 @@ class RenderEngine:
             stage_sum2(ray0, bf, s)
             stage_out(ray0, bf, s)
 
-        if slots:
-            # ---- the slot schedule.  cpn_encode_key is bound by its L1 / LDS pipes and lock step (2.5 TB/s of stores), the
-            #      two hidden sums by HBM reads (6.5 TB/s); one after the other they take 12.2 + 8.5 ms per image.  In slot k
-            #      the 8-wave form of the encoder (cpn_encode_key_beside: it leaves a third of every CU's registers free)
-            #      works on chunk k while a second stream sums round 1 of chunk k - 1 and round 2 of chunk k - 2 ON THE
-            #      SAME CUs; the small stages between them (LDS-heavy GEMMs / MLPs that cannot co-reside with the encoder)
-            #      run on the whole chip between two slots.  Three buffer sets; results bit-identical to the serial order.
-            side = self._slot_stream(dev)
-            sets = [lane_buffers(f"s{i}") for i in range(3)]
-            starts = list(range(0, nray_total, C))
-            trace = self.slot_trace
-            for k in range(nchunks + 2):
-                go = torch.cuda.Event(enable_timing=trace is not None)
-                go.record(main)
-                if k < nchunks:
-                    stage_encode(starts[k], sets[k % 3], s, beside=True)
-                if trace is not None:
-                    enc_end = torch.cuda.Event(enable_timing=True)
-                    enc_end.record(main)
-                if k >= 1:
-                    side.wait_event(go)
-                    if k <= nchunks:
-                        stage_sum1(starts[k - 1], sets[(k - 1) % 3], side.cuda_stream)
-                    if k >= 2:
-                        stage_sum2(starts[k - 2], sets[(k - 2) % 3], side.cuda_stream)
-                    back = torch.cuda.Event(enable_timing=trace is not None)
-                    back.record(side)
-                    main.wait_event(back)
-                if trace is not None:
-                    trace.append((k, go, enc_end, back if k >= 1 else enc_end))
-                if k < nchunks:
-                    stage_embed(starts[k], sets[k % 3], s)
-                    stage_logits(starts[k], sets[k % 3], s)
-                if 1 <= k <= nchunks:
-                    stage_query2(starts[k - 1], sets[(k - 1) % 3], s)
-                if k >= 2:
-                    stage_out(starts[k - 2], sets[(k - 2) % 3], s)
-        elif nlanes == 1:
+        if nlanes == 1:
             bf = lane_buffers(0)
             for ray0 in range(0, nray_total, C):
                 run_chunk(ray0, bf, s)

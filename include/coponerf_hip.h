@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 6
+#define CPN_ABI_VERSION 7
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -162,35 +162,33 @@ int cpn_node_features(const uint16_t* map0, const uint16_t* map1, const uint16_t
 int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                       const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                       int B, int V, int R, int S, int ray0, int nrays, uint16_t* hid, void* stream);
-/* cpn_encode_key (round 4, csrc/encode_key.hip): cpn_encode_hidden with the folded key_map layer behind it
- * (models/CoPoNeRF.py:404-407 after :387-397; folding: DESIGN.md 4.3) — the 64-channel slices of hid are the K panel
- * of the 1664 -> 128 contraction while they are still in registers, so the key path no longer reads hid back from HBM.
- *   kw (128, 1664) fp16 row-major = (Wk_a W2 | Wk_b W2), kbias (128) fp32 = Wk_a b2 + Wk_b b2 + bk
- *   hid as above (still written: the two hidden sums read it); kh (rays*V*S, 128) fp16 = ReLU(kw . [hid_own ; hid_other] + kbias),
- *   rows in the order of this header — the A operand of cpn_gemm_f16_rowdot (key_map_2 + logit).
- *   group = 0: the K = 80 fragments (wfrag, bias) stay resident in LDS, the key weights go through a one-slice ring (one
- *       workgroup barrier per slice; the fastest).  group = 1 or 3: nothing resident; every slice's K = 80 block comes from k80blk
- *       (13 x CPN_K80_BLOCK_HALVES fp16: the slice's main fragments [k < 2][tile < 4][lane] half8 as in wfrag, then its tail
- *       fragments [tile < 4][48] half4 with the bias folded in as an fp16 (hi, lo) pair, zero pad) together with its key
- *       weights, and the waves of a workgroup meet once per `group` slices.  group = 4: group 0 with kw pre-packed in the
- *       order the ring streams it - (2 images, 13 slices, 8 tiles, 2 k steps, 64 lanes = row + 16 * 8-column group, 8) fp16, every
- *       1 KiB DMA piece contiguous (no L1 tag-conflict stalls: 353 M cycles per launch with the row-major pieces; 0.1 ms of 12).
- *       Results are identical for every group.                 */
-#define CPN_K80_BLOCK_HALVES 5120
+/* cpn_encode_key (csrc/encode_fused.hip; round 5 form of round 4's kernel): cpn_encode_hidden with the folded key_map layer
+ * behind it (models/CoPoNeRF.py:404-407 after :387-397; folding: DESIGN.md 4.3) - the 64-channel slices of hid are the K panel
+ * of the 1664 -> 128 contraction while they are still in registers, so the key path never reads hid back from HBM.
+ *   kwring (2 images, 13 slices, 8 tiles, 2 k steps, 64 lanes = row + 16 * 8-column group, 8) fp16: the folded key matrix
+ *       (Wk_a W2 | Wk_b W2) (128, 1664) in the order the kernel streams it through its two-slot LDS ring - piece (t, k) of slice
+ *       step (j, n) holds, in lane (a, g), W'[16 t + a][832 j + 64 n + 32 k + 8 g .. +8]: every 1 KiB DMA piece is contiguous;
+ *       kbias (128) fp32 = Wk_a b2 + Wk_b b2 + bk
+ *   hid as for cpn_encode_hidden (still written: the two hidden sums read it); kh (rays*V*S, 128) fp16 =
+ *       ReLU(W' . [hid_own ; hid_other] + kbias), rows in the order of this header - the A operand of cpn_gemm_f16_rowdot.
+ *   hid and kh are bit-identical to cpn_encode_hidden + cpn_gemm_f16(W', relu).                                          */
 int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                    const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
-                   const uint16_t* k80blk, int group, const uint16_t* kw, const float* kbias, int B, int V, int R, int S,
-                   int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream);
-/* cpn_encode_key_beside (round 4): the resident form (group 0) of cpn_encode_key with 8 waves per workgroup instead of 12.
- * Two waves x 160 VGPRs per SIMD and 155.5 KiB of LDS leave a third of every CU's register file and 4.5 KiB of its LDS
- * free: cpn_attend_hidden launches of EARLIER ray chunks, issued on a second stream, run on the same CUs under this launch
- * (the along-ray sums of models/CoPoNeRF.py:456-461 / :481-485 read hid at the HBM rate while this kernel, bound by its
- * L1 / LDS pipes, leaves 70 % of that rate unused).  Same arguments and bit-identical hid / kh; alone 5-7 % slower than
- * cpn_encode_key - it is for the slot schedule of coponerf_amd/render.py only.                                        */
-int cpn_encode_key_beside(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
-                          const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
-                          const uint16_t* kw, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
-                          uint16_t* hid, uint16_t* kh, void* stream);
+                   const uint16_t* kwring, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
+                   uint16_t* hid, uint16_t* kh, void* stream);
+/* cpn_encode_project (round 5, csrc/encode_fused.hip; "project before you store", opt-in): the same kernel with the folded
+ * latent_value projection (models/CoPoNeRF.py:404) behind the first layer as well - hid never reaches HBM:
+ *   val (rays*V*S, 416) fp16 = (Wv_a W2 | Wv_b W2) . [hid_own ; hid_other]   (the folded constant is added by cpn_attend_value)
+ *   kh as above (bit-identical to cpn_encode_key's).
+ *   wring (2 images, 13 slices, CPN_PROJECT_STEP_HALVES) fp16: per slice step the 34 x 2 weight fragments of the key (tiles
+ *       0-7) and value (tiles 8-33) matrices in the piece order of kwring, then the slice's K = 80 block of the first layer
+ *       (CPN_K80_BLOCK_HALVES fp16: its main fragments [k < 2][tile < 4][lane] half8 as in wfrag, then its tail fragments
+ *       [tile < 4][48] half4 with the bias folded in as an fp16 (hi, lo) pair, zero pad): nothing is resident in LDS.    */
+#define CPN_K80_BLOCK_HALVES 5120
+#define CPN_PROJECT_STEP_HALVES (34 * 2 * 64 * 8 + CPN_K80_BLOCK_HALVES)
+int cpn_encode_project(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                       const float* sec_grid, const float* pe6, const uint16_t* wring, const float* kbias, int B, int V,
+                       int R, int S, int ray0, int nrays, uint16_t* kh, uint16_t* val, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).
@@ -222,6 +220,13 @@ int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const
  *   formed them (cpn_gemm_f16_rowdot / cpn_local_mlp with logits_out); then qa, qb may be NULL                 */
 int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const float* logits, const uint16_t* hid, int B, int V,
                       int R, int S, int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream);
+
+/* ---- K4'': the same joint softmax over the per-sample VALUES of cpn_encode_project (round 5) ----------------
+ *   zout[ray] = sum_rows w[row] * val[row] + vbias (+ zprev_scale * zprev[ray] when zprev != NULL: round 2 adds V times the
+ *   round-1 vector, CoPoNeRF.py:481-485);  val (rays*V*S, 416) fp16, vbias (416) fp32 = the folded constant
+ *   Wv_a b2 + Wv_b b2 + bv, logits (rays*V*S) fp32, zout / zprev (rays, 416) fp32, at_wt (N,R,S) or NULL               */
+int cpn_attend_value(const float* logits, const uint16_t* val, const float* vbias, const float* zprev, float zprev_scale,
+                     int B, int V, int R, int S, int ray0, int nrays, float* zout, float* at_wt, void* stream);
 
 /* ---- K5: exact-fp32 per-ray linear layer (MFMA 16x16x4 f32)  Y = act_out( act_in(X) . W^T + bias + res ) --
  * replaces nn.Conv1d encode_latent (CoPoNeRF.py:468) and lightfield.ResnetFC (models/lightfield.py:131-167).

@@ -526,7 +526,7 @@ def test_table_mode_matches_gather_mode(model, dev, weights):
 
 
 def test_fused_key_mode_matches_separate_key_mode(model, dev, weights):
-    """cpn_encode_key (round 4: the folded key_map contraction on the slices of hid while they are in registers, then
+    """cpn_encode_key (the folded key_map contraction on the slices of hid while they are in registers, then
     cpn_gemm_f16_rowdot) against the round-3 order (cpn_encode_hidden, then cpn_gemm_f16_chain_rowdot reading hid back):
     same fp16 operands, same k order of the MFMA accumulation -> the attention weights and the image must agree to
     rounding of the last bits, on every fixture case incl. the ragged one (dead rows / dead units at the end of a range)
@@ -551,75 +551,137 @@ def test_fused_key_mode_matches_separate_key_mode(model, dev, weights):
         assert (out_f["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
 
 
-def test_encode_key_entry_every_group_is_bit_identical(model, dev, weights):
-    """The C entry itself: cpn_encode_key with group 0 (K = 80 fragments resident, one barrier per slice), 1 and 3 (all weights
-    streamed, one barrier per 1 / 3 slices) writes the same bits of hid as cpn_encode_hidden and the same kh as
-    cpn_gemm_f16 on that hid — on a ragged chunk (ray0 > 0, a ray count that is no multiple of 4, dead units at the end of
-    most workgroups' ranges)."""
-    from coponerf_amd._hip import call
-    cfg, _ = load_case("wide_val")
+def _encode_entry_setup(model, dev, cfg):
     inp, z, rel, flow = case_inputs(cfg)
-    B, H, R, S, V = cfg["B"], cfg["H"], cfg["R"], cfg["S"], 2
+    H, S = cfg["H"], cfg["S"]
     eng = model._engine
     model.npoints = S
     w = eng._weights(model._render_params())
     maps, tabs = eng._feature_maps(to_device(z, dev), w)
     ctx, qry = to_device(inp["context"], dev), to_device(inp["query"], dev)
     g = eng._geometry(ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], rel.to(dev), cfg["val"], S, H, H)
+    geo = (tabs[0].data_ptr(), maps[3].data_ptr(), H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr())
+    return w, geo, (maps, tabs, g)
+
+
+def test_encode_key_entry_is_bit_identical(model, dev, weights):
+    """The C entry itself: cpn_encode_key (csrc/encode_fused.hip: several units per wave, the taps of slice n + 1 issued before
+    the key MFMAs of slice n) writes the same bits of hid as cpn_encode_hidden and the same kh as cpn_gemm_f16 on that hid —
+    on a ragged chunk (ray0 > 0, a ray count that is no multiple of 4, dead units at the end of most workgroups' ranges)
+    and on a whole fixture case."""
+    from coponerf_amd._hip import call
+    cfg, _ = load_case("wide_val")
+    B, R, S, V = cfg["B"], cfg["R"], cfg["S"], 2
+    w, geo, keep = _encode_entry_setup(model, dev, cfg)
     s = torch.cuda.current_stream().cuda_stream
-    ray0, n = 7, R - 18
-    rows2 = n * V * S * 2
-    args = (tabs[0].data_ptr(), maps[3].data_ptr(), H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(),
-            w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr())
-    hid_ref = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
-    call("cpn_encode_hidden", *args, B, V, R, S, ray0, n, hid_ref.data_ptr(), s)
-    kh_ref = torch.empty(rows2 // 2, 128, dtype=torch.float16, device=dev)
-    call("cpn_gemm_f16", hid_ref.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664, w["key_fold.b"].data_ptr(), kh_ref.data_ptr(), 128,
-         rows2 // 2, 128, 1664, 1, 0, s)
-    assert int((hid_ref == -1).sum()) == 0
-    for group in (0, 1, 3, 4):                      # 4 = group 0 with the key matrix pre-packed in ring-piece order
-        hid = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
-        kh = torch.full((rows2 // 2, 128), -1.0, dtype=torch.float16, device=dev)
-        call("cpn_encode_key", *args, w["enc.k80blk"].data_ptr(), group, w["key_fold.wpk" if group == 4 else "key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
-             B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
-        assert torch.equal(hid, hid_ref), (group, int((hid != hid_ref).sum()))
-        assert torch.equal(kh, kh_ref), (group, int((kh != kh_ref).sum()))
-    with pytest.raises(Exception):
-        call("cpn_encode_key", *args, w["enc.k80blk"].data_ptr(), 2, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
-             B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
-    # the 8-wave form that leaves room on its CUs for the hidden sums of other chunks: same bits
-    hid = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
-    kh = torch.full((rows2 // 2, 128), -1.0, dtype=torch.float16, device=dev)
-    call("cpn_encode_key_beside", *args, w["key_fold.w16"].data_ptr(), w["key_fold.b"].data_ptr(),
-         B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
-    assert torch.equal(hid, hid_ref) and torch.equal(kh, kh_ref)
+    for ray0, n in ((7, R - 18), (0, B * R), (R - 3, 5 if B > 1 else 3)):
+        rows2 = n * V * S * 2
+        hid_ref = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
+        call("cpn_encode_hidden", *geo, w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(), B, V, R, S, ray0, n,
+             hid_ref.data_ptr(), s)
+        kh_ref = torch.empty(rows2 // 2, 128, dtype=torch.float16, device=dev)
+        call("cpn_gemm_f16", hid_ref.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664, w["key_fold.b"].data_ptr(), kh_ref.data_ptr(), 128,
+             rows2 // 2, 128, 1664, 1, 0, s)
+        assert int((hid_ref == -1).sum()) == 0
+        hid = torch.full((rows2 + 64, 832), -1.0, dtype=torch.float16, device=dev)        # + a guard band behind the chunk
+        kh = torch.full((rows2 // 2 + 64, 128), -1.0, dtype=torch.float16, device=dev)
+        call("cpn_encode_key", *geo, w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(), w["key_fold.wpk"].data_ptr(),
+             w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
+        assert torch.equal(hid[:rows2], hid_ref), (ray0, n, int((hid[:rows2] != hid_ref).sum()))
+        assert torch.equal(kh[:rows2 // 2], kh_ref), (ray0, n, int((kh[:rows2 // 2] != kh_ref).sum()))
+        assert bool((hid[rows2:] == -1).all()) and bool((kh[rows2 // 2:] == -1).all()), "wrote past the chunk"
 
 
-def test_slot_schedule_is_bit_identical(model, dev, weights):
-    """RenderEngine.slot_rays > 0: the encoder of chunk k (cpn_encode_key_beside) on the call's stream, the hidden sums of
-    chunks k - 1 (round 1) and k - 2 (round 2) on a second stream under it, the small stages between two slots, three buffer
-    sets — against the serial chunk loop, incl. a last chunk that is not full and a call too short for the schedule."""
-    H, S = 64, 32
-    inp = syn.make_inputs(2, H, H, 0, seed=71, full_image=True)            # 2 x 4 096 rays
-    z, rel, flow = syn.make_latents(2, H, H, seed=72)
-    model.npoints = S
+def test_encode_project_entry_against_hidden_path(model, dev, weights):
+    """cpn_encode_project ("project before you store"): kh must be the bits of cpn_encode_key's, val (rows, 416) fp16 must agree with
+    the fp32 product of the SAME fp16 operands (hid of cpn_encode_hidden . value_fold^T) to fp16 rounding of the result; ragged
+    chunk and whole case; nothing is written past the chunk."""
+    from coponerf_amd._hip import call
+    from coponerf_amd.render import pack_k80_blocks, pack_project_ring
+    cfg, _ = load_case("wide_val")
+    B, R, S, V = cfg["B"], cfg["R"], cfg["S"], 2
+    w, geo, keep = _encode_entry_setup(model, dev, cfg)
+    ring = pack_project_ring(w["key_fold.w16"], w["value_fold.w16"], pack_k80_blocks(w["enc.frag"], w["query_encode_latent.b"]))
+    assert ring.shape == (2, 13, 34 * 2 * 64 * 8 + 5120)
+    s = torch.cuda.current_stream().cuda_stream
+    for ray0, n in ((7, R - 18), (0, B * R)):
+        rows = n * V * S
+        hid_ref = torch.empty(rows * 2, 832, dtype=torch.float16, device=dev)
+        call("cpn_encode_hidden", *geo, w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(), B, V, R, S, ray0, n,
+             hid_ref.data_ptr(), s)
+        kh_ref = torch.empty(rows, 128, dtype=torch.float16, device=dev)
+        call("cpn_gemm_f16", hid_ref.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664, w["key_fold.b"].data_ptr(), kh_ref.data_ptr(), 128,
+             rows, 128, 1664, 1, 0, s)
+        val_ref = hid_ref.view(rows, 1664).float() @ w["value_fold.w16"].float().t()
+        kh = torch.full((rows + 64, 128), -1.0, dtype=torch.float16, device=dev)
+        val = torch.full((rows + 64, 416), -7.0, dtype=torch.float16, device=dev)
+        call("cpn_encode_project", *geo, ring.data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, kh.data_ptr(), val.data_ptr(), s)
+        assert torch.equal(kh[:rows], kh_ref), int((kh[:rows] != kh_ref).sum())
+        err = (val[:rows].float() - val_ref).abs()
+        scale = float(val_ref.abs().max())
+        print("project: val max |err|", float(err.max()), "of", scale)
+        assert float(err.max()) <= 1.5e-3 * max(1.0, scale)                 # fp16 rounding of the stored value (+ accumulation order)
+        assert float(err.pow(2).mean().sqrt()) <= 2e-4 * max(1.0, scale)
+        assert bool((kh[rows:] == -1).all()) and bool((val[rows:] == -7).all()), "wrote past the chunk"
+
+
+def test_attend_value_against_torch(dev):
+    """cpn_attend_value: joint softmax of the logits / 11.31 over the V*S samples of a ray, weighted sum of the (rows, 416) fp16
+    values + the folded constant (+ V * zprev in round 2), against float64 torch; at_wt scattered to (N, R, S)."""
+    from coponerf_amd._hip import call
+    gen = torch.Generator().manual_seed(5)
+    B, V, R, S = 2, 2, 37, 24
+    ray0, n = 3, B * R - 5
+    rows = n * V * S
+    lg = (torch.randn(rows, generator=gen) * 30).to(dev)
+    val = torch.randn(rows, 416, generator=gen).half().to(dev)
+    vb = torch.randn(416, generator=gen).to(dev)
+    zp = torch.randn(n, 416, generator=gen).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    wt = torch.softmax(lg.double().view(n, V * S) / 11.31, dim=1)
+    zsum = torch.einsum("rt,rtc->rc", wt, val.double().view(n, V * S, 416)) + vb.double()
+    for zprev in (None, zp):
+        out = torch.empty(n, 416, dtype=torch.float32, device=dev)
+        at = torch.full((B * V, R, S), -1.0, dtype=torch.float32, device=dev)
+        call("cpn_attend_value", lg.data_ptr(), val.data_ptr(), vb.data_ptr(), 0 if zprev is None else zprev.data_ptr(), 2.0,
+             B, V, R, S, ray0, n, out.data_ptr(), at.data_ptr(), s)
+        ref = zsum if zprev is None else zsum + 2.0 * zprev.double()
+        assert float((out.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        rays = torch.arange(ray0, ray0 + n, device=dev)
+        b, r = rays // R, rays % R
+        for v in range(V):
+            got = at[b * V + v, r]                                           # (n, S)
+            assert float((got.double() - wt[:, v * S:(v + 1) * S]).abs().max()) <= 1e-6
+        mask = torch.ones(B * R, dtype=torch.bool, device=dev)
+        mask[ray0:ray0 + n] = False
+        dead = torch.nonzero(mask).flatten()
+        assert bool((at.view(B, V, R, S)[dead // R, :, dead % R] == -1).all()), "weights written for rays outside the range"
+
+
+def test_project_mode_matches_hidden_mode(model, dev, weights):
+    """RenderEngine(project=True) — cpn_encode_project + cpn_attend_value: hid never reaches HBM — against the default order on
+    every fixture case: same sample coordinates, attention weights and image to rounding, and both against the oracle and
+    the upstream fixture."""
     eng = model._engine
-    old = (eng.slot_rays, eng.chunk_rays)
-    try:
-        with torch.no_grad():
-            dinp, dz, dflow = to_device(inp, dev), to_device(z, dev), to_device(flow, dev)
-            eng.slot_rays, eng.chunk_rays = 0, 0
-            ref = model(dinp, z=dz, rel_pose=rel.to(dev), val=True, flow=dflow)
-            ref = {k: ref[k].clone() for k in ("rgb", "at_wt", "valid_mask", "depth_ray")}
-            for sr in (1024, 1536, 2048, 4096):                          # 8 chunks; 5 1/3; 4; 2 (< SLOT_MIN_CHUNKS: serial)
-                eng.slot_rays = sr
-                for _ in range(2):                                       # the second call reuses the buffer sets
-                    out = model(dinp, z=dz, rel_pose=rel.to(dev), val=True, flow=dflow)
-                    for k in ref:
-                        assert torch.equal(out[k], ref[k]), (sr, k)
-    finally:
-        eng.slot_rays, eng.chunk_rays = old
-        eng._ws.clear()
+    assert not eng.project
+    for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
+        cfg, gold = load_case(name)
+        ref, out_h = run_pair(model, dev, weights, cfg)
+        eng.project = True
+        try:
+            _, out_p = run_pair(model, dev, weights, cfg)
+        finally:
+            eng.project = False
+        assert torch.equal(out_h["pixel_val"], out_p["pixel_val"])
+        d_wt = float((out_h["at_wt"] - out_p["at_wt"]).abs().max())
+        d_rgb = float((out_h["rgb"] - out_p["rgb"]).abs().max())
+        print(name, "project vs hidden-sum path: at_wt", d_wt, "rgb", d_rgb,
+              "rgb vs oracle", float((out_p["rgb"].cpu() - ref["rgb"]).abs().max()))
+        assert d_wt <= 1e-5 and d_rgb <= 3e-4, (name, d_wt, d_rgb)
+        assert (out_p["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
+        assert (out_p["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max() <= RGB_TOL
+        assert (out_p["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+    eng._ws.clear()
 
 
 def test_feature_cache_is_keyed_on_identity(model, dev, weights):

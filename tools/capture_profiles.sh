@@ -19,17 +19,17 @@ python - "$OUT" <<'PY'
 import hashlib, json, os, sys
 root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
 fused = os.environ.get("COPONERF_FUSE_KEY", "1") != "0"
-src = os.path.join(root, "coponerf_amd", "csrc", "encode_key.hip" if fused else "encode.hip")
-json.dump({"kernel": "encode_key_kernel" if fused else "encode_hidden_kernel",
+src = os.path.join(root, "coponerf_amd", "csrc", "encode_fused.hip" if fused else "encode.hip")
+json.dump({"kernel": "encode_fused_kernel" if fused else "encode_hidden_kernel",
            "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "rows_per_launch": 16777216,
            "command": "python bench.py --no-image --no-ref-loop --no-two-stream-pass --cpu-rays 0 --train-steps 0 --steps 5 (under rocprofv3 --kernel-trace --stats)"},
           open(os.path.join(sys.argv[1], "render_kernel_stats.meta.json"), "w"), indent=1)
 PY
-tools/pmc_passes.sh "$OUT/pmc_encode" encode_key -- python "$ROOT/tools/encode_bench.py" --only fused --iters 3 --rays 65536 > "$OUT/pmc_encode.log" 2>&1
+tools/pmc_passes.sh "$OUT/pmc_encode" encode_fused -- python "$ROOT/tools/encode_bench.py" --only fused --iters 3 --rays 65536 > "$OUT/pmc_encode.log" 2>&1
 python tools/make_traffic_json.py "$OUT/pmc_encode/summary.json" 16777216 "$OUT/traffic.json" encode_key >> "$OUT/pmc_encode.log" 2>&1
 tools/pmc_passes.sh "$OUT/pmc_encode_hidden" encode_hidden -- python "$ROOT/tools/encode_bench.py" --only tables --iters 3 --rays 65536 > "$OUT/pmc_encode_hidden.log" 2>&1
 python tools/make_traffic_json.py "$OUT/pmc_encode_hidden/summary.json" 16777216 "$OUT/traffic_encode_hidden.json" >> "$OUT/pmc_encode_hidden.log" 2>&1
-python tools/ek_ablate.py > "$OUT/encode_key_ablation.json" 2>/dev/null
+python tools/ef_check.py --no-check > "$OUT/encode_fused_ablation.json" 2>/dev/null
 COPONERF_FUSE_KEY=0 python bench.py --no-image --no-ref-loop --cpu-rays 0 --train-steps 0 > "$OUT/bench_separate_key_kernel.json" 2>> "$OUT/bench.err"
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/getz_prof" -o g -- python "$ROOT/tools/getz_time.py" ) > "$OUT/getz_prof.log" 2>&1
 python tools/trace_step.py "$(find "$OUT/getz_prof" -name '*kernel_trace.csv' | head -1)" soft_argmax_cols 45 > "$OUT/getz_step_kernels.txt" 2>&1

@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--rig", default="narrow")
-    ap.add_argument("--group", type=int, default=int(os.environ.get("COPONERF_KEY_GROUP", "4")), help="cpn_encode_key group (0, 1, 3, 4)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     H = S = None
@@ -73,7 +72,7 @@ def main():
         def enck():
             call("cpn_encode_key", tabs[0].data_ptr(), maps[3].data_ptr(), H, H,
                  g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(), g["pe6"].data_ptr(), w["enc.frag"].data_ptr(),
-                 w["query_encode_latent.b"].data_ptr(), w["enc.k80blk"].data_ptr(), a.group, w["key_fold.wpk" if a.group == 4 else "key_fold.w16"].data_ptr(),
+                 w["query_encode_latent.b"].data_ptr(), w["key_fold.wpk"].data_ptr(),
                  w["key_fold.b"].data_ptr(), B, V, R, S, min(16384, R - n), n, hid.data_ptr(), kh.data_ptr(), s)
         ms = timeit(enck)
         res["encode_key_ms"] = ms

@@ -1,3 +1,4 @@
+// ROUND-4 FORM, kept as the timing reference of tools/ef_check.py (exports renamed *_r4; not part of the product library).
 // K2+K3a+K3c — the first encoder layer on the node tables (encode.hip) WITH the folded key_map contraction behind it:
 //     hid[row]  = ReLU(query_encode_latent([gather ‖ tanh(pt/5)]))                       (written once, for the two hidden sums)
 //     kh[sample] = ReLU( (Wk_a W2 | Wk_b W2) . [hid_own ; hid_other] + c' )                (128 wide, fp16)
@@ -561,7 +562,7 @@ static int encode_key_launch(const uint16_t* tab, const uint16_t* map3, int H, i
     return 0;
 }
 
-extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+extern "C" int cpn_encode_key_r4(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                               const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                               const uint16_t* k80blk, int group, const uint16_t* kw, const float* kbias, int B, int V, int R,
                               int S, int ray0, int nrays, uint16_t* hid, uint16_t* kh, void* stream) {
@@ -574,7 +575,7 @@ extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, 
 // chunks before this one (53 VGPRs, 544 B), launched on a second stream, then runs UNDER this launch instead of behind it
 // (coponerf_amd/render.py: the slot schedule; tools/coresident_probe.py).  Alone it is 5-7 % slower than the 12-wave form.
 // hid / kh are bit-identical to cpn_encode_key's.
-extern "C" int cpn_encode_key_beside(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+extern "C" int cpn_encode_key_beside_r4(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                                      const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                                      const uint16_t* kw, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
                                      uint16_t* hid, uint16_t* kh, void* stream) {
