@@ -22,16 +22,27 @@ _SEG = np.dtype([("p", "<u8"), ("g", "<u8"), ("off", "<i8"), ("n", "<i4"), ("ste
 assert _SEG.itemsize == _hip.ADAM_SEG_BYTES
 
 
-class OneLaunchAdam:
+class OneLaunchAdam(torch.optim.Optimizer):
     """Adam (no weight decay, no amsgrad) over fp32 CUDA parameters.  `step(gscale)`: gscale = optional device scalar
     multiplied into every gradient first (the clip coefficient).  A parameter without a gradient is skipped and keeps its
-    update count, like torch.optim.Adam."""
+    update count, like torch.optim.Adam.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
-        self.params = list(params)
+    A torch.optim.Optimizer: `param_groups` (lr / betas / eps are read from them at every step, so `ExponentialLR` and the
+    reference's MultiLR wrapper drive it - /root/reference train.py:106-108, wrapper.py:134-136), and `state_dict()` /
+    `load_state_dict()` in torch.optim.Adam's layout (per parameter `step`, `exp_avg`, `exp_avg_sq`: the reference's
+    checkpoints hold `optimizer.state_dict()`, wrapper.py:98).  All groups must share one learning rate (the reference's two
+    do): it is a scalar argument of the single launch."""
+
+    def __init__(self, params: Iterable, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        # the keys of torch.optim.Adam's groups, at the values this kernel implements: a checkpoint written here loads into
+        # the library's Adam and back
+        ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=float(lr), betas=betas, eps=float(eps)).defaults
+        defaults = dict(ref, lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=0.0,
+                        amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self.params = [p for g in self.param_groups for p in g["params"]]
         assert self.params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in self.params), \
             "OneLaunchAdam: fp32 contiguous CUDA parameters only"
-        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         dev = self.params[0].device
         n = len(self.params)
         offs, off = [], 0
@@ -58,6 +69,66 @@ class OneLaunchAdam:
         self._dev = [torch.empty(n * _SEG.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
         self._sent = [None, None]
         self._turn = 0
+
+    # ---- the hyper-parameters live in param_groups (schedulers write `lr` there)
+    def _hyper(self):
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:
+            if g["lr"] != g0["lr"] or tuple(g["betas"]) != tuple(g0["betas"]) or g["eps"] != g0["eps"]:
+                raise NotImplementedError("OneLaunchAdam: every param group must share lr / betas / eps (one launch, scalar arguments)")
+        if any(g.get("weight_decay") or g.get("amsgrad") or g.get("maximize") for g in self.param_groups):
+            raise NotImplementedError("OneLaunchAdam: plain Adam only (no weight decay, amsgrad or maximize)")
+        return float(g0["lr"]), (float(g0["betas"][0]), float(g0["betas"][1])), float(g0["eps"])
+
+    @property
+    def lr(self) -> float:
+        return self._hyper()[0]
+
+    @lr.setter
+    def lr(self, value: float) -> None:
+        for g in self.param_groups:
+            g["lr"] = float(value)
+
+    @property
+    def betas(self):
+        return self._hyper()[1]
+
+    @property
+    def eps(self) -> float:
+        return self._hyper()[2]
+
+    # ---- checkpoints: torch.optim.Adam's layout
+    def state_dict(self):
+        """{'state': {index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} as torch.optim.Adam writes it
+        (a device read of the update counts: synchronises).  Parameters that never received an update have no entry."""
+        steps = self.steps
+        self.state.clear()
+        for i, p in enumerate(self.params):
+            if steps[i] > 0:
+                m, v = self.moments(i)
+                self.state[p] = {"step": torch.tensor(float(steps[i])), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        try:
+            return super().state_dict()
+        finally:
+            self.state.clear()
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)                   # param_groups + per-parameter state, cast to the parameters' device
+        counts = np.zeros(len(self.params), dtype=np.int32)
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, p in enumerate(self.params):
+            st = self.state.get(p)
+            if not st:
+                continue
+            m, v = self.moments(i)
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            counts[i] = int(round(float(st["step"])))
+        self._counts[self._count_turn & 1].copy_(torch.from_numpy(counts))
+        self.state.clear()
+        self._prepared = False
 
     def moments(self, i: int):
         """(exp_avg, exp_avg_sq) of parameter i as views shaped like it."""
@@ -103,10 +174,14 @@ class OneLaunchAdam:
         self._prepared = False
         cin, cout = self._counts[self._count_turn & 1], self._counts[(self._count_turn + 1) & 1]
         self._count_turn += 1
-        b1, b2 = self.betas
+        lr, (b1, b2), eps = self._hyper()
         call("cpn_adam_step", self._dev[i].data_ptr(), self._blocks.data_ptr(), self.nblocks, self.exp_avg.data_ptr(),
              self.exp_avg_sq.data_ptr(), 0 if gscale is None else gscale.data_ptr(), 0 if gate is None else gate.data_ptr(),
-             cin.data_ptr(), cout.data_ptr(), self.lr, b1, b2, self.eps, _stream_handle())
+             cin.data_ptr(), cout.data_ptr(), lr, b1, b2, eps, _stream_handle())
+        # the kernel wrote the parameters through raw pointers: tell autograd (every derived-weight cache of the inference
+        # path - RenderEngine._weights, the trunk / UFC packs, the captured get_z graphs - is keyed on `_version`, and
+        # torch.optim.Adam, which this replaces, bumped it).  Host-only, no launch.
+        torch.autograd.graph.increment_version([p for p in self.params if p.grad is not None])
 
     @property
     def steps(self) -> np.ndarray:
@@ -123,3 +198,8 @@ class OneLaunchAdam:
                 p.grad = None
             elif p.grad is not None:
                 p.grad.zero_()
+
+    def add_param_group(self, param_group) -> None:
+        if getattr(self, "exp_avg", None) is not None:
+            raise NotImplementedError("OneLaunchAdam: parameters are fixed at construction (flat moment buffers)")
+        super().add_param_group(param_group)

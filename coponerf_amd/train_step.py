@@ -22,11 +22,16 @@ class _LazyFlag:
     when the step was issued)."""
 
     def __init__(self, host: torch.Tensor, event):
-        self._host, self._event = host, event
+        self._host, self._event, self._value = host, event, None
 
     def __bool__(self) -> bool:
-        self._event.synchronize()
-        return bool(self._host.item() > 0)
+        # read ONCE: the pinned word is one of a few that TrainStep rotates through (it resolves every flag itself before the
+        # word comes round again), so a caller that keeps the flag of an old step must get that step's answer
+        if self._value is None:
+            self._event.synchronize()
+            self._value = bool(self._host.item() > 0)
+            self._host = self._event = None
+        return self._value
 
     def __repr__(self) -> str:
         return f"_LazyFlag({bool(self)})"
@@ -55,7 +60,9 @@ class TrainStep:
         self.timing: Optional[Dict[str, list]] = None                    # set to {} to collect HIP-event timings
         # fp16 activation gradients carry a static per-pass scale (train_fns.GradScale).  If they overflow the guard
         # skips the step and the next pass would pick the same scale: back the target off (x 1/4 per skipped step, down
-        # to 1) and restore it (x 2 every `growth_interval` good steps) like an AMP GradScaler does.
+        # to 1) and restore it (x 2 every `growth_interval` good steps) like an AMP GradScaler does.  Where the guard runs on
+        # the device the outcome of a step reaches this adaptation one or two steps LATE (its 4-byte copy is not waited for):
+        # after an overflow the next one or two steps reuse the scale and are skipped as well, then the back-off applies.
         self.skipped_in_a_row = 0
         self.skipped_total = 0
         self.growth_interval = 200
@@ -76,7 +83,7 @@ class TrainStep:
         timed = self.timing is not None and torch.cuda.is_available()
         # steps whose guard ran on the device: their outcome reaches the scale adaptation when its 4-byte copy has landed —
         # normally one step late, never by waiting (unless three are outstanding)
-        while self._pending and (self._pending[0]._event.query() or len(self._pending) > 2):
+        while self._pending and (self._pending[0]._value is not None or self._pending[0]._event.query() or len(self._pending) > 2):
             self._adapt_grad_scale(bool(self._pending.popleft()))
         e0 = self._ev() if timed else None
         out = self.model(model_input, val=False)

@@ -56,9 +56,11 @@ def wgrad_f32(dY2, X2, want_bias: bool):
     ok = (dY2.is_cuda and dY2.dtype == torch.float32 and X2.dtype == torch.float32 and R >= WGRAD_MIN_ROWS
           and O % 4 == 0 and I % 4 == 0)
     if ok:
-        if dY2.stride(1) != 1 or dY2.stride(0) % 4 or dY2.data_ptr() % 16:
+        # cpn_wgrad_f32 wants unit column stride, 16-byte aligned rows and a leading dimension that covers a row (a row-expanded
+        # gradient has stride(0) == 0, a column slice of a narrower parent stride(0) < O)
+        if dY2.stride(1) != 1 or dY2.stride(0) % 4 or dY2.stride(0) < O or dY2.data_ptr() % 16:
             dY2 = dY2.contiguous()
-        if X2.stride(1) != 1 or X2.stride(0) % 4 or X2.data_ptr() % 16:
+        if X2.stride(1) != 1 or X2.stride(0) % 4 or X2.stride(0) < I or X2.data_ptr() % 16:
             X2 = X2.contiguous()
         dW = torch.empty(O, I, dtype=torch.float32, device=dY2.device)
         db = torch.empty(O, dtype=torch.float32, device=dY2.device) if want_bias else None

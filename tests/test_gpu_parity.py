@@ -850,6 +850,84 @@ def test_config5_batch2_full_image_against_oracle(model, dev, weights):
     assert torch.equal(got["valid_mask"][:, sel].cpu(), ref["valid_mask"])
 
 
+def _strided_query(inp, sel):
+    return {"context": inp["context"], "query": {k: (v[:, :, sel].contiguous() if k in ("uv", "rgb") else v)
+                                                 for k, v in inp["query"].items()}}
+
+
+def test_config4_full_image_wide_rig_against_oracle(model, dev, weights):
+    """BASELINE configs[3] at its real size: the ACID-like WIDE-baseline rig, 256x256, all 65 536 rays in one
+    call (one chunk), 64 samples - the case whose reprojected secondary samples leave the other image over large parts of
+    the frame (zero-padded table rim, clipped segments).  Oracle on every 251st ray (prime stride: all rows, all columns)."""
+    from oracle import render_ref as orc
+    H, S = 256, 64
+    inp = syn.make_inputs(1, H, H, 0, seed=33, rig="wide", full_image=True)
+    z, rel, flow = syn.make_latents(1, H, H, seed=34)
+    R = inp["query"]["uv"].shape[2]
+    sel = torch.arange(0, R, 251)
+    old_n = model.npoints
+    model.npoints = S
+    try:
+        with torch.no_grad():
+            out = model(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=True, flow=to_device(flow, dev))
+            ref = orc.forward(_strided_query(inp, sel), z, rel, flow, True, weights, npoints=S)
+        got = {k: out[k] for k in ("pixel_val", "rgb", "at_wt", "valid_mask")}
+        del out
+    finally:
+        model.npoints = old_n
+    assert torch.equal(got["pixel_val"][:, sel], ref["pixel_val"])
+    err = (got["rgb"][:, :, sel].cpu() - ref["rgb"]).abs()
+    invalid = int((ref["valid_mask"] == 0).sum())
+    print(f"configs[3] full image, wide rig: rgb max-abs vs oracle {float(err.max()):.2e} over {len(sel)} rays ({invalid} without overlap)")
+    assert err.max() <= RGB_TOL
+    assert (got["at_wt"][:, sel].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+    assert torch.equal(got["valid_mask"][:, sel].cpu(), ref["valid_mask"])
+    assert torch.isfinite(got["rgb"]).all()
+
+
+def test_config5_batch8_against_oracle_pair_by_pair(model, dev, weights):
+    """BASELINE configs[4] at its real batch: 8 pairs of 512x512, 128 samples, all 8 x 262 144 rays in ONE
+    call (128 chunks of 16 384 rays; 16 node tables = 2 GB).  The oracle renders every 2 039th ray (prime) of every pair,
+    pair by pair (its own memory stays that of one pair)."""
+    from oracle import render_ref as orc
+    H, S, B = 512, 128, 8
+    inp = syn.make_inputs(B, H, H, 0, seed=57, full_image=True)
+    z, rel, flow = syn.make_latents(B, H, H, seed=58)
+    R = inp["query"]["uv"].shape[2]
+    sel = torch.arange(0, R, 2039)
+    old_n, old_c = model.npoints, model._engine.chunk_rays
+    model.npoints, model._engine.chunk_rays = S, 16384
+    try:
+        with torch.no_grad():
+            out = model(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=True, flow=to_device(flow, dev))
+            got = {"pixel_val": out["pixel_val"][:, sel].cpu(), "rgb": out["rgb"][:, :, sel].cpu(),
+                   "at_wt": out["at_wt"][:, sel].cpu(), "valid_mask": out["valid_mask"][:, sel].cpu()}
+            finite = bool(torch.isfinite(out["rgb"]).all())
+            del out
+    finally:
+        model.npoints, model._engine.chunk_rays = old_n, old_c
+        model._engine._ws.clear()
+        model._engine.invalidate()                                    # 2 GB of tables, 1 GB of NHWC maps
+        torch.cuda.empty_cache()
+    assert finite
+    worst = 0.0
+    for b in range(B):
+        one = lambda o: ({k: one(v) for k, v in o.items()} if isinstance(o, dict) else
+                         (type(o)(one(v) for v in o) if isinstance(o, (list, tuple)) else o[b:b + 1]))
+        sub = _strided_query(one(inp), sel)
+        zb = [t[2 * b:2 * b + 2] for t in z]
+        fb = tuple(t[b:b + 1] for t in flow) if isinstance(flow, (list, tuple)) else flow[b:b + 1]
+        with torch.no_grad():
+            ref = orc.forward(sub, zb, rel[b:b + 1], fb, True, weights, npoints=S)
+        assert torch.equal(got["pixel_val"][2 * b:2 * b + 2], ref["pixel_val"]), b
+        err = float((got["rgb"][b:b + 1] - ref["rgb"]).abs().max())
+        worst = max(worst, err)
+        assert err <= RGB_TOL, (b, err)
+        assert (got["at_wt"][2 * b:2 * b + 2] - ref["at_wt"]).abs().max() <= 2e-3, b
+        assert torch.equal(got["valid_mask"][b:b + 1], ref["valid_mask"]), b
+    print(f"configs[4] B=8: rgb max-abs vs oracle {worst:.2e} over {B * len(sel)} rays")
+
+
 def test_layer_by_layer_intermediates_against_upstream(dev, weights):
     """RenderEngine(fold_value=False) forms every per-sample tensor of the reference's ordering (CoPoNeRF.py:387-408,
     450-485): compare them ON THE GPU with the upstream model's own intermediates (tests/golden/inter.npz), not only

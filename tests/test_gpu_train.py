@@ -588,6 +588,108 @@ def test_one_launch_adam_equals_library_adam():
 
 
 @pytest.mark.gpu
+def test_one_launch_adam_is_a_torch_optimizer():
+    """the reference checkpoints `optimizer.state_dict()` and drives the learning rate with ExponentialLR(0.95) through
+    its MultiLR wrapper (/root/reference train.py:102-108, wrapper.py:98, 134-136).  OneLaunchAdam: a torch.optim.Optimizer with
+    param_groups a scheduler writes; state_dict() in torch.optim.Adam's layout, loadable by either optimizer; a resumed
+    optimizer continues exactly; parameter versions are bumped by a step (the inference caches are keyed on them)."""
+    from coponerf_amd.optim import OneLaunchAdam
+    dev = torch.device("cuda:0")
+    shapes = [(7,), (130, 3), (2049,), (64, 33)]
+    new = lambda: [torch.nn.Parameter(syn.normal(s, seed=40 + i).to(dev)) for i, s in enumerate(shapes)]
+    mine, ref = new(), new()
+    a = OneLaunchAdam([{"params": mine[:2]}, {"params": mine[2:]}], lr=1e-3)
+    b = torch.optim.Adam([{"params": ref[:2]}, {"params": ref[2:]}], lr=1e-3)
+    assert isinstance(a, torch.optim.Optimizer) and len(a.param_groups) == 2
+    sa, sb = torch.optim.lr_scheduler.ExponentialLR(a, 0.95), torch.optim.lr_scheduler.ExponentialLR(b, 0.95)
+
+    def grads(ps, qs, step):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            if step == 1 and i == 1:
+                p.grad = q.grad = None
+                continue
+            g = syn.normal(shapes[i], seed=100 * step + i).to(dev)
+            p.grad, q.grad = g.clone(), g.clone()
+    for step in range(3):
+        grads(mine, ref, step)
+        v0 = [p._version for p in mine]
+        a.step()
+        b.step()
+        assert all(p._version > v for p, v, in zip(mine, v0) if p.grad is not None), "a step must bump the parameters' versions"
+        sa.step()
+        sb.step()
+        assert a.param_groups[0]["lr"] == pytest.approx(b.param_groups[0]["lr"]) and a.lr == pytest.approx(1e-3 * 0.95 ** (step + 1))
+    for p, q in zip(mine, ref):
+        assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-9
+    sd_a, sd_b = a.state_dict(), b.state_dict()
+    assert sd_a["param_groups"][1]["params"] == sd_b["param_groups"][1]["params"] == [2, 3]
+    assert set(sd_a["state"]) == set(sd_b["state"]) == {0, 1, 2, 3}
+    for k in sd_b["state"]:
+        assert float(sd_a["state"][k]["step"]) == float(sd_b["state"][k]["step"]), k         # index 1 missed one update
+        for name in ("exp_avg", "exp_avg_sq"):
+            x, y = sd_a["state"][k][name], sd_b["state"][k][name]
+            assert x.shape == y.shape and float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()) + 1e-12
+    # resume: a fresh OneLaunchAdam from ITS checkpoint and one from the library's continue like the library's
+    cont = []
+    for sd in (sd_a, sd_b):
+        ps = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+        o = OneLaunchAdam([{"params": ps[:2]}, {"params": ps[2:]}], lr=123.0)
+        o.load_state_dict(sd)
+        assert o.lr == pytest.approx(a.lr) and o.steps.tolist() == [3, 2, 3, 3]
+        cont.append((ps, o))
+    lib = torch.optim.Adam([{"params": ref[:2]}, {"params": ref[2:]}], lr=1.0)
+    lib.load_state_dict(sd_a)                                                 # and the library's Adam reads ours
+    for step in (3, 4):
+        for ps, o in cont:
+            grads(ps, ref, step)
+            o.step()
+        lib.step()
+        for ps, _ in cont:
+            for p, q in zip(ps, ref):
+                assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-9
+    a.param_groups[1]["lr"] = 0.5
+    with pytest.raises(NotImplementedError):
+        grads(mine, ref, 5)
+        a.step()
+
+
+@pytest.mark.gpu
+def test_eval_after_training_sees_the_updated_weights():
+    """the loop validates between training steps (/root/reference wrapper.py:134, 178-188).  Every
+    derived-weight cache of the inference path is keyed on the parameters' versions, and the one-launch optimizer writes
+    them through raw pointers: eval, train k steps, eval again must render the second image with the NEW weights - i.e.
+    equal to a fresh model that loads the trained state_dict."""
+    from coponerf_amd import CoPoNeRF
+    from coponerf_amd.train_step import TrainStep
+    dev = torch.device("cuda:0")
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes), strict=True)
+    model = model.to(dev)
+    inp = to_device(syn.make_inputs(1, 256, 256, 128, seed=61), dev)
+
+    def evaluate(m):
+        m.eval()
+        with torch.no_grad():
+            z, rel, flow = m.get_z(inp)
+            out = m(inp, z=z, rel_pose=rel, val=True, flow=flow)
+        return out["rgb"].clone(), rel.clone()
+    rgb0, rel0 = evaluate(model)
+    model.train()
+    step = TrainStep(model, lr=2e-3)
+    for _ in range(3):
+        r = step(inp, inp["query"]["rgb"])
+    assert bool(r["stepped"])
+    rgb1, rel1 = evaluate(model)
+    fresh = CoPoNeRF.CoPoNeRF(n_view=2)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    rgb2, rel2 = evaluate(fresh.to(dev))
+    assert float((rgb1 - rgb0).abs().max()) > 1e-4, "three steps at lr 2e-3 must move the image"
+    assert float((rgb1 - rgb2).abs().max()) <= 2e-6, float((rgb1 - rgb2).abs().max())
+    assert float((rel1 - rel2).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
 def test_train_step_guards_on_the_device():
     """TrainStep on one device (no exchange): the finite-gradient guard and the clip coefficient stay on the device, the
     update kernel is gated by the flag.  A step whose gradients hold a NaN changes nothing (parameters, moments, counts)
