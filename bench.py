@@ -137,6 +137,10 @@ def measure_train(args, dev, rank, world, steps, warmup):
     res = {"rays_per_s": rays, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
            "pairs_per_gpu": B, "rays_per_pair": R, "samples": S, "n_gpus": world,
            "collectives_per_step": info["collectives"], "allreduce_bytes_per_step": info["allreduce_bytes"],
+           # ranks whose gradients were exchanged over RCCL in the timed steps (1: no exchange ran) and device -> host reads
+           # the step makes (the guard flag gates the update kernel on the device, with or without an exchange)
+           "rccl_ranks": world if distributed else 1, "host_reads_per_step": info["host_reads"],
+           "gradient_mask_exchanges": info["mask_exchanges"],
            "broadcast_collectives": nbcast, "stepped": bool(info["stepped"]), "loss": float(info["loss"]),
            "phases_ms": phases, "peak_mem_GB": max(0.0, torch.cuda.max_memory_allocated(dev) - resident) / 2 ** 30,
            # forward + backward ~ 3x the forward's algorithmic FLOPs; get_z 227.8 GFLOP per pair

@@ -162,6 +162,110 @@ def average_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 
     return len(handles)
 
 
+class DeviceExchange:
+    """The gradient exchange of a training step WITHOUT a device -> host read (round 5; `average_gradients` + `guard_and_clip`
+    above read the MIN-reduced flag with `.item()` and the has-gradient mask with `.tolist()` every step, i.e. the host waits
+    for the end of the backward pass twice and the GPU idles while it catches up):
+
+      * which parameters take part - the union over the ranks of "has a gradient" (wrapper.py:26 skips None) - is agreed
+        HOST to host over a gloo side group (a 636-entry CPU all-reduce; with the main group on gloo, that group itself),
+        and only when some rank's own mask differs from the one it had at the last agreement: one 1-entry CPU vote per step
+        otherwise.  The mask is a property of the loss configuration: in practice it is exchanged once;
+      * the finite flag is MIN-all-reduced as a device scalar and GATES the update kernel (optim.OneLaunchAdam.step(gate));
+      * the gradients are packed (x the rank's own clip coefficient: the reference clips BEFORE it averages, wrapper.py:142-148)
+        into persistent flat buckets - one `_foreach_copy_` + one multiply per bucket, no `torch.cat` - summed by one
+        asynchronous all-reduce per bucket, and handed to the optimizer AS views of those buckets with 1 / world as its
+        gradient scale: no copy back.
+    A rank that lacks a gradient of the union contributes zeros and receives the average, so all replicas update the same
+    parameters.  `host_reads` counts device -> host reads made here (none in steady state)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None, force: bool = False):
+        self.params = list(params)
+        self.bucket_bytes, self.group, self.force = int(bucket_bytes), group, bool(force)
+        self.active = _exchanging(group, force)
+        self.host_reads = 0
+        self.mask_exchanges = 0
+        self._local = None                         # this rank's mask at the last agreement
+        self._union: List[bool] = []
+        self._flats = []                           # [(flat buffer, [(param index, offset, numel)])]
+        self._views: List = [None] * len(self.params)
+        self._side = None
+        self._inv_world = None
+        if self.active:
+            if dist.get_backend(group) == "gloo":
+                self._side = group
+            else:
+                ranks = dist.get_process_group_ranks(group) if group is not None else None
+                self._side = dist.new_group(ranks=ranks, backend="gloo")       # every rank of the group constructs one
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if self.active else 1
+
+    def agree(self) -> List[bool]:
+        """Host half, callable as soon as the backward pass is ENQUEUED (whether a parameter has a `.grad` is known then)."""
+        local = [p.grad is not None for p in self.params]
+        vote = torch.tensor([0 if local == self._local else 1], dtype=torch.int32)
+        dist.all_reduce(vote, op=dist.ReduceOp.MAX, group=self._side)
+        if int(vote) != 0:
+            mask = torch.tensor(local, dtype=torch.int32)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self._side)
+            self._local, self._union = local, mask.bool().tolist()
+            self.mask_exchanges += 1
+            self._build()
+        return self._union
+
+    def _build(self) -> None:
+        members = [(i, self.params[i]) for i, u in enumerate(self._union) if u]
+        self._flats, self._views = [], [None] * len(self.params)
+        for bucket in _buckets(members, self.bucket_bytes, key=lambda t: t[1]):
+            n = sum(p.numel() for _, p in bucket)
+            flat = torch.zeros(n, dtype=bucket[0][1].dtype, device=bucket[0][1].device)
+            entries, off = [], 0
+            for i, p in bucket:
+                entries.append((i, off, p.numel()))
+                self._views[i] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self._flats.append((flat, entries))
+        dev = members[0][1].device if members else "cpu"
+        self._inv_world = torch.full((), 1.0 / self.world, dtype=torch.float32, device=dev)
+
+    def grad_views(self) -> List:
+        """Per parameter: where its averaged gradient will be (a view of a persistent bucket; None outside the union)."""
+        return self._views
+
+    @property
+    def nbytes(self) -> int:
+        return sum(f.numel() * f.element_size() for f, _ in self._flats)
+
+    def exchange(self, ok: torch.Tensor, coef=None):
+        """ok: this rank's finite flag (fp32 scalar on the gradients' device), coef: its clip coefficient (device scalar) or
+        None.  Returns (ok MIN-reduced over the ranks, 1 / world as a device scalar, collectives issued); afterwards every
+        parameter of the union has `.grad` = its view of the SUM over the ranks of coef_r * grad_r.  Nothing here waits on
+        the host for the device (on RCCL `wait()` orders the streams)."""
+        works = [dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group, async_op=True)]
+        for flat, entries in self._flats:
+            src, dst = [], []
+            for i, _, _ in entries:
+                g = self.params[i].grad
+                if g is None:
+                    self._views[i].zero_()                     # this rank lacks a gradient another rank has
+                elif g.data_ptr() != self._views[i].data_ptr():
+                    src.append(g.detach())
+                    dst.append(self._views[i])
+            if src:
+                torch._foreach_copy_(dst, src)
+            if coef is not None:
+                flat.mul_(coef.to(flat.dtype))
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        for i, v in enumerate(self._views):
+            if v is not None:
+                self.params[i].grad = v
+        return ok, self._inv_world, len(works)
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 64 << 20, group=None,
                          force: bool = False) -> int:
     """Initial weight sync (train.py:58-60), parameters AND floating-point buffers, in flat buckets."""

@@ -137,10 +137,11 @@ class OneLaunchAdam(torch.optim.Optimizer):
         return self.exp_avg[o:o + p.numel()].view_as(p), self.exp_avg_sq[o:o + p.numel()].view_as(p)
 
     @torch.no_grad()
-    def prepare(self) -> None:
+    def prepare(self, grads=None) -> None:
         """Host half of a step: collect the gradient addresses, write the table, start its upload.  Callable as soon as the
         backward pass is ENQUEUED (addresses exist then) — a caller that reads a device flag before it steps does this first,
-        so the ~0.8 ms of Python run under the GPU's backward pass."""
+        so the ~0.8 ms of Python run under the GPU's backward pass.  `grads`: per parameter the tensor the update will
+        read instead of `p.grad` (None: no gradient) — the bucket views of dist.DeviceExchange, known before the exchange ran."""
         i = self._turn & 1
         if self._sent[i] is not None:
             self._sent[i].synchronize()                       # the copy two steps ago read this pinned block
@@ -148,11 +149,12 @@ class OneLaunchAdam(torch.optim.Optimizer):
         n = len(self.params)
         pptr, gptr = np.empty(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
         for j, p in enumerate(self.params):
-            g = p.grad
+            g = p.grad if grads is None else grads[j]
             pptr[j] = p.data_ptr()
             if g is None:
                 continue
             if not (g.is_contiguous() and g.dtype == torch.float32):
+                assert grads is None, "OneLaunchAdam.prepare: explicit gradient tensors must be fp32 and contiguous"
                 g = p.grad = g.contiguous().float()
             gptr[j] = g.data_ptr()
         seg["p"], seg["g"] = pptr, gptr                       # (step size / bias corrections: formed on the device from its counts)

@@ -69,6 +69,7 @@ class TrainStep:
         self._good = 0
         eng = getattr(model, "_engine", None)
         self._scale_ceiling = float(eng.grad_scale_target) if eng is not None else 0.0
+        self._exchange = None                                            # dist.DeviceExchange, built at the first exchanging step
         self._pending = collections.deque()                              # `stepped` flags of steps guarded on the device
         self._flag_host = [torch.zeros(1).pin_memory() for _ in range(4)] if on_gpu else None
         self._flag_turn = 0
@@ -97,12 +98,27 @@ class TrainStep:
         # the flag and multiplies the coefficient in — so the host never waits for the backward pass (behind a `.item()` it
         # is no longer ahead of the GPU, and everything it does until the next step's first launch is GPU idle time: 0.4-0.9 ms
         # per step depending on the host)
-        on_device = self._one_launch and not cdist._exchanging(self.group, self.force_collectives)
+        exchanging = cdist._exchanging(self.group, self.force_collectives)
+        on_device = self._one_launch
         ncoll, nbytes = 0, 0
+        if exchanging and self._exchange is None:
+            self._exchange = cdist.DeviceExchange(self.params, self.bucket_bytes, self.group, self.force_collectives)
+        ex = self._exchange if exchanging else None
         if on_device:
-            self.opt.prepare()
+            # N > 1 is as host-free as N = 1 (round 5): the union of the ranks' gradient masks is agreed host to host (a CPU
+            # vote over gloo), the finite flag is MIN-reduced ON THE DEVICE and gates the update, the buckets are persistent
+            # and the optimizer reads the averaged gradients in place (dist.DeviceExchange)
+            if ex is not None:
+                ex.agree()
+                self.opt.prepare(grads=ex.grad_views())
+            else:
+                self.opt.prepare()
             ok, _, coef = cdist.guard_on_device(self.params, float(self.clip_grad or 0.0))
-            e3 = e4 = self._ev() if timed else None
+            e3 = self._ev() if timed else None
+            if ex is not None:
+                ok, inv_world, ncoll = ex.exchange(ok, coef)
+                nbytes, coef = ex.nbytes, inv_world
+            e4 = self._ev() if timed else None
             self.opt.step(gscale=coef, gate=ok)
             host = self._flag_host[self._flag_turn & 3]
             self._flag_turn += 1
@@ -112,28 +128,29 @@ class TrainStep:
             stepped = _LazyFlag(host, ev)
             self._pending.append(stepped)
         else:
-            if self._one_launch:
-                self.opt.prepare()        # under the backward pass; the exchange averages INTO the same gradient tensors
-            stepped, _ = cdist.guard_and_clip(self.params, float(self.clip_grad or 0.0), group=self.group,
-                                              force=self.force_collectives)
+            # parameters on the CPU (the gloo tests) / a stock optimizer without a gate: the same exchange, then the flag is
+            # read where reading it costs nothing
+            ok, _, coef = cdist.guard_on_device(self.params, float(self.clip_grad or 0.0))
+            e3 = self._ev() if timed else None
+            grads = [p.grad for p in self.params if p.grad is not None]
+            if ex is not None:
+                ex.agree()
+                ok, inv_world, ncoll = ex.exchange(ok, coef)
+                nbytes, coef = ex.nbytes, inv_world
+                grads = [p.grad for p in self.params if p.grad is not None]
+            e4 = self._ev() if timed else None
+            stepped = bool(ok.item() > 0)
             if stepped:
-                e3 = self._ev() if timed else None
-                ncoll = cdist.average_gradients(self.params, bucket_bytes=self.bucket_bytes, group=self.group,
-                                                force=self.force_collectives)
-                if ncoll:
-                    nbytes = sum(p.grad.numel() * p.grad.element_size() for p in self.params if p.grad is not None)
-                e4 = self._ev() if timed else None
+                if coef is not None and grads:
+                    torch._foreach_mul_(grads, coef)
                 self.opt.step()
-            else:
-                e3 = e4 = self._ev() if timed else None
-                if self._one_launch:
-                    self.opt.discard()
             self._adapt_grad_scale(stepped)
         self.opt.zero_grad(set_to_none=True)
         e5 = self._ev() if timed else None
         if timed:
             self.timing.setdefault("events", []).append((e0, e1, e2, e3, e4, e5))
         return {"loss": loss.detach(), "stepped": stepped, "collectives": ncoll, "allreduce_bytes": nbytes,
+                "host_reads": 0 if on_device else 1, "mask_exchanges": 0 if ex is None else ex.mask_exchanges,
                 "at_wt": out["at_wt"].detach(), "skipped_in_a_row": self.skipped_in_a_row}
 
     def _adapt_grad_scale(self, stepped: bool) -> None:

@@ -113,7 +113,10 @@ class _TinyRenderer(torch.nn.Module):
     def forward(self, inp, val=False):
         uv = inp["query"]["uv"]
         h = torch.tanh(self.a(uv / 64.0))
-        return {"rgb": self.b(h) * inp["scale"], "at_wt": h.detach()[..., :1]}
+        rgb = self.b(h) * inp["scale"]
+        if inp.get("use_extra"):                             # a loss term only some ranks have (their gradient masks differ)
+            rgb = rgb + 0.1 * self.unused(h[..., :4])[..., :3]
+        return {"rgb": rgb, "at_wt": h.detach()[..., :1]}
 
 
 def _train_worker(rank, world, port, q):
@@ -153,9 +156,21 @@ def _train_worker(rank, world, port, q):
     info_bad = step(bad, gt)
     unchanged = all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
     info_ok = step(batch, gt)                                # and training goes on afterwards
+    masks_so_far = int(info_ok["mask_exchanges"])            # the has-gradient union was agreed ONCE in three steps
+    # rank 1 alone gains a gradient (`unused` enters its loss): its vote re-opens the agreement on BOTH ranks, rank 0
+    # contributes zeros and receives the average - the replicas stay identical; afterwards the mask is cached again
+    extra = dict(batch, use_extra=(rank == 1))
+    before_unused = model.unused.weight.detach().clone()
+    info_x = step(extra, gt)
+    info_x2 = step(extra, gt)
+    w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    both = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(both, w)
+    mask_ok = (masks_so_far == 1 and int(info_x["mask_exchanges"]) == 2 and int(info_x2["mask_exchanges"]) == 2
+               and bool(torch.equal(both[0], both[1])) and not torch.equal(before_unused, model.unused.weight.detach()))
     q.put((rank, float(info["loss"]), bool(info["stepped"]), int(info["collectives"]), same, replicas_equal,
            bool(info_bad["stepped"]), unchanged, int(info_bad["skipped_in_a_row"]), bool(info_ok["stepped"]),
-           int(info_ok["skipped_in_a_row"]), all(p.grad is None for p in model.parameters())))
+           int(info_ok["skipped_in_a_row"]), all(p.grad is None for p in model.parameters()), mask_ok))
     dist.destroy_process_group()
 
 
@@ -170,8 +185,8 @@ def test_train_step_world2_matches_reference_semantics_and_skips_together():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, loss, stepped, ncoll, same, replicas_equal, bad_stepped, unchanged, skipped, ok_stepped, skipped_after, cleared in res:
-        assert stepped and ncoll >= 1 and same and replicas_equal, res
+    for rank, loss, stepped, ncoll, same, replicas_equal, bad_stepped, unchanged, skipped, ok_stepped, skipped_after, cleared, mask_ok in res:
+        assert stepped and ncoll >= 1 and same and replicas_equal and mask_ok, res
         assert bad_stepped is False and unchanged and skipped == 1, res          # BOTH ranks, though only rank 1 saw the NaN
         assert ok_stepped and skipped_after == 0 and cleared, res
     assert res[0][1] != res[1][1]                                                # the ranks really trained on different data

@@ -48,7 +48,16 @@ def _worker(rank, world, port, q):
             continue
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         ok &= bool(torch.allclose(p.grad, g / world, rtol=1e-5, atol=1e-8))
-    w0 = model.query_encode_latent.weight.detach().clone()
+    # two whole TrainSteps through dist.DeviceExchange (device-side flag, persistent buckets, gradients read in place):
+    # the replicas hold identical weights afterwards, no device -> host read was made
+    from coponerf_amd.train_step import TrainStep
+    model.zero_grad(set_to_none=True)
+    step = TrainStep(model)
+    r1 = step(inp, inp["query"]["rgb"])
+    r2 = step(inp, inp["query"]["rgb"])
+    ok &= bool(r1["stepped"]) and bool(r2["stepped"]) and r2["host_reads"] == 0 and r2["mask_exchanges"] == 1
+    w0 = torch.cat([p.detach().reshape(-1) for p in (model.query_encode_latent.weight, model.phi.lin_out.weight,
+                                                      model.conv_map.weight)])
     gathered = [torch.zeros_like(w0) for _ in range(world)]
     dist.all_gather(gathered, w0)
     q.put((rank, bool(ok), ncoll, bool(torch.equal(gathered[0], gathered[1]))))
@@ -110,8 +119,14 @@ def _worker_world1(port, q):
     r1 = step(inp, inp["query"]["rgb"])
     r2 = step(inp, inp["query"]["rgb"])
     torch.cuda.synchronize()
-    q.put(dict(nb=nb, same_after_bcast=same_after_bcast, finite=finite, ncoll=ncoll, ident=ident,
-               stepped=(r1["stepped"], r2["stepped"]), collectives=r1["collectives"], nbytes=r1["allreduce_bytes"],
+    # the step with the exchange is as host-free as the step without it (dist.DeviceExchange): the flags come back lazily,
+    # no device -> host read, the gradient-mask union agreed once
+    from coponerf_amd.train_step import _LazyFlag
+    lazy = isinstance(r1["stepped"], _LazyFlag)
+    w_ex = model.query_encode_latent.weight.detach().clone()
+    q.put(dict(nb=nb, same_after_bcast=same_after_bcast, finite=finite, ncoll=ncoll, ident=ident, lazy=lazy,
+               host_reads=(r1["host_reads"], r2["host_reads"]), mask_exchanges=r2["mask_exchanges"],
+               stepped=(bool(r1["stepped"]), bool(r2["stepped"])), collectives=r1["collectives"], nbytes=r1["allreduce_bytes"],
                losses=(float(r1["loss"]), float(r2["loss"])),
                moved=not torch.equal(before, model.query_encode_latent.weight.detach())))
     dist.barrier()
@@ -142,4 +157,5 @@ def test_rccl_world1_forced_exchange_runs_on_device():
     assert res["nb"] >= 1 and res["same_after_bcast"] and res["finite"] and res["ident"]
     assert res["ncoll"] >= 5                             # ~143 MB of gradients in 16 MB buckets
     assert all(res["stepped"]) and res["collectives"] >= 2 and res["nbytes"] > 100e6 and res["moved"]
+    assert res["lazy"] and res["host_reads"] == (0, 0) and res["mask_exchanges"] == 1
     assert all(l == l and l < 10 for l in res["losses"])
