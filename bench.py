@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-tables", action="store_true",
                     help="first encoder layer as gather + 835->832 GEMM instead of the projected-table form")
     ap.add_argument("--no-image", action="store_true", help="skip the secondary image-pipeline figures (get_z + render)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the reference-arithmetic (fp32-operand) pass of the same step")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-two-stream-pass", action="store_true",
                     help="skip the second timed pass with consecutive calls on two streams (keeps a rocprofv3 kernel "
@@ -288,6 +289,31 @@ def run(args):
         with torch.no_grad():
             step()                                              # back to the headline pair (re-primes its caches)
 
+    # ---- the same step in the reference's arithmetic: fp32 operands in every per-sample layer (RenderEngine.precision = "f32":
+    #      exact fp32 MFMA, layer by layer, nothing fused) - the same-precision number beside the headline, and how far the
+    #      fp16-operand image is from it.  One untimed + one timed step (it is ~40 x slower).
+    f32 = None
+    if B == 1 and not args.pair_by_pair and not args.no_f32 and world == 1:
+        eng = model._engine
+        rgb16 = out["rgb"].clone()
+        eng.precision = "f32"
+        try:
+            step()
+            _fence(distributed)
+            t0 = time.perf_counter()
+            o32 = step()
+            _fence(distributed)
+            f32 = {"seconds_per_step": time.perf_counter() - t0,
+                   "rgb_max_abs_f16_vs_f32": float((rgb16 - o32["rgb"]).abs().max())}
+            f32["rays_per_s_f32"] = rays_per_step / f32["seconds_per_step"]
+            del o32
+        finally:
+            eng.precision = "f16"
+            for k in [k for k in eng._ws if "f32." in k]:
+                del eng._ws[k]                                  # ~10 GB of fp32 chunk buffers
+            eng._m32 = None
+            torch.cuda.empty_cache()
+
     value = rays_per_step * world * args.steps / elapsed
     tables = model._engine.tables
     # executed FLOPs per ray: value/key projections folded; with tables the 3 x 256 coarse channels
@@ -316,6 +342,9 @@ def run(args):
         # a new pair every step (tables, NHWC copies, camera upload and flow products rebuilt inside the timed region)
         "rays_per_s_fresh_pair": None if fresh is None else rays_per_step * world * args.steps / fresh,
         "ms_per_step_fresh_pair": None if fresh is None else 1e3 * fresh / args.steps,
+        # the reference's arithmetic (fp32 operands, layer by layer) on the same workload, and the image's distance from it
+        "rays_per_s_f32": None if f32 is None else f32["rays_per_s_f32"],
+        "rgb_max_abs_f16_vs_f32": None if f32 is None else f32["rgb_max_abs_f16_vs_f32"],
         "path_tflops": value * f_ray(S) / 1e12,          # algorithmic FLOPs of the reference formulation
         "executed_tflops": value * exec_per_ray / 1e12,  # what the kernels execute after the restructurings
     }

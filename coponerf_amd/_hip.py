@@ -40,6 +40,8 @@ SIGNATURES: Dict[str, List] = {
     "cpn_gemm_f16_fewrows": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "cpn_attend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_attend_hidden": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_attend_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_gather_rows_f32": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "cpn_attend_value": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_linear_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],

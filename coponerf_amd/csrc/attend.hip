@@ -104,6 +104,73 @@ __global__ __launch_bounds__(256) void attend_kernel(const __half* __restrict__ 
     }
 }
 
+// The same round with fp32 query operands (round 5, RenderEngine(precision="f32"): every per-sample layer in fp32 - the
+// reference's arithmetic - as an opt-in verification mode): logits from (rows,128) fp32 matrices, everything else as above.
+__global__ __launch_bounds__(256) void attend_f32_kernel(const float* __restrict__ qa, const float* __restrict__ qb,
+                                                         const float* __restrict__ value, const float* __restrict__ zprev,
+                                                         int V, int R, int S, int ray0, float* __restrict__ zout,
+                                                         float* __restrict__ at_wt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wts = reinterpret_cast<float*>(smem_raw);
+    float* red = wts + V * S;
+    const int T = V * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long lray = blockIdx.x;
+    const size_t row0 = (size_t)lray * T;
+    float lmax = -INFINITY;
+    for (int base = 0; base < T; base += 8) {                  // 32 lanes per row, 4 floats each
+        const int row = base + (tid >> 5);
+        const int rr = row < T ? row : T - 1;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(qa + (row0 + rr) * 128 + (tid & 31) * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(qb + (row0 + rr) * 128 + (tid & 31) * 4);
+        float acc = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (row < T) {
+            const float logit = acc / 11.31f;
+            if ((tid & 31) == 0) wts[row] = logit;
+            lmax = fmaxf(lmax, logit);
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+    for (int row = tid; row < T; row += 256) {
+        const float e = __expf(wts[row] - gmax);
+        wts[row] = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    for (int row = tid; row < T; row += 256) {
+        const float w = wts[row] * inv;
+        wts[row] = w;
+        if (at_wt) {
+            const unsigned ray = (unsigned)ray0 + (unsigned)lray;
+            const int b = (int)(ray / (unsigned)R), r = (int)(ray % (unsigned)R);
+            const int v = row / S, s = row - v * S;
+            at_wt[(((size_t)(b * V + v)) * R + r) * S + s] = w;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < CH; c += 256) {
+        float total = 0.f;
+        for (int v = 0; v < V; ++v) {
+            float acc = 0.f;
+            const float* vp = value + (row0 + (size_t)v * S) * CH + c;
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) acc += wts[v * S + s] * vp[(size_t)s * CH];
+            if (zprev) acc += zprev[(size_t)lray * CH + c];
+            total += acc;
+        }
+        zout[(size_t)lray * CH + c] = total;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Folded variant: there is no non-linearity between query_encode_latent_2 and latent_value
 // (CoPoNeRF.py:387-404) and the softmax weights of a ray sum to 1, so
@@ -348,6 +415,20 @@ extern "C" int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* v
     hipLaunchKernelGGL(attend_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream, (const __half*)qa,
                        (const __half*)qb, value, zprev, V, R, S, ray0, zout, at_wt);
     CPN_LAUNCH_CHECK("cpn_attend");
+    return 0;
+}
+
+extern "C" int cpn_attend_f32(const float* qa, const float* qb, const float* value, const float* zprev, int B, int V, int R,
+                              int S, int ray0, int nrays, float* zout, float* at_wt, void* stream) {
+    CPN_REQUIRE(qa && qb && value && zout, CPN_E_ARG, "cpn_attend_f32: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && V * S <= 4096, CPN_E_SHAPE, "cpn_attend_f32: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_attend_f32: ray range outside B*R");
+    CPN_REQUIRE(((uintptr_t)qa % 16) == 0 && ((uintptr_t)qb % 16) == 0, CPN_E_ARG, "cpn_attend_f32: operands must be 16-byte aligned");
+    const size_t lds = (size_t)(V * S + 8) * sizeof(float);
+    hipLaunchKernelGGL(attend_f32_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream, qa, qb, value, zprev, V, R, S, ray0,
+                       zout, at_wt);
+    CPN_LAUNCH_CHECK("cpn_attend_f32");
     return 0;
 }
 

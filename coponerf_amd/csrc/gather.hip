@@ -462,6 +462,69 @@ extern "C" int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Reference-arithmetic form of the gather (round 5, RenderEngine(precision="f32")): fp32 maps (NHWC), fp32 rows, the four
+// taps summed in ATen's order (nw, ne, sw, se) without contraction into the fp16 pipeline.  A plain kernel - thread = 4
+// channels of one row - for an opt-in verification mode, not for speed.  Row layout as cpn_gather_rows: 832 features |
+// tanh(pt/5) (3) | zeros up to ld.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(
+    const float* __restrict__ map0, const float* __restrict__ map1, const float* __restrict__ map2,
+    const float* __restrict__ map3, int H, int W, const float* __restrict__ pixel_val, const float* __restrict__ sec_grid,
+    const float* __restrict__ pe6, int V, int R, int S, int ray0, long long nrows2, float* __restrict__ xin, int ld) {
+    const int quads = ld >> 2;                                         // 4-channel groups per row
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = gid / quads;
+    if (row >= nrows2) return;
+    const int c0 = (int)(gid - row * quads) * 4;
+    const int j = (int)(row & 1);
+    long long t = row >> 1;
+    const int s = (int)(t % S); t /= S;
+    const int v = (int)(t % V); t /= V;
+    const long long ray = (long long)ray0 + t;
+    const int b = (int)(ray / R), r = (int)(ray % R);
+    const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + s;
+    float* o = xin + (size_t)row * ld + c0;
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < 832) {
+        const int lvl = c0 < 768 ? c0 >> 8 : 3;
+        const int cl = c0 - (lvl == 3 ? 768 : lvl * 256);
+        const int shift = 4 - lvl - (lvl == 3);
+        const int Hl = H >> shift, Wl = W >> shift, C = lvl == 3 ? 64 : 256;
+        const float* base = lvl == 0 ? map0 : lvl == 1 ? map1 : lvl == 2 ? map2 : map3;
+        const float2 g = *reinterpret_cast<const float2*>((j == 0 ? pixel_val : sec_grid) + sidx * 2);
+        const int img = b * V + (j == 0 ? v : (V - 1 - v));
+        const Taps tp = make_taps(g.x, g.y, Wl, Hl, j == 0);
+        const float* m = base + (size_t)img * Hl * Wl * C + cl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 tex = *reinterpret_cast<const f32x4*>(m + (size_t)tp.off[k] * C);
+            out += tex * tp.w[k];
+        }
+    } else if (c0 == 832) {
+        const float* pe = pe6 + sidx * 6 + j * 3;
+        out = f32x4{pe[0], pe[1], pe[2], 0.f};
+    }
+    *reinterpret_cast<f32x4*>(o) = out;
+}
+
+extern "C" int cpn_gather_rows_f32(const float* map0, const float* map1, const float* map2, const float* map3, int H, int W,
+                                   const float* pixel_val, const float* sec_grid, const float* pe6, int B, int V, int R, int S,
+                                   int ray0, int nrays, float* xin, int ld, void* stream) {
+    CPN_REQUIRE(map0 && map1 && map2 && map3 && pixel_val && sec_grid && pe6 && xin, CPN_E_ARG, "cpn_gather_rows_f32: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && W >= 16 && (H % 16) == 0 && (W % 16) == 0 && ld >= 836 && (ld % 4) == 0,
+                CPN_E_SHAPE, "cpn_gather_rows_f32: need V==2, H,W multiples of 16, ld >= 836 and a multiple of 4");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_gather_rows_f32: ray range outside B*R");
+    const long long nrows2 = (long long)nrays * V * S * 2;
+    const long long total = nrows2 * (ld >> 2);
+    CPN_REQUIRE(total / 256 + 1 < (1LL << 31), CPN_E_SHAPE, "cpn_gather_rows_f32: chunk too large");
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, map0, map1,
+                       map2, map3, H, W, pixel_val, sec_grid, pe6, V, R, S, ray0, nrows2, xin, ld);
+    CPN_LAUNCH_CHECK("cpn_gather_rows_f32");
+    return 0;
+}
+
 extern "C" int cpn_local_hidden(const float* loc8, const float* coords9, const float* w, int ldw, const float* bias,
                                 const float* add, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out,
                                 void* stream) {

@@ -405,6 +405,16 @@ class RenderEngine:
         # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
         # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it
         self.fold_value = bool(fold_value)
+        # precision="f32" (COPONERF_PRECISION=f32; round 5): every per-sample layer with fp32 operands on the exact fp32 MFMA, in
+        # the reference's own order (gather, query_encode_latent(+_2), latent_value, key_map(+_2), query_embed(+_2), both attention
+        # rounds, query_repeat_embed(+_2): models/CoPoNeRF.py:312-485) - the reference's arithmetic on this device.  An opt-in
+        # verification / escape-hatch mode (~40 x slower: fp32 MFMA peaks at 157 TFLOP/s and nothing is fused): the test suite
+        # bounds |rgb_f16 - rgb_f32| with it and bench.py reports it as `rays_per_s_f32` beside the headline.
+        self.precision = os.environ.get("COPONERF_PRECISION", "f16")
+        self.f32_chunk_rays = 4096
+        self._w32key = None
+        self._w32: Dict[str, torch.Tensor] = {}
+        self._m32 = None
         self._wkey = None
         self._w: Dict[str, torch.Tensor] = {}
         self._mkey = None
@@ -441,6 +451,84 @@ class RenderEngine:
             self._ws[name] = t
         return t[:n].view(*shape)
 
+    # ---- the reference-arithmetic mode (precision="f32") ---------------------------------------------------------
+    def _weights_f32(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        key = tuple((id(p), p.data_ptr(), p._version) for p in params.values())
+        if key == self._w32key:
+            return self._w32
+        f = lambda n, rows: params[n + ".weight"].detach().reshape(rows, -1).float().contiguous()
+        b = lambda n: params[n + ".bias"].detach().float().contiguous()
+        w = {}
+        w1 = f("query_encode_latent", 832)                                   # (832, 835) -> K padded to 848 = 53 x 16
+        w["qel.w"] = torch.zeros(832, 848, dtype=torch.float32, device=w1.device)
+        w["qel.w"][:, :835] = w1
+        w["qel.b"] = b("query_encode_latent")
+        for short, name, rows in (("qel2", "query_encode_latent_2", 416), ("val", "latent_value", 416), ("key", "key_map", 128),
+                                  ("key2", "key_map_2", 128), ("qe", "query_embed", 128), ("qe2", "query_embed_2", 128),
+                                  ("qr2", "query_repeat_embed_2", 128)):
+            w[short + ".w"], w[short + ".b"] = f(name, rows), b(name)
+        wr = f("query_repeat_embed", 128)                                    # (128, 144) = [encode_latent(z) 128 | local_coords 16]
+        w["qr.w_z"], w["qr.w_l"], w["qr.b"] = wr[:, :128].contiguous(), wr[:, 128:].contiguous(), b("query_repeat_embed")
+        w["el.w"], w["el.b"] = f("encode_latent", 128), b("encode_latent")
+        self._w32, self._w32key = w, key
+        return w
+
+    def _per_sample_f32(self, pz, wpack, B, R, S, H, W, pixel_val, sec_grid, pe6, loc8, coords9, zl, at_wt, s) -> None:
+        """zl, at_wt of a call with fp32 operands throughout, layer by layer in the reference's order (see __init__)."""
+        params, z = pz
+        w = self._weights_f32(params)
+        dev = zl.device
+        f32 = torch.float32
+        mk = tuple((id(t), t._version) for t in z)
+        if self._m32 is None or self._m32[0] != mk or any(a is not b for a, b in zip(self._m32[1], z)):
+            self._m32 = (mk, tuple(z), [t.detach().float().permute(0, 2, 3, 1).contiguous() for t in z])      # NHWC fp32
+        maps = self._m32[2]
+        T = V * S
+        nray = B * R
+        # local_coords (16 channels, CoPoNeRF.py:411-445) of every sample in row order: [ctx ray dir 3 | 0 0 0 | query dir 3 |
+        # tanh(depth x {1, .1, .01, .001}) 4 | query origin 3] from the per-sample / per-ray pieces cpn_sample_geometry wrote
+        l8 = loc8.view(B, V, R, S, 8).permute(0, 2, 1, 3, 4)                  # (B,R,V,S,8)
+        c9 = coords9.view(B, V, R, 1, 9).permute(0, 2, 1, 3, 4).expand(B, R, V, S, 9)
+        loc16 = torch.cat((l8[..., 0:3], torch.zeros_like(l8[..., 0:3]), c9[..., 0:3], l8[..., 3:7], c9[..., 6:9]), dim=-1)
+        loc16 = loc16.reshape(nray * T, 16).contiguous()
+        C = min(self.f32_chunk_rays, nray)
+
+        def lin(x, ldx, wt, bias, y, ldy, m, n, k, relu, res=None):
+            for n0 in range(0, n, 128):
+                nb = min(128, n - n0)
+                call("cpn_linear_f32", x.data_ptr(), ldx, wt.data_ptr() + n0 * wt.shape[1] * 4, wt.shape[1],
+                     0 if bias is None else bias.data_ptr() + n0 * 4, 0 if res is None else res.data_ptr() + n0 * 4,
+                     0 if res is None else res.shape[1], y.data_ptr() + n0 * 4, ldy, m, nb, k, 0, int(relu), s)
+
+        t = lambda name, shape: self._buf("f32." + name, shape, f32, dev)
+        for ray0 in range(0, nray, C):
+            n = min(C, nray - ray0)
+            rows, rows2 = n * T, n * T * 2
+            xin, hid, enc = t("xin", (rows2, 848)), t("hid", (rows2, 832)), t("enc", (rows2, 416))
+            call("cpn_gather_rows_f32", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, W,
+                 pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, ray0, n, xin.data_ptr(), 848, s)
+            lin(xin, 848, w["qel.w"], w["qel.b"], hid, 832, rows2, 832, 848, True)
+            lin(hid, 832, w["qel2.w"], w["qel2.b"], enc, 416, rows2, 416, 832, False)
+            value, kh, key2 = t("value", (rows, 416)), t("kh", (rows, 128)), t("key2", (rows, 128))
+            lin(enc, 832, w["val.w"], w["val.b"], value, 416, rows, 416, 832, False)       # enc viewed as (rows, 832) = [own | other]
+            lin(enc, 832, w["key.w"], w["key.b"], kh, 128, rows, 128, 832, True)
+            lin(kh, 128, w["key2.w"], w["key2.b"], key2, 128, rows, 128, 128, False)
+            lc = loc16[ray0 * T:(ray0 + n) * T]
+            hq, ce = t("hq", (rows, 128)), t("ce", (rows, 128))
+            lin(lc, 16, w["qe.w"], w["qe.b"], hq, 128, rows, 128, 16, True)
+            lin(hq, 128, w["qe2.w"], w["qe2.b"], ce, 128, rows, 128, 128, False)
+            z1, ze, aq = t("z1", (n, 416)), t("ze", (n, 128)), t("aq", (n, 128))
+            call("cpn_attend_f32", key2.data_ptr(), ce.data_ptr(), value.data_ptr(), 0, B, V, R, S, ray0, n, z1.data_ptr(),
+                 at_wt.data_ptr(), s)
+            lin(z1, 416, w["el.w"], w["el.b"], ze, 128, n, 128, 416, False)
+            lin(ze, 128, w["qr.w_z"], None, aq, 128, n, 128, 128, False)
+            aq_rows = aq[:n].repeat_interleave(T, dim=0)                                     # the ray's vector on each of its samples
+            q2 = t("q2", (rows, 128))
+            lin(lc, 16, w["qr.w_l"], w["qr.b"], hq, 128, rows, 128, 16, True, res=aq_rows)
+            lin(hq, 128, w["qr2.w"], w["qr2.b"], q2, 128, rows, 128, 128, False)
+            call("cpn_attend_f32", q2.data_ptr(), ce.data_ptr(), value.data_ptr(), z1.data_ptr(), B, V, R, S, ray0, n,
+                 zl[ray0:ray0 + n].data_ptr(), 0, s)
+
     def invalidate(self) -> None:
         """Drop the packed-weight / feature-map caches.  The caches are keyed on tensor identity and `_version`;
         writes that bypass the version counter (`p.data.copy_`, `dist.broadcast(p.data)`: /root/reference
@@ -452,12 +540,14 @@ class RenderEngine:
         self._l3_hint = None
         self._hostc = None
         self._camc = None
+        self._w32key, self._m32 = None, None
         self.epoch += 1
 
     def __deepcopy__(self, memo):
         # caches, streams and workspace are derived state: a copied model gets a fresh engine with the same settings
         new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables, self.fuse_key, self.project)
         new.grad_scale_target, new.call_lanes, new.lazy_pixel_val = self.grad_scale_target, self.call_lanes, self.lazy_pixel_val
+        new.precision = self.precision
         return new
 
     def _host_inputs(self, *mats):
@@ -838,7 +928,7 @@ class RenderEngine:
         fresh = self._misses != miss0 or seen is None or seen[0] is not base or seen[1] != base._version or \
             uvc.untyped_storage().data_ptr() != uv.untyped_storage().data_ptr()
         self._uv_seen = (base, base._version)
-        pre = (w, maps, tabs, up, self._interval[ikey], uvc, uvs, fp)
+        pre = (w, maps, tabs, up, self._interval[ikey], uvc, uvs, fp, (params, z))
         if side is None:
             self._ws_prefix = ""
             return self._render_body(pre, B, R, S, H, W, dev, debug, inp)
@@ -860,7 +950,7 @@ class RenderEngine:
 
     def _render_body(self, pre, B, R, S, H, W, dev, debug, inp) -> Dict[str, torch.Tensor]:
         """The launches of one render call on the current stream; `pre` = what render() resolved from the caches."""
-        w, maps, tabs, up, interval, uvc, uvs, fp = pre
+        w, maps, tabs, up, interval, uvc, uvs, fp = pre[:8]
         N = B * V
         s = _stream()
         cam = up["cam"]
@@ -1080,7 +1170,9 @@ class RenderEngine:
             stage_sum2(ray0, bf, s)
             stage_out(ray0, bf, s)
 
-        if nlanes == 1:
+        if self.precision == "f32":
+            self._per_sample_f32(pre[8], w, B, R, S, H, W, pixel_val, sec_grid, pe6, loc8, coords9, zl, at_wt, s)
+        elif nlanes == 1:
             bf = lane_buffers(0)
             for ray0 in range(0, nray_total, C):
                 run_chunk(ray0, bf, s)

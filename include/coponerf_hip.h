@@ -159,6 +159,12 @@ long long cpn_encode_table_nodes(int H, int W);
 int cpn_pack_encode_weights(const float* W, int ldw, uint16_t* wfrag, uint16_t* wtab, void* stream);
 int cpn_node_features(const uint16_t* map0, const uint16_t* map1, const uint16_t* map2, int H, int W, int nimg,
                       uint16_t* out, void* stream);
+/* cpn_gather_rows in fp32 (round 5; the reference-arithmetic mode RenderEngine(precision="f32")): maps NHWC fp32 (N,h,w,C), rows
+ * (rays*V*S*2, ld >= 836, ld % 4 == 0) fp32 = 832 features | tanh(pt/5) (3) | zeros; F.grid_sample semantics and row order as
+ * cpn_gather_rows (CoPoNeRF.py:312, 370, 384-394).                                                                     */
+int cpn_gather_rows_f32(const float* map0, const float* map1, const float* map2, const float* map3, int H, int W,
+                        const float* pixel_val, const float* sec_grid, const float* pe6, int B, int V, int R, int S,
+                        int ray0, int nrays, float* xin, int ld, void* stream);
 int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                       const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                       int B, int V, int R, int S, int ray0, int nrays, uint16_t* hid, void* stream);
@@ -220,6 +226,10 @@ int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const
  *   formed them (cpn_gemm_f16_rowdot / cpn_local_mlp with logits_out); then qa, qb may be NULL                 */
 int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const float* logits, const uint16_t* hid, int B, int V,
                       int R, int S, int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream);
+
+/* cpn_attend with fp32 query operands (qa, qb (rays*V*S, 128) fp32) - the reference-arithmetic mode, RenderEngine(precision="f32") */
+int cpn_attend_f32(const float* qa, const float* qb, const float* value, const float* zprev, int B, int V, int R, int S,
+                   int ray0, int nrays, float* zout, float* at_wt, void* stream);
 
 /* ---- K4'': the same joint softmax over the per-sample VALUES of cpn_encode_project (round 5) ----------------
  *   zout[ray] = sum_rows w[row] * val[row] + vbias (+ zprev_scale * zprev[ray] when zprev != NULL: round 2 adds V times the

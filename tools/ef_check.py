@@ -19,18 +19,19 @@ sys.path.insert(0, ROOT)
 BUILD = os.path.join(ROOT, "tools", "_build")
 # tag -> -D flags
 VARIANTS = {
-    "k_w12u1s2": dict(KEY_WAVES=12, KEY_UNITS=1, KEY_SITE=2, STAGE=0),
-    "k_w12u1s2_rot": dict(KEY_WAVES=12, KEY_UNITS=1, KEY_SITE=2, STAGE=0, ROTATE=1),
-    "k_w12u1s2_stage_rot": dict(KEY_WAVES=12, KEY_UNITS=1, KEY_SITE=2, STAGE=1, ROTATE=1),
-    "k_w8u2s2_rot": dict(KEY_WAVES=8, KEY_UNITS=2, KEY_SITE=2, STAGE=0, ROTATE=1),
-    "p_w8u1": dict(PROJ_WAVES=8, PROJ_UNITS=1),
-    "p_w8u1_rot": dict(PROJ_WAVES=8, PROJ_UNITS=1, ROTATE=1),
-    "p_w8u1_dma_rot": dict(PROJ_WAVES=8, PROJ_UNITS=1, STAGE_PROJECT=0, ROTATE=1),
-    "p_w4u2_rot": dict(PROJ_WAVES=4, PROJ_UNITS=2, ROTATE=1),
+    "k_w12u1s2": dict(KEY_WAVES=12, KEY_UNITS=1, KEY_SITE=2),               # the product form
+    "k_w12u1s2_stage": dict(KEY_WAVES=12, KEY_UNITS=1, KEY_SITE=2, STAGE=1),
+    "k_w12u1s1": dict(KEY_WAVES=12, KEY_UNITS=1, KEY_SITE=1),
+    "k_w12u1s2_p1": dict(KEY_WAVES=12, KEY_UNITS=1, KEY_SITE=2, PRIO=1),
+    "k_w8u2s2": dict(KEY_WAVES=8, KEY_UNITS=2, KEY_SITE=2),
+    "k_w8u2s1": dict(KEY_WAVES=8, KEY_UNITS=2, KEY_SITE=1),
+    "p_w8u1": dict(PROJ_WAVES=8, PROJ_UNITS=1),                              # the product form of cpn_encode_project
+    "p_w8u1_dma": dict(PROJ_WAVES=8, PROJ_UNITS=1, STAGE_PROJECT=0),
+    "p_w4u2": dict(PROJ_WAVES=4, PROJ_UNITS=2),
 }
 ABLATIONS = {1: "no table taps", 2: "no hid / val stores", 4: "no K=80 MFMA", 8: "no key/value MFMA + ring reads", 64: "no ring DMA / barrier",
              72: "no ring, no key/value MFMA", 256: "no DMA, barrier kept", 512: "no barrier, DMA kept", 1024: "16 of the step's pieces fetched"}
-ABLATE_TAGS = ()
+ABLATE_TAGS = ("k_w12u1s2", "p_w8u1")
 
 
 def build(only=""):
