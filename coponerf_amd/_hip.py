@@ -29,8 +29,9 @@ SIGNATURES: Dict[str, List] = {
     "cpn_pack_encode_weights": [_P, _I, _P, _P, _P],
     "cpn_node_features": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cpn_encode_hidden": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "cpn_encode_project": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "cpn_encode_project": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "cpn_local_units": [_I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
@@ -149,6 +150,8 @@ def lib() -> ctypes.CDLL:
     handle.cpn_stream_cu_count.restype = ctypes.c_int
     handle.cpn_encode_table_nodes.argtypes = [_I, _I]
     handle.cpn_encode_table_nodes.restype = ctypes.c_longlong
+    handle.cpn_encode_units.argtypes = [_I] * 5
+    handle.cpn_encode_units.restype = ctypes.c_longlong
     handle.cpn_linear_attention_scratch.argtypes = [_I, _I, _I, _I]
     handle.cpn_linear_attention_scratch.restype = ctypes.c_longlong
     handle.cpn_cost_volume_attention_scratch.argtypes = [_I] * 5

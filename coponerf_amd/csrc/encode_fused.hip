@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
     const half8* __restrict__ wfrag, const float* __restrict__ bias, const __half* __restrict__ wring,
     const float* __restrict__ kbias, int V, int R, int S, int ray0, int nrays, int nsblk,
     int groups_per_b, long long group0, long long nunits, __half* __restrict__ hid, __half* __restrict__ kh,
-    __half* __restrict__ val) {
+    __half* __restrict__ val, int kh_units) {
     constexpr bool PROJECT = NV > 0;
     constexpr bool STORE_HID = !PROJECT;
     constexpr int NTOT = KT + NV;                              // accumulator tiles per unit
@@ -207,10 +207,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
         RowId lid[U], mid[U];
         size_t sidx_l[U];
         int hoffA[U], hoffB[U];
-        long long trow0[U];
+        long long trow0[U], uidx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long long uu_raw = x_begin + (long long)it * per_iter + ((long long)wgx * WAVES + wave) * U + u;
+            uidx[u] = uu_raw;
             ulive[u] = uu_raw < x_end;
             const long long uu = ulive[u] ? uu_raw : x_begin;  // a dead unit walks a live unit's addresses with every row masked
             usb[u] = (int)(uu % nsblk);
@@ -413,6 +414,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
                 half8 xb[U][2];                                // ... and as the B operand of the key / value layer
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    if (CPN_EF_ABLATE & 2048) {
+                        // (timing only: the accumulators stay where they are)
+                    } else {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
                             const float t = acc[u][nt][i];
                             acc[u][nt][i] = __int_as_float(__builtin_amdgcn_ds_bpermute(to_ll, __float_as_int(t)));
                         }
+                    }
                     // ---- 4 table taps per row in fp32 on top of it, ReLU, fp16
                     if (!(CPN_EF_ABLATE & 1)) {
 #pragma unroll
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const unsigned sv = src[i];
-                            dst[i] = (unsigned)__builtin_amdgcn_ds_bpermute(to_mfma, (int)sv);
+                            dst[i] = (CPN_EF_ABLATE & 4096) ? sv : (unsigned)__builtin_amdgcn_ds_bpermute(to_mfma, (int)sv);
                         }
                         xb[u][k] = __builtin_bit_cast(half8, dst);
                     }
@@ -557,13 +562,20 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
                 hw[t][0] = w2[0];
                 hw[t][1] = w2[1];
             }
-            __half* kdst = kh + srow * 128 + (g & 1) * 16 + (g >> 1) * 8;
+            // kh_units: the (rows, 128) matrix in UNIT order (include/coponerf_hip.h) - [unit][32-column block q][lane = row of the
+            // unit + 16 * 8-column group][8]: the swapped piece of lane (r, g) is the 8-column group fg = 2 (g & 1) + (g >> 1) of
+            // block q, i.e. exactly the MFMA B fragment the per-sample kernels behind this one read (cpn_local_units), and the
+            // wave's store is 1 KiB of contiguous memory; otherwise row-major rows (64 contiguous bytes per row and store)
+            __half* kdst = kh_units ? kh + ((size_t)uidx[u] * 4 * 64 + (r + 16 * (2 * (g & 1) + (g >> 1)))) * 8
+                                    : kh + srow * 128 + (g & 1) * 16 + (g >> 1) * 8;
+            const bool kstore = kh_units ? ulive[u] : store;
+            const int kstep = kh_units ? 64 * 8 : 32;
 #pragma unroll
             for (int qq = 0; qq < KT / 2; ++qq) {
                 const u32x2 lo = __builtin_amdgcn_permlane16_swap(hw[2 * qq][0], hw[2 * qq + 1][0], false, false);
                 const u32x2 hi = __builtin_amdgcn_permlane16_swap(hw[2 * qq][1], hw[2 * qq + 1][1], false, false);
                 const u32x4 piece = {lo[0], hi[0], lo[1], hi[1]};
-                if (store) *reinterpret_cast<u32x4*>(kdst + qq * 32) = piece;
+                if (kstore) *reinterpret_cast<u32x4*>(kdst + qq * kstep) = piece;
             }
             if constexpr (PROJECT) {
                 __half* vdst = val + srow * (NV * 16) + (g & 1) * 16 + (g >> 1) * 8;
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
 static int encode_fused_launch(bool project, const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                                const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                                const uint16_t* wring, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
-                               uint16_t* hid, uint16_t* kh, uint16_t* val, void* stream, const char* who) {
+                               uint16_t* hid, uint16_t* kh, uint16_t* val, int kh_units, void* stream, const char* who) {
     CPN_REQUIRE(tab && map3 && pixel_val && sec_grid && pe6 && wring && kbias && kh, CPN_E_ARG, "%s: null pointer", who);
     CPN_REQUIRE(project ? (val != nullptr) : (wfrag && bias && hid), CPN_E_ARG, "%s: null pointer", who);
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && W >= 16 && (H % 16) == 0 && (W % 16) == 0,
@@ -632,14 +644,14 @@ static int encode_fused_launch(bool project, const uint16_t* tab, const uint16_t
         hipLaunchKernelGGL((encode_fused_kernel<WV, UN, 26, 0>), dim3(grid), dim3(64 * WV), 0, (hipStream_t)stream,
                            (const __half*)tab, (const __half*)map3, H, W, pixel_val, sec_grid, pe6, (const half8*)wfrag, bias,
                            (const __half*)wring, kbias, V, R, S, ray0, nrays, nsblk, groups_per_b, group0, nunits,
-                           (__half*)hid, (__half*)kh, (__half*)val);
+                           (__half*)hid, (__half*)kh, (__half*)val, kh_units);
     } else {
         constexpr int WV = CPN_EF_KEY_WAVES, UN = CPN_EF_KEY_UNITS;
         const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nunits, WV * UN));
         hipLaunchKernelGGL((encode_fused_kernel<WV, UN, 0, CPN_EF_KEY_SITE>), dim3(grid), dim3(64 * WV), 0, (hipStream_t)stream,
                            (const __half*)tab, (const __half*)map3, H, W, pixel_val, sec_grid, pe6, (const half8*)wfrag, bias,
                            (const __half*)wring, kbias, V, R, S, ray0, nrays, nsblk, groups_per_b, group0, nunits,
-                           (__half*)hid, (__half*)kh, (__half*)val);
+                           (__half*)hid, (__half*)kh, (__half*)val, kh_units);
     }
     CPN_LAUNCH_CHECK(who);
     return 0;
@@ -648,14 +660,24 @@ static int encode_fused_launch(bool project, const uint16_t* tab, const uint16_t
 extern "C" int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                                const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                                const uint16_t* kwring, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
-                               uint16_t* hid, uint16_t* kh, void* stream) {
+                               uint16_t* hid, uint16_t* kh, int kh_units, void* stream) {
     return encode_fused_launch(false, tab, map3, H, W, pixel_val, sec_grid, pe6, wfrag, bias, kwring, kbias, B, V, R, S, ray0,
-                               nrays, hid, kh, nullptr, stream, "cpn_encode_key");
+                               nrays, hid, kh, nullptr, kh_units, stream, "cpn_encode_key");
+}
+
+// units (4 rays x 4 samples of one view) a launch over rays [ray0, ray0 + nrays) walks: the row count / 16 of its unit-order outputs
+extern "C" long long cpn_encode_units(int B, int R, int S, int ray0, int nrays) {
+    if (B <= 0 || R <= 0 || S <= 0 || ray0 < 0 || nrays <= 0 || (long long)ray0 + nrays > (long long)B * R) return -1;
+    const int groups_per_b = (int)cpn_cdiv(R, TG);
+    const int b_lo = ray0 / R, b_hi = (ray0 + nrays - 1) / R;
+    const long long group0 = (long long)b_lo * groups_per_b + (ray0 - b_lo * R) / TG;
+    const long long group1 = (long long)b_hi * groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
+    return (group1 - group0 + 1) * 2 * (long long)cpn_cdiv(S, TSW);
 }
 
 extern "C" int cpn_encode_project(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                                   const float* sec_grid, const float* pe6, const uint16_t* wring, const float* kbias, int B,
-                                  int V, int R, int S, int ray0, int nrays, uint16_t* kh, uint16_t* val, void* stream) {
+                                  int V, int R, int S, int ray0, int nrays, uint16_t* kh, uint16_t* val, int kh_units, void* stream) {
     return encode_fused_launch(true, tab, map3, H, W, pixel_val, sec_grid, pe6, nullptr, nullptr, wring, kbias, B, V, R, S, ray0,
-                               nrays, nullptr, kh, val, stream, "cpn_encode_project");
+                               nrays, nullptr, kh, val, kh_units, stream, "cpn_encode_project");
 }

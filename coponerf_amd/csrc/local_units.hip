@@ -1,0 +1,201 @@
+// K3b/K4 logits in UNIT order (round 5) — the per-sample query / key tails of the two attention rounds on the 16-row units the
+// first-layer kernel works in (4 rays x 4 samples of one view, csrc/encode_fused.hip), so that its 128-wide key hidden layer
+// reaches them as ready MFMA B fragments and the key / coords_embed matrices never exist in row-major form:
+//
+//   mode 0 (round 1, /root/reference models/CoPoNeRF.py:408, 446, 450):
+//       ce    = query_embed_2(ReLU(query_embed(local_coords)))                         -> ce_u (unit order, for round 2)
+//       key   = key_map_2(kh)            kh = cpn_encode_key's unit-order output
+//       logit = <fp16(key), fp16(ce)>                                                   -> logits[row] (row order, for the sums)
+//     replaces cpn_local_mlp (coords_embed) + cpn_gemm_f16_rowdot (key_map_2 + logit): one pass instead of two, kh read as
+//     1 KiB fragments, 2.1 GB of coords_embed written once and read once (round 2) instead of written once and read twice.
+//   mode 1 (round 2, :472-475):
+//       q2    = query_repeat_embed_2(ReLU(W_l . local_coords + b + add[ray]))           add = W_z . encode_latent(z_local)
+//       logit = <fp16(q2), ce_u>                                                        -> logits[row]
+//     = cpn_local_mlp's logits form with the unit row map.
+// Unit order of a (rows, 128) fp16 matrix X: [unit][32-column block p][lane = c + 16 fg][8] holds X[row(unit, c)][32 p + 8 fg .. +8],
+// c = (sample & 3) * 4 + (ray & 3) — a wave's access to one block is 1 KiB of contiguous memory and IS the B operand of
+// v_mfma_f32_16x16x32_f16 for the k block p.  Structure (8 waves share the layer-2 fragments in LDS, first layer on the
+// fp32 MFMA with its bias on the unused K slot, inputs of the next unit requested before the MFMAs of the current one):
+// cpn_local_mlp's (csrc/gather.hip).
+#include <algorithm>
+
+#include "encode_common.h"
+
+namespace {
+
+struct UnitGeo {
+    int V, R, S, ray0, nrays, nsblk, groups_per_b;
+    long long group0, nunits;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void local_units_kernel(
+    const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
+    const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
+    const float* __restrict__ b2, const __half* __restrict__ wk2, int ldwk2, const float* __restrict__ bk2,
+    const __half* __restrict__ kh_u, UnitGeo geo, __half* __restrict__ ce_u, float* __restrict__ logits) {
+    __shared__ __attribute__((aligned(16))) half8 w2l[8 * 4 * 64];                       // [tile t][k block p][lane]
+    __shared__ __attribute__((aligned(16))) half8 wkl[MODE == 0 ? 8 * 4 * 64 : 1];      // key_map_2, same layout
+    __shared__ __attribute__((aligned(16))) float b2s[128];
+    __shared__ __attribute__((aligned(16))) float bks[128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int a = lane & 15, fg = lane >> 4;
+    for (int i = threadIdx.x; i < 8 * 4 * 64; i += 512) {
+        const int l = i & 63, p = (i >> 6) & 3, t = i >> 8;
+        const int ch = (t >> 1) * 32 + ((l & 15) >> 2) * 8 + (t & 1) * 4 + (l & 3);       // output channel of tile row
+        w2l[i] = *reinterpret_cast<const half8*>(w2 + (size_t)ch * ldw2 + p * 32 + (l >> 4) * 8);
+        if constexpr (MODE == 0) wkl[i] = *reinterpret_cast<const half8*>(wk2 + (size_t)ch * ldwk2 + p * 32 + (l >> 4) * 8);
+    }
+    if (threadIdx.x < 128) {
+        b2s[threadIdx.x] = b2[threadIdx.x];
+        bks[threadIdx.x] = MODE == 0 ? bk2[threadIdx.x] : 0.0f;
+    }
+    f32x4 wv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int ch = (t >> 1) * 32 + (a >> 2) * 8 + (t & 1) * 4 + (a & 3);
+        wv[t] = *reinterpret_cast<const f32x4*>(w1 + (size_t)ch * ldw1 + fg * 4);
+        if (fg == 0) wv[t][3] = b1[ch];                        // K slot 3 is unused by the inputs: bias x 1.0
+    }
+    __syncthreads();
+    const unsigned nunits = (unsigned)geo.nunits;
+    const unsigned wave_id = blockIdx.x * 8 + wave, nwaves = gridDim.x * 8;
+    const int V = geo.V, R = geo.R, S = geo.S;
+
+    struct RowIn {
+        f32x4 lv;          // this lane's 4 K entries of the 16-wide input
+        unsigned rayrel;   // ray - ray0 (row of `add`)
+        long long srow;    // row of the (rows, .) arrays in row order; -1: dead row of the unit
+    };
+    // row c of unit uu: the map of encode_fused.hip (uu = ((ray group - group0) * V + v) * nsblk + sample block)
+    auto fetch = [&](unsigned uu) {
+        const int sblk = (int)(uu % (unsigned)geo.nsblk);
+        const int v = (int)((uu / (unsigned)geo.nsblk) % (unsigned)V);
+        const long long gq = geo.group0 + uu / ((unsigned)geo.nsblk * (unsigned)V);
+        const int b = (int)(gq / geo.groups_per_b), rgroup = (int)(gq % geo.groups_per_b);
+        const RowId id = tile_row(a, rgroup, sblk, S, R, b, geo.ray0, geo.nrays);
+        const int r = min(id.r, R - 1), s = min(id.s, S - 1);
+        const size_t nr = ((size_t)(b * V + v)) * R + r;
+        const float* lp = loc8 + (nr * S + s) * 8;
+        const float* c9 = coords9 + nr * 9;
+        RowIn o;
+        const long long rayrel = (long long)b * R + r - geo.ray0;
+        o.rayrel = (unsigned)max(0LL, min(rayrel, (long long)geo.nrays - 1));
+        o.srow = id.live ? (rayrel * V + v) * S + s : -1;
+        if (fg == 0) { const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp); o.lv = f32x4{l0[0], l0[1], l0[2], 1.0f}; }
+        else if (fg == 1) o.lv = f32x4{0.f, 0.f, c9[0], c9[1]};
+        else if (fg == 2) o.lv = f32x4{c9[2], lp[3], lp[4], lp[5]};
+        else o.lv = f32x4{lp[6], c9[6], c9[7], c9[8]};
+        return o;
+    };
+
+    RowIn cur = fetch(wave_id < nunits ? wave_id : 0);
+    for (unsigned uu = wave_id; uu < nunits; uu += nwaves) {
+        const RowIn nxt = fetch(uu + nwaves < nunits ? uu + nwaves : uu);
+        // the other operand of the dot product, as B fragments / accumulator-layout rows: 4 x 1 KiB of contiguous memory
+        half8 cv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(MODE == 0 ? kh_u : ce_u) + ((size_t)uu * 4 + p) * 64 + lane);
+        f32x4 acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1)
+                acc[t] = *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], cur.lv[e], acc[t], 0, 0, 0);
+        // hidden layer -> fp16 B operands: K block p = channels p*32 .. p*32+31, this lane holds fg*8 .. fg*8+7 of it
+        half8 hb[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hb[p][i] = (_Float16)fmaxf(acc[2 * p][i], 0.0f);
+                hb[p][4 + i] = (_Float16)fmaxf(acc[2 * p + 1][i], 0.0f);
+            }
+        f32x4 o2[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            o2[t] = *reinterpret_cast<const f32x4*>(b2s + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                o2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[(t * 4 + p) * 64 + lane], hb[p], o2[t], 0, 0, 0);
+        }
+        const long long srow = cur.srow;
+        cur = nxt;
+        float dsum = 0.0f;
+        if constexpr (MODE == 0) {
+            // coords_embed leaves in unit order as it is (the accumulator layout is the fragment layout), and meets the key:
+            // key_map_2 on the B fragments of kh, in the same accumulator layout
+            half8 ce[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ce[p][i] = (_Float16)o2[2 * p][i];
+                    ce[p][4 + i] = (_Float16)o2[2 * p + 1][i];
+                }
+                reinterpret_cast<half8*>(ce_u)[((size_t)uu * 4 + p) * 64 + lane] = ce[p];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f32x4 k2 = *reinterpret_cast<const f32x4*>(bks + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    k2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wkl[(t * 4 + p) * 64 + lane], cv[p], k2, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dsum += (float)(_Float16)k2[i] * (float)ce[t >> 1][(t & 1) * 4 + i];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dsum += (float)(_Float16)o2[2 * p][i] * (float)cv[p][i];
+                    dsum += (float)(_Float16)o2[2 * p + 1][i] * (float)cv[p][4 + i];
+                }
+        }
+        dsum += __shfl_xor(dsum, 16);
+        dsum += __shfl_xor(dsum, 32);
+        if (srow >= 0 && fg == 0) logits[srow] = dsum;
+    }
+}
+
+}  // namespace
+
+extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
+                               const float* add, const uint16_t* w2, int ldw2, const float* b2, const uint16_t* wk2, int ldwk2,
+                               const float* bk2, const uint16_t* kh_u, int B, int V, int R, int S, int ray0, int nrays,
+                               uint16_t* ce_u, float* logits, void* stream) {
+    CPN_REQUIRE(mode == 0 || mode == 1, CPN_E_ARG, "cpn_local_units: mode must be 0 or 1 (got %d)", mode);
+    CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && ce_u && logits, CPN_E_ARG, "cpn_local_units: null pointer");
+    CPN_REQUIRE(mode == 0 ? (wk2 && bk2 && kh_u) : (add != nullptr), CPN_E_ARG, "cpn_local_units: null pointer for mode %d", mode);
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && ldw1 >= 16 && ldw2 >= 128 && (ldw2 % 8) == 0 &&
+                    (mode == 1 || (ldwk2 >= 128 && (ldwk2 % 8) == 0)), CPN_E_SHAPE, "cpn_local_units: bad shape");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
+                "cpn_local_units: ray range outside B*R");
+    CPN_REQUIRE(((uintptr_t)ce_u % 16) == 0 && ((uintptr_t)kh_u % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wk2 % 16) == 0,
+                CPN_E_ARG, "cpn_local_units: fp16 operands must be 16-byte aligned");
+    UnitGeo geo;
+    geo.V = V; geo.R = R; geo.S = S; geo.ray0 = ray0; geo.nrays = nrays;
+    geo.nsblk = (int)cpn_cdiv(S, TSW);
+    geo.groups_per_b = (int)cpn_cdiv(R, TG);
+    const int b_lo = ray0 / R, b_hi = (ray0 + nrays - 1) / R;
+    geo.group0 = (long long)b_lo * geo.groups_per_b + (ray0 - b_lo * R) / TG;
+    const long long group1 = (long long)b_hi * geo.groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
+    geo.nunits = (group1 - geo.group0 + 1) * V * geo.nsblk;
+    CPN_REQUIRE(geo.nunits * 16 < (1LL << 31), CPN_E_SHAPE, "cpn_local_units: chunk too large for 32-bit indexing");
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(geo.nunits, 8), mode == 0 ? 512 : 1024);
+    if (mode == 0)
+        hipLaunchKernelGGL(local_units_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+                           (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, (const __half*)kh_u, geo, (__half*)ce_u, logits);
+    else
+        hipLaunchKernelGGL(local_units_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+                           (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, (const __half*)kh_u, geo, (__half*)ce_u, logits);
+    CPN_LAUNCH_CHECK("cpn_local_units");
+    return 0;
+}

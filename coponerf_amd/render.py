@@ -180,6 +180,38 @@ def pack_project_ring(wk: torch.Tensor, wv: torch.Tensor, k80blk: torch.Tensor) 
     return torch.cat((frags, blk), dim=2).contiguous()
 
 
+def unit_rows(B: int, R: int, S: int, ray0: int, nrays: int, device=None) -> torch.Tensor:
+    """(units * 16,) int64: for every row slot of a UNIT-order matrix of a launch over rays [ray0, ray0 + nrays) (include/
+    coponerf_hip.h, cpn_encode_key kh_units / cpn_local_units) the row of the row-order matrix it holds - ((ray - ray0) * V + v) * S
+    + s - or -1 for the dead rows of partial units.  Unit u = ((ray group - first group) * V + v) * ceil(S/4) + sample block, row
+    slot c = (sample & 3) * 4 + (ray & 3)."""
+    gpb, nsblk = (R + 3) // 4, (S + 3) // 4
+    b_lo, b_hi = ray0 // R, (ray0 + nrays - 1) // R
+    g0 = b_lo * gpb + (ray0 - b_lo * R) // 4
+    g1 = b_hi * gpb + (ray0 + nrays - 1 - b_hi * R) // 4
+    gq = torch.arange(g0, g1 + 1, device=device).view(-1, 1, 1, 1)
+    v = torch.arange(V, device=device).view(1, -1, 1, 1)
+    sblk = torch.arange(nsblk, device=device).view(1, 1, -1, 1)
+    c = torch.arange(16, device=device).view(1, 1, 1, -1)
+    b, rg = gq // gpb, gq % gpb
+    r, s = rg * 4 + (c & 3), sblk * 4 + (c >> 2)
+    ray = b * R + r
+    live = (r < R) & (s < S) & (ray >= ray0) & (ray < ray0 + nrays)
+    row = ((ray - ray0) * V + v) * S + s
+    return torch.where(live, row, torch.full_like(row, -1)).reshape(-1)
+
+
+def rows_from_unit_order(x: torch.Tensor, B: int, R: int, S: int, ray0: int, nrays: int) -> torch.Tensor:
+    """A (rows, 128) fp16 matrix stored in unit order -> row-major (nrays * V * S, 128)."""
+    idx = unit_rows(B, R, S, ray0, nrays, x.device)
+    units = idx.numel() // 16
+    t = x.reshape(-1)[:units * 16 * 128].reshape(units, 4, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(units * 16, 128)   # [unit][p][fg][c][8]
+    out = torch.zeros(nrays * V * S, 128, dtype=x.dtype, device=x.device)
+    keep = idx >= 0
+    out[idx[keep]] = t[keep]
+    return out
+
+
 def rows_from_frag_order(x: torch.Tensor, rows: int) -> torch.Tensor:
     """A (rows, 128) fp16 matrix stored in the fragment order of cpn_local_mlp (rows_frag = 1) / cpn_gemm_f16_rowdot
     (ldq = 0) - [16-row group][32-column block][lane = row + 16 * 8-column group][8] - back as row-major rows."""
@@ -402,6 +434,10 @@ class RenderEngine:
         self.lanes = max(1, int(lanes))
         self._lane_streams: List[torch.cuda.Stream] = []
         self.ce_frag = os.environ.get("COPONERF_CE_FRAG", "1") != "0"
+        # unit_order=True (round 5; needs the fused key layer): the 128-wide per-sample matrices kh and coords_embed live in the
+        # unit order of the first-layer kernel (include/coponerf_hip.h) and ONE kernel forms coords_embed, key_map_2 and the
+        # round-1 logit (cpn_local_units: cpn_local_mlp + cpn_gemm_f16_rowdot before).  COPONERF_UNIT_ORDER=0: the round-4 stages
+        self.unit_order = os.environ.get("COPONERF_UNIT_ORDER", "1") != "0"
         # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
         # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it
         self.fold_value = bool(fold_value)
@@ -982,6 +1018,7 @@ class RenderEngine:
         # whole-line accesses.  Only where every user of the buffer understands it: the folded path (cpn_attend reads rows)
         ce_frag = self.fold_value and self.ce_frag
         project = self.project and fused_key
+        units = self.unit_order and fused_key
         C = min(self.chunk_rays if self.chunk_rays > 0 else self._auto_chunk(S, dev, nray_total), nray_total)
         T = V * S                       # rows per ray for the attention stage
         GW = dict(self.GEMM_WEIGHTS, key_fold=(128, 1664, 1664), value_fold=(416, 1664, 1664))
@@ -993,8 +1030,10 @@ class RenderEngine:
 
         def lane_buffers(lane):
             t = lambda name, shape, dt: self._buf(f"{name}.{lane}", shape, dt, dev)
-            bufs = {  # coords_embed: whole 16-row groups (the fragment-order stores write them whole)
-                    "ce": t("ce", ((C * T + 15) // 16 * 16, 128), f16), "lg": t("lg", (C * T,), f32),
+            # coords_embed: whole 16-row groups (the fragment-order stores write them whole); in unit order: 16 rows per unit
+            # incl. the dead rows of partial units (at most one ray group more per batch element and chunk edge)
+            rows128 = ((C + 3) // 4 + B + 1) * V * ((S + 3) // 4) * 16 if units else (C * T + 15) // 16 * 16
+            bufs = {"ce": t("ce", (rows128, 128), f16), "lg": t("lg", (C * T,), f32),
                     "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
             if not self.tables:
@@ -1004,7 +1043,7 @@ class RenderEngine:
             else:
                 bufs["hid"] = t("hid", (C * T * 2, 832), f16)
             if fused_key:
-                bufs["khf"] = t("khf", (C * T, 128), f16)
+                bufs["khf"] = t("khf", (rows128 if units else C * T, 128), f16)
             if not self.fold_value:
                 bufs["enc"] = t("enc", (C * T, 832), f16)
                 bufs["value"] = t("value", (C * T, 416), f32)
@@ -1045,12 +1084,12 @@ class RenderEngine:
                 if project:
                     call("cpn_encode_project", tabs[0].data_ptr(), maps[3].data_ptr(), H, W, pixel_val.data_ptr(),
                          sec_grid.data_ptr(), pe6.data_ptr(), w["proj.ring"].data_ptr(), w["key_fold.b"].data_ptr(),
-                         B, V, R, S, ray0, n, bf["khf"].data_ptr(), bf["val"].data_ptr(), s)
+                         B, V, R, S, ray0, n, bf["khf"].data_ptr(), bf["val"].data_ptr(), int(units), s)
                 elif fused_key:
                     call("cpn_encode_key", tabs[0].data_ptr(), maps[3].data_ptr(),
                          H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
                          w["query_encode_latent.b"].data_ptr(), w["key_fold.wpk"].data_ptr(), w["key_fold.b"].data_ptr(),
-                         B, V, R, S, ray0, n, hid.data_ptr(), bf["khf"].data_ptr(), s)
+                         B, V, R, S, ray0, n, hid.data_ptr(), bf["khf"].data_ptr(), int(units), s)
                 else:
                     call("cpn_encode_hidden", tabs[0].data_ptr(), maps[3].data_ptr(),
                          H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), w["enc.frag"].data_ptr(),
@@ -1074,6 +1113,8 @@ class RenderEngine:
         def stage_embed(ray0, bf, s):
             """M1: coords_embed = query_embed_2(ReLU(query_embed(local_coords)))  [CoPoNeRF.py:446]"""
             n = min(C, nray_total - ray0)
+            if units:
+                return                                          # coords_embed is formed with the round-1 logit (stage_logits)
             call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
                  w["query_embed.b"].data_ptr(), 0, w["query_embed_2.w16"].data_ptr(), 128,
                  w["query_embed_2.b"].data_ptr(), B, V, R, S, ray0, n, bf["ce"].data_ptr(), 0, 0, int(ce_frag), s)
@@ -1090,7 +1131,13 @@ class RenderEngine:
                 if prof is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                if fused_key:
+                if units:
+                    # coords_embed (both query layers), key_map_2 on the unit-order kh of cpn_encode_key and <key, coords_embed>
+                    call("cpn_local_units", 0, loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
+                         w["query_embed.b"].data_ptr(), 0, w["query_embed_2.w16"].data_ptr(), 128, w["query_embed_2.b"].data_ptr(),
+                         w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(), bf["khf"].data_ptr(), B, V, R, S, ray0, n,
+                         ce.data_ptr(), lg.data_ptr(), s)
+                elif fused_key:
                     # the 1664 -> 128 layer already ran inside cpn_encode_key: key_map_2 + <key, coords_embed> on its output
                     call("cpn_gemm_f16_rowdot", bf["khf"].data_ptr(), 128, w["key_map_2.w16"].data_ptr(), 128,
                          w["key_map_2.b"].data_ptr(), ce.data_ptr(), 0 if ce_frag else 128, lg.data_ptr(), rows, 128, 128, s)
@@ -1100,8 +1147,9 @@ class RenderEngine:
                          ce.data_ptr(), 0 if ce_frag else 128, lg.data_ptr(), rows, 1664, s)
                 if prof is not None:
                     e1.record()
-                    prof.setdefault("gemm_f16:key_map_2" if fused_key else "gemm_f16:key_fold+key_map_2", []).append(
-                        (e0, e1, 2.0 * rows * 128 * (128 if fused_key else 1664 + 128)))
+                    prof.setdefault("local_units:query_embed+key_map_2" if units else "gemm_f16:key_map_2" if fused_key
+                                    else "gemm_f16:key_fold+key_map_2", []).append(
+                        (e0, e1, 2.0 * rows * 128 * ((128 + 128 + 16) if units else 128 if fused_key else 1664 + 128)))
             else:
                 _gemm(s, bf["kh"], 128, "key_map_2", bf["key2"], 128, rows, 128, 128, False, False)
 
@@ -1128,7 +1176,12 @@ class RenderEngine:
                  w["encode_latent.b"].data_ptr(), 0, 0, ze.data_ptr(), 128, n, 128, 416, 0, 0, s)
             call("cpn_linear_f32", ze.data_ptr(), 128, w["query_repeat_embed.w_z"].data_ptr(), 128, 0, 0, 0,
                  addq.data_ptr(), 128, n, 128, 128, 0, 0, s)
-            if self.fold_value:
+            if units:
+                call("cpn_local_units", 1, loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
+                     w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
+                     w["query_repeat_embed_2.b"].data_ptr(), 0, 0, 0, 0, B, V, R, S, ray0, n, bf["ce"].data_ptr(),
+                     bf["lg"].data_ptr(), s)
+            elif self.fold_value:
                 # the second query only enters through <query2, coords_embed>: local_mlp writes that logit directly
                 call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
                      w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,

@@ -177,11 +177,17 @@ int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int H, int W, c
  *       kbias (128) fp32 = Wk_a b2 + Wk_b b2 + bk
  *   hid as for cpn_encode_hidden (still written: the two hidden sums read it); kh (rays*V*S, 128) fp16 =
  *       ReLU(W' . [hid_own ; hid_other] + kbias), rows in the order of this header - the A operand of cpn_gemm_f16_rowdot.
- *   hid and kh are bit-identical to cpn_encode_hidden + cpn_gemm_f16(W', relu).                                          */
+ *   hid and kh are bit-identical to cpn_encode_hidden + cpn_gemm_f16(W', relu).
+ *   kh_units = 1: kh leaves in UNIT order instead of row-major - the 16 rows of a unit (4 adjacent rays x 4 consecutive samples of
+ *       one view; unit u of a launch = ((ray group - first group) * V + view) * ceil(S/4) + sample block, cpn_encode_units() of them)
+ *       as [unit][32-column block p][lane = c + 16 fg][8] = kh[row(unit, c)][32 p + 8 fg .. +8], c = (sample & 3) * 4 + (ray & 3):
+ *       every store of a wave is 1 KiB of contiguous memory and every block is a ready MFMA B fragment for cpn_local_units.
+ *       The buffer holds cpn_encode_units() * 16 rows (dead rows of partial units included).                                */
 int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                    const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
                    const uint16_t* kwring, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
-                   uint16_t* hid, uint16_t* kh, void* stream);
+                   uint16_t* hid, uint16_t* kh, int kh_units, void* stream);
+long long cpn_encode_units(int B, int R, int S, int ray0, int nrays);
 /* cpn_encode_project (round 5, csrc/encode_fused.hip; "project before you store", opt-in): the same kernel with the folded
  * latent_value projection (models/CoPoNeRF.py:404) behind the first layer as well - hid never reaches HBM:
  *   val (rays*V*S, 416) fp16 = (Wv_a W2 | Wv_b W2) . [hid_own ; hid_other]   (the folded constant is added by cpn_attend_value)
@@ -194,7 +200,19 @@ int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, cons
 #define CPN_PROJECT_STEP_HALVES (34 * 2 * 64 * 8 + CPN_K80_BLOCK_HALVES)
 int cpn_encode_project(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
                        const float* sec_grid, const float* pe6, const uint16_t* wring, const float* kbias, int B, int V,
-                       int R, int S, int ray0, int nrays, uint16_t* kh, uint16_t* val, void* stream);
+                       int R, int S, int ray0, int nrays, uint16_t* kh, uint16_t* val, int kh_units, void* stream);
+
+/* ---- the per-sample query / key tails of the two attention rounds in UNIT order (round 5, csrc/local_units.hip) ------------
+ * mode 0 (CoPoNeRF.py:408, 446, 450): ce = query_embed_2(ReLU(query_embed(local_coords))) -> ce_u (unit order, cpn_encode_units()
+ *   * 16 rows); logits[row] = < fp16(key_map_2(kh_u[row])), fp16(ce[row]) >, kh_u = cpn_encode_key's unit-order output.  Replaces
+ *   cpn_local_mlp + cpn_gemm_f16_rowdot.  w1 (128, ldw1 >= 16) fp32 / b1: first layer; w2 (128, ldw2) fp16 / b2: second layer;
+ *   wk2 (128, ldwk2) fp16 / bk2: key_map_2.
+ * mode 1 (:472-475): logits[row] = < fp16(query_repeat_embed_2(ReLU(w1 . local_coords + b1 + add[ray]))), ce_u[row] >, add (nrays,
+ *   128) fp32.  logits (nrays*V*S) fp32 in row order; rows of a partial unit that lie outside the ray range are skipped.   */
+int cpn_local_units(int mode, const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
+                    const float* add, const uint16_t* w2, int ldw2, const float* b2, const uint16_t* wk2, int ldwk2,
+                    const float* bk2, const uint16_t* kh_u, int B, int V, int R, int S, int ray0, int nrays,
+                    uint16_t* ce_u, float* logits, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).

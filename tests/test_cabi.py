@@ -15,7 +15,7 @@ def test_library_is_built_and_exports_header_symbols():
     assert len(declared) >= 12
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/coponerf_hip.h but not exported"
-    assert set(_hip.SIGNATURES) | {"cpn_abi_version", "cpn_last_error", "cpn_gather_bwd_chunks", "cpn_conv_wgrad_scratch", "cpn_wgrad_tall_scratch", "cpn_conv4d_scratch", "cpn_conv4d_strided_bwd_scratch", "cpn_gn_stats_doubles", "cpn_scatter_tables_scratch", "cpn_encode_table_nodes", "cpn_linear_attention_scratch", "cpn_cost_volume_attention_scratch", "cpn_linear_attention_bwd_scratch", "cpn_cross_attention_bwd_scratch", "cpn_dwconv3x3_tokens_wgrad_scratch", "cpn_wgrad_f32_scratch_floats", "cpn_adam_chunk", "cpn_trunk_conv_scratch_floats", "cpn_device_cu_count", "cpn_stream_cu_count"} == set(declared)
+    assert set(_hip.SIGNATURES) | {"cpn_abi_version", "cpn_last_error", "cpn_gather_bwd_chunks", "cpn_conv_wgrad_scratch", "cpn_wgrad_tall_scratch", "cpn_conv4d_scratch", "cpn_conv4d_strided_bwd_scratch", "cpn_gn_stats_doubles", "cpn_scatter_tables_scratch", "cpn_encode_table_nodes", "cpn_encode_units", "cpn_linear_attention_scratch", "cpn_cost_volume_attention_scratch", "cpn_linear_attention_bwd_scratch", "cpn_cross_attention_bwd_scratch", "cpn_dwconv3x3_tokens_wgrad_scratch", "cpn_wgrad_f32_scratch_floats", "cpn_adam_chunk", "cpn_trunk_conv_scratch_floats", "cpn_device_cu_count", "cpn_stream_cu_count"} == set(declared)
     assert lib.cpn_abi_version() == _hip.ABI_VERSION
 
 

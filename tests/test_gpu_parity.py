@@ -151,7 +151,8 @@ def test_rows_in_fragment_order_are_the_same_numbers(model, dev, weights):
              rows, 128, 128, s)
         lg[f] = (a, b)
     assert torch.equal(lg[0][0], lg[1][0]) and torch.equal(lg[0][1], lg[1][1])
-    old = eng.ce_frag
+    old, old_u = eng.ce_frag, eng.unit_order
+    eng.unit_order = False                                  # (the unit-order stages do not pass through these kernels)
     try:
         outs = {}
         for f in (True, False):
@@ -161,7 +162,7 @@ def test_rows_in_fragment_order_are_the_same_numbers(model, dev, weights):
         for k in ("rgb", "at_wt"):
             assert torch.equal(outs[True][k], outs[False][k]), k
     finally:
-        eng.ce_frag = old
+        eng.ce_frag, eng.unit_order = old, old_u
 
 
 def test_gemm_f16_against_torch(dev):
@@ -586,10 +587,23 @@ def test_encode_key_entry_is_bit_identical(model, dev, weights):
         hid = torch.full((rows2 + 64, 832), -1.0, dtype=torch.float16, device=dev)        # + a guard band behind the chunk
         kh = torch.full((rows2 // 2 + 64, 128), -1.0, dtype=torch.float16, device=dev)
         call("cpn_encode_key", *geo, w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(), w["key_fold.wpk"].data_ptr(),
-             w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), s)
+             w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), 0, s)
         assert torch.equal(hid[:rows2], hid_ref), (ray0, n, int((hid[:rows2] != hid_ref).sum()))
         assert torch.equal(kh[:rows2 // 2], kh_ref), (ray0, n, int((kh[:rows2 // 2] != kh_ref).sum()))
         assert bool((hid[rows2:] == -1).all()) and bool((kh[rows2 // 2:] == -1).all()), "wrote past the chunk"
+        # kh_units = 1: the same numbers in UNIT order (what cpn_local_units reads as MFMA B fragments); units * 16 row slots
+        from coponerf_amd import _hip
+        from coponerf_amd.render import rows_from_unit_order, unit_rows
+        units = int(_hip.lib().cpn_encode_units(B, R, S, ray0, n))
+        idx = unit_rows(B, R, S, ray0, n)
+        assert idx.numel() == units * 16 and sorted(idx[idx >= 0].tolist()) == list(range(rows2 // 2))
+        khu = torch.full((units * 16 + 64, 128), -1.0, dtype=torch.float16, device=dev)
+        hid.fill_(-1.0)
+        call("cpn_encode_key", *geo, w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(), w["key_fold.wpk"].data_ptr(),
+             w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), khu.data_ptr(), 1, s)
+        assert torch.equal(hid[:rows2], hid_ref)
+        assert torch.equal(rows_from_unit_order(khu, B, R, S, ray0, n), kh_ref)
+        assert bool((khu[units * 16:] == -1).all()), "wrote past the unit-order buffer"
 
 
 def test_encode_project_entry_against_hidden_path(model, dev, weights):
@@ -615,7 +629,7 @@ def test_encode_project_entry_against_hidden_path(model, dev, weights):
         val_ref = hid_ref.view(rows, 1664).float() @ w["value_fold.w16"].float().t()
         kh = torch.full((rows + 64, 128), -1.0, dtype=torch.float16, device=dev)
         val = torch.full((rows + 64, 416), -7.0, dtype=torch.float16, device=dev)
-        call("cpn_encode_project", *geo, ring.data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, kh.data_ptr(), val.data_ptr(), s)
+        call("cpn_encode_project", *geo, ring.data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, kh.data_ptr(), val.data_ptr(), 0, s)
         assert torch.equal(kh[:rows], kh_ref), int((kh[:rows] != kh_ref).sum())
         err = (val[:rows].float() - val_ref).abs()
         scale = float(val_ref.abs().max())
@@ -623,6 +637,80 @@ def test_encode_project_entry_against_hidden_path(model, dev, weights):
         assert float(err.max()) <= 1.5e-3 * max(1.0, scale)                 # fp16 rounding of the stored value (+ accumulation order)
         assert float(err.pow(2).mean().sqrt()) <= 2e-4 * max(1.0, scale)
         assert bool((kh[rows:] == -1).all()) and bool((val[rows:] == -7).all()), "wrote past the chunk"
+
+
+def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights):
+    """cpn_local_units (round 5: coords_embed + key_map_2 + round-1 logit in one kernel on the unit-order kh; round-2 logit on the
+    unit-order coords_embed) against the kernels it replaces (cpn_local_mlp, cpn_gemm_f16_rowdot) on a ragged chunk (ray0 > 0,
+    ray count no multiple of 4: partial units at both ends): coords_embed carries the same bits, both logits agree to the
+    rounding of an fp32 sum taken in another order, rows outside the range are left alone."""
+    from coponerf_amd import _hip
+    from coponerf_amd._hip import call
+    from coponerf_amd.render import rows_from_unit_order, unit_rows
+    cfg, _ = load_case("wide_val")
+    B, R, S, V = cfg["B"], cfg["R"], cfg["S"], 2
+    w, geo, (maps, tabs, g) = _encode_entry_setup(model, dev, cfg)
+    s = torch.cuda.current_stream().cuda_stream
+    dp = lambda t: t.data_ptr()
+    for ray0, n in ((7, R - 18), (0, B * R), (R - 3, 5 if B > 1 else 3)):
+        rows = n * V * S
+        units = int(_hip.lib().cpn_encode_units(B, R, S, ray0, n))
+        kh = (torch.randn(rows, 128, device=dev) * 0.5).half()
+        idx = unit_rows(B, R, S, ray0, n, dev)
+        khu = torch.zeros(units * 16, 128, dtype=torch.float16, device=dev)
+        tmp = torch.zeros(units * 16, 128, dtype=torch.float16, device=dev)
+        tmp[idx >= 0] = kh[idx[idx >= 0]]
+        khu.view(units, 4, 4, 16, 8).copy_(tmp.view(units, 16, 4, 4, 8).permute(0, 2, 3, 1, 4))       # rows -> [unit][p][fg][c][8]
+        assert torch.equal(rows_from_unit_order(khu, B, R, S, ray0, n), kh)
+        addq = torch.randn(n, 128, device=dev)
+        # the round-4 kernels
+        ce_r = torch.empty((rows + 15) // 16 * 16, 128, dtype=torch.float16, device=dev)
+        call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
+             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), B, V, R, S, ray0, n, dp(ce_r), 0, 0, 0, s)
+        lg1_r, lg2_r = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+        call("cpn_gemm_f16_rowdot", dp(kh), 128, dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), dp(ce_r), 128, dp(lg1_r), rows, 128, 128, s)
+        call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]), dp(addq),
+             dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), B, V, R, S, ray0, n, 0, dp(ce_r), dp(lg2_r), 0, s)
+        # the unit-order kernel
+        ce_u = torch.full((units * 16 + 16, 128), -1.0, dtype=torch.float16, device=dev)
+        lg1 = torch.full((rows + 8,), -7.0, device=dev)
+        lg2 = torch.full((rows + 8,), -7.0, device=dev)
+        call("cpn_local_units", 0, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
+             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), dp(khu),
+             B, V, R, S, ray0, n, dp(ce_u), dp(lg1), s)
+        call("cpn_local_units", 1, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
+             dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), 0, 0, 0, 0, B, V, R, S, ray0, n,
+             dp(ce_u), dp(lg2), s)
+        assert torch.equal(rows_from_unit_order(ce_u, B, R, S, ray0, n), ce_r[:rows]), "coords_embed differs"
+        assert bool((ce_u[units * 16:] == -1).all()) and bool((lg1[rows:] == -7).all()) and bool((lg2[rows:] == -7).all())
+        for a, b, name in ((lg1[:rows], lg1_r, "round 1"), (lg2[:rows], lg2_r, "round 2")):
+            scale = float(b.abs().max())
+            err = float((a - b).abs().max())
+            assert err <= 2e-4 * max(1.0, scale), (name, ray0, n, err, scale)     # (an fp16 ulp of the key where the bias enters the fp32 sum first / last)
+
+
+def test_unit_order_mode_matches_row_order_mode(model, dev, weights):
+    """The engine with the unit-order stages (the default) against the round-4 stages (COPONERF_UNIT_ORDER=0: cpn_local_mlp,
+    cpn_gemm_f16_rowdot, row-major kh) on every fixture case: identical sample coordinates, attention weights and image to the
+    rounding of the logits' fp32 sums - and both against the oracle."""
+    eng = model._engine
+    assert eng.unit_order
+    for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
+        cfg, gold = load_case(name)
+        ref, out_u = run_pair(model, dev, weights, cfg)
+        eng.unit_order = False
+        try:
+            _, out_r = run_pair(model, dev, weights, cfg)
+        finally:
+            eng.unit_order = True
+        assert torch.equal(out_u["pixel_val"], out_r["pixel_val"])
+        d_wt = float((out_u["at_wt"] - out_r["at_wt"]).abs().max())
+        d_rgb = float((out_u["rgb"] - out_r["rgb"]).abs().max())
+        print(name, "unit-order vs row-order stages: at_wt", d_wt, "rgb", d_rgb)
+        assert d_wt <= 2e-6 and d_rgb <= 5e-6, (name, d_wt, d_rgb)
+        assert (out_u["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
+        assert (out_u["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+    eng._ws.clear()
 
 
 def test_attend_value_against_torch(dev):

@@ -30,7 +30,8 @@ VARIANTS = {
     "p_w4u2": dict(PROJ_WAVES=4, PROJ_UNITS=2),
 }
 ABLATIONS = {1: "no table taps", 2: "no hid / val stores", 4: "no K=80 MFMA", 8: "no key/value MFMA + ring reads", 64: "no ring DMA / barrier",
-             72: "no ring, no key/value MFMA", 256: "no DMA, barrier kept", 512: "no barrier, DMA kept", 1024: "16 of the step's pieces fetched"}
+             72: "no ring, no key/value MFMA", 256: "no DMA, barrier kept", 512: "no barrier, DMA kept", 1024: "16 of the step's pieces fetched",
+             2048: "no bpermute of the K=80 accumulators", 4096: "no bpermute of hid to the B layout", 6144: "no bpermutes at all"}
 ABLATE_TAGS = ("k_w12u1s2", "p_w8u1")
 
 
@@ -171,23 +172,23 @@ def main():
         project = tag.startswith("p_")
         if project:
             fn = lib.cpn_encode_project
-            fn.argtypes = [P, P, I, I, P, P, P, P, P, I, I, I, I, I, I, P, P, P]
+            fn.argtypes = [P, P, I, I, P, P, P, P, P, I, I, I, I, I, I, P, P, I, P]
             fn.restype = I
 
             def run():
                 rc = fn(tabs[0].data_ptr(), maps[3].data_ptr(), H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(),
                         g["pe6"].data_ptr(), wring_p.data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, 0, n, kh.data_ptr(),
-                        val.data_ptr(), s)
+                        val.data_ptr(), 0, s)
                 assert rc == 0, rc
         else:
             fn = lib.cpn_encode_key
-            fn.argtypes = [P, P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P]
+            fn.argtypes = [P, P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, I, P]
             fn.restype = I
 
             def run():
                 rc = fn(tabs[0].data_ptr(), maps[3].data_ptr(), H, H, g["pixel_val"].data_ptr(), g["sec_grid"].data_ptr(),
                         g["pe6"].data_ptr(), w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(),
-                        w["key_fold.wpk"].data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, 0, n, hid.data_ptr(), kh.data_ptr(), s)
+                        w["key_fold.wpk"].data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, 0, n, hid.data_ptr(), kh.data_ptr(), 0, s)
                 assert rc == 0, rc
         entry = {}
         if not a.no_check and "_a" not in tag:
