@@ -14,9 +14,8 @@
 //     = cpn_local_mlp's logits form with the unit row map.
 // Unit order of a (rows, 128) fp16 matrix X: [unit][32-column block p][lane = c + 16 fg][8] holds X[row(unit, c)][32 p + 8 fg .. +8],
 // c = (sample & 3) * 4 + (ray & 3) — a wave's access to one block is 1 KiB of contiguous memory and IS the B operand of
-// v_mfma_f32_16x16x32_f16 for the k block p.  Structure (8 waves share the layer-2 fragments in LDS, first layer on the
-// fp32 MFMA with its bias on the unused K slot, inputs of the next unit requested before the MFMAs of the current one):
-// cpn_local_mlp's (csrc/gather.hip).
+// v_mfma_f32_16x16x32_f16 for the k block p.  Structure (8 waves share the layer-2 fragments in LDS, the first layer's bias on
+// the unused K slot, inputs of the next unit requested before the MFMAs of the current one): cpn_local_mlp's (csrc/gather.hip).
 #include <algorithm>
 
 #include "encode_common.h"
@@ -50,12 +49,21 @@ __global__ __launch_bounds__(512, 4) void local_units_kernel(
         b2s[threadIdx.x] = b2[threadIdx.x];
         bks[threadIdx.x] = MODE == 0 ? bk2[threadIdx.x] : 0.0f;
     }
-    f32x4 wv[8];
+    // First layer (K = 16, fp32 weights and inputs) on the fp16 MFMA as a hi / lo split - w = wh + wl, x = xh + xl (each part
+    // an fp16), w . x = wh xh + wh xl + wl xh up to 2^-22 |w x| - three v_mfma_f32_16x16x16_f16 of 8 cycles per tile instead
+    // of four v_mfma_f32_16x16x4_f32 of 32: the fp32 MFMA runs at 1/16 of the fp16 rate and was two thirds of this
+    // kernel's matrix time (cpn_local_mlp keeps the fp32 form).
+    half4 wh[8], wl[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int ch = (t >> 1) * 32 + (a >> 2) * 8 + (t & 1) * 4 + (a & 3);
-        wv[t] = *reinterpret_cast<const f32x4*>(w1 + (size_t)ch * ldw1 + fg * 4);
-        if (fg == 0) wv[t][3] = b1[ch];                        // K slot 3 is unused by the inputs: bias x 1.0
+        f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + (size_t)ch * ldw1 + fg * 4);
+        if (fg == 0) wv[3] = b1[ch];                           // K slot 3 is unused by the inputs: bias x 1.0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wh[t][i] = (_Float16)wv[i];
+            wl[t][i] = (_Float16)(wv[i] - (float)wh[t][i]);
+        }
     }
     __syncthreads();
     const unsigned nunits = (unsigned)geo.nunits;
@@ -104,10 +112,18 @@ __global__ __launch_bounds__(512, 4) void local_units_kernel(
             if (MODE == 1)
                 acc[t] = *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
         }
+        half4 xh, xl;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int i = 0; i < 4; ++i) {
+            xh[i] = (_Float16)cur.lv[i];
+            xl[i] = (_Float16)(cur.lv[i] - (float)xh[i]);
+        }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][e], cur.lv[e], acc[t], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[t], xh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[t], xl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[t], xh, acc[t], 0, 0, 0);
+        }
         // hidden layer -> fp16 B operands: K block p = channels p*32 .. p*32+31, this lane holds fg*8 .. fg*8+7 of it
         half8 hb[4];
 #pragma unroll

@@ -642,8 +642,7 @@ def test_encode_project_entry_against_hidden_path(model, dev, weights):
 def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights):
     """cpn_local_units (round 5: coords_embed + key_map_2 + round-1 logit in one kernel on the unit-order kh; round-2 logit on the
     unit-order coords_embed) against the kernels it replaces (cpn_local_mlp, cpn_gemm_f16_rowdot) on a ragged chunk (ray0 > 0,
-    ray count no multiple of 4: partial units at both ends): coords_embed carries the same bits, both logits agree to the
-    rounding of an fp32 sum taken in another order, rows outside the range are left alone."""
+    ray count no multiple of 4: partial units at both ends): coords_embed and both logits agree to an fp16 ulp of single terms, rows outside the range are left alone."""
     from coponerf_amd import _hip
     from coponerf_amd._hip import call
     from coponerf_amd.render import rows_from_unit_order, unit_rows
@@ -681,12 +680,18 @@ def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights)
         call("cpn_local_units", 1, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
              dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), 0, 0, 0, 0, B, V, R, S, ray0, n,
              dp(ce_u), dp(lg2), s)
-        assert torch.equal(rows_from_unit_order(ce_u, B, R, S, ray0, n), ce_r[:rows]), "coords_embed differs"
+        # (first layer as an fp16 hi / lo split on the fp16 MFMA here, on the fp32 MFMA there: 2^-22 apart before the fp16
+        # rounding of the hidden layer, so a few outputs differ by an fp16 ulp)
+        d_ce = (rows_from_unit_order(ce_u, B, R, S, ray0, n).float() - ce_r[:rows].float()).abs()
+        assert float(d_ce.max()) <= 2e-3 * float(ce_r[:rows].float().abs().max()) and float(d_ce.mean()) <= 1e-5, "coords_embed differs"
         assert bool((ce_u[units * 16:] == -1).all()) and bool((lg1[rows:] == -7).all()) and bool((lg2[rows:] == -7).all())
         for a, b, name in ((lg1[:rows], lg1_r, "round 1"), (lg2[:rows], lg2_r, "round 2")):
             scale = float(b.abs().max())
             err = float((a - b).abs().max())
-            assert err <= 2e-4 * max(1.0, scale), (name, ray0, n, err, scale)     # (an fp16 ulp of the key where the bias enters the fp32 sum first / last)
+            # an fp16 ulp of single terms: the key where the bias enters the fp32 sum first / last, hidden activations whose fp32
+            # values differ by 2^-22 across an fp16 rounding boundary (test-sized `add` rows make them O(1)); the logits are
+            # divided by 11.31 before the softmax
+            assert err <= 1e-3 * max(1.0, scale), (name, ray0, n, err, scale)
 
 
 def test_unit_order_mode_matches_row_order_mode(model, dev, weights):
@@ -707,7 +712,7 @@ def test_unit_order_mode_matches_row_order_mode(model, dev, weights):
         d_wt = float((out_u["at_wt"] - out_r["at_wt"]).abs().max())
         d_rgb = float((out_u["rgb"] - out_r["rgb"]).abs().max())
         print(name, "unit-order vs row-order stages: at_wt", d_wt, "rgb", d_rgb)
-        assert d_wt <= 2e-6 and d_rgb <= 5e-6, (name, d_wt, d_rgb)
+        assert d_wt <= 2e-5 and d_rgb <= 2e-5, (name, d_wt, d_rgb)
         assert (out_u["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
         assert (out_u["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
     eng._ws.clear()
