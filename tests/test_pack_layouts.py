@@ -1,5 +1,5 @@
 """Host-side packing of operands into MFMA fragment order (coponerf_amd/render.py) against the element maps the kernels document
-(include/coponerf_hip.h: cpn_lightfield_decode wpack, cpn_encode_key group 4, cpn_local_mlp rows_frag).  CPU only."""
+(include/coponerf_hip.h: cpn_lightfield_decode wpack, cpn_encode_key kwring / kh_units, cpn_encode_project wring, cpn_local_mlp rows_frag).  CPU only."""
 import torch
 
 from coponerf_amd.render import frag_order_f32, pack_key_ring, rows_from_frag_order
@@ -40,3 +40,55 @@ def test_rows_from_frag_order_inverts_the_accumulator_layout():
         assert flat[(((g * 4 + p) * 64) + (a + 16 * fg)) * 8 + e] == x[row, col]
     assert torch.equal(rows_from_frag_order(packed, rows), x)
     assert torch.equal(rows_from_frag_order(packed, rows - 3), x[:rows - 3])
+
+
+def test_pack_project_ring_matches_the_documented_element_map():
+    """cpn_encode_project's slot images (include/coponerf_hip.h): per slice step 34 x 2 weight fragments (key tiles 0-7, value
+    tiles 8-33) in pack_key_ring's piece order, then the slice's K = 80 block."""
+    from coponerf_amd.render import pack_project_ring
+    torch.manual_seed(3)
+    wk, wv = torch.randn(128, 1664).half(), torch.randn(416, 1664).half()
+    blk = torch.randn(13, 5120).half()
+    ring = pack_project_ring(wk, wv, blk)
+    assert ring.shape == (2, 13, 34 * 2 * 64 * 8 + 5120)
+    w = torch.cat((wk, wv))
+    for j, n, t, k, lane, e in ((0, 0, 0, 0, 0, 0), (1, 12, 33, 1, 63, 7), (1, 0, 8, 0, 21, 5), (0, 5, 7, 1, 48, 2), (1, 7, 20, 0, 17, 3)):
+        want = w[16 * t + (lane & 15), 832 * j + 64 * n + 32 * k + 8 * (lane >> 4) + e]
+        assert ring[j, n, ((t * 2 + k) * 64 + lane) * 8 + e] == want
+    for j in (0, 1):
+        assert torch.equal(ring[j, :, 34 * 2 * 64 * 8:], blk)
+
+
+def test_unit_rows_is_the_encoders_row_map():
+    """render.unit_rows against the unit / row arithmetic of csrc/encode_fused.hip and csrc/local_units.hip restated as loops: unit
+    u = ((ray group - first group) * V + view) * ceil(S/4) + sample block; slot c = (sample & 3) * 4 + (ray & 3); rows of a partial
+    unit outside the ray range (or past R / S) are dead; every live row appears exactly once."""
+    from coponerf_amd.render import rows_from_unit_order, unit_rows
+    V = 2
+    for B, R, S, ray0, n in ((1, 8, 8, 0, 8), (2, 7, 6, 3, 9), (3, 5, 9, 4, 7), (1, 64, 32, 13, 40), (2, 10, 4, 9, 3)):
+        gpb, nsblk = (R + 3) // 4, (S + 3) // 4
+        b_lo, b_hi = ray0 // R, (ray0 + n - 1) // R
+        g0 = b_lo * gpb + (ray0 - b_lo * R) // 4
+        g1 = b_hi * gpb + (ray0 + n - 1 - b_hi * R) // 4
+        want = []
+        for gq in range(g0, g1 + 1):
+            b, rg = gq // gpb, gq % gpb
+            for v in range(V):
+                for sb in range(nsblk):
+                    for c in range(16):
+                        r, s = rg * 4 + (c & 3), sb * 4 + (c >> 2)
+                        ray = b * R + r
+                        live = r < R and s < S and ray0 <= ray < ray0 + n
+                        want.append(((ray - ray0) * V + v) * S + s if live else -1)
+        got = unit_rows(B, R, S, ray0, n).tolist()
+        assert got == want, (B, R, S, ray0, n)
+        assert sorted(x for x in got if x >= 0) == list(range(n * V * S))
+        # and the inverse used by the tests: a unit-order matrix built from rows comes back as those rows
+        rows = n * V * S
+        x = torch.randn(rows, 128).half()
+        idx = torch.tensor(got)
+        units = len(got) // 16
+        tmp = torch.zeros(units * 16, 128, dtype=torch.float16)
+        tmp[idx >= 0] = x[idx[idx >= 0]]
+        xu = tmp.view(units, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+        assert torch.equal(rows_from_unit_order(xu, B, R, S, ray0, n), x)
