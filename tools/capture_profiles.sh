@@ -12,7 +12,7 @@ export TMPDIR=/tmp PYTHONPATH=$ROOT
 cd "$ROOT"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --no-tables --cpu-rays 0 --train-steps 0 > "$OUT/bench_gather_gemm_form.json" 2>> "$OUT/bench.err"
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render_prof" -o r -- python "$ROOT/bench.py" --no-image --no-ref-loop --no-two-stream-pass --cpu-rays 0 --train-steps 0 --steps 5 ) > "$OUT/bench_under_rocprof.json" 2> "$OUT/render_prof.log"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render_prof" -o r -- python "$ROOT/bench.py" --no-image --no-ref-loop --no-two-stream-pass --no-f32 --cpu-rays 0 --train-steps 0 --steps 5 ) > "$OUT/bench_under_rocprof.json" 2> "$OUT/render_prof.log"
 python tools/summarize_pmc.py "$(find "$OUT/render_prof" -name '*kernel_stats.csv' | head -1)" "$OUT/render_kernel_stats.summary.csv" 40
 # sidecar of the kernel statistics: which kernel source / launch shape they were taken on (bench.py roofline.rocprof)
 python - "$OUT" <<'PY'
@@ -22,7 +22,7 @@ fused = os.environ.get("COPONERF_FUSE_KEY", "1") != "0"
 src = os.path.join(root, "coponerf_amd", "csrc", "encode_fused.hip" if fused else "encode.hip")
 json.dump({"kernel": "encode_fused_kernel" if fused else "encode_hidden_kernel",
            "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "rows_per_launch": 16777216,
-           "command": "python bench.py --no-image --no-ref-loop --no-two-stream-pass --cpu-rays 0 --train-steps 0 --steps 5 (under rocprofv3 --kernel-trace --stats)"},
+           "command": "python bench.py --no-image --no-ref-loop --no-two-stream-pass --no-f32 --cpu-rays 0 --train-steps 0 --steps 5 (under rocprofv3 --kernel-trace --stats)"},
           open(os.path.join(sys.argv[1], "render_kernel_stats.meta.json"), "w"), indent=1)
 PY
 tools/pmc_passes.sh "$OUT/pmc_encode" encode_fused -- python "$ROOT/tools/encode_bench.py" --only fused --iters 3 --rays 65536 > "$OUT/pmc_encode.log" 2>&1
@@ -30,13 +30,14 @@ python tools/make_traffic_json.py "$OUT/pmc_encode/summary.json" 16777216 "$OUT/
 tools/pmc_passes.sh "$OUT/pmc_encode_hidden" encode_hidden -- python "$ROOT/tools/encode_bench.py" --only tables --iters 3 --rays 65536 > "$OUT/pmc_encode_hidden.log" 2>&1
 python tools/make_traffic_json.py "$OUT/pmc_encode_hidden/summary.json" 16777216 "$OUT/traffic_encode_hidden.json" >> "$OUT/pmc_encode_hidden.log" 2>&1
 python tools/ef_check.py --no-check > "$OUT/encode_fused_ablation.json" 2>/dev/null
-COPONERF_FUSE_KEY=0 python bench.py --no-image --no-ref-loop --cpu-rays 0 --train-steps 0 > "$OUT/bench_separate_key_kernel.json" 2>> "$OUT/bench.err"
+COPONERF_UNIT_ORDER=0 python bench.py --no-image --no-ref-loop --no-f32 --cpu-rays 0 --train-steps 0 > "$OUT/bench_row_order_stages.json" 2>> "$OUT/bench.err"
+COPONERF_PROJECT=1 python bench.py --no-image --no-ref-loop --no-f32 --cpu-rays 0 --train-steps 0 > "$OUT/bench_project_before_store.json" 2>> "$OUT/bench.err"
+COPONERF_FUSE_KEY=0 python bench.py --no-image --no-ref-loop --no-f32 --cpu-rays 0 --train-steps 0 > "$OUT/bench_separate_key_kernel.json" 2>> "$OUT/bench.err"
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/getz_prof" -o g -- python "$ROOT/tools/getz_time.py" ) > "$OUT/getz_prof.log" 2>&1
 python tools/trace_step.py "$(find "$OUT/getz_prof" -name '*kernel_trace.csv' | head -1)" soft_argmax_cols 45 > "$OUT/getz_step_kernels.txt" 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/train_prof" -o t -- python "$ROOT/tools/train_time.py" --steps 3 ) > "$OUT/train_prof.log" 2>&1
 python tools/trace_step.py "$(find "$OUT/train_prof" -name '*kernel_trace.csv' | head -1)" project_rays 60 > "$OUT/train_step_kernels.txt" 2>&1
 grep -h train_ms_per_step "$OUT/train_prof.log" > "$OUT/train_step.json"
-python tools/encode_ablate.py > "$OUT/encode_ablation.json" 2>/dev/null
 python tools/aten_time.py --top 120 > "$OUT/aten_train.txt" 2>&1
 python tools/wgrad_f32_bench.py > "$OUT/wgrad_f32_bench.json" 2>/dev/null
 python tools/trunk_conv_bench.py > "$OUT/trunk_conv_bench.json" 2>/dev/null
