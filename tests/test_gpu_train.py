@@ -73,6 +73,59 @@ def test_render_gradients_match_oracle_autograd(dev):
     check_against_fixture(grads, rel_l2=5e-2, rel_max=0.1)          # fixture holds a 1-in-61 sample per tensor
 
 
+def test_render_training_converges_like_the_fp32_oracle(dev):
+    """the HIP backward carries fp16 activation gradients (one static scale per pass) and agrees with upstream's
+    gradients only to ~1e-2 per tensor - what does that do to TRAINING?  Twelve Adam steps on the render weights (latents given,
+    a target image rendered by a perturbed copy of the weights): the HIP path on the device beside float32 autograd through the
+    CPU oracle from the same start.  The loss curves must coincide (every step within 3 % of the loss; measured: 4 digits at first, 1 % after twelve steps),
+    and the weights must have moved to the same place (distance between the two end points small against the distance moved)."""
+    from coponerf_amd import CoPoNeRF
+    from oracle import render_ref as orc
+    B, H, R, S, steps, lr = 1, 64, 192, 32, 12, 2e-4
+    start = syn.make_render_weights(seed=23)
+    teacher = {k: v + 0.3 * syn.normal(tuple(v.shape), seed=900 + i) * v.abs().mean() for i, (k, v) in enumerate(start.items())}
+    inp = syn.make_inputs(B, H, H, R, seed=71)
+    z, rel, flow = syn.make_latents(B, H, H, seed=72)
+    with torch.no_grad():
+        target = orc.forward(inp, z, rel, flow, False, teacher, npoints=S)["rgb"]
+    trained = [k for k in start if not k.startswith(("corr_embed", "latent_avg"))]
+    # ---- float32 autograd through the oracle (CPU)
+    w_ref = {k: v.clone().requires_grad_(k in trained) for k, v in start.items()}
+    opt_ref = torch.optim.Adam([w_ref[k] for k in trained], lr=lr)
+    loss_ref = []
+    for _ in range(steps):
+        opt_ref.zero_grad()
+        l = (orc.forward(inp, z, rel, flow, False, w_ref, npoints=S)["rgb"] - target).abs().mean()
+        l.backward()
+        opt_ref.step()
+        loss_ref.append(float(l))
+    # ---- the HIP training path (device)
+    model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+    model.load_state_dict(start, strict=False)
+    model = model.to(dev).train()
+    P = dict(model.named_parameters())
+    opt = torch.optim.Adam([P[k] for k in trained], lr=lr)
+    d_inp, d_z, d_flow, d_tgt = to_device(inp, dev), to_device(z, dev), to_device(flow, dev), target.to(dev)
+    loss_hip = []
+    for _ in range(steps):
+        opt.zero_grad()
+        l = (model(d_inp, z=d_z, rel_pose=rel.to(dev), val=False, flow=d_flow)["rgb"] - d_tgt).abs().mean()
+        l.backward()
+        opt.step()
+        loss_hip.append(float(l))
+    print("loss, fp32 oracle:", [round(x, 5) for x in loss_ref])
+    print("loss, HIP path   :", [round(x, 5) for x in loss_hip])
+    # (at this learning rate Adam's first steps throw the loss from 0.04 to 0.35 and it comes back over the next ten: a
+    # trajectory that amplifies differences - the comparison is only meaningful if the run moves the loss a lot)
+    assert max(loss_ref) > 2 * min(loss_ref)
+    for k, (a, b) in enumerate(zip(loss_hip, loss_ref)):
+        assert abs(a - b) <= 3e-2 * b, (k, a, b)
+    moved = sum(float((w_ref[k].detach() - start[k]).pow(2).sum()) for k in trained) ** 0.5
+    apart = sum(float((P[k].detach().cpu() - w_ref[k].detach()).pow(2).sum()) for k in trained) ** 0.5
+    print(f"weights moved {moved:.4f}, HIP end point {apart:.4f} from the oracle's ({apart / moved:.3f} of the way)")
+    assert apart <= 0.15 * moved, (apart, moved)
+
+
 def test_full_training_step_end_to_end(dev):
     """get_z + render + backward + SGD step at 256x256: gradients reach encoder, UFC and render weights, loss moves."""
     from coponerf_amd import CoPoNeRF
