@@ -943,6 +943,8 @@ class RenderEngine:
         B, _, R, _ = uv.shape
         if z[0].shape[0] != B * V or len(z) != 4:
             raise ValueError("expected 4 latent maps with a leading dimension of B*2")
+        if self.precision not in ("f16", "f32"):
+            raise ValueError(f"RenderEngine.precision must be 'f16' or 'f32' (got {self.precision!r})")
         main = torch.cuda.current_stream()
         miss0 = self._misses
         w = self._weights(params)
