@@ -196,7 +196,13 @@ class DeviceExchange:
                 self._side = group
             else:
                 ranks = dist.get_process_group_ranks(group) if group is not None else None
-                self._side = dist.new_group(ranks=ranks, backend="gloo")       # every rank of the group constructs one
+                try:
+                    self._side = dist.new_group(ranks=ranks, backend="gloo")   # every rank of the group constructs one
+                except Exception as e:                                          # e.g. no usable network interface for gloo
+                    import warnings
+                    warnings.warn(f"coponerf_amd.dist.DeviceExchange: no gloo side group ({e}); the gradient-mask agreement "
+                                  "falls back to a device all-reduce with a host read per step")
+                    self._side = None
 
     @property
     def world(self) -> int:
@@ -205,6 +211,18 @@ class DeviceExchange:
     def agree(self) -> List[bool]:
         """Host half, callable as soon as the backward pass is ENQUEUED (whether a parameter has a `.grad` is known then)."""
         local = [p.grad is not None for p in self.params]
+        if self._side is None and dist.get_backend(self.group) != "gloo":
+            # fallback without a host-side channel: the round-4 exchange of the mask on the device, one read per step
+            dev = next((p.device for p in self.params), "cpu")
+            mask = torch.tensor(local, dtype=torch.int32, device=dev)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+            union = mask.bool().tolist()
+            self.host_reads += 1
+            if union != self._union or not self._flats:
+                self._local, self._union = local, union
+                self.mask_exchanges += 1
+                self._build()
+            return self._union
         vote = torch.tensor([0 if local == self._local else 1], dtype=torch.int32)
         dist.all_reduce(vote, op=dist.ReduceOp.MAX, group=self._side)
         if int(vote) != 0:

@@ -70,6 +70,7 @@ class TrainStep:
         eng = getattr(model, "_engine", None)
         self._scale_ceiling = float(eng.grad_scale_target) if eng is not None else 0.0
         self._exchange = None                                            # dist.DeviceExchange, built at the first exchanging step
+        self._ex_reads_seen = 0
         self._pending = collections.deque()                              # `stepped` flags of steps guarded on the device
         self._flag_host = [torch.zeros(1).pin_memory() for _ in range(4)] if on_gpu else None
         self._flag_turn = 0
@@ -146,11 +147,13 @@ class TrainStep:
                 self.opt.step()
             self._adapt_grad_scale(stepped)
         self.opt.zero_grad(set_to_none=True)
+        reads_before, self._ex_reads_seen = self._ex_reads_seen, (0 if ex is None else ex.host_reads)
         e5 = self._ev() if timed else None
         if timed:
             self.timing.setdefault("events", []).append((e0, e1, e2, e3, e4, e5))
         return {"loss": loss.detach(), "stepped": stepped, "collectives": ncoll, "allreduce_bytes": nbytes,
-                "host_reads": 0 if on_device else 1, "mask_exchanges": 0 if ex is None else ex.mask_exchanges,
+                "host_reads": (0 if on_device else 1) + (0 if ex is None else ex.host_reads - reads_before),
+                "mask_exchanges": 0 if ex is None else ex.mask_exchanges,
                 "at_wt": out["at_wt"].detach(), "skipped_in_a_row": self.skipped_in_a_row}
 
     def _adapt_grad_scale(self, stepped: bool) -> None:
