@@ -33,3 +33,5 @@ def test_modes_parse():
     a = bench.parse_args(["--mode", "train", "--gpus", "8"])
     assert a.mode == "train" and a.gpus == 8 and a.train_rays == 4096
     assert bench.parse_args([]).mode == "render"
+    # round 5: the reference-arithmetic pass of the same step runs by default and can be switched off
+    assert bench.parse_args([]).no_f32 is False and bench.parse_args(["--no-f32"]).no_f32 is True
