@@ -159,3 +159,79 @@ def test_rccl_world1_forced_exchange_runs_on_device():
     assert all(res["stepped"]) and res["collectives"] >= 2 and res["nbytes"] > 100e6 and res["moved"]
     assert res["lazy"] and res["host_reads"] == (0, 0) and res["mask_exchanges"] == 1
     assert all(l == l and l < 10 for l in res["losses"])
+
+
+def _worker_two_ranks_one_device(rank, world, port, q):
+    """Two ranks on ONE MI355X over backend gloo (it all-reduces device tensors through the host): everything of the N > 1 step
+    except RCCL itself runs on the device - the MIN-reduced flag gating cpn_adam_step, the persistent buckets, the optimizer
+    reading the summed gradients in place with 1 / world as its scale."""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import torch.distributed as dist
+    from coponerf_amd import CoPoNeRF, dist as cd, synthetic as syn
+    from coponerf_amd.train_step import TrainStep, _LazyFlag
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    model = CoPoNeRF.CoPoNeRF(n_view=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(syn.make_full_weights(shapes, seed=11 + rank), strict=True)          # ranks start different ...
+    model = model.to(dev).train()
+    cd.broadcast_parameters(model)                                                             # ... train.py:58-60
+    mv = lambda o: {k: mv(v) for k, v in o.items()} if isinstance(o, dict) else (o.to(dev) if torch.is_tensor(o) else o)
+    inp = mv(syn.make_inputs(1, 256, 256, 128, seed=61 + rank))                                # independent batches
+    probe = model.query_encode_latent.weight
+    w0 = probe.detach().clone()
+    # the local gradient of this rank's batch, for the hand-made reference of the first update
+    out = model(inp, val=False)
+    (out["rgb"] - inp["query"]["rgb"]).abs().mean().backward()
+    g_local = probe.grad.detach().clone()
+    total = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in model.parameters() if p.grad is not None))
+    coef = float(torch.clamp(1.0 / (total + 1e-6), max=1.0))                                   # per-rank clip BEFORE the exchange
+    model.zero_grad(set_to_none=True)
+    g_sum = g_local * coef
+    dist.all_reduce(g_sum, op=dist.ReduceOp.SUM)
+    step = TrainStep(model, lr=1e-3)
+    r1 = step(inp, inp["query"]["rgb"])
+    # Adam's first update is -lr * sign-like g / (|g| + eps): compare with the averaged, clipped gradient
+    g_avg = g_sum / world
+    want = w0 - 1e-3 * g_avg / (g_avg.abs() + 1e-8)
+    big = g_avg.abs() > 1e-3 * g_avg.abs().max()            # (where |g| is near Adam's eps the ratio is ill-conditioned)
+    first_ok = bool(big.float().mean() > 0.2) and bool(torch.allclose(probe.detach()[big], want[big], rtol=0, atol=2e-5))
+    r2 = step(inp, inp["query"]["rgb"])
+    w = torch.cat([p.detach().reshape(-1) for p in (model.query_encode_latent.weight, model.phi.lin_out.weight, model.conv_map.weight)])
+    both = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(both, w)
+    q.put(dict(rank=rank, lazy=isinstance(r1["stepped"], _LazyFlag), stepped=(bool(r1["stepped"]), bool(r2["stepped"])),
+               host_reads=(r1["host_reads"], r2["host_reads"]), mask_exchanges=r2["mask_exchanges"], collectives=r2["collectives"],
+               equal=bool(torch.equal(both[0], both[1])), first_ok=first_ok, moved=not torch.equal(w0, probe.detach())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_device_over_gloo():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_ranks_one_device, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    import queue
+    for _ in range(900):
+        try:
+            res.append(q.get(timeout=1))
+        except queue.Empty:
+            if not any(p.is_alive() for p in procs):
+                break
+        if len(res) == 2:
+            break
+    for p in procs:
+        p.join(timeout=120)
+    assert len(res) == 2 and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for r in res:
+        print("two ranks, one device:", r)
+        assert r["lazy"] and all(r["stepped"]) and r["host_reads"] == (0, 0) and r["mask_exchanges"] == 1 and r["collectives"] >= 2
+        assert r["equal"] and r["first_ok"] and r["moved"]
