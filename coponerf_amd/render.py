@@ -583,7 +583,7 @@ class RenderEngine:
         # caches, streams and workspace are derived state: a copied model gets a fresh engine with the same settings
         new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables, self.fuse_key, self.project)
         new.grad_scale_target, new.call_lanes, new.lazy_pixel_val = self.grad_scale_target, self.call_lanes, self.lazy_pixel_val
-        new.precision = self.precision
+        new.precision, new.unit_order, new.f32_chunk_rays = self.precision, self.unit_order, self.f32_chunk_rays
         return new
 
     def _host_inputs(self, *mats):
