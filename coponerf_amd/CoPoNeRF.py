@@ -134,6 +134,16 @@ class CoPoNeRF(nn.Module):
             ops = HipOps()
         return _getz.get_z(self, input, ops)
 
+    def prepare_next(self, input, z, rel_pose, flow=None) -> None:
+        """Optional, inference only: announce the pair whose forward(input, z=z, rel_pose=rel_pose, flow=flow) calls come
+        AFTER the next forward() call(s) of the current pair.  Its per-pair preparation (camera copy to the host, feature
+        tables, flow products) then runs beside the current pair's kernels on a stream of its own, and the first forward()
+        on it starts without a device synchronisation (RenderEngine.prepare_next).  Outputs are unchanged; a pair that was
+        never announced is prepared inside its first forward() as before."""
+        ctx, qry = input["context"], input["query"]
+        self._engine.prepare_next(self._render_params(), ctx["cam2world"], ctx["intrinsics"], qry["cam2world"],
+                                  qry["intrinsics"], z, rel_pose, flow=flow, width=ctx["rgb"].shape[-2])
+
     def forward(self, input, z=None, rel_pose=None, val: bool = False, flow=None, debug: bool = False):
         if self.n_view != 2:
             raise NotImplementedError(f"the HIP render path is specialised for n_view=2 (got {self.n_view})")

@@ -64,7 +64,7 @@ def _reproject(kp, depth, Ki_inv, Kj, T):
     return r[..., :-1] / (r[..., -1:] + 1e-6)
 
 
-_FLOW_CACHE: Dict[str, tuple] = {}
+_FLOW_CACHE: Dict[str, list] = {}
 
 
 def _flow_products(flow: Sequence[torch.Tensor], width: int):
@@ -73,19 +73,53 @@ def _flow_products(flow: Sequence[torch.Tensor], width: int):
 
 def flow_products(flow: Sequence[torch.Tensor], width: int):
     """((cycle mask of view 2, flow upsampled to 256x256), cache hit?): functions of the flows alone, so a full-image
-    render that calls forward() once per ray chunk with the same `flow` tensors computes them once."""
+    render that calls forward() once per ray chunk with the same `flow` tensors computes them once.  The cache holds the
+    three most recently used pairs: the one being rendered and the (up to two) pairs RenderEngine.prepare_next() built
+    beside it on its own stream - such an entry carries the event of its last kernel; its first use makes the current
+    stream wait for it and is reported as a miss (the caller orders its other streams after a miss)."""
     key = tuple((f._version, tuple(f.shape)) for f in flow[:2]) + (width,)
-    hit = _FLOW_CACHE.get("entry")
-    # the entry holds the flow tensors themselves and is matched on IDENTITY (+ version): a new pair's flows that
+    entries = _FLOW_CACHE.setdefault("entries", [])
+    # an entry holds the flow tensors themselves and is matched on IDENTITY (+ version): a new pair's flows that
     # happen to be allocated at a freed pair's addresses can never hit it
-    if hit is not None and hit[0] == key and hit[3][0] is flow[0] and hit[3][1] is flow[1]:
-        return (hit[1], hit[2]), True
+    for i, e in enumerate(entries):
+        if e[0] == key and e[3][0] is flow[0] and e[3][1] is flow[1]:
+            hit = True
+            if e[4] is not None:
+                cur = torch.cuda.current_stream(e[1].device)
+                cur.wait_event(e[4])
+                e[1].record_stream(cur)
+                e[2].record_stream(cur)
+                e, hit = e[:4] + (None,), False
+            if i or not hit:
+                entries.pop(i)
+                entries.insert(0, e)
+            return (e[1], e[2]), hit
     _, mask2 = cycle_masks(flow, width)
     mask2 = mask2.contiguous()
     flow_up = (F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])).contiguous()
     if not any(f.requires_grad for f in flow[:2]):
-        _FLOW_CACHE["entry"] = (key, mask2, flow_up, (flow[0], flow[1]))
+        entries.insert(0, (key, mask2, flow_up, (flow[0], flow[1]), None))
+        del entries[3:]
     return (mask2, flow_up), False
+
+
+def prepare_flow_products(flow: Sequence[torch.Tensor], width: int, stream: "torch.cuda.Stream") -> None:
+    """flow_products() of a pair that is rendered LATER, computed on `stream` (which the caller has ordered after the
+    flows' producer) and parked in the cache (least recently used entry out)."""
+    if any(f.requires_grad for f in flow[:2]):
+        return
+    key = tuple((f._version, tuple(f.shape)) for f in flow[:2]) + (width,)
+    entries = _FLOW_CACHE.setdefault("entries", [])
+    if any(e[0] == key and e[3][0] is flow[0] and e[3][1] is flow[1] for e in entries):
+        return
+    with torch.cuda.stream(stream):
+        _, mask2 = cycle_masks(flow, width)
+        mask2 = mask2.contiguous()
+        flow_up = (F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])).contiguous()
+        ready = torch.cuda.Event()
+        ready.record(stream)
+    entries.insert(0, (key, mask2, flow_up, (flow[0], flow[1]), ready))
+    del entries[3:]
 
 
 def aux_outputs(inp: Dict, flow: Sequence[torch.Tensor], at_wt: torch.Tensor, pt: torch.Tensor,

@@ -28,13 +28,16 @@ def _stream() -> int:
     return _hip.stream_handle()
 
 
-def _to_host(*mats: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:
-    """float32 CPU copies of a few small device tensors with ONE device->host transfer (each .cpu() is a host sync)."""
+def _flat_on_device(mats: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
+    """The live tensors of `mats` as ONE float32 device vector (None when all of them are on the host already)."""
     live = [m for m in mats if m is not None]
     if not live or all(m.device.type == "cpu" for m in live):
-        return [None if m is None else m.detach().float() for m in mats]
+        return None
     dev = next(m.device for m in live if m.device.type != "cpu")
-    flat = torch.cat([m.detach().float().to(dev).reshape(-1) for m in live]).cpu()
+    return torch.cat([m.detach().float().to(dev).reshape(-1) for m in live])
+
+
+def _split_host(mats: Sequence[Optional[torch.Tensor]], flat: torch.Tensor) -> List[Optional[torch.Tensor]]:
     out, off = [], 0
     for m in mats:
         if m is None:
@@ -43,6 +46,14 @@ def _to_host(*mats: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:
         out.append(flat[off:off + m.numel()].view(m.shape).clone())
         off += m.numel()
     return out
+
+
+def _to_host(*mats: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:
+    """float32 CPU copies of a few small device tensors with ONE device->host transfer (each .cpu() is a host sync)."""
+    flat = _flat_on_device(mats)
+    if flat is None:
+        return [None if m is None else m.detach().float() for m in mats]
+    return _split_host(mats, flat.cpu())
 
 
 # ----------------------------------------------------------------------------------------------
@@ -461,6 +472,8 @@ class RenderEngine:
         self._l3_hint = None            # (z[3] tensor, its version, NHWC fp16 copy) handed over by get_z's conv_map kernel
         self._hostc = None              # (input tensors, their versions, host copies) of the last call's 4x4 inputs
         self._camc = None               # the device-side products of those inputs (_camera)
+        self._next: List[Dict] = []     # what prepare_next() started for the (up to two) pairs after the current one
+        self._prep_stream: Optional[torch.cuda.Stream] = None
         self._ws: Dict[str, torch.Tensor] = {}
         self._interval: Dict[Tuple[int, str], torch.Tensor] = {}
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops)
@@ -576,6 +589,7 @@ class RenderEngine:
         self._l3_hint = None
         self._hostc = None
         self._camc = None
+        self._next = []
         self._w32key, self._m32 = None, None
         self.epoch += 1
 
@@ -594,7 +608,14 @@ class RenderEngine:
         if c is not None and len(c[0]) == len(mats) and all(
                 (a is b) and (a is None or a._version == v) for a, b, v in zip(c[0], mats, c[1])):
             return c[2]
-        host = _to_host(*mats)
+        nx = next((e for e in self._next if e["stage"] is not None and len(e["mats"]) == len(mats) and all(
+            (a is b) and (a is None or a._version == v) for a, b, v in zip(e["mats"], mats, e["versions"]))), None)
+        if nx is not None:
+            nx["copied"].synchronize()          # the copy was queued a whole call ago: normally complete already
+            host = _split_host(mats, nx["stage"])
+            nx["stage"] = nx["flat"] = None
+        else:
+            host = _to_host(*mats)
         self._hostc = (mats, tuple(None if m is None else m._version for m in mats), host)
         return host
 
@@ -715,10 +736,30 @@ class RenderEngine:
         first encoder layer (tables, csrc/encode.hip).  Cached per (z tensors, weight generation): the entry holds
         strong references to the z tensors and compares identity, so a freed-and-reallocated tensor at the same
         address can never hit it."""
-        key = tuple((t._version, tuple(t.shape)) for t in z) + (self._wgen if self.tables else -1,)
+        key = self._maps_key(z)
         if key == self._mkey and len(self._mrefs) == len(z) and all(a is b for a, b in zip(self._mrefs, z)):
             return self._maps, self._tabs
         self._misses += 1
+        nx = next((e for e in self._next if e["mkey"] == key and len(e["z"]) == len(z) and
+                   all(a is b for a, b in zip(e["z"], z))), None)
+        if nx is not None:
+            # built by prepare_next() on its own stream while the previous pair rendered
+            cur = torch.cuda.current_stream(z[0].device)
+            cur.wait_event(nx["built"])
+            maps, tabs = nx["maps"], nx["tabs"]
+            for t in maps + tabs:
+                t.record_stream(cur)
+            nx["mkey"], nx["maps"], nx["tabs"] = None, None, None
+        else:
+            maps, tabs = self._build_maps(z, w)
+        self._maps, self._tabs, self._mkey, self._mrefs = maps, tabs, key, tuple(z)
+        return maps, tabs
+
+    def _maps_key(self, z: Sequence[torch.Tensor]):
+        return tuple((t._version, tuple(t.shape)) for t in z) + (self._wgen if self.tables else -1,)
+
+    def _build_maps(self, z: Sequence[torch.Tensor], w: Dict[str, torch.Tensor]):
+        """The launches behind _feature_maps, on the current stream."""
         maps, tabs, s = [], [], _stream()
         hint = self._l3_hint
         for i, t in enumerate(z):
@@ -742,8 +783,58 @@ class RenderEngine:
             call("cpn_gemm_f16", feat.data_ptr(), 768, w["enc.wtab"].data_ptr(), 768, w["enc.zero_bias"].data_ptr(),
                  tab.data_ptr(), _hip.TAB_LD, nodes, _hip.TAB_LD, 768, 0, 0, s)
             tabs.append(tab)
-        self._maps, self._tabs, self._mkey, self._mrefs = maps, tabs, key, tuple(z)
         return maps, tabs
+
+    @torch.no_grad()
+    def prepare_next(self, params: Dict[str, torch.Tensor], ctx_c2w, ctx_K, qry_c2w, qry_K, z: Sequence[torch.Tensor],
+                     rel_pose, flow=None, width: Optional[int] = None) -> None:
+        """Start the per-pair preparation of the pair that will be rendered AFTER the one about to be rendered (or being
+        rendered): the device->host copy of its 4x4 inputs, the NHWC fp16 copies of its latent maps, its node tables and,
+        with `flow` and `width` (the context images' height) given, its flow products — on a stream of their own that is
+        ordered after everything queued on the caller's stream so far.  The render() call on these SAME tensors (identity
+        + version) then finds them instead of rebuilding: its host pose algebra needs no device synchronisation behind the
+        previous pair's kernels, and its table build ran beside them (0.35 ms of kernels at 256x256).
+        Call it before render() of the current pair is queued so that the copy is not ordered behind that render:
+            prepare_next(pair[i+1]); render(pair[i]); prepare_next(pair[i+2]); render(pair[i+1]); ...
+        Two prepared pairs are held (the one about to be rendered and the one after it); a third replaces the older.  Results are those of an unprepared call, bit for bit
+        (the same kernels on the same inputs)."""
+        dev = z[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("coponerf_amd renders on a HIP device only (got z on %s)" % dev)
+        if self.precision == "f32":
+            return
+        main = torch.cuda.current_stream(dev)
+        w = self._weights(params)
+        if self._prep_stream is None or self._prep_stream.device != dev:
+            self._prep_stream = torch.cuda.Stream(device=dev)
+        side = self._prep_stream
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        mats = (ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
+        nx: Dict = {"mats": mats, "versions": tuple(None if m is None else m._version for m in mats), "z": tuple(z),
+                    "stage": None, "flat": None, "copied": None}
+        with torch.cuda.stream(side):
+            flat = _flat_on_device(mats)
+            if flat is not None:
+                nx["flat"] = flat               # kept until the copy has been consumed
+                nx["stage"] = torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True)
+                nx["stage"].copy_(flat, non_blocking=True)
+                nx["copied"] = torch.cuda.Event()
+                nx["copied"].record(side)
+            key = self._maps_key(z)
+            if key == self._mkey and len(self._mrefs) == len(z) and all(a is b for a, b in zip(self._mrefs, z)):
+                nx["mkey"], nx["maps"], nx["tabs"], nx["built"] = None, None, None, None
+            else:
+                nx["maps"], nx["tabs"] = self._build_maps(z, w)
+                nx["mkey"] = key
+                nx["built"] = torch.cuda.Event()
+                nx["built"].record(side)
+        if flow is not None and width is not None:
+            from .aux_outputs import prepare_flow_products
+            prepare_flow_products(flow, int(width), side)
+        # entries whose pieces were all consumed have nothing left to hand over
+        self._next = [nx] + [e for e in self._next if e["stage"] is not None or e["mkey"] is not None][:1]
 
     # ---- geometry shared by the inference and the training pass (never differentiated) ----------------
     @torch.no_grad()

@@ -777,6 +777,58 @@ def test_project_mode_matches_hidden_mode(model, dev, weights):
     eng._ws.clear()
 
 
+def test_announced_pair_is_bit_identical(model, dev):
+    """CoPoNeRF.prepare_next(): the per-pair preparation (camera copy to the host, NHWC maps, node tables, flow products)
+    started on its own stream while the previous pair renders.  Every output of the following forward() equals the
+    unannounced call's bit for bit, the prepared pieces were the ones used (consumed, no rebuild), an unannounced pair
+    still works in between, and a pair announced but changed in place before its call is rebuilt, not served stale."""
+    eng = model._engine
+    pairs = []
+    for name in ("c1_val", "wide_val", "c1_val"):
+        cfg, _ = load_case(name)
+        inp, z, rel, flow = case_inputs(cfg)
+        pairs.append((cfg, to_device(inp, dev), to_device(z, dev), rel.to(dev), to_device(flow, dev)))
+    keys = ("rgb", "at_wt", "valid_mask", "depth_ray", "mask_c2", "matchability_cycle_mask", "gt_rel_pose", "rel_pose_flip")
+
+    def fwd(p):
+        model.npoints = p[0]["S"]
+        with torch.no_grad():
+            o = model(p[1], z=p[2], rel_pose=p[3], val=p[0]["val"], flow=p[4])
+        return {k: o[k].clone() for k in keys} | {"pixel_val": o["pixel_val"].clone()}
+
+    plain = [fwd(p) for p in pairs]
+    for lanes in (1, 2):
+        eng.call_lanes = lanes
+        eng.invalidate()
+        model.prepare_next(*pairs[0][1:])
+        got = []
+        for i, p in enumerate(pairs):
+            if i + 1 < len(pairs):
+                nxt = pairs[i + 1]
+                model.prepare_next(nxt[1], nxt[2], nxt[3], nxt[4])
+                assert eng._next[0]["stage"] is not None and eng._next[0]["mkey"] is not None
+            mine = next(e for e in eng._next if e["z"][0] is p[2][0])
+            got.append(fwd(p))
+            assert mine["stage"] is None and mine["mkey"] is None, "the prepared pieces were not the ones used"
+            if i + 1 < len(pairs):
+                assert eng._next[0]["z"][0] is pairs[i + 1][2][0] and eng._next[0]["mkey"] is not None   # parked for the next call
+        for a, b in zip(plain, got):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (lanes, k)
+    # announced, then its latent maps change in place before the call: the version check must drop the prepared tables
+    p = pairs[1]
+    model.prepare_next(*p[1:])
+    p[2][0].mul_(0.5)
+    changed = fwd(p)
+    assert eng._next[0]["mkey"] is not None, "stale tables were adopted"
+    eng.invalidate()
+    again = fwd(p)
+    assert torch.equal(changed["rgb"], again["rgb"]) and not torch.equal(changed["rgb"], plain[1]["rgb"])
+    p[2][0].mul_(2.0)
+    eng.call_lanes = 2
+    eng._ws.clear()
+
+
 def test_f32_mode_is_the_reference_arithmetic(model, dev, weights):
     """RenderEngine.precision = "f32" (VERDICT r4 missing #4): every per-sample layer with fp32 operands on the exact fp32 MFMA,
     layer by layer in the reference's order.  (1) It reproduces the fp32 CPU oracle / the upstream fixture to fp32 rounding
