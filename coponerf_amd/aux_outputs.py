@@ -85,10 +85,9 @@ def flow_products(flow: Sequence[torch.Tensor], width: int):
         if e[0] == key and e[3][0] is flow[0] and e[3][1] is flow[1]:
             hit = True
             if e[4] is not None:
-                cur = torch.cuda.current_stream(e[1].device)
-                cur.wait_event(e[4])
-                e[1].record_stream(cur)
-                e[2].record_stream(cur)
+                # no record_stream: when the entry is dropped its blocks return to the preparation stream's pool, and that
+                # stream starts every preparation by waiting for what the caller's stream holds at that moment
+                torch.cuda.current_stream(e[1].device).wait_event(e[4])
                 e, hit = e[:4] + (None,), False
             if i or not hit:
                 entries.pop(i)

@@ -473,6 +473,7 @@ class RenderEngine:
         self._hostc = None              # (input tensors, their versions, host copies) of the last call's 4x4 inputs
         self._camc = None               # the device-side products of those inputs (_camera)
         self._next: List[Dict] = []     # what prepare_next() started for the (up to two) pairs after the current one
+        self._early: Optional[Dict] = None   # the current pair's own host copy, started by render() ahead of its builds
         self._prep_stream: Optional[torch.cuda.Stream] = None
         self._ws: Dict[str, torch.Tensor] = {}
         self._interval: Dict[Tuple[int, str], torch.Tensor] = {}
@@ -590,6 +591,7 @@ class RenderEngine:
         self._hostc = None
         self._camc = None
         self._next = []
+        self._early = None
         self._w32key, self._m32 = None, None
         self.epoch += 1
 
@@ -600,24 +602,73 @@ class RenderEngine:
         new.precision, new.unit_order, new.f32_chunk_rays = self.precision, self.unit_order, self.f32_chunk_rays
         return new
 
+    @staticmethod
+    def _same_inputs(held, versions, mats) -> bool:
+        return len(held) == len(mats) and all((a is b) and (a is None or a._version == v)
+                                              for a, b, v in zip(held, mats, versions))
+
     def _host_inputs(self, *mats):
         """Host copies of the call's 4x4 inputs.  The device->host read is a stream synchronisation, and a full-image
         render calls forward() once per ray chunk with the SAME camera tensors (/root/reference test.py:176-190,
-        wrapper.py:180-188): the copies are cached on tensor identity + version (the entry holds the tensors)."""
+        wrapper.py:180-188): the copies are cached on tensor identity + version (the entry holds the tensors).  A copy
+        that prepare_next() or _early_host_copy() started on the preparation stream is waited for and used instead of
+        a synchronous read behind everything queued on the caller's stream."""
         c = self._hostc
-        if c is not None and len(c[0]) == len(mats) and all(
-                (a is b) and (a is None or a._version == v) for a, b, v in zip(c[0], mats, c[1])):
+        if c is not None and self._same_inputs(c[0], c[1], mats):
             return c[2]
-        nx = next((e for e in self._next if e["stage"] is not None and len(e["mats"]) == len(mats) and all(
-            (a is b) and (a is None or a._version == v) for a, b, v in zip(e["mats"], mats, e["versions"]))), None)
+        nx = next((e for e in [self._early] + self._next if e is not None and e["stage"] is not None and
+                   self._same_inputs(e["mats"], e["versions"], mats)), None)
         if nx is not None:
-            nx["copied"].synchronize()          # the copy was queued a whole call ago: normally complete already
+            nx["copied"].synchronize()
             host = _split_host(mats, nx["stage"])
             nx["stage"] = nx["flat"] = None
         else:
             host = _to_host(*mats)
+        self._early = None
         self._hostc = (mats, tuple(None if m is None else m._version for m in mats), host)
         return host
+
+    def _camera_entry(self, mats, val: bool, H: int, dev):
+        c = self._camc
+        if c is not None and c[1] == (bool(val), H, dev) and c[3]["_flat"]._version == c[2] and \
+                self._same_inputs(c[0][0], c[0][1], mats):
+            return c[3]
+        return None
+
+    def _prep(self, dev) -> "torch.cuda.Stream":
+        if self._prep_stream is None or self._prep_stream.device != dev:
+            self._prep_stream = torch.cuda.Stream(device=dev)
+        return self._prep_stream
+
+    def _start_host_copy_of(self, mats, main, side) -> Dict:
+        """One pinned device->host copy of the live 4x4 inputs on `side`, ordered after what `main` holds now."""
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        e: Dict = {"mats": mats, "versions": tuple(None if m is None else m._version for m in mats), "stage": None,
+                   "flat": None, "copied": None}
+        with torch.cuda.stream(side):
+            flat = _flat_on_device(mats)
+            if flat is not None:
+                e["flat"] = flat                # kept until the copy has been consumed
+                e["stage"] = torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True)
+                e["stage"].copy_(flat, non_blocking=True)
+                e["copied"] = torch.cuda.Event()
+                e["copied"].record(side)
+        return e
+
+    def _early_host_copy(self, mats, val: bool, H: int, dev) -> None:
+        """render() calls this BEFORE it queues a new pair's device-side builds (maps, tables, flow products): the copy of
+        the 4x4 inputs to the host is ordered after the work queued so far only, so the host pose algebra of _camera
+        (0.5 ms) runs while the device builds the tables instead of after them with the device idle."""
+        if self._camera_entry(mats, val, H, dev) is not None:
+            return
+        c = self._hostc
+        if c is not None and self._same_inputs(c[0], c[1], mats):
+            return
+        if any(e["stage"] is not None and self._same_inputs(e["mats"], e["versions"], mats) for e in self._next):
+            return
+        self._early = self._start_host_copy_of(mats, torch.cuda.current_stream(dev), self._prep(dev))
 
     def _camera(self, ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose, val: bool, H: int, dev) -> Dict[str, torch.Tensor]:
         """Device copies of everything the O(B) host pose algebra produces for a call (camera block, Tq, the output-side
@@ -626,10 +677,9 @@ class RenderEngine:
         (/root/reference test.py:176-190).  The entries are views of one flat buffer that is also handed to the caller
         (gt_rel_pose ...): an in-place write to any of them bumps the buffer's version and drops the entry."""
         mats = (ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
-        c = self._camc
-        if c is not None and c[1] == (bool(val), H, dev) and c[3]["_flat"]._version == c[2] and all(
-                (a is b) and (a is None or a._version == v) for a, b, v in zip(c[0][0], mats, c[0][1])):
-            return c[3]
+        hit = self._camera_entry(mats, val, H, dev)
+        if hit is not None:
+            return hit
         self._misses += 1
         hc2w, hK, hqc2w, hqK, hrel = self._host_inputs(*mats)
         cam_cpu, Tq_cpu = build_camera_block(hc2w, hK, hqc2w, hqK, hrel, val, H)
@@ -744,11 +794,11 @@ class RenderEngine:
                    all(a is b for a, b in zip(e["z"], z))), None)
         if nx is not None:
             # built by prepare_next() on its own stream while the previous pair rendered
-            cur = torch.cuda.current_stream(z[0].device)
-            cur.wait_event(nx["built"])
+            # (no record_stream on the adopted tensors: when this entry is dropped their blocks return to the preparation
+            # stream's pool, and that stream begins every preparation by waiting for what the caller's stream holds at
+            # that moment - which includes every reader queued before the drop, the lanes' completion events too)
+            torch.cuda.current_stream(z[0].device).wait_event(nx["built"])
             maps, tabs = nx["maps"], nx["tabs"]
-            for t in maps + tabs:
-                t.record_stream(cur)
             nx["mkey"], nx["maps"], nx["tabs"] = None, None, None
         else:
             maps, tabs = self._build_maps(z, w)
@@ -805,23 +855,11 @@ class RenderEngine:
             return
         main = torch.cuda.current_stream(dev)
         w = self._weights(params)
-        if self._prep_stream is None or self._prep_stream.device != dev:
-            self._prep_stream = torch.cuda.Stream(device=dev)
-        side = self._prep_stream
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
+        side = self._prep(dev)
         mats = (ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
-        nx: Dict = {"mats": mats, "versions": tuple(None if m is None else m._version for m in mats), "z": tuple(z),
-                    "stage": None, "flat": None, "copied": None}
+        nx = self._start_host_copy_of(mats, main, side)
+        nx["z"] = tuple(z)
         with torch.cuda.stream(side):
-            flat = _flat_on_device(mats)
-            if flat is not None:
-                nx["flat"] = flat               # kept until the copy has been consumed
-                nx["stage"] = torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True)
-                nx["stage"].copy_(flat, non_blocking=True)
-                nx["copied"] = torch.cuda.Event()
-                nx["copied"].record(side)
             key = self._maps_key(z)
             if key == self._mkey and len(self._mrefs) == len(z) and all(a is b for a, b in zip(self._mrefs, z)):
                 nx["mkey"], nx["maps"], nx["tabs"], nx["built"] = None, None, None, None
@@ -1039,18 +1077,21 @@ class RenderEngine:
         main = torch.cuda.current_stream()
         miss0 = self._misses
         w = self._weights(params)
+        # a new pair: its 4x4 inputs start their way to the host first, its device-side builds are queued next, and the
+        # host pose algebra (which has to wait for that copy only) runs while the device builds
+        self._early_host_copy((ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose), val, H, dev)
         maps, tabs = self._feature_maps(z, w)
+        fp = None
+        if flow is not None and inp is not None:
+            from .aux_outputs import flow_products
+            fp, hit = flow_products(flow, inp["context"]["rgb"].shape[-2])
+            self._misses += 0 if hit else 1
         up = self._camera(ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose, val, H, dev)
         ikey = (S, str(dev))
         if ikey not in self._interval:
             self._interval[ikey] = torch.linspace(0, 1, S).to(dev)       # CPU linspace, as the oracle's
             self._misses += 1
         uvc, uvs = _uv_rows(uv, B, R)
-        fp = None
-        if flow is not None and inp is not None:
-            from .aux_outputs import flow_products
-            fp, hit = flow_products(flow, inp["context"]["rgb"].shape[-2])
-            self._misses += 0 if hit else 1
         base = uv._base if uv._base is not None else uv
         side = self._call_stream(dev)            # may install new lane streams, which resets _uv_seen (-> fresh)
         seen = self._uv_seen
