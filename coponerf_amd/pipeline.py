@@ -134,15 +134,31 @@ def render_images(model, inputs: Iterable[Dict], getz_batch: int = 1, graph: boo
                                             # is already on the main stream (the previous group), not for these renders
             nstate = None
             lo = 0
+            # the pairs of a batched group as (z, rel_pose, flow, full-resolution NHWC copy) slices, made ONCE: the engine
+            # matches what prepare_next() built to the later forward() by tensor identity
+            parts = []
+            if len(cur) > 1:
+                for n in sizes:
+                    l3 = hint[2][2 * lo:2 * (lo + n)] if hint is not None and hint[0] is z[3] else None
+                    parts.append((_pair_slice(z, lo, lo + n, 2), rel_pose[lo:lo + n], _pair_slice(flow, lo, lo + n, 1), l3))
+                    lo += n
+            lo = 0
             for i, inp in enumerate(cur):
                 hi = lo + sizes[i]
                 with torch.cuda.stream(main):                      # closed again before the yield below
                     if len(cur) == 1:
                         zi, ri, fi = z, rel_pose, flow
                     else:
-                        zi, ri, fi = _pair_slice(z, lo, hi, 2), rel_pose[lo:hi], _pair_slice(flow, lo, hi, 1)
-                        if hint is not None and hint[0] is z[3]:
-                            engine.adopt_level3(zi[3], hint[2][2 * lo:2 * hi])
+                        if i + 1 < len(cur):
+                            # the next pair of the group is known already: its per-pair preparation runs on the engine's
+                            # own stream under this pair's kernels (CoPoNeRF.prepare_next)
+                            zn, rn, fn, l3n = parts[i + 1]
+                            if l3n is not None:
+                                engine.adopt_level3(zn[3], l3n)
+                            model.prepare_next(cur[i + 1], zn, rn, fn)
+                        zi, ri, fi, l3 = parts[i]
+                        if l3 is not None:
+                            engine.adopt_level3(zi[3], l3)
                     model.H, model.W = H, W
                     # 1. the render of this pair: a few dozen launches, asynchronous
                     if nchunks:

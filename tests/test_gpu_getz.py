@@ -191,6 +191,9 @@ def test_pipelined_images_equal_serial(dev):
         piped = [out["rgb"].clone() for _, out in render_images(model, pairs)]
         overlapped = [out["rgb"].clone() for _, out in render_images(model, pairs, overlap=True)]   # get_z on a second stream
         batched = [out["rgb"].clone() for _, out in render_images(model, pairs, getz_batch=2)]   # groups of 2 + 1
+        # the second pair of the first group was announced while the first rendered (CoPoNeRF.prepare_next): what was built
+        # for it on the preparation stream is what its forward() used
+        assert model._engine._next and all(e["mkey"] is None and e["stage"] is None for e in model._engine._next)
         parted = [out["rgb"].clone() for _, out in render_images(model, pairs, cu_split=(192, 64))]   # partitioned chip
         lanes_after = model._engine.call_lanes
         # the callers' 5-call loop per image inside the render share, consecutive calls on two masked lanes
