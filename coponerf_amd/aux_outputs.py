@@ -11,6 +11,7 @@ utils_training/geometry.py:395-406.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, Sequence
 
 import torch
@@ -79,10 +80,12 @@ def flow_products(flow: Sequence[torch.Tensor], width: int):
     stream wait for it and is reported as a miss (the caller orders its other streams after a miss)."""
     key = tuple((f._version, tuple(f.shape)) for f in flow[:2]) + (width,)
     entries = _FLOW_CACHE.setdefault("entries", [])
-    # an entry holds the flow tensors themselves and is matched on IDENTITY (+ version): a new pair's flows that
-    # happen to be allocated at a freed pair's addresses can never hit it
+    # an entry is matched on the IDENTITY (+ version) of the flow tensors, held as weak references: a new pair's flows that
+    # happen to be allocated at a freed pair's addresses can never hit it, and this module-level cache never keeps a
+    # tensor of a captured get_z graph's private pool alive past the graph (freeing one after the graph is gone crashed
+    # at interpreter exit)
     for i, e in enumerate(entries):
-        if e[0] == key and e[3][0] is flow[0] and e[3][1] is flow[1]:
+        if e[0] == key and e[3][0]() is flow[0] and e[3][1]() is flow[1]:
             hit = True
             if e[4] is not None:
                 # no record_stream: when the entry is dropped its blocks return to the preparation stream's pool, and that
@@ -97,7 +100,7 @@ def flow_products(flow: Sequence[torch.Tensor], width: int):
     mask2 = mask2.contiguous()
     flow_up = (F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])).contiguous()
     if not any(f.requires_grad for f in flow[:2]):
-        entries.insert(0, (key, mask2, flow_up, (flow[0], flow[1]), None))
+        entries.insert(0, (key, mask2, flow_up, (weakref.ref(flow[0]), weakref.ref(flow[1])), None))
         del entries[3:]
     return (mask2, flow_up), False
 
@@ -109,7 +112,7 @@ def prepare_flow_products(flow: Sequence[torch.Tensor], width: int, stream: "tor
         return
     key = tuple((f._version, tuple(f.shape)) for f in flow[:2]) + (width,)
     entries = _FLOW_CACHE.setdefault("entries", [])
-    if any(e[0] == key and e[3][0] is flow[0] and e[3][1] is flow[1] for e in entries):
+    if any(e[0] == key and e[3][0]() is flow[0] and e[3][1]() is flow[1] for e in entries):
         return
     with torch.cuda.stream(stream):
         _, mask2 = cycle_masks(flow, width)
@@ -117,7 +120,7 @@ def prepare_flow_products(flow: Sequence[torch.Tensor], width: int, stream: "tor
         flow_up = (F.interpolate(flow[1], (256, 256), mode="bilinear") * (256 / flow[1].shape[2])).contiguous()
         ready = torch.cuda.Event()
         ready.record(stream)
-    entries.insert(0, (key, mask2, flow_up, (flow[0], flow[1]), ready))
+    entries.insert(0, (key, mask2, flow_up, (weakref.ref(flow[0]), weakref.ref(flow[1])), ready))
     del entries[3:]
 
 
