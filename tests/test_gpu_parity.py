@@ -777,6 +777,25 @@ def test_project_mode_matches_hidden_mode(model, dev, weights):
     eng._ws.clear()
 
 
+def test_psnr_against_ground_truth_within_a_tenth_of_a_db(model, dev, weights):
+    """north_star: "PSNR within 0.1 dB of reference".  PSNR of the rendered rays against the query image's own pixels (the
+    quantity test.py:218-224 reports, images in [-1, 1]: peak-to-peak 2) for the HIP path, the fp32 CPU oracle and the upstream
+    fixture on every fixture case: the three agree to 0.01 dB, and the HIP render against the oracle's is above 70 dB."""
+    def psnr(a, b):
+        return float(10 * torch.log10(4.0 / ((a - b) ** 2).mean().clamp_min(1e-20)))
+    for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
+        cfg, gold = load_case(name)
+        ref, out = run_pair(model, dev, weights, cfg)
+        inp = case_inputs(cfg)[0]
+        gt = inp["query"]["rgb"].float()
+        ours, want, up = out["rgb"].cpu(), ref["rgb"], torch.from_numpy(gold["rgb"])
+        p_ours, p_ref, p_up = psnr(ours, gt), psnr(want, gt), psnr(up, gt)
+        print(name, "PSNR vs ground truth: HIP %.4f  oracle %.4f  upstream %.4f dB;  HIP vs oracle %.1f dB" %
+              (p_ours, p_ref, p_up, psnr(ours, want)))
+        assert abs(p_ours - p_ref) <= 0.01 and abs(p_ours - p_up) <= 0.01, (name, p_ours, p_ref, p_up)
+        assert psnr(ours, want) >= 70.0
+
+
 def test_announced_pair_is_bit_identical(model, dev):
     """CoPoNeRF.prepare_next(): the per-pair preparation (camera copy to the host, NHWC maps, node tables, flow products)
     started on its own stream while the previous pair renders.  Every output of the following forward() equals the
