@@ -31,7 +31,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_encode_hidden": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "cpn_encode_project": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
-    "cpn_local_units": [_I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_local_units": [_I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
@@ -104,7 +104,7 @@ TAB_LD = 832
 K80_BLOCK_HALVES = 5120          # CPN_K80_BLOCK_HALVES: one slice of the streamed K = 80 weight block (cpn_encode_project)
 RAYC_STRIDE = 64
 LIGHTFIELD_PACK_FLOATS = 128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 ADAM_SEG_BYTES = 48
 
 

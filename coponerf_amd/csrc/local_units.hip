@@ -12,6 +12,10 @@
 //       q2    = query_repeat_embed_2(ReLU(W_l . local_coords + b + add[ray]))           add = W_z . encode_latent(z_local)
 //       logit = <fp16(q2), ce_u>                                                        -> logits[row]
 //     = cpn_local_mlp's logits form with the unit row map.
+//   mode 2 (round 2 with coords_embed RECOMPUTED): mode 1 without its 256-byte-per-sample read of ce_u - the two query_embed
+//     layers are evaluated again from the local coordinates the kernel reads anyway (56 more MFMAs per unit, the same
+//     instructions in the same order as mode 0: the same bits), and mode 0 is then called with ce_u = NULL and stores nothing:
+//     2.1 GB less written and 2.1 GB less read per 65 536-ray image, both kernels were bound by that traffic.
 // Unit order of a (rows, 128) fp16 matrix X: [unit][32-column block p][lane = c + 16 fg][8] holds X[row(unit, c)][32 p + 8 fg .. +8],
 // c = (sample & 3) * 4 + (ray & 3) — a wave's access to one block is 1 KiB of contiguous memory and IS the B operand of
 // v_mfma_f32_16x16x32_f16 for the k block p.  Structure (8 waves share the layer-2 fragments in LDS, the first layer's bias on
@@ -27,14 +31,16 @@ struct UnitGeo {
     long long group0, nunits;
 };
 
+// MODE 2: (w1, b1, add, w2, b2) are the round-2 query layers as in mode 1; (w1b, b1b) = query_embed, (wk2, bk2) = query_embed_2
 template <int MODE>
-__global__ __launch_bounds__(512, 4) void local_units_kernel(
+__global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
     const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
     const float* __restrict__ b2, const __half* __restrict__ wk2, int ldwk2, const float* __restrict__ bk2,
+    const float* __restrict__ w1b, int ldw1b, const float* __restrict__ b1b,
     const __half* __restrict__ kh_u, UnitGeo geo, __half* __restrict__ ce_u, float* __restrict__ logits) {
     __shared__ __attribute__((aligned(16))) half8 w2l[8 * 4 * 64];                       // [tile t][k block p][lane]
-    __shared__ __attribute__((aligned(16))) half8 wkl[MODE == 0 ? 8 * 4 * 64 : 1];      // key_map_2, same layout
+    __shared__ __attribute__((aligned(16))) half8 wkl[MODE != 1 ? 8 * 4 * 64 : 1];      // key_map_2 (mode 0) / query_embed_2 (mode 2), same layout
     __shared__ __attribute__((aligned(16))) float b2s[128];
     __shared__ __attribute__((aligned(16))) float bks[128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -43,26 +49,41 @@ __global__ __launch_bounds__(512, 4) void local_units_kernel(
         const int l = i & 63, p = (i >> 6) & 3, t = i >> 8;
         const int ch = (t >> 1) * 32 + ((l & 15) >> 2) * 8 + (t & 1) * 4 + (l & 3);       // output channel of tile row
         w2l[i] = *reinterpret_cast<const half8*>(w2 + (size_t)ch * ldw2 + p * 32 + (l >> 4) * 8);
-        if constexpr (MODE == 0) wkl[i] = *reinterpret_cast<const half8*>(wk2 + (size_t)ch * ldwk2 + p * 32 + (l >> 4) * 8);
+        if constexpr (MODE != 1) wkl[i] = *reinterpret_cast<const half8*>(wk2 + (size_t)ch * ldwk2 + p * 32 + (l >> 4) * 8);
     }
     if (threadIdx.x < 128) {
         b2s[threadIdx.x] = b2[threadIdx.x];
-        bks[threadIdx.x] = MODE == 0 ? bk2[threadIdx.x] : 0.0f;
+        bks[threadIdx.x] = MODE != 1 ? bk2[threadIdx.x] : 0.0f;
     }
     // First layer (K = 16, fp32 weights and inputs) on the fp16 MFMA as a hi / lo split - w = wh + wl, x = xh + xl (each part
     // an fp16), w . x = wh xh + wh xl + wl xh up to 2^-22 |w x| - three v_mfma_f32_16x16x16_f16 of 8 cycles per tile instead
     // of four v_mfma_f32_16x16x4_f32 of 32: the fp32 MFMA runs at 1/16 of the fp16 rate and was two thirds of this
     // kernel's matrix time (cpn_local_mlp keeps the fp32 form).
-    half4 wh[8], wl[8];
+    // (the A fragments live in LDS - [set][tile][lane] half4, sets: hi, lo (, query_embed's hi, lo in mode 2) - and are read where
+    // they are used: held in registers they were 32 (64) of the 128 a wave may have at four waves per SIMD)
+    __shared__ __attribute__((aligned(8))) half4 w1s[MODE == 2 ? 4 : 2][8][64];
+    if (wave == 0) {
+        auto split = [&](const float* wsrc, int ldw, const float* bsrc, int ch, half4& hi, half4& lo) {
+            f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + (size_t)ch * ldw + fg * 4);
+            if (fg == 0) wv[3] = bsrc[ch];                     // K slot 3 is unused by the inputs: bias x 1.0
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int ch = (t >> 1) * 32 + (a >> 2) * 8 + (t & 1) * 4 + (a & 3);
-        f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + (size_t)ch * ldw1 + fg * 4);
-        if (fg == 0) wv[3] = b1[ch];                           // K slot 3 is unused by the inputs: bias x 1.0
+            for (int i = 0; i < 4; ++i) {
+                hi[i] = (_Float16)wv[i];
+                lo[i] = (_Float16)(wv[i] - (float)hi[i]);
+            }
+        };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wh[t][i] = (_Float16)wv[i];
-            wl[t][i] = (_Float16)(wv[i] - (float)wh[t][i]);
+        for (int t = 0; t < 8; ++t) {
+            const int ch = (t >> 1) * 32 + (a >> 2) * 8 + (t & 1) * 4 + (a & 3);
+            half4 hi, lo;
+            split(w1, ldw1, b1, ch, hi, lo);
+            w1s[0][t][lane] = hi;
+            w1s[1][t][lane] = lo;
+            if constexpr (MODE == 2) {
+                split(w1b, ldw1b, b1b, ch, hi, lo);
+                w1s[2][t][lane] = hi;
+                w1s[3][t][lane] = lo;
+            }
         }
     }
     __syncthreads();
@@ -101,15 +122,18 @@ __global__ __launch_bounds__(512, 4) void local_units_kernel(
     for (unsigned uu = wave_id; uu < nunits; uu += nwaves) {
         const RowIn nxt = fetch(uu + nwaves < nunits ? uu + nwaves : uu);
         // the other operand of the dot product, as B fragments / accumulator-layout rows: 4 x 1 KiB of contiguous memory
+        // (requesting it a unit ahead was measured: no change - the kernel is not waiting for it)
         half8 cv[4];
+        if constexpr (MODE != 2) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(MODE == 0 ? kh_u : ce_u) + ((size_t)uu * 4 + p) * 64 + lane);
+            for (int p = 0; p < 4; ++p)
+                cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(MODE == 0 ? kh_u : ce_u) + ((size_t)uu * 4 + p) * 64 + lane);
+        }
         f32x4 acc[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (MODE == 1)
+            if (MODE != 0)
                 acc[t] = *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
         }
         half4 xh, xl;
@@ -118,11 +142,41 @@ __global__ __launch_bounds__(512, 4) void local_units_kernel(
             xh[i] = (_Float16)cur.lv[i];
             xl[i] = (_Float16)(cur.lv[i] - (float)xh[i]);
         }
+        if constexpr (MODE == 2) {
+            // coords_embed of this unit, exactly as mode 0 forms it (same instructions, same order: the bits mode 0 would have stored)
+            f32x4 ab[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                ab[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const half4 whb = w1s[2][t][lane], wlb = w1s[3][t][lane];
+                ab[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wlb, xh, ab[t], 0, 0, 0);
+                ab[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(whb, xl, ab[t], 0, 0, 0);
+                ab[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(whb, xh, ab[t], 0, 0, 0);
+            }
+            half8 hq[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hq[p][i] = (_Float16)fmaxf(ab[2 * p][i], 0.0f);
+                    hq[p][4 + i] = (_Float16)fmaxf(ab[2 * p + 1][i], 0.0f);
+                }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f32x4 o = *reinterpret_cast<const f32x4*>(bks + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_f16(wkl[(t * 4 + p) * 64 + lane], hq[p], o, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cv[t >> 1][(t & 1) * 4 + i] = (_Float16)o[i];
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[t], xh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[t], xl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[t], xh, acc[t], 0, 0, 0);
+            const half4 wh = w1s[0][t][lane], wl = w1s[1][t][lane];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, xh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xh, acc[t], 0, 0, 0);
         }
         // hidden layer -> fp16 B operands: K block p = channels p*32 .. p*32+31, this lane holds fg*8 .. fg*8+7 of it
         half8 hb[4];
@@ -155,7 +209,7 @@ __global__ __launch_bounds__(512, 4) void local_units_kernel(
                     ce[p][i] = (_Float16)o2[2 * p][i];
                     ce[p][4 + i] = (_Float16)o2[2 * p + 1][i];
                 }
-                reinterpret_cast<half8*>(ce_u)[((size_t)uu * 4 + p) * 64 + lane] = ce[p];
+                if (ce_u) reinterpret_cast<half8*>(ce_u)[((size_t)uu * 4 + p) * 64 + lane] = ce[p];   // NULL: round 2 recomputes it (mode 2)
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -185,17 +239,20 @@ __global__ __launch_bounds__(512, 4) void local_units_kernel(
 
 extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
                                const float* add, const uint16_t* w2, int ldw2, const float* b2, const uint16_t* wk2, int ldwk2,
-                               const float* bk2, const uint16_t* kh_u, int B, int V, int R, int S, int ray0, int nrays,
-                               uint16_t* ce_u, float* logits, void* stream) {
-    CPN_REQUIRE(mode == 0 || mode == 1, CPN_E_ARG, "cpn_local_units: mode must be 0 or 1 (got %d)", mode);
-    CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && ce_u && logits, CPN_E_ARG, "cpn_local_units: null pointer");
-    CPN_REQUIRE(mode == 0 ? (wk2 && bk2 && kh_u) : (add != nullptr), CPN_E_ARG, "cpn_local_units: null pointer for mode %d", mode);
+                               const float* bk2, const float* w1b, int ldw1b, const float* b1b, const uint16_t* kh_u, int B,
+                               int V, int R, int S, int ray0, int nrays, uint16_t* ce_u, float* logits, void* stream) {
+    CPN_REQUIRE(mode >= 0 && mode <= 2, CPN_E_ARG, "cpn_local_units: mode must be 0, 1 or 2 (got %d)", mode);
+    CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && logits, CPN_E_ARG, "cpn_local_units: null pointer");
+    CPN_REQUIRE(mode == 0 ? (wk2 && bk2 && kh_u) : mode == 1 ? (add && ce_u) : (add && wk2 && bk2 && w1b && b1b), CPN_E_ARG,
+                "cpn_local_units: null pointer for mode %d", mode);
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && ldw1 >= 16 && ldw2 >= 128 && (ldw2 % 8) == 0 &&
-                    (mode == 1 || (ldwk2 >= 128 && (ldwk2 % 8) == 0)), CPN_E_SHAPE, "cpn_local_units: bad shape");
+                    (mode == 1 || (ldwk2 >= 128 && (ldwk2 % 8) == 0)) && (mode != 2 || ldw1b >= 16), CPN_E_SHAPE,
+                "cpn_local_units: bad shape");
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_local_units: ray range outside B*R");
-    CPN_REQUIRE(((uintptr_t)ce_u % 16) == 0 && ((uintptr_t)kh_u % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wk2 % 16) == 0,
-                CPN_E_ARG, "cpn_local_units: fp16 operands must be 16-byte aligned");
+    CPN_REQUIRE(((uintptr_t)ce_u % 16) == 0 && ((uintptr_t)kh_u % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wk2 % 16) == 0 &&
+                    ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)w1b % 16) == 0,
+                CPN_E_ARG, "cpn_local_units: fp16 operands and first-layer weights must be 16-byte aligned");
     UnitGeo geo;
     geo.V = V; geo.R = R; geo.S = S; geo.ray0 = ray0; geo.nrays = nrays;
     geo.nsblk = (int)cpn_cdiv(S, TSW);
@@ -205,13 +262,19 @@ extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9
     const long long group1 = (long long)b_hi * geo.groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
     geo.nunits = (group1 - geo.group0 + 1) * V * geo.nsblk;
     CPN_REQUIRE(geo.nunits * 16 < (1LL << 31), CPN_E_SHAPE, "cpn_local_units: chunk too large for 32-bit indexing");
-    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(geo.nunits, 8), mode == 0 ? 512 : 1024);
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(geo.nunits, 8), mode == 1 ? 1024 : 512);
     if (mode == 0)
         hipLaunchKernelGGL(local_units_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
-                           (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, (const __half*)kh_u, geo, (__half*)ce_u, logits);
-    else
+                           (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
+                           (__half*)ce_u, logits);
+    else if (mode == 1)
         hipLaunchKernelGGL(local_units_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
-                           (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, (const __half*)kh_u, geo, (__half*)ce_u, logits);
+                           (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
+                           (__half*)ce_u, logits);
+    else
+        hipLaunchKernelGGL(local_units_kernel<2>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+                           (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
+                           (__half*)ce_u, logits);
     CPN_LAUNCH_CHECK("cpn_local_units");
     return 0;
 }

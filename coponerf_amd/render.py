@@ -449,6 +449,10 @@ class RenderEngine:
         # unit order of the first-layer kernel (include/coponerf_hip.h) and ONE kernel forms coords_embed, key_map_2 and the
         # round-1 logit (cpn_local_units: cpn_local_mlp + cpn_gemm_f16_rowdot before).  COPONERF_UNIT_ORDER=0: the round-4 stages
         self.unit_order = os.environ.get("COPONERF_UNIT_ORDER", "1") != "0"
+        # ce_recompute (unit order only): round 2 evaluates the two query_embed layers again from the local coordinates it reads
+        # anyway (cpn_local_units mode 2) instead of reading coords_embed back - 2 x 256 bytes per sample less HBM traffic, the
+        # same logits bit for bit.  COPONERF_CE_RECOMPUTE=0: coords_embed stored by round 1, read by round 2 (mode 1)
+        self.ce_recompute = os.environ.get("COPONERF_CE_RECOMPUTE", "1") != "0"
         # fold_value=True: value/key projections folded through query_encode_latent_2 (36 % fewer FLOPs, same
         # result up to rounding); False: layer-by-layer evaluation exactly as the reference orders it
         self.fold_value = bool(fold_value)
@@ -600,6 +604,7 @@ class RenderEngine:
         new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables, self.fuse_key, self.project)
         new.grad_scale_target, new.call_lanes, new.lazy_pixel_val = self.grad_scale_target, self.call_lanes, self.lazy_pixel_val
         new.precision, new.unit_order, new.f32_chunk_rays = self.precision, self.unit_order, self.f32_chunk_rays
+        new.ce_recompute = self.ce_recompute
         return new
 
     @staticmethod
@@ -1153,6 +1158,7 @@ class RenderEngine:
         ce_frag = self.fold_value and self.ce_frag
         project = self.project and fused_key
         units = self.unit_order and fused_key
+        recompute = units and self.ce_recompute          # round 2 forms coords_embed again: it is never stored (cpn_local_units mode 2)
         C = min(self.chunk_rays if self.chunk_rays > 0 else self._auto_chunk(S, dev, nray_total), nray_total)
         T = V * S                       # rows per ray for the attention stage
         GW = dict(self.GEMM_WEIGHTS, key_fold=(128, 1664, 1664), value_fold=(416, 1664, 1664))
@@ -1167,9 +1173,11 @@ class RenderEngine:
             # coords_embed: whole 16-row groups (the fragment-order stores write them whole); in unit order: 16 rows per unit
             # incl. the dead rows of partial units (at most one ray group more per batch element and chunk edge)
             rows128 = ((C + 3) // 4 + B + 1) * V * ((S + 3) // 4) * 16 if units else (C * T + 15) // 16 * 16
-            bufs = {"ce": t("ce", (rows128, 128), f16), "lg": t("lg", (C * T,), f32),
+            bufs = {"lg": t("lg", (C * T,), f32),
                     "z1": t("z1", (C, 416), f32), "ze": t("ze", (C, 128), f32), "addq": t("addq", (C, 128), f32),
                     "hbar": t("hbar", (C, 1664), f16), "zs": t("zs", (C, 416), f32)}
+            if not recompute:
+                bufs["ce"] = t("ce", (rows128, 128), f16)
             if not self.tables:
                 bufs["xin"] = t("xin", (C * T * 2, _hip.XIN_STRIDE), f16)
             if project:
@@ -1257,7 +1265,7 @@ class RenderEngine:
             """G: key_map_2 (+ the folded key_map layer when it did not run inside E) and <key, coords_embed>  [:408, :450]"""
             n = min(C, nray_total - ray0)
             rows = n * T
-            ce, lg = bf["ce"], bf["lg"]
+            ce, lg = bf.get("ce"), bf["lg"]
             if self.fold_value:
                 # folded key_map -> ReLU -> key_map_2 -> <key, coords_embed> in ONE kernel over hid viewed as (rows,1664):
                 # neither the 128-wide hidden layer nor the key reaches HBM, only 4 bytes of logit per row
@@ -1267,10 +1275,11 @@ class RenderEngine:
                     e0.record()
                 if units:
                     # coords_embed (both query layers), key_map_2 on the unit-order kh of cpn_encode_key and <key, coords_embed>
+                    # (ce_recompute: round 2 forms coords_embed again instead of reading it back, nothing is stored here)
                     call("cpn_local_units", 0, loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
                          w["query_embed.b"].data_ptr(), 0, w["query_embed_2.w16"].data_ptr(), 128, w["query_embed_2.b"].data_ptr(),
-                         w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(), bf["khf"].data_ptr(), B, V, R, S, ray0, n,
-                         ce.data_ptr(), lg.data_ptr(), s)
+                         w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(), 0, 0, 0, bf["khf"].data_ptr(), B, V, R, S,
+                         ray0, n, 0 if recompute else ce.data_ptr(), lg.data_ptr(), s)
                 elif fused_key:
                     # the 1664 -> 128 layer already ran inside cpn_encode_key: key_map_2 + <key, coords_embed> on its output
                     call("cpn_gemm_f16_rowdot", bf["khf"].data_ptr(), 128, w["key_map_2.w16"].data_ptr(), 128,
@@ -1310,10 +1319,16 @@ class RenderEngine:
                  w["encode_latent.b"].data_ptr(), 0, 0, ze.data_ptr(), 128, n, 128, 416, 0, 0, s)
             call("cpn_linear_f32", ze.data_ptr(), 128, w["query_repeat_embed.w_z"].data_ptr(), 128, 0, 0, 0,
                  addq.data_ptr(), 128, n, 128, 128, 0, 0, s)
-            if units:
+            if recompute:
+                call("cpn_local_units", 2, loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
+                     w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
+                     w["query_repeat_embed_2.b"].data_ptr(), w["query_embed_2.w16"].data_ptr(), 128, w["query_embed_2.b"].data_ptr(),
+                     w["query_embed.w"].data_ptr(), 16, w["query_embed.b"].data_ptr(), 0, B, V, R, S, ray0, n, 0,
+                     bf["lg"].data_ptr(), s)
+            elif units:
                 call("cpn_local_units", 1, loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
                      w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
-                     w["query_repeat_embed_2.b"].data_ptr(), 0, 0, 0, 0, B, V, R, S, ray0, n, bf["ce"].data_ptr(),
+                     w["query_repeat_embed_2.b"].data_ptr(), 0, 0, 0, 0, 0, 0, 0, B, V, R, S, ray0, n, bf["ce"].data_ptr(),
                      bf["lg"].data_ptr(), s)
             elif self.fold_value:
                 # the second query only enters through <query2, coords_embed>: local_mlp writes that logit directly

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 7
+#define CPN_ABI_VERSION 8
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -208,11 +208,15 @@ int cpn_encode_project(const uint16_t* tab, const uint16_t* map3, int H, int W, 
  *   cpn_local_mlp + cpn_gemm_f16_rowdot.  w1 (128, ldw1 >= 16) fp32 / b1: first layer; w2 (128, ldw2) fp16 / b2: second layer;
  *   wk2 (128, ldwk2) fp16 / bk2: key_map_2.
  * mode 1 (:472-475): logits[row] = < fp16(query_repeat_embed_2(ReLU(w1 . local_coords + b1 + add[ray]))), ce_u[row] >, add (nrays,
- *   128) fp32.  logits (nrays*V*S) fp32 in row order; rows of a partial unit that lie outside the ray range are skipped.   */
+ *   128) fp32.  logits (nrays*V*S) fp32 in row order; rows of a partial unit that lie outside the ray range are skipped.
+ * mode 2: mode 1 with coords_embed RECOMPUTED from the local coordinates instead of read back (the same instructions in the same
+ *   order as mode 0 formed it with: the same logits, bit for bit): w1b (128, ldw1b >= 16) fp32 / b1b = query_embed, wk2 / bk2 =
+ *   query_embed_2; ce_u is not touched.  Mode 0 with ce_u = NULL then stores no coords_embed at all (2 x 256 bytes per sample
+ *   less HBM traffic; both kernels were bound by it).  w1b / b1b are ignored by modes 0 and 1.                               */
 int cpn_local_units(int mode, const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
                     const float* add, const uint16_t* w2, int ldw2, const float* b2, const uint16_t* wk2, int ldwk2,
-                    const float* bk2, const uint16_t* kh_u, int B, int V, int R, int S, int ray0, int nrays,
-                    uint16_t* ce_u, float* logits, void* stream);
+                    const float* bk2, const float* w1b, int ldw1b, const float* b1b, const uint16_t* kh_u, int B, int V,
+                    int R, int S, int ray0, int nrays, uint16_t* ce_u, float* logits, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).

@@ -675,11 +675,22 @@ def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights)
         lg1 = torch.full((rows + 8,), -7.0, device=dev)
         lg2 = torch.full((rows + 8,), -7.0, device=dev)
         call("cpn_local_units", 0, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
-             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), dp(khu),
-             B, V, R, S, ray0, n, dp(ce_u), dp(lg1), s)
+             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), 0, 0, 0,
+             dp(khu), B, V, R, S, ray0, n, dp(ce_u), dp(lg1), s)
         call("cpn_local_units", 1, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
-             dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), 0, 0, 0, 0, B, V, R, S, ray0, n,
-             dp(ce_u), dp(lg2), s)
+             dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), 0, 0, 0, 0, 0, 0, 0, B, V, R, S,
+             ray0, n, dp(ce_u), dp(lg2), s)
+        # the product's pair: round 1 storing no coords_embed (ce_u = NULL), round 2 recomputing it (mode 2) - the same logits, bit
+        # for bit, as the stored form above
+        lg1n = torch.full((rows + 8,), -7.0, device=dev)
+        lg2n = torch.full((rows + 8,), -7.0, device=dev)
+        call("cpn_local_units", 0, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
+             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), 0, 0, 0,
+             dp(khu), B, V, R, S, ray0, n, 0, dp(lg1n), s)
+        call("cpn_local_units", 2, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
+             dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), dp(w["query_embed_2.w16"]), 128,
+             dp(w["query_embed_2.b"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0, B, V, R, S, ray0, n, 0, dp(lg2n), s)
+        assert torch.equal(lg1n, lg1) and torch.equal(lg2n, lg2), "recomputed coords_embed gives other logits than the stored one"
         # (first layer as an fp16 hi / lo split on the fp16 MFMA here, on the fp32 MFMA there: 2^-22 apart before the fp16
         # rounding of the hidden layer, so a few outputs differ by an fp16 ulp)
         d_ce = (rows_from_unit_order(ce_u, B, R, S, ray0, n).float() - ce_r[:rows].float()).abs()
@@ -699,7 +710,7 @@ def test_unit_order_mode_matches_row_order_mode(model, dev, weights):
     cpn_gemm_f16_rowdot, row-major kh) on every fixture case: identical sample coordinates, attention weights and image to the
     rounding of the logits' fp32 sums - and both against the oracle."""
     eng = model._engine
-    assert eng.unit_order
+    assert eng.unit_order and eng.ce_recompute
     for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
         cfg, gold = load_case(name)
         ref, out_u = run_pair(model, dev, weights, cfg)
@@ -708,6 +719,14 @@ def test_unit_order_mode_matches_row_order_mode(model, dev, weights):
             _, out_r = run_pair(model, dev, weights, cfg)
         finally:
             eng.unit_order = True
+        # coords_embed stored by round 1 and read back by round 2 (cpn_local_units mode 1) instead of recomputed (mode 2, the
+        # default): the same image bit for bit
+        eng.ce_recompute = False
+        try:
+            _, out_s = run_pair(model, dev, weights, cfg)
+        finally:
+            eng.ce_recompute = True
+        assert torch.equal(out_s["rgb"], out_u["rgb"]) and torch.equal(out_s["at_wt"], out_u["at_wt"]), name
         assert torch.equal(out_u["pixel_val"], out_r["pixel_val"])
         d_wt = float((out_u["at_wt"] - out_r["at_wt"]).abs().max())
         d_rgb = float((out_u["rgb"] - out_r["rgb"]).abs().max())

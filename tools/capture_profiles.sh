@@ -31,6 +31,7 @@ tools/pmc_passes.sh "$OUT/pmc_encode_hidden" encode_hidden -- python "$ROOT/tool
 python tools/make_traffic_json.py "$OUT/pmc_encode_hidden/summary.json" 16777216 "$OUT/traffic_encode_hidden.json" >> "$OUT/pmc_encode_hidden.log" 2>&1
 python tools/ef_check.py --no-check > "$OUT/encode_fused_ablation.json" 2>/dev/null
 COPONERF_UNIT_ORDER=0 python bench.py --no-image --no-ref-loop --no-f32 --cpu-rays 0 --train-steps 0 > "$OUT/bench_row_order_stages.json" 2>> "$OUT/bench.err"
+COPONERF_CE_RECOMPUTE=0 python bench.py --no-image --no-ref-loop --no-f32 --cpu-rays 0 --train-steps 0 > "$OUT/bench_coords_embed_stored.json" 2>> "$OUT/bench.err"
 COPONERF_PROJECT=1 python bench.py --no-image --no-ref-loop --no-f32 --cpu-rays 0 --train-steps 0 > "$OUT/bench_project_before_store.json" 2>> "$OUT/bench.err"
 COPONERF_FUSE_KEY=0 python bench.py --no-image --no-ref-loop --no-f32 --cpu-rays 0 --train-steps 0 > "$OUT/bench_separate_key_kernel.json" 2>> "$OUT/bench.err"
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/getz_prof" -o g -- python "$ROOT/tools/getz_time.py" ) > "$OUT/getz_prof.log" 2>&1
