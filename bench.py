@@ -64,6 +64,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-image", action="store_true", help="skip the secondary image-pipeline figures (get_z + render)")
     ap.add_argument("--no-f32", action="store_true", help="skip the reference-arithmetic (fp32-operand) pass of the same step")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-fresh-pair", action="store_true",
+                    help="skip the two loops over NEW stereo pairs (rays_per_s_fresh_pair[_announced]); the profiled command of "
+                         "tools/capture_profiles.sh uses it: the announced loop's preparation kernels run BESIDE the render "
+                         "kernels on their own stream and would show up in the kernel statistics with their co-run durations")
     ap.add_argument("--no-two-stream-pass", action="store_true",
                     help="skip the second timed pass with consecutive calls on two streams (keeps a rocprofv3 kernel "
                          "trace of this command to the one-stream headline loop, whose kernels never overlap)")
@@ -264,7 +268,7 @@ def run(args):
     #      copies of the latent maps, the node tables (node features + a 97 GFLOP projection GEMM per pair), the camera
     #      block upload, the flow products — is rebuilt inside the timed region (four pairs in turn; the caches hold one)
     fresh = announced = None
-    if not args.pair_by_pair and B == 1:
+    if not args.pair_by_pair and B == 1 and not args.no_fresh_pair:
         fjobs = []
         for j in range(4):
             ic = syn.make_inputs(1, H, H, 0, seed=500 + rank + 1000 * j, full_image=True, rig=args.rig)

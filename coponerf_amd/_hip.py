@@ -22,7 +22,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_stream_create_cu_range": [_I, _I, ctypes.POINTER(ctypes.c_void_p)],
     "cpn_stream_destroy": [_P],
     "cpn_project_rays": [_P, _P, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P],
-    "cpn_sample_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "cpn_sample_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "cpn_nchw_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
     "cpn_pack_weight_f16": [_P, _I, _I, _P, _I, _P],
     "cpn_gather_rows": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
@@ -31,7 +31,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_encode_hidden": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "cpn_encode_project": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
-    "cpn_local_units": [_I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cpn_local_units": [_I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],

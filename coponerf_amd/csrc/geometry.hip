@@ -137,7 +137,7 @@ __global__ void sample_geometry_kernel(const float* __restrict__ cam, const floa
                                        int N, int R, int S, int H, int W,
                                        float* __restrict__ pixel_val, float* __restrict__ pt_out,
                                        float* __restrict__ sec_grid, float* __restrict__ pe6,
-                                       float* __restrict__ loc8) {
+                                       float* __restrict__ loc8, float* __restrict__ lv_u, int V) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)N * R * S;
     if (idx >= total) return;
@@ -231,6 +231,19 @@ __global__ void sample_geometry_kernel(const float* __restrict__ cam, const floa
     lc[5] = tanhf(depth / 100.0f);
     lc[6] = tanhf(depth / 1000.0f);
     lc[7] = 0.0f;
+    if (lv_u) {
+        // the same 16 inputs (local_coords, CoPoNeRF.py:411-445) once more, in the UNIT order cpn_local_units multiplies in
+        // (include/coponerf_hip.h): lane c + 16 fg of unit ((b * ceil(R/4) + r/4) * V + v) * ceil(S/4) + s/4, c = (s & 3) * 4 +
+        // (r & 3), holds K entries 4 fg .. 4 fg + 3 - a wave of that kernel then reads its unit's inputs as ONE 1 KiB line
+        // instead of five scattered 4 - 16 byte accesses per lane
+        const int r = (int)(nr % R), b = n / V, v = n - b * V;
+        const long long unit = ((((long long)b * ((R + 3) >> 2) + (r >> 2)) * V + v) * ((S + 3) >> 2)) + (s >> 2);
+        f32x4* dst = reinterpret_cast<f32x4*>(lv_u) + unit * 64 + ((s & 3) * 4 + (r & 3));
+        dst[0] = f32x4{lc[0], lc[1], lc[2], 1.0f};            // (the 1.0 multiplies the first layer's bias)
+        dst[16] = f32x4{0.0f, 0.0f, c9[0], c9[1]};
+        dst[32] = f32x4{c9[2], lc[3], lc[4], lc[5]};
+        dst[48] = f32x4{lc[6], c9[6], c9[7], c9[8]};
+    }
 }
 
 __global__ void mask_rgb_kernel(const float* __restrict__ rgb_raw, int ld, const uint8_t* __restrict__ overlaps,
@@ -262,13 +275,14 @@ extern "C" int cpn_project_rays(const float* cam, const float* uv, long long uv_
 
 extern "C" int cpn_sample_geometry(const float* cam, const float* coords9, const float* seg, const float* interval,
                                    int B, int V, int R, int S, int H, int W, float* pixel_val, float* pt,
-                                   float* sec_grid, float* pe6, float* loc8, void* stream) {
+                                   float* sec_grid, float* pe6, float* loc8, float* lv_u, void* stream) {
     CPN_REQUIRE(cam && coords9 && seg && interval && pixel_val && pt && sec_grid && pe6 && loc8, CPN_E_ARG,
                 "cpn_sample_geometry: null pointer");
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H > 1 && W > 1, CPN_E_SHAPE, "cpn_sample_geometry: bad shape");
+    CPN_REQUIRE(((uintptr_t)lv_u % 16) == 0, CPN_E_ARG, "cpn_sample_geometry: lv_u must be 16-byte aligned");
     const long long total = (long long)B * V * R * S;
     hipLaunchKernelGGL(sample_geometry_kernel, dim3(cpn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       cam, coords9, seg, interval, B * V, R, S, H, W, pixel_val, pt, sec_grid, pe6, loc8);
+                       cam, coords9, seg, interval, B * V, R, S, H, W, pixel_val, pt, sec_grid, pe6, loc8, lv_u, V);
     CPN_LAUNCH_CHECK("cpn_sample_geometry");
     return 0;
 }

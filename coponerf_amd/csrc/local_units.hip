@@ -24,6 +24,13 @@
 
 #include "encode_common.h"
 
+// timing-only ablations (tools/lu_check.py; results are wrong when non-zero): 1 = the other operand (kh / ce fragments) is not
+// loaded, 2 = no `add` rows, 4 = the per-row inputs are fetched once (no loads inside the loop), 8 = no stores,
+// 16 = no 128 -> 128 layers (their LDS reads and MFMAs)
+#ifndef CPN_LU_ABLATE
+#define CPN_LU_ABLATE 0
+#endif
+
 namespace {
 
 struct UnitGeo {
@@ -32,13 +39,33 @@ struct UnitGeo {
 };
 
 // MODE 2: (w1, b1, add, w2, b2) are the round-2 query layers as in mode 1; (w1b, b1b) = query_embed, (wk2, bk2) = query_embed_2
+// two accumulator tiles (channels 8 fg .. + 4 and + 4 .. + 8 of a 32-block) -> one fp16 B-operand / fragment register quad, as
+// PACKED conversions (v_cvt_pk_f16_f32, round to nearest even) and a packed ReLU behind the rounding (the same value as rounding
+// behind the ReLU: rounding is monotone and keeps the sign) - written element by element the compiler emitted a v_max_f32, a
+// v_cvt_f16_f32 and half a v_perm_b32 per value, and the kernel's SIMDs were issue-bound (VALU 51 % + MFMA 44 % of their cycles)
+template <bool RELU>
+__device__ __forceinline__ half8 pack_tiles(const f32x4& lo, const f32x4& hi) {
+    half8 out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4& src = q < 2 ? lo : hi;
+        const f32x2v two = {src[2 * (q & 1)], src[2 * (q & 1) + 1]};
+        half2v hv = __builtin_convertvector(two, half2v);
+        if (RELU) hv = __builtin_elementwise_max(hv, (half2v){(_Float16)0.0f, (_Float16)0.0f});
+        out[2 * q] = hv[0];
+        out[2 * q + 1] = hv[1];
+    }
+    return out;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
     const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
     const float* __restrict__ b2, const __half* __restrict__ wk2, int ldwk2, const float* __restrict__ bk2,
     const float* __restrict__ w1b, int ldw1b, const float* __restrict__ b1b,
-    const __half* __restrict__ kh_u, UnitGeo geo, __half* __restrict__ ce_u, float* __restrict__ logits) {
+    const __half* __restrict__ kh_u, UnitGeo geo, __half* __restrict__ ce_u, const f32x4* __restrict__ lv_u,
+    float* __restrict__ logits) {
     __shared__ __attribute__((aligned(16))) half8 w2l[8 * 4 * 64];                       // [tile t][k block p][lane]
     __shared__ __attribute__((aligned(16))) half8 wkl[MODE != 1 ? 8 * 4 * 64 : 1];      // key_map_2 (mode 0) / query_embed_2 (mode 2), same layout
     __shared__ __attribute__((aligned(16))) float b2s[128];
@@ -111,6 +138,14 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
         const long long rayrel = (long long)b * R + r - geo.ray0;
         o.rayrel = (unsigned)max(0LL, min(rayrel, (long long)geo.nrays - 1));
         o.srow = id.live ? (rayrel * V + v) * S + s : -1;
+        if (lv_u) {
+            // the lane's four inputs as cpn_sample_geometry packed them: ONE coalesced 1 KiB read per unit instead of five
+            // scattered ones (3 - 16 bytes per lane from 16 rows and 4 rays: 0.26 of mode 0's 0.9 ms, 0.5 of mode 2's 1.2 ms,
+            // tools/lu_check.py).  Rows that do not exist (R or S no multiple of 4) hold whatever the buffer held: their
+            // MFMA columns are their own and nothing of them is stored
+            o.lv = __builtin_nontemporal_load(lv_u + (size_t)uu * 64 + lane);
+            return o;
+        }
         if (fg == 0) { const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp); o.lv = f32x4{l0[0], l0[1], l0[2], 1.0f}; }
         else if (fg == 1) o.lv = f32x4{0.f, 0.f, c9[0], c9[1]};
         else if (fg == 2) o.lv = f32x4{c9[2], lp[3], lp[4], lp[5]};
@@ -118,23 +153,65 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
         return o;
     };
 
+    // A 128 -> 128 layer on the unit: o[t] = bias + sum_p W(t, p) . b[p], the 32 fragments read from LDS FD ahead of the MFMA that
+    // uses them, k block outer (two MFMAs on one accumulator are 8 instructions apart) - left to itself the compiler reads one
+    // fragment, waits for it, multiplies (64 waits per unit in the mode-2 loop: the LDS latency 64 times in series).  Each
+    // accumulator still receives bias, p = 0, 1, 2, 3 in that order: the results do not change.
+    auto layer128 = [&](const half8* wfr, const float* bias_s, const half8 (&b)[4], f32x4 (&o)[8]) {
+        constexpr int NF = 32, FD = 4;
+        if (CPN_LU_ABLATE & 16) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] = f32x4{b[t & 3][0], b[t & 3][1], b[t & 3][2], b[t & 3][3]};
+            return;
+        }
+        half8 af[FD];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) af[d] = wfr[(((d & 7) * 4) + (d >> 3)) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] = *reinterpret_cast<const f32x4*>(bias_s + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int t = i & 7, pblk = i >> 3;
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i % FD], b[pblk], o[t], 0, 0, 0);
+            if (i + FD < NF) af[i % FD] = wfr[((((i + FD) & 7) * 4) + ((i + FD) >> 3)) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, FD + 8, 0);      // the first FD fragments + the 8 bias reads
+#pragma unroll
+        for (int i = 0; i < NF - FD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, FD, 0);
+    };
+
     RowIn cur = fetch(wave_id < nunits ? wave_id : 0);
+    f32x4 addn[MODE == 2 ? 8 : 1];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            addn[t] = (CPN_LU_ABLATE & 2) ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                          : *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+    }
     for (unsigned uu = wave_id; uu < nunits; uu += nwaves) {
-        const RowIn nxt = fetch(uu + nwaves < nunits ? uu + nwaves : uu);
+        const RowIn nxt = (CPN_LU_ABLATE & 4) ? cur : fetch(uu + nwaves < nunits ? uu + nwaves : uu);
         // the other operand of the dot product, as B fragments / accumulator-layout rows: 4 x 1 KiB of contiguous memory
         // (requesting it a unit ahead was measured: no change - the kernel is not waiting for it)
         half8 cv[4];
         if constexpr (MODE != 2) {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                cv[p] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(MODE == 0 ? kh_u : ce_u) + ((size_t)uu * 4 + p) * 64 + lane);
+                cv[p] = (CPN_LU_ABLATE & 1) ? half8{} : __builtin_nontemporal_load(reinterpret_cast<const half8*>(MODE == 0 ? kh_u : ce_u) + ((size_t)uu * 4 + p) * 64 + lane);
         }
         f32x4 acc[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (MODE != 0)
+            if (MODE == 2 && !(CPN_LU_ABLATE & 2)) {
+                acc[t] = addn[t];                              // requested a unit ahead (mode 2 has the registers: 1.17 -> 0.91 ms)
+                addn[t] = *reinterpret_cast<const f32x4*>(add + (size_t)nxt.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+            } else if (MODE == 1 && !(CPN_LU_ABLATE & 2)) {
                 acc[t] = *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+            }
         }
         half4 xh, xl;
 #pragma unroll
@@ -155,21 +232,11 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
             }
             half8 hq[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < 4; ++p) hq[p] = pack_tiles<true>(ab[2 * p], ab[2 * p + 1]);
+            f32x4 oq[8];
+            layer128(wkl, bks, hq, oq);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    hq[p][i] = (_Float16)fmaxf(ab[2 * p][i], 0.0f);
-                    hq[p][4 + i] = (_Float16)fmaxf(ab[2 * p + 1][i], 0.0f);
-                }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                f32x4 o = *reinterpret_cast<const f32x4*>(bks + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    o = __builtin_amdgcn_mfma_f32_16x16x32_f16(wkl[(t * 4 + p) * 64 + lane], hq[p], o, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cv[t >> 1][(t & 1) * 4 + i] = (_Float16)o[i];
-            }
+            for (int p = 0; p < 4; ++p) cv[p] = pack_tiles<false>(oq[2 * p], oq[2 * p + 1]);
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -182,19 +249,9 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
         half8 hb[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                hb[p][i] = (_Float16)fmaxf(acc[2 * p][i], 0.0f);
-                hb[p][4 + i] = (_Float16)fmaxf(acc[2 * p + 1][i], 0.0f);
-            }
+            hb[p] = pack_tiles<true>(acc[2 * p], acc[2 * p + 1]);
         f32x4 o2[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            o2[t] = *reinterpret_cast<const f32x4*>(b2s + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                o2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[(t * 4 + p) * 64 + lane], hb[p], o2[t], 0, 0, 0);
-        }
+        layer128(w2l, b2s, hb, o2);
         const long long srow = cur.srow;
         cur = nxt;
         float dsum = 0.0f;
@@ -204,34 +261,31 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
             half8 ce[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ce[p][i] = (_Float16)o2[2 * p][i];
-                    ce[p][4 + i] = (_Float16)o2[2 * p + 1][i];
-                }
-                if (ce_u) reinterpret_cast<half8*>(ce_u)[((size_t)uu * 4 + p) * 64 + lane] = ce[p];   // NULL: round 2 recomputes it (mode 2)
+                ce[p] = pack_tiles<false>(o2[2 * p], o2[2 * p + 1]);
+                if (ce_u && !(CPN_LU_ABLATE & 8)) reinterpret_cast<half8*>(ce_u)[((size_t)uu * 4 + p) * 64 + lane] = ce[p];   // NULL: round 2 recomputes it (mode 2)
             }
+            f32x4 k2[8];
+            layer128(wkl, bks, cv, k2);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                f32x4 k2 = *reinterpret_cast<const f32x4*>(bks + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+            for (int p = 0; p < 4; ++p) {
+                const half8 kp = pack_tiles<false>(k2[2 * p], k2[2 * p + 1]);
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    k2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wkl[(t * 4 + p) * 64 + lane], cv[p], k2, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dsum += (float)(_Float16)k2[i] * (float)ce[t >> 1][(t & 1) * 4 + i];
+                for (int e = 0; e < 8; ++e) dsum += (float)kp[e] * (float)ce[p][e];
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < 4; ++p) {
+                const half8 qp = pack_tiles<false>(o2[2 * p], o2[2 * p + 1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    dsum += (float)(_Float16)o2[2 * p][i] * (float)cv[p][i];
-                    dsum += (float)(_Float16)o2[2 * p + 1][i] * (float)cv[p][4 + i];
+                    dsum += (float)qp[i] * (float)cv[p][i];
+                    dsum += (float)qp[4 + i] * (float)cv[p][4 + i];
                 }
+            }
         }
         dsum += __shfl_xor(dsum, 16);
         dsum += __shfl_xor(dsum, 32);
-        if (srow >= 0 && fg == 0) logits[srow] = dsum;
+        if (srow >= 0 && fg == 0 && (!(CPN_LU_ABLATE & 8) || dsum == 12345.678f)) logits[srow] = dsum;
     }
 }
 
@@ -240,7 +294,8 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
 extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
                                const float* add, const uint16_t* w2, int ldw2, const float* b2, const uint16_t* wk2, int ldwk2,
                                const float* bk2, const float* w1b, int ldw1b, const float* b1b, const uint16_t* kh_u, int B,
-                               int V, int R, int S, int ray0, int nrays, uint16_t* ce_u, float* logits, void* stream) {
+                               int V, int R, int S, int ray0, int nrays, uint16_t* ce_u, const float* lv_u, float* logits,
+                               void* stream) {
     CPN_REQUIRE(mode >= 0 && mode <= 2, CPN_E_ARG, "cpn_local_units: mode must be 0, 1 or 2 (got %d)", mode);
     CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && logits, CPN_E_ARG, "cpn_local_units: null pointer");
     CPN_REQUIRE(mode == 0 ? (wk2 && bk2 && kh_u) : mode == 1 ? (add && ce_u) : (add && wk2 && bk2 && w1b && b1b), CPN_E_ARG,
@@ -251,7 +306,7 @@ extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_local_units: ray range outside B*R");
     CPN_REQUIRE(((uintptr_t)ce_u % 16) == 0 && ((uintptr_t)kh_u % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wk2 % 16) == 0 &&
-                    ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)w1b % 16) == 0,
+                    ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)w1b % 16) == 0 && ((uintptr_t)lv_u % 16) == 0,
                 CPN_E_ARG, "cpn_local_units: fp16 operands and first-layer weights must be 16-byte aligned");
     UnitGeo geo;
     geo.V = V; geo.R = R; geo.S = S; geo.ray0 = ray0; geo.nrays = nrays;
@@ -262,19 +317,21 @@ extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9
     const long long group1 = (long long)b_hi * geo.groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
     geo.nunits = (group1 - geo.group0 + 1) * V * geo.nsblk;
     CPN_REQUIRE(geo.nunits * 16 < (1LL << 31), CPN_E_SHAPE, "cpn_local_units: chunk too large for 32-bit indexing");
+    // lv_u covers the whole (B, R, S) problem in unit order (cpn_sample_geometry); this launch's units start at its first ray group
+    const f32x4* lv_chunk = lv_u ? reinterpret_cast<const f32x4*>(lv_u) + (size_t)geo.group0 * V * geo.nsblk * 64 : nullptr;
     const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(geo.nunits, 8), mode == 1 ? 1024 : 512);
     if (mode == 0)
         hipLaunchKernelGGL(local_units_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
                            (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
-                           (__half*)ce_u, logits);
+                           (__half*)ce_u, lv_chunk, logits);
     else if (mode == 1)
         hipLaunchKernelGGL(local_units_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
                            (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
-                           (__half*)ce_u, logits);
+                           (__half*)ce_u, lv_chunk, logits);
     else
         hipLaunchKernelGGL(local_units_kernel<2>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
                            (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
-                           (__half*)ce_u, logits);
+                           (__half*)ce_u, lv_chunk, logits);
     CPN_LAUNCH_CHECK("cpn_local_units");
     return 0;
 }

@@ -903,7 +903,7 @@ class RenderEngine:
              g["overlaps"].data_ptr(), s)
         call("cpn_sample_geometry", cam.data_ptr(), g["coords9"].data_ptr(), g["seg"].data_ptr(), interval.data_ptr(),
              B, V, R, S, H, W, g["pixel_val"].data_ptr(), g["pt"].data_ptr(), g["sec_grid"].data_ptr(),
-             g["pe6"].data_ptr(), g["loc8"].data_ptr(), s)
+             g["pe6"].data_ptr(), g["loc8"].data_ptr(), 0, s)
         return g
 
     def _start_host_copy(self, t):
@@ -1140,11 +1140,18 @@ class RenderEngine:
         sec_grid = self._buf("sec_grid", (N, R, S, 2), f32, dev)
         pe6 = self._buf("pe6", (N, R, S, 6), f32, dev)
         loc8 = self._buf("loc8", (N, R, S, 8), f32, dev)
+        # unit-order stages: the per-sample inputs of the two query MLPs once more in the order cpn_local_units multiplies in (one
+        # coalesced line per unit instead of scattered reads of loc8 / coords9; include/coponerf_hip.h, cpn_sample_geometry)
+        lvu = None
+        if self.unit_order and self.fuse_key and self.tables and self.fold_value and self.precision != "f32":
+            lvu = self._buf("lvu", (B * ((R + 3) // 4) * V * ((S + 3) // 4) * 64, 4), f32, dev)
+            if (R | S) & 3:
+                lvu.zero_()                 # slots of rays / samples that do not exist are never written
         call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), uvs, B, V, R, coords9.data_ptr(), seg.data_ptr(),
              overlaps.data_ptr(), s)
         call("cpn_sample_geometry", cam.data_ptr(), coords9.data_ptr(), seg.data_ptr(), interval.data_ptr(),
              B, V, R, S, H, W, pixel_val.data_ptr(), pt.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(),
-             loc8.data_ptr(), s)
+             loc8.data_ptr(), lvu.data_ptr() if lvu is not None else 0, s)
 
         # the caller contract wants pixel_val on the CPU (CoPoNeRF.py:490): start the 8*N*R*S-byte device->host copy
         # now, into pinned memory on a side stream, so it overlaps the GEMMs instead of stalling the step's tail
@@ -1279,7 +1286,7 @@ class RenderEngine:
                     call("cpn_local_units", 0, loc8.data_ptr(), coords9.data_ptr(), w["query_embed.w"].data_ptr(), 16,
                          w["query_embed.b"].data_ptr(), 0, w["query_embed_2.w16"].data_ptr(), 128, w["query_embed_2.b"].data_ptr(),
                          w["key_map_2.w16"].data_ptr(), 128, w["key_map_2.b"].data_ptr(), 0, 0, 0, bf["khf"].data_ptr(), B, V, R, S,
-                         ray0, n, 0 if recompute else ce.data_ptr(), lg.data_ptr(), s)
+                         ray0, n, 0 if recompute else ce.data_ptr(), lvu.data_ptr(), lg.data_ptr(), s)
                 elif fused_key:
                     # the 1664 -> 128 layer already ran inside cpn_encode_key: key_map_2 + <key, coords_embed> on its output
                     call("cpn_gemm_f16_rowdot", bf["khf"].data_ptr(), 128, w["key_map_2.w16"].data_ptr(), 128,
@@ -1296,6 +1303,17 @@ class RenderEngine:
             else:
                 _gemm(s, bf["kh"], 128, "key_map_2", bf["key2"], 128, rows, 128, 128, False, False)
 
+        def timed(name, flops, fn):
+            """fn() between two events when bench.py asked for per-kernel times (self.profile)"""
+            prof = self.profile
+            if prof is None:
+                return fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            prof.setdefault(name, []).append((e0, e1, flops))
+
         def stage_sum1(ray0, bf, s):
             """A1: joint softmax over the 2 x S samples of a ray + the weighted sum, round 1  [:450-461]"""
             n = min(C, nray_total - ray0)
@@ -1303,8 +1321,9 @@ class RenderEngine:
                 call("cpn_attend_value", bf["lg"].data_ptr(), bf["val"].data_ptr(), w["value_fold.b"].data_ptr(), 0, 0.0,
                      B, V, R, S, ray0, n, bf["z1"].data_ptr(), at_wt.data_ptr(), s)
             elif self.fold_value:
-                call("cpn_attend_hidden", 0, 0, bf["lg"].data_ptr(), bf["hid"].data_ptr(), B, V, R, S, ray0, n,
-                     bf["hbar"].data_ptr(), at_wt.data_ptr(), s)
+                timed("attend_hidden:round1", 2.0 * n * T * 1664, lambda: call(
+                    "cpn_attend_hidden", 0, 0, bf["lg"].data_ptr(), bf["hid"].data_ptr(), B, V, R, S, ray0, n,
+                    bf["hbar"].data_ptr(), at_wt.data_ptr(), s))
             else:
                 call("cpn_attend", bf["key2"].data_ptr(), bf["ce"].data_ptr(), bf["value"].data_ptr(), 0, B, V, R, S, ray0, n,
                      bf["z1"].data_ptr(), at_wt.data_ptr(), s)
@@ -1320,16 +1339,18 @@ class RenderEngine:
             call("cpn_linear_f32", ze.data_ptr(), 128, w["query_repeat_embed.w_z"].data_ptr(), 128, 0, 0, 0,
                  addq.data_ptr(), 128, n, 128, 128, 0, 0, s)
             if recompute:
-                call("cpn_local_units", 2, loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
-                     w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
-                     w["query_repeat_embed_2.b"].data_ptr(), w["query_embed_2.w16"].data_ptr(), 128, w["query_embed_2.b"].data_ptr(),
-                     w["query_embed.w"].data_ptr(), 16, w["query_embed.b"].data_ptr(), 0, B, V, R, S, ray0, n, 0,
-                     bf["lg"].data_ptr(), s)
+                timed("local_units:round2+query_embed", 2.0 * n * T * 128 * (2 * 128 + 2 * 16), lambda: call(
+                    "cpn_local_units", 2, loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
+                    w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
+                    w["query_repeat_embed_2.b"].data_ptr(), w["query_embed_2.w16"].data_ptr(), 128, w["query_embed_2.b"].data_ptr(),
+                    w["query_embed.w"].data_ptr(), 16, w["query_embed.b"].data_ptr(), 0, B, V, R, S, ray0, n, 0,
+                    lvu.data_ptr(), bf["lg"].data_ptr(), s))
             elif units:
-                call("cpn_local_units", 1, loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
-                     w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
-                     w["query_repeat_embed_2.b"].data_ptr(), 0, 0, 0, 0, 0, 0, 0, B, V, R, S, ray0, n, bf["ce"].data_ptr(),
-                     bf["lg"].data_ptr(), s)
+                timed("local_units:round2", 2.0 * n * T * 128 * (128 + 16), lambda: call(
+                    "cpn_local_units", 1, loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
+                    w["query_repeat_embed.b"].data_ptr(), addq.data_ptr(), w["query_repeat_embed_2.w16"].data_ptr(), 128,
+                    w["query_repeat_embed_2.b"].data_ptr(), 0, 0, 0, 0, 0, 0, 0, B, V, R, S, ray0, n, bf["ce"].data_ptr(),
+                    lvu.data_ptr(), bf["lg"].data_ptr(), s))
             elif self.fold_value:
                 # the second query only enters through <query2, coords_embed>: local_mlp writes that logit directly
                 call("cpn_local_mlp", loc8.data_ptr(), coords9.data_ptr(), w["query_repeat_embed.w_l"].data_ptr(), 16,
@@ -1349,8 +1370,9 @@ class RenderEngine:
                 call("cpn_attend_value", bf["lg"].data_ptr(), bf["val"].data_ptr(), w["value_fold.b"].data_ptr(),
                      bf["z1"].data_ptr(), float(V), B, V, R, S, ray0, n, zl[ray0:ray0 + n].data_ptr(), 0, s)
             elif self.fold_value:
-                call("cpn_attend_hidden", 0, 0, bf["lg"].data_ptr(), bf["hid"].data_ptr(), B, V, R, S, ray0, n,
-                     bf["hbar"].data_ptr(), 0, s)
+                timed("attend_hidden:round2", 2.0 * n * T * 1664, lambda: call(
+                    "cpn_attend_hidden", 0, 0, bf["lg"].data_ptr(), bf["hid"].data_ptr(), B, V, R, S, ray0, n,
+                    bf["hbar"].data_ptr(), 0, s))
             else:
                 call("cpn_attend", bf["q2"].data_ptr(), bf["ce"].data_ptr(), bf["value"].data_ptr(), bf["z1"].data_ptr(), B, V, R, S,
                      ray0, n, zl[ray0:ray0 + n].data_ptr(), 0, s)

@@ -83,10 +83,15 @@ int cpn_project_rays(const float* cam, const float* uv, long long uv_batch_strid
  *   interval (S) = linspace(0,1,S) as the host computes it
  *   pixel_val (N,R,S,2)   pt (N,R,S,3)   sec_grid (N,R,S,2): coords of this sample's 3-D point in the OTHER image
  *   pe6 (N,R,S,6) = tanh(nan_to_num(pt_own)/5) | tanh(nan_to_num(pt_other)/5)
- *   loc8 (N,R,S,8) = context-pixel ray dir 3 | tanh(depth*{1,.1,.01,.001}) 4 | 0                                */
+ *   loc8 (N,R,S,8) = context-pixel ray dir 3 | tanh(depth*{1,.1,.01,.001}) 4 | 0
+ *   lv_u, optional (NULL: not written): (B * ceil(R/4) * V * ceil(S/4) units, 64 lanes, 4) fp32 - the 16 local_coords inputs of
+ *       every sample (loc8's 7 values, 6 of coords9, a 1.0 for the bias, zeros; CoPoNeRF.py:411-445) in the UNIT order of
+ *       cpn_local_units: lane c + 16 fg of unit ((b * ceil(R/4) + r/4) * V + v) * ceil(S/4) + s/4, c = (s & 3) * 4 + (r & 3),
+ *       holds K entries 4 fg .. 4 fg + 3 = {dir3, 1} | {0, 0, c9[0], c9[1]} | {c9[2], tanh(depth * {1, .1, .01})} |
+ *       {tanh(depth / 1000), c9[6..8]}.  Slots of rays >= R / samples >= S are not written.                              */
 int cpn_sample_geometry(const float* cam, const float* coords9, const float* seg, const float* interval,
                         int B, int V, int R, int S, int H, int W,
-                        float* pixel_val, float* pt, float* sec_grid, float* pe6, float* loc8, void* stream);
+                        float* pixel_val, float* pt, float* sec_grid, float* pe6, float* loc8, float* lv_u, void* stream);
 
 /* ---- layout: (N,C,h,w) fp32 -> (N,h,w,C) fp16 feature map (once per get_z) --------------------- */
 int cpn_nchw_to_nhwc_f16(const float* src, uint16_t* dst, int N, int C, int h, int w, void* stream);
@@ -212,11 +217,15 @@ int cpn_encode_project(const uint16_t* tab, const uint16_t* map3, int H, int W, 
  * mode 2: mode 1 with coords_embed RECOMPUTED from the local coordinates instead of read back (the same instructions in the same
  *   order as mode 0 formed it with: the same logits, bit for bit): w1b (128, ldw1b >= 16) fp32 / b1b = query_embed, wk2 / bk2 =
  *   query_embed_2; ce_u is not touched.  Mode 0 with ce_u = NULL then stores no coords_embed at all (2 x 256 bytes per sample
- *   less HBM traffic; both kernels were bound by it).  w1b / b1b are ignored by modes 0 and 1.                               */
+ *   less HBM traffic; both kernels were bound by it).  w1b / b1b are ignored by modes 0 and 1.
+ *   lv_u, optional (NULL: the kernel reads loc8 / coords9 itself): the unit-order copy of the rows' 16 first-layer inputs that
+ *   cpn_sample_geometry writes for the WHOLE (B, R, S) problem - every mode then reads ONE coalesced 1 KiB line per unit instead
+ *   of five scattered 4 - 16 byte accesses per lane (the same values: the same logits); the launch's units start at its first
+ *   ray group inside it.                                                                                                    */
 int cpn_local_units(int mode, const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
                     const float* add, const uint16_t* w2, int ldw2, const float* b2, const uint16_t* wk2, int ldwk2,
                     const float* bk2, const float* w1b, int ldw1b, const float* b1b, const uint16_t* kh_u, int B, int V,
-                    int R, int S, int ray0, int nrays, uint16_t* ce_u, float* logits, void* stream);
+                    int R, int S, int ray0, int nrays, uint16_t* ce_u, const float* lv_u, float* logits, void* stream);
 
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).

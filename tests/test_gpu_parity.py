@@ -651,6 +651,28 @@ def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights)
     w, geo, (maps, tabs, g) = _encode_entry_setup(model, dev, cfg)
     s = torch.cuda.current_stream().cuda_stream
     dp = lambda t: t.data_ptr()
+    # the unit-order copy of the rows' inputs (cpn_sample_geometry's optional output, the whole problem): against the same
+    # values placed by torch from loc8 / coords9, bit for bit; slots of rays / samples that do not exist stay untouched
+    gpb, nsb = (R + 3) // 4, (S + 3) // 4
+    lvu = torch.full((B * gpb * V * nsb * 64, 4), -3.0, device=dev)
+    scratch = {k: torch.empty_like(g[k]) for k in ("pixel_val", "pt", "sec_grid", "pe6", "loc8")}
+    call("cpn_sample_geometry", dp(g["host"]["cam"]), dp(g["coords9"]), dp(g["seg"]), dp(model._engine._interval[(S, str(dev))]),
+         B, V, R, S, cfg["H"], cfg["H"], dp(scratch["pixel_val"]), dp(scratch["pt"]), dp(scratch["sec_grid"]), dp(scratch["pe6"]),
+         dp(scratch["loc8"]), dp(lvu), s)
+    assert all(torch.equal(scratch[k], g[k]) for k in scratch)
+    l8, c9 = g["loc8"].view(B, V, R, S, 8), g["coords9"].view(B, V, R, 1, 9).expand(B, V, R, S, 9)
+    one, zero = torch.ones_like(l8[..., :1]), torch.zeros_like(l8[..., :1])
+    lv16 = torch.cat((l8[..., 0:3], one, zero, zero, c9[..., 0:2], c9[..., 2:3], l8[..., 3:6], l8[..., 6:7], c9[..., 6:9]), dim=-1)
+    want = torch.full((B, gpb, V, nsb, 4, 4, 4, 4), -3.0, device=dev)            # [b][group][v][sblk][fg][s & 3][r & 3][4]
+    rp, sp = gpb * 4, nsb * 4
+    full = torch.full((B, V, rp, sp, 16), float("nan"), device=dev)
+    full[:, :, :R, :S] = lv16
+    live = torch.zeros(B, V, rp, sp, dtype=torch.bool, device=dev)
+    live[:, :, :R, :S] = True
+    arr = full.view(B, V, gpb, 4, nsb, 4, 4, 4).permute(0, 2, 1, 4, 6, 5, 3, 7)   # -> [b][group][v][sblk][fg][s&3][r&3][4]
+    lmask = live.view(B, V, gpb, 4, nsb, 4).permute(0, 2, 1, 4, 5, 3)[:, :, :, :, None, :, :, None].expand_as(arr)
+    want = torch.where(lmask, arr, want)
+    assert torch.equal(lvu.view_as(want), want), "unit-order inputs differ from loc8 / coords9"
     for ray0, n in ((7, R - 18), (0, B * R), (R - 3, 5 if B > 1 else 3)):
         rows = n * V * S
         units = int(_hip.lib().cpn_encode_units(B, R, S, ray0, n))
@@ -676,21 +698,27 @@ def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights)
         lg2 = torch.full((rows + 8,), -7.0, device=dev)
         call("cpn_local_units", 0, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
              dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), 0, 0, 0,
-             dp(khu), B, V, R, S, ray0, n, dp(ce_u), dp(lg1), s)
+             dp(khu), B, V, R, S, ray0, n, dp(ce_u), 0, dp(lg1), s)
         call("cpn_local_units", 1, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
              dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), 0, 0, 0, 0, 0, 0, 0, B, V, R, S,
-             ray0, n, dp(ce_u), dp(lg2), s)
+             ray0, n, dp(ce_u), 0, dp(lg2), s)
         # the product's pair: round 1 storing no coords_embed (ce_u = NULL), round 2 recomputing it (mode 2) - the same logits, bit
         # for bit, as the stored form above
         lg1n = torch.full((rows + 8,), -7.0, device=dev)
         lg2n = torch.full((rows + 8,), -7.0, device=dev)
         call("cpn_local_units", 0, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
              dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), 0, 0, 0,
-             dp(khu), B, V, R, S, ray0, n, 0, dp(lg1n), s)
+             dp(khu), B, V, R, S, ray0, n, 0, dp(lvu), dp(lg1n), s)
         call("cpn_local_units", 2, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
              dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), dp(w["query_embed_2.w16"]), 128,
-             dp(w["query_embed_2.b"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0, B, V, R, S, ray0, n, 0, dp(lg2n), s)
+             dp(w["query_embed_2.b"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0, B, V, R, S, ray0, n, 0, dp(lvu), dp(lg2n), s)
         assert torch.equal(lg1n, lg1) and torch.equal(lg2n, lg2), "recomputed coords_embed gives other logits than the stored one"
+        # ... and mode 2 without the packed inputs (lv_u = NULL: its own scattered reads of loc8 / coords9)
+        lg2m = torch.full((rows + 8,), -7.0, device=dev)
+        call("cpn_local_units", 2, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
+             dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), dp(w["query_embed_2.w16"]), 128,
+             dp(w["query_embed_2.b"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0, B, V, R, S, ray0, n, 0, 0, dp(lg2m), s)
+        assert torch.equal(lg2m, lg2)
         # (first layer as an fp16 hi / lo split on the fp16 MFMA here, on the fp32 MFMA there: 2^-22 apart before the fp16
         # rounding of the hidden layer, so a few outputs differ by an fp16 ulp)
         d_ce = (rows_from_unit_order(ce_u, B, R, S, ray0, n).float() - ce_r[:rows].float()).abs()

@@ -12,7 +12,7 @@ export TMPDIR=/tmp PYTHONPATH=$ROOT
 cd "$ROOT"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --no-tables --cpu-rays 0 --train-steps 0 > "$OUT/bench_gather_gemm_form.json" 2>> "$OUT/bench.err"
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render_prof" -o r -- python "$ROOT/bench.py" --no-image --no-ref-loop --no-two-stream-pass --no-f32 --cpu-rays 0 --train-steps 0 --steps 5 ) > "$OUT/bench_under_rocprof.json" 2> "$OUT/render_prof.log"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/render_prof" -o r -- python "$ROOT/bench.py" --no-image --no-ref-loop --no-two-stream-pass --no-fresh-pair --no-f32 --cpu-rays 0 --train-steps 0 --steps 5 ) > "$OUT/bench_under_rocprof.json" 2> "$OUT/render_prof.log"
 python tools/summarize_pmc.py "$(find "$OUT/render_prof" -name '*kernel_stats.csv' | head -1)" "$OUT/render_kernel_stats.summary.csv" 40
 # sidecar of the kernel statistics: which kernel source / launch shape they were taken on (bench.py roofline.rocprof)
 python - "$OUT" <<'PY'
@@ -22,7 +22,7 @@ fused = os.environ.get("COPONERF_FUSE_KEY", "1") != "0"
 src = os.path.join(root, "coponerf_amd", "csrc", "encode_fused.hip" if fused else "encode.hip")
 json.dump({"kernel": "encode_fused_kernel" if fused else "encode_hidden_kernel",
            "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "rows_per_launch": 16777216,
-           "command": "python bench.py --no-image --no-ref-loop --no-two-stream-pass --no-f32 --cpu-rays 0 --train-steps 0 --steps 5 (under rocprofv3 --kernel-trace --stats)"},
+           "command": "python bench.py --no-image --no-ref-loop --no-two-stream-pass --no-fresh-pair --no-f32 --cpu-rays 0 --train-steps 0 --steps 5 (under rocprofv3 --kernel-trace --stats)"},
           open(os.path.join(sys.argv[1], "render_kernel_stats.meta.json"), "w"), indent=1)
 PY
 tools/pmc_passes.sh "$OUT/pmc_encode" encode_fused -- python "$ROOT/tools/encode_bench.py" --only fused --iters 3 --rays 65536 > "$OUT/pmc_encode.log" 2>&1
