@@ -58,8 +58,11 @@ __device__ __forceinline__ half8 pack_tiles(const f32x4& lo, const f32x4& hi) {
     return out;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
+#ifndef CPN_LU_UNITS
+#define CPN_LU_UNITS 2         // units per wave in modes 0 and 2 (mode 1 keeps one: 128 registers, four waves per SIMD)
+#endif
+template <int MODE, int U>
+__global__ __launch_bounds__(512, (MODE == 2 || U > 1) ? 2 : 4) void local_units_kernel(
     const float* __restrict__ loc8, const float* __restrict__ coords9, const float* __restrict__ w1, int ldw1,
     const float* __restrict__ b1, const float* __restrict__ add, const __half* __restrict__ w2, int ldw2,
     const float* __restrict__ b2, const __half* __restrict__ wk2, int ldwk2, const float* __restrict__ bk2,
@@ -153,139 +156,194 @@ __global__ __launch_bounds__(512, MODE == 2 ? 2 : 4) void local_units_kernel(
         return o;
     };
 
-    // A 128 -> 128 layer on the unit: o[t] = bias + sum_p W(t, p) . b[p], the 32 fragments read from LDS FD ahead of the MFMA that
-    // uses them, k block outer (two MFMAs on one accumulator are 8 instructions apart) - left to itself the compiler reads one
-    // fragment, waits for it, multiplies (64 waits per unit in the mode-2 loop: the LDS latency 64 times in series).  Each
-    // accumulator still receives bias, p = 0, 1, 2, 3 in that order: the results do not change.
-    auto layer128 = [&](const half8* wfr, const float* bias_s, const half8 (&b)[4], f32x4 (&o)[8]) {
+    // A 128 -> 128 layer on the wave's U units: o[u][t] = bias + sum_p W(t, p) . b[u][p].  The 32 fragments are read from LDS FD
+    // ahead of the MFMAs that use them, k block outer (two MFMAs on one accumulator are 8 U instructions apart), and every
+    // fragment is multiplied against ALL the wave's units: with one unit per wave the 1 KiB fragment read (4 clocks of the CU's
+    // one LDS pipe) feeds a single 16-clock MFMA, and four SIMDs asking for one each saturate that pipe exactly when the matrix
+    // cores would (measured floor with no global loads at all: 0.55 / 0.67 ms for 0.26 / 0.30 ms of MFMA).  Each accumulator
+    // still receives bias, p = 0, 1, 2, 3 in that order: the results do not change.
+    auto layer128 = [&](const half8* wfr, const float* bias_s, const half8 (&b)[U][4], f32x4 (&o)[U][8]) {
         constexpr int NF = 32, FD = 4;
         if (CPN_LU_ABLATE & 16) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) o[t] = f32x4{b[t & 3][0], b[t & 3][1], b[t & 3][2], b[t & 3][3]};
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o[u][t] = f32x4{b[u][t & 3][0], b[u][t & 3][1], b[u][t & 3][2], b[u][t & 3][3]};
             return;
         }
         half8 af[FD];
 #pragma unroll
         for (int d = 0; d < FD; ++d) af[d] = wfr[(((d & 7) * 4) + (d >> 3)) * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) o[t] = *reinterpret_cast<const f32x4*>(bias_s + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+        for (int t = 0; t < 8; ++t) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+#pragma unroll
+            for (int u = 0; u < U; ++u) o[u][t] = bv;
+        }
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int t = i & 7, pblk = i >> 3;
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i % FD], b[pblk], o[t], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i % FD], b[u][pblk], o[u][t], 0, 0, 0);
             if (i + FD < NF) af[i % FD] = wfr[((((i + FD) & 7) * 4) + ((i + FD) >> 3)) * 64 + lane];
         }
         __builtin_amdgcn_sched_group_barrier(0x100, FD + 8, 0);      // the first FD fragments + the 8 bias reads
 #pragma unroll
         for (int i = 0; i < NF - FD; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, U, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, FD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, FD * U, 0);
     };
-
-    RowIn cur = fetch(wave_id < nunits ? wave_id : 0);
-    f32x4 addn[MODE == 2 ? 8 : 1];
-    if constexpr (MODE == 2) {
+    // the first layer (K = 16 as three hi / lo MFMAs per tile) of set `ws` (0: w1 / b1, 2: w1b / b1b) on the U units
+    auto layer16 = [&](int ws, const half4 (&xh)[U], const half4 (&xl)[U], f32x4 (&o)[U][8]) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const half4 wh = w1s[ws][t][lane], wl = w1s[ws + 1][t][lane];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                o[u][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, xh[u], o[u][t], 0, 0, 0);
+                o[u][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xl[u], o[u][t], 0, 0, 0);
+                o[u][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xh[u], o[u][t], 0, 0, 0);
+            }
+        }
+    };
+    auto add_rows = [&](unsigned rayrel, f32x4 (&dst)[8]) {
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            addn[t] = (CPN_LU_ABLATE & 2) ? f32x4{0.f, 0.f, 0.f, 0.f}
-                                          : *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+            dst[t] = (CPN_LU_ABLATE & 2) ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                         : *reinterpret_cast<const f32x4*>(add + (size_t)rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+    };
+
+    // a wave takes the units wave_id + (it * U + u) * nwaves; past the end it walks the last unit again with nothing stored
+    auto unit_of = [&](unsigned first, int u) { return min(first + (unsigned)u * nwaves, nunits - 1); };
+    RowIn cur[U];
+    constexpr bool ADD_AHEAD = MODE == 2 && U == 1;            // (two units per wave leave no registers for it, and need it less)
+    f32x4 addn[ADD_AHEAD ? U : 1][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        cur[u] = fetch(unit_of(wave_id, u));
+        if constexpr (ADD_AHEAD) add_rows(cur[u].rayrel, addn[u]);
     }
-    for (unsigned uu = wave_id; uu < nunits; uu += nwaves) {
-        const RowIn nxt = (CPN_LU_ABLATE & 4) ? cur : fetch(uu + nwaves < nunits ? uu + nwaves : uu);
+    for (unsigned uu = wave_id; uu < nunits; uu += U * nwaves) {
+        RowIn nxt[U];
+        unsigned un[U];
+        bool ulive[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            un[u] = unit_of(uu, u);
+            ulive[u] = uu + (unsigned)u * nwaves < nunits;
+            nxt[u] = (CPN_LU_ABLATE & 4) ? cur[u] : fetch(unit_of(uu + U * nwaves, u));
+        }
         // the other operand of the dot product, as B fragments / accumulator-layout rows: 4 x 1 KiB of contiguous memory
         // (requesting it a unit ahead was measured: no change - the kernel is not waiting for it)
-        half8 cv[4];
+        half8 cv[U][4];
         if constexpr (MODE != 2) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                cv[p] = (CPN_LU_ABLATE & 1) ? half8{} : __builtin_nontemporal_load(reinterpret_cast<const half8*>(MODE == 0 ? kh_u : ce_u) + ((size_t)uu * 4 + p) * 64 + lane);
-        }
-        f32x4 acc[8];
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (MODE == 2 && !(CPN_LU_ABLATE & 2)) {
-                acc[t] = addn[t];                              // requested a unit ahead (mode 2 has the registers: 1.17 -> 0.91 ms)
-                addn[t] = *reinterpret_cast<const f32x4*>(add + (size_t)nxt.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
-            } else if (MODE == 1 && !(CPN_LU_ABLATE & 2)) {
-                acc[t] = *reinterpret_cast<const f32x4*>(add + (size_t)cur.rayrel * 128 + (t >> 1) * 32 + fg * 8 + (t & 1) * 4);
+                for (int p = 0; p < 4; ++p)
+                    cv[u][p] = (CPN_LU_ABLATE & 1) ? half8{} : __builtin_nontemporal_load(
+                        reinterpret_cast<const half8*>(MODE == 0 ? kh_u : ce_u) + ((size_t)un[u] * 4 + p) * 64 + lane);
+        }
+        f32x4 acc[U][8];
+        half4 xh[U], xl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (ADD_AHEAD) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[u][t] = addn[u][t];        // requested an iteration ahead (1.17 -> 0.91 ms)
+                add_rows(nxt[u].rayrel, addn[u]);
+            } else if constexpr (MODE != 0) {
+                add_rows(cur[u].rayrel, acc[u]);
             }
-        }
-        half4 xh, xl;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xh[i] = (_Float16)cur.lv[i];
-            xl[i] = (_Float16)(cur.lv[i] - (float)xh[i]);
+            for (int i = 0; i < 4; ++i) {
+                xh[u][i] = (_Float16)cur[u].lv[i];
+                xl[u][i] = (_Float16)(cur[u].lv[i] - (float)xh[u][i]);
+            }
         }
         if constexpr (MODE == 2) {
-            // coords_embed of this unit, exactly as mode 0 forms it (same instructions, same order: the bits mode 0 would have stored)
-            f32x4 ab[8];
+            // coords_embed of these units, exactly as mode 0 forms it (same instructions, same order: the bits mode 0 would have stored)
+            f32x4 ab[U][8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                ab[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const half4 whb = w1s[2][t][lane], wlb = w1s[3][t][lane];
-                ab[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wlb, xh, ab[t], 0, 0, 0);
-                ab[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(whb, xl, ab[t], 0, 0, 0);
-                ab[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(whb, xh, ab[t], 0, 0, 0);
-            }
-            half8 hq[4];
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) hq[p] = pack_tiles<true>(ab[2 * p], ab[2 * p + 1]);
-            f32x4 oq[8];
+                for (int t = 0; t < 8; ++t) ab[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            layer16(2, xh, xl, ab);
+            half8 hq[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) hq[u][p] = pack_tiles<true>(ab[u][2 * p], ab[u][2 * p + 1]);
+            f32x4 oq[U][8];
             layer128(wkl, bks, hq, oq);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) cv[p] = pack_tiles<false>(oq[2 * p], oq[2 * p + 1]);
-        }
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const half4 wh = w1s[0][t][lane], wl = w1s[1][t][lane];
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, xh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xh, acc[t], 0, 0, 0);
+                for (int p = 0; p < 4; ++p) cv[u][p] = pack_tiles<false>(oq[u][2 * p], oq[u][2 * p + 1]);
         }
+        layer16(0, xh, xl, acc);
         // hidden layer -> fp16 B operands: K block p = channels p*32 .. p*32+31, this lane holds fg*8 .. fg*8+7 of it
-        half8 hb[4];
+        half8 hb[U][4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            hb[p] = pack_tiles<true>(acc[2 * p], acc[2 * p + 1]);
-        f32x4 o2[8];
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) hb[u][p] = pack_tiles<true>(acc[u][2 * p], acc[u][2 * p + 1]);
+        f32x4 o2[U][8];
         layer128(w2l, b2s, hb, o2);
-        const long long srow = cur.srow;
-        cur = nxt;
-        float dsum = 0.0f;
+        long long srow[U];
+        float dsum[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            srow[u] = ulive[u] ? cur[u].srow : -1;
+            cur[u] = nxt[u];
+            dsum[u] = 0.0f;
+        }
         if constexpr (MODE == 0) {
             // coords_embed leaves in unit order as it is (the accumulator layout is the fragment layout), and meets the key:
             // key_map_2 on the B fragments of kh, in the same accumulator layout
-            half8 ce[4];
+            half8 ce[U][4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ce[p] = pack_tiles<false>(o2[2 * p], o2[2 * p + 1]);
-                if (ce_u && !(CPN_LU_ABLATE & 8)) reinterpret_cast<half8*>(ce_u)[((size_t)uu * 4 + p) * 64 + lane] = ce[p];   // NULL: round 2 recomputes it (mode 2)
-            }
-            f32x4 k2[8];
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    ce[u][p] = pack_tiles<false>(o2[u][2 * p], o2[u][2 * p + 1]);
+                    if (ce_u && ulive[u] && !(CPN_LU_ABLATE & 8))                     // NULL: round 2 recomputes it (mode 2)
+                        reinterpret_cast<half8*>(ce_u)[((size_t)un[u] * 4 + p) * 64 + lane] = ce[u][p];
+                }
+            f32x4 k2[U][8];
             layer128(wkl, bks, cv, k2);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const half8 kp = pack_tiles<false>(k2[2 * p], k2[2 * p + 1]);
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dsum += (float)kp[e] * (float)ce[p][e];
-            }
+                for (int p = 0; p < 4; ++p) {
+                    const half8 kp = pack_tiles<false>(k2[u][2 * p], k2[u][2 * p + 1]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dsum[u] += (float)kp[e] * (float)ce[u][p][e];
+                }
         } else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const half8 qp = pack_tiles<false>(o2[2 * p], o2[2 * p + 1]);
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    dsum += (float)qp[i] * (float)cv[p][i];
-                    dsum += (float)qp[4 + i] * (float)cv[p][4 + i];
+                for (int p = 0; p < 4; ++p) {
+                    const half8 qp = pack_tiles<false>(o2[u][2 * p], o2[u][2 * p + 1]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        dsum[u] += (float)qp[i] * (float)cv[u][p][i];
+                        dsum[u] += (float)qp[4 + i] * (float)cv[u][p][4 + i];
+                    }
                 }
-            }
         }
-        dsum += __shfl_xor(dsum, 16);
-        dsum += __shfl_xor(dsum, 32);
-        if (srow >= 0 && fg == 0 && (!(CPN_LU_ABLATE & 8) || dsum == 12345.678f)) logits[srow] = dsum;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float d = dsum[u];
+            d += __shfl_xor(d, 16);
+            d += __shfl_xor(d, 32);
+            if (srow[u] >= 0 && fg == 0 && (!(CPN_LU_ABLATE & 8) || d == 12345.678f)) logits[srow[u]] = d;
+        }
     }
 }
 
@@ -319,17 +377,17 @@ extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9
     CPN_REQUIRE(geo.nunits * 16 < (1LL << 31), CPN_E_SHAPE, "cpn_local_units: chunk too large for 32-bit indexing");
     // lv_u covers the whole (B, R, S) problem in unit order (cpn_sample_geometry); this launch's units start at its first ray group
     const f32x4* lv_chunk = lv_u ? reinterpret_cast<const f32x4*>(lv_u) + (size_t)geo.group0 * V * geo.nsblk * 64 : nullptr;
-    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(geo.nunits, 8), mode == 1 ? 1024 : 512);
+    const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(geo.nunits, 8), mode == 1 ? 1024 : (CPN_LU_UNITS > 1 ? 256 : 512));
     if (mode == 0)
-        hipLaunchKernelGGL(local_units_kernel<0>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+        hipLaunchKernelGGL((local_units_kernel<0, CPN_LU_UNITS>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
                            (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
                            (__half*)ce_u, lv_chunk, logits);
     else if (mode == 1)
-        hipLaunchKernelGGL(local_units_kernel<1>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+        hipLaunchKernelGGL((local_units_kernel<1, 1>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
                            (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
                            (__half*)ce_u, lv_chunk, logits);
     else
-        hipLaunchKernelGGL(local_units_kernel<2>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+        hipLaunchKernelGGL((local_units_kernel<2, CPN_LU_UNITS>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
                            (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
                            (__half*)ce_u, lv_chunk, logits);
     CPN_LAUNCH_CHECK("cpn_local_units");
