@@ -163,10 +163,12 @@ def main():
         idx = torch.arange(0, rows, 997, device=dev)
         val_ref = (hid_ref.view(rows, 1664)[idx].float() @ w["value_fold.w16"].float().t())
 
-    tags = [t for t in VARIANTS] + [f"{t}_a{k}" for t in ABLATE_TAGS for k in ABLATIONS]
+    # "k_product": cpn_encode_key of the product library as it was last built (coponerf_amd/libcoponerf_hip.so) - with the source
+    # edited and not yet rebuilt, the previous kernel beside the new variants on the same box
+    tags = ["k_product"] + [t for t in VARIANTS] + [f"{t}_a{k}" for t in ABLATE_TAGS for k in ABLATIONS]
     for tag in tags:
-        path = os.path.join(BUILD, f"libef_{tag}.so")
-        if (a.only and a.only not in tag) or not os.path.exists(path):
+        path = _hip.LIB_PATH if tag == "k_product" else os.path.join(BUILD, f"libef_{tag}.so")
+        if (a.only and a.only not in tag and tag != "k_product") or not os.path.exists(path):
             continue
         lib = ctypes.CDLL(path)
         project = tag.startswith("p_")
