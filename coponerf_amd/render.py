@@ -1144,9 +1144,13 @@ class RenderEngine:
         # coalesced line per unit instead of scattered reads of loc8 / coords9; include/coponerf_hip.h, cpn_sample_geometry)
         lvu = None
         if self.unit_order and self.fuse_key and self.tables and self.fold_value and self.precision != "f32":
+            had = self._ws.get(self._ws_prefix + "lvu")
             lvu = self._buf("lvu", (B * ((R + 3) // 4) * V * ((S + 3) // 4) * 64, 4), f32, dev)
-            if (R | S) & 3:
-                lvu.zero_()                 # slots of rays / samples that do not exist are never written
+            if self._ws[self._ws_prefix + "lvu"] is not had:
+                # slots of rays / samples that do not exist (R or S no multiple of 4) are never written: whatever finite values
+                # they hold feed MFMA columns of their own whose results are dropped - fresh memory is cleared once so that
+                # nothing there is a NaN pattern either (a fill per call cost the callers' 18-call loop a launch per call)
+                self._ws[self._ws_prefix + "lvu"].zero_()
         call("cpn_project_rays", cam.data_ptr(), uvc.data_ptr(), uvs, B, V, R, coords9.data_ptr(), seg.data_ptr(),
              overlaps.data_ptr(), s)
         call("cpn_sample_geometry", cam.data_ptr(), coords9.data_ptr(), seg.data_ptr(), interval.data_ptr(),
