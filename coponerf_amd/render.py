@@ -484,6 +484,7 @@ class RenderEngine:
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event, algorithmic_flops)
         self.profile: Optional[Dict[str, list]] = None
         self._copy_stream: Optional[torch.cuda.Stream] = None
+        self._pinned_sizes: set = set()     # pixel_val sizes whose second pinned buffer has been parked (_start_host_copy)
         # pixel_val is handed to the caller as a PendingHostTensor (waits for its copy at the first use of the values)
         self.lazy_pixel_val = os.environ.get("COPONERF_EAGER_PIXEL_VAL", "0") != "1"
         self.epoch = 0                  # invalidate() calls so far (captured get_z graphs are keyed on it)
@@ -913,6 +914,14 @@ class RenderEngine:
         if self._copy_stream is None or self._copy_stream.device != dev:
             self._copy_stream = torch.cuda.Stream(device=dev)
         host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        nbytes = t.numel() * t.element_size()
+        if nbytes not in self._pinned_sizes:
+            # a caller that still holds one call's pixel_val while it makes the next call (`out = model(...)` in a loop) needs two
+            # such buffers, and pinning 67 MB takes milliseconds: the second one is pinned with the first, inside the first call
+            # of this size, and parked in torch's caching host allocator (a loop's SECOND call was 3.8 ms slower than its third)
+            self._pinned_sizes.add(nbytes)
+            spare = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            del spare
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(self._copy_stream):
