@@ -119,3 +119,47 @@ def test_guard_on_device_matches_the_host_guard():
         p.grad = None
     ok4, tot4, c4 = cd.guard_on_device(ps, 0.5)
     assert float(ok4) == 1.0 and float(tot4) == 0.0 and c4 is None
+
+
+def test_flow_product_cache_is_lru_weak_and_version_checked():
+    """aux_outputs.flow_products: the products of a flow pair are computed once per pair (a full-image render is 18 forward()
+    calls on the same flows); the cache holds the three most recently used pairs, matches on tensor IDENTITY and version, and
+    keeps the flow tensors only weakly (a captured get_z graph's output outliving its graph crashed the interpreter at exit)."""
+    import gc
+    import weakref
+
+    import torch
+
+    from coponerf_amd import aux_outputs as ao
+
+    ao._FLOW_CACHE.clear()
+    mk = lambda seed: [torch.randn(1, 2, 64, 64, generator=torch.Generator().manual_seed(seed + i)) for i in range(4)]
+    pairs = [mk(10 * k) for k in range(4)]
+    (m0, u0), hit = ao.flow_products(pairs[0], 256)
+    assert not hit and m0.shape == (1, 256, 256) and u0.shape == (1, 2, 256, 256)
+    (m0b, u0b), hit = ao.flow_products(pairs[0], 256)
+    assert hit and m0b is m0 and u0b is u0
+    # equal values in other tensors are another pair
+    clone = [t.clone() for t in pairs[0]]
+    (_, _), hit = ao.flow_products(clone, 256)
+    assert not hit
+    # an in-place change bumps the version: recomputed
+    pairs[0][1].mul_(0.5)
+    (m0c, _), hit = ao.flow_products(pairs[0], 256)
+    assert not hit and m0c is not m0
+    # three entries, least recently used out
+    ao._FLOW_CACHE.clear()
+    for p in pairs[:3]:
+        assert not ao.flow_products(p, 256)[1]
+    assert ao.flow_products(pairs[0], 256)[1]                      # 0 is now the most recent, 1 the oldest
+    assert not ao.flow_products(pairs[3], 256)[1]                  # evicts 1
+    assert ao.flow_products(pairs[0], 256)[1] and ao.flow_products(pairs[2], 256)[1] and ao.flow_products(pairs[3], 256)[1]
+    assert not ao.flow_products(pairs[1], 256)[1]
+    # the cache does not keep a pair's flow tensors alive
+    ref = weakref.ref(pairs[1][0])
+    ao.flow_products(pairs[1], 256)
+    pairs[1] = None
+    gc.collect()
+    assert ref() is None
+    assert not ao.flow_products(mk(99), 256)[1]                    # a dead entry in the list is skipped, not dereferenced into a match
+    ao._FLOW_CACHE.clear()
