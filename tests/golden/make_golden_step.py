@@ -3,6 +3,9 @@
 upstream reference imported read-only from /root/reference.  Runs ONLY in the build container.
 
     python tests/golden/make_golden_step.py        # writes tests/golden/step.npz  (about a minute on 8 cores)
+    python tests/golden/make_golden_step.py --rays 4096 --tags img,aux --out step_r4096.npz
+                                                   # the same step at the training ray count of BASELINE configs[2] per pair
+                                                   # (one pair: four would not fit this container's 62 GB); ~10 minutes
 
 Case: one 256x256 synthetic pair, 256 query rays, 64 samples, val=False, the module in the mode the reference trains it in
 (never switched to eval: batch statistics in the trunk's BatchNorm), deterministic values for all 744 state_dict
@@ -52,6 +55,13 @@ def sample_stride(numel: int) -> int:
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=CFG["R"])
+    ap.add_argument("--tags", default="img,full,aux")
+    ap.add_argument("--out", default="step.npz")
+    args = ap.parse_args()
+    CFG["R"] = args.rays
     ref_shim.install()
     for name in ("lietorch", "lpips"):                     # imported at module level by loss_function.py, unused by these terms
         sys.modules.setdefault(name, types.ModuleType(name))
@@ -62,8 +72,8 @@ def main():
     shapes = {k: tuple(v.shape) for k, v in prod.CoPoNeRF(n_view=2).state_dict().items()}
     weights = syn.make_full_weights(shapes)
     c = CFG
-    rec = {"nsample": np.int64(c["nsample"])}
-    for tag in ("img", "full", "aux"):
+    rec = {"nsample": np.int64(c["nsample"]), "rays": np.int64(c["R"])}
+    for tag in args.tags.split(","):
         with contextlib.redirect_stdout(io.StringIO()):
             model = ref_mod.CoPoNeRF(n_view=2, npoints=c["S"])
         model.load_state_dict(weights, strict=True)
@@ -102,7 +112,7 @@ def main():
             rec[f"{tag}|{name}|sample"] = flat[:: sample_stride(flat.numel())].numpy().astype(np.float32)
         rec[f"{tag}|none"] = np.array(none)
         print(tag, "parameters without gradient:", len(none))
-    path = os.path.join(HERE, "step.npz")
+    path = os.path.join(HERE, args.out)
     np.savez_compressed(path, **rec)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

@@ -15,13 +15,14 @@ CFG = dict(B=1, H=256, R=256, S=64, iseed=71)
 TAGS = ("img", "full", "aux")
 
 
-def fixture():
-    return np.load(os.path.join(GOLDEN, "step.npz"))
+def fixture(name: str = "step.npz"):
+    return np.load(os.path.join(GOLDEN, name))
 
 
-def inputs():
+def inputs(rays: int = 0):
+    """rays = 0: the 256-ray case of step.npz; 4096: the case of step_r4096.npz (make_golden_step.py --rays 4096)."""
     c = CFG
-    inp = syn.make_inputs(c["B"], c["H"], c["H"], c["R"], seed=c["iseed"])
+    inp = syn.make_inputs(c["B"], c["H"], c["H"], rays or c["R"], seed=c["iseed"])
     return inp, inp["query"]["rgb"].clone()
 
 
