@@ -88,7 +88,7 @@ int cpn_project_rays(const float* cam, const float* uv, long long uv_batch_strid
  *       every sample (loc8's 7 values, 6 of coords9, a 1.0 for the bias, zeros; CoPoNeRF.py:411-445) in the UNIT order of
  *       cpn_local_units: lane c + 16 fg of unit ((b * ceil(R/4) + r/4) * V + v) * ceil(S/4) + s/4, c = (s & 3) * 4 + (r & 3),
  *       holds K entries 4 fg .. 4 fg + 3 = {dir3, 1} | {0, 0, c9[0], c9[1]} | {c9[2], tanh(depth * {1, .1, .01})} |
- *       {tanh(depth / 1000), c9[6..8]}.  Slots of rays >= R / samples >= S are not written.                              */
+ *       {tanh(depth / 1000), c9[6..8]}.  Slots of rays >= R / samples >= S are written as zeros.                               */
 int cpn_sample_geometry(const float* cam, const float* coords9, const float* seg, const float* interval,
                         int B, int V, int R, int S, int H, int W,
                         float* pixel_val, float* pt, float* sec_grid, float* pe6, float* loc8, float* lv_u, void* stream);

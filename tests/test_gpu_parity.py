@@ -652,7 +652,7 @@ def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights)
     s = torch.cuda.current_stream().cuda_stream
     dp = lambda t: t.data_ptr()
     # the unit-order copy of the rows' inputs (cpn_sample_geometry's optional output, the whole problem): against the same
-    # values placed by torch from loc8 / coords9, bit for bit; slots of rays / samples that do not exist stay untouched
+    # values placed by torch from loc8 / coords9, bit for bit; slots of rays / samples that do not exist are written as zeros
     gpb, nsb = (R + 3) // 4, (S + 3) // 4
     lvu = torch.full((B * gpb * V * nsb * 64, 4), -3.0, device=dev)
     scratch = {k: torch.empty_like(g[k]) for k in ("pixel_val", "pt", "sec_grid", "pe6", "loc8")}
@@ -663,7 +663,7 @@ def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights)
     l8, c9 = g["loc8"].view(B, V, R, S, 8), g["coords9"].view(B, V, R, 1, 9).expand(B, V, R, S, 9)
     one, zero = torch.ones_like(l8[..., :1]), torch.zeros_like(l8[..., :1])
     lv16 = torch.cat((l8[..., 0:3], one, zero, zero, c9[..., 0:2], c9[..., 2:3], l8[..., 3:6], l8[..., 6:7], c9[..., 6:9]), dim=-1)
-    want = torch.full((B, gpb, V, nsb, 4, 4, 4, 4), -3.0, device=dev)            # [b][group][v][sblk][fg][s & 3][r & 3][4]
+    want = torch.zeros((B, gpb, V, nsb, 4, 4, 4, 4), device=dev)                  # [b][group][v][sblk][fg][s & 3][r & 3][4]
     rp, sp = gpb * 4, nsb * 4
     full = torch.full((B, V, rp, sp, 16), float("nan"), device=dev)
     full[:, :, :R, :S] = lv16
