@@ -50,6 +50,7 @@ SIGNATURES: Dict[str, List] = {
     "cpn_ray_outputs": [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_hid_grad_combine": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_gemm_f16_combine": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_wgrad_skinny_f16": [_P, _P, _I, ctypes.c_longlong, _P, _P, _P],
     "cpn_wgrad_tall_f16": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
     "cpn_local_hidden_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -104,7 +105,7 @@ TAB_LD = 832
 K80_BLOCK_HALVES = 5120          # CPN_K80_BLOCK_HALVES: one slice of the streamed K = 80 weight block (cpn_encode_project)
 RAYC_STRIDE = 64
 LIGHTFIELD_PACK_FLOATS = 128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 ADAM_SEG_BYTES = 48
 
 

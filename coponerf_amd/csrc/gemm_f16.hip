@@ -96,6 +96,16 @@ __device__ __forceinline__ TileWalk tile_walk(int total) {
 // Q (key_map -> ReLU -> key_map_2 -> logit in one kernel).  The accumulator layout of the first layer (lane = row,
 // columns nt*16 + fk*4 + 0..3) serves directly as the MFMA B operand of K block p = tile pair (2p, 2p+1); the W2
 // fragments are laid out in LDS for exactly that k order (k = 32p + fk*4 + e, 32p + 16 + fk*4 + e).
+// DOT = 3 ("combine", training): C is the data gradient of the folded key map, d(hid) through the key path, and the epilogue
+// finishes the gradient of the first layer's pre-activation while the tile is still on chip,
+//     out[row, c] = hid[row, c] > 0 ? fp16(C[row, c]) + w1[row] * dh1[ray, c] + w2[row] * dh2[ray, c] : 0
+// i.e. what cpn_hid_grad_combine computes from the stored C (a 7 GB write + a 7 GB read less per training step).  Q = hid
+// (row stride ldq = ldc).  The read-back of the staged tile gives a lane ONE 8-column chunk (lane % 26, 52 live lanes, two rows
+// per instruction), so the ray's two dhbar chunks are loaded once per tile and stay in registers.
+struct CombineArgs {
+    const float* w1; const float* dh1; const float* w2; const float* dh2;      // (N, R, S) weights, (rays, 1664) fp32 dhbar
+    int V, R, S, ray0;
+};
 #ifndef CPN_HID_READ_NT
 #define CPN_HID_READ_NT 1
 #endif
@@ -106,7 +116,8 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
                                                              void* __restrict__ Cv, int ldc, int M, int K32, int n_tiles,
                                                              int total_tiles, const __half* __restrict__ Q = nullptr,
                                                              int ldq = 0, const __half* __restrict__ W2 = nullptr,
-                                                             int ldw2 = 0, const float* __restrict__ bias2 = nullptr) {
+                                                             int ldw2 = 0, const float* __restrict__ bias2 = nullptr,
+                                                             CombineArgs ca = CombineArgs{}) {
     using C_ = Cfg<NT>;
     // the chained key kernel streams hid (7 GB per chunk, read once per pass): non-temporal, so that the node tables
     // of encode_hidden stay in L2 / Infinity Cache across the chunk loop
@@ -228,8 +239,22 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         half8 xa0[2], wb0[NT], xa1[2], wb1[NT];
-        half4 qv[DOT ? 2 : 1][DOT ? NT : 1];               // DOT: the Q rows of this tile, in flight under the main loop
-        if constexpr (DOT != 0) {
+        half4 qv[(DOT == 1 || DOT == 2) ? 2 : 1][(DOT == 1 || DOT == 2) ? NT : 1];   // DOT 1/2: the Q rows of this tile, in flight under the main loop
+        f32x4 cdh[DOT == 3 ? 4 : 1];                       // DOT 3: dh1 / dh2 chunks (8 columns) of this wave's ray
+        if constexpr (DOT == 3) {
+            constexpr int CPR = C_::BN / 8;
+            const int T = ca.V * ca.S;
+            int t = (m0 + wave * 32) / T;                  // 32 | T: the wave's 32 rows belong to one ray
+            const int tl = (M - 1) / T;
+            t = t < tl ? t : tl;
+            const int c = lane % CPR;
+            const size_t off = (size_t)t * ldc + n0 + c * 8;
+            cdh[0] = ca.dh1 ? *reinterpret_cast<const f32x4*>(ca.dh1 + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            cdh[1] = ca.dh1 ? *reinterpret_cast<const f32x4*>(ca.dh1 + off + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            cdh[2] = ca.dh2 ? *reinterpret_cast<const f32x4*>(ca.dh2 + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            cdh[3] = ca.dh2 ? *reinterpret_cast<const f32x4*>(ca.dh2 + off + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (DOT == 1 || DOT == 2) {
 #ifndef CPN_ROWDOT_NOQ                                     /* timing-only ablation: the Q rows never loaded */
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -357,7 +382,59 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
             }
         }
 
-        if constexpr (DOT != 0) {
+        if constexpr (DOT == 3) {
+            constexpr int RS = C_::BN * 2 + 16;
+            constexpr int CPR = C_::BN / 8;
+            static_assert(8 * 16 * RS <= 2 * C_::A_BYTES, "staging must fit activation slots 1-2");
+            static_assert(2 * CPR <= 64, "two rows of chunks per instruction");
+            char* cw = smem + C_::A_BYTES + wave * (16 * RS);
+            const int c = lane % CPR, rsel = lane / CPR;               // rsel 0 / 1 live, 2 = idle lanes
+            const int T = ca.V * ca.S;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int rbase = m0 + wave * 32 + mt * 16;
+                // loads first: the hid chunks and the softmax weights of this lane's 8 rows
+                const int rb = rbase < M ? rbase : M - 16;             // M % 16 == 0 (checked by the entry point)
+                const int t = rb / T, rem = rb - t * T;
+                const int v = rem / ca.S, s0 = rem - v * ca.S;
+                const int ray = ca.ray0 + t;
+                const int b = ray / ca.R, rr = ray - b * ca.R;
+                const size_t wbase = (((size_t)(b * ca.V + v)) * ca.R + rr) * ca.S + s0;
+                half8 hv[8];
+                float wa[8], wb_[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = i * 2 + (rsel & 1);
+                    hv[i] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(Q + (size_t)(rb + r) * ldq + n0 + c * 8));
+                    wa[i] = ca.w1 ? ca.w1[wbase + r] : 0.0f;
+                    wb_[i] = ca.w2 ? ca.w2[wbase + r] : 0.0f;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    half4 h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = (_Float16)acc[mt][nt][i];
+                    *reinterpret_cast<half4*>(cw + (lane & 15) * RS + (nt * 16 + (lane >> 4) * 4) * 2) = h;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __half* cbase = (__half*)Cv + (size_t)rbase * ldc + n0 + c * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = i * 2 + (rsel & 1);
+                    const half8 d = *reinterpret_cast<const half8*>(cw + r * RS + c * 16);
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float a = (float)d[e];
+                        a += wa[i] * cdh[e >> 2][e & 3];
+                        a += wb_[i] * cdh[2 + (e >> 2)][e & 3];
+                        o[e] = (float)hv[i][e] > 0.0f ? (_Float16)a : (_Float16)0.0f;
+                    }
+                    if (rsel < 2 && rbase + r < M) *reinterpret_cast<half8*>(cbase + (size_t)r * ldc) = o;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        } else if constexpr (DOT != 0) {
             float dsum[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -481,7 +558,7 @@ int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias
     const int num_cu = cpn_stream_cus((void*)stream);       // persistent grid: the CUs this stream may use
     dim3 grid((unsigned)std::min<long long>(total, num_cu));       // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles, (int)total,
-                       (const __half*)nullptr, 0, (const __half*)nullptr, 0, (const float*)nullptr);
+                       (const __half*)nullptr, 0, (const __half*)nullptr, 0, (const float*)nullptr, CombineArgs{});
     CPN_LAUNCH_CHECK("cpn_gemm_f16");
     return 0;
 }
@@ -506,8 +583,36 @@ int launch_rowdot(const __half* A, int lda, const __half* W, int ldw, const floa
     const int num_cu = cpn_stream_cus((void*)stream);       // persistent grid: the CUs this stream may use
     dim3 grid((unsigned)std::min<long long>(total, num_cu));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, (void*)logits, 0, M, K32, 1, (int)total, Q,
-                       ldq, W2, ldw2, bias2);
+                       ldq, W2, ldw2, bias2, CombineArgs{});
     CPN_LAUNCH_CHECK("cpn_gemm_f16_rowdot");
+    return 0;
+}
+
+int launch_combine(const __half* A, int lda, const __half* W, int ldw, const __half* hid, const CombineArgs& ca, __half* out,
+                   int ld, int M, int N, int K32, hipStream_t stream) {
+    using C_ = Cfg<13>;
+    const size_t lds = C_::LDS_BYTES;
+    auto kern = gemm_f16_kernel<13, false, false, 3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            cpn_set_error("cpn_gemm_f16_combine: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int n_tiles = N / C_::BN;
+    const long long total = (long long)cpn_cdiv(M, BM) * n_tiles;
+    if (total >= (1LL << 31)) {
+        cpn_set_error("cpn_gemm_f16_combine: %lld output tiles exceed the 32-bit tile index", total);
+        return CPN_E_SHAPE;
+    }
+    const int num_cu = cpn_stream_cus((void*)stream);
+    dim3 grid((unsigned)std::min<long long>(total, num_cu));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, (const float*)nullptr, (void*)out, ld, M, K32, n_tiles,
+                       (int)total, hid, ld, (const __half*)nullptr, 0, (const float*)nullptr, ca);
+    CPN_LAUNCH_CHECK("cpn_gemm_f16_combine");
     return 0;
 }
 
@@ -721,6 +826,26 @@ extern "C" int cpn_gemm_f16(const uint16_t* A, int lda, const uint16_t* W, int l
     if (N % 128 == 0) return dispatch<8>(a, lda, w, ldw, bias, C, ldc, M, N, K / 32, relu, out_f32, s);
     cpn_set_error("cpn_gemm_f16: N=%d is neither a multiple of 208 nor of 128", N);
     return CPN_E_SHAPE;
+}
+
+extern "C" int cpn_gemm_f16_combine(const uint16_t* dkh, int lda, const uint16_t* Wt, int ldw, const uint16_t* hid, const float* w1,
+                                    const float* dh1, const float* w2, const float* dh2, int B, int V, int R, int S, int ray0,
+                                    int nrays, int K, uint16_t* out, void* stream) {
+    CPN_REQUIRE(dkh && Wt && hid && out && (!w1 || dh1) && (!w2 || dh2), CPN_E_ARG, "cpn_gemm_f16_combine: null pointer");
+    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && (S % 16) == 0, CPN_E_SHAPE, "cpn_gemm_f16_combine: need V == 2, S %% 16 == 0");
+    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_SHAPE,
+                "cpn_gemm_f16_combine: ray range outside B*R");
+    CPN_REQUIRE(K > 0 && (K % 32) == 0 && lda >= K && ldw >= K && (lda % 8) == 0 && (ldw % 8) == 0, CPN_E_SHAPE,
+                "cpn_gemm_f16_combine: bad K / leading dimension");
+    const long long M = (long long)nrays * V * S;
+    CPN_REQUIRE(M < (1LL << 31) && (long long)256 * lda * 2 < (1LL << 31) && (long long)1664 * ldw * 2 < (1LL << 31), CPN_E_SHAPE,
+                "cpn_gemm_f16_combine: problem exceeds the 32-bit index range");
+    CPN_REQUIRE(((uintptr_t)dkh % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)hid % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                    ((uintptr_t)dh1 % 16) == 0 && ((uintptr_t)dh2 % 16) == 0, CPN_E_ARG,
+                "cpn_gemm_f16_combine: pointers must be 16-byte aligned");
+    CombineArgs ca{w1, dh1, w2, dh2, V, R, S, ray0};
+    return launch_combine((const __half*)dkh, lda, (const __half*)Wt, ldw, (const __half*)hid, ca, (__half*)out, 1664, (int)M, 1664,
+                          K / 32, (hipStream_t)stream);
 }
 
 extern "C" int cpn_gemm_f16_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,

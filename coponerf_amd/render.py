@@ -971,7 +971,7 @@ class RenderEngine:
 
         Wkf, ckf = fold("key_map", 128)
         Wvf, cvf = fold("latent_value", 416)
-        kh = GemmFn.apply(hid2, Wkf, ckf, True, False, gs)
+        kh = GemmFn.apply(hid2, Wkf, ckf, True, False, gs, None, dims, hp)    # last consumer of hid in the backward pass
         key2 = GemmFn.apply(kh, mat("key_map_2", 128), bias("key_map_2"), False, False, gs)
         hq = LocalHiddenFn.apply(g["loc8"], g["coords9"], mat("query_embed", 128), bias("query_embed"), None, dims, gs)
         ce = GemmFn.apply(hq, mat("query_embed_2", 128), bias("query_embed_2"), False, False, gs)

@@ -53,6 +53,8 @@ class GradScale:
 # first-layer backward in the table form (csrc/encode_bwd.hip); COPONERF_TABLE_BACKWARD=0 restores the round-2 form
 # (re-gather + 835-wide weight-gradient GEMM + data-gradient GEMM + 832-column scatter into the maps)
 TABLE_BACKWARD = os.environ.get("COPONERF_TABLE_BACKWARD", "1") != "0"
+# cpn_hid_grad_combine as the epilogue of the key path's data-gradient GEMM (cpn_gemm_f16_combine; round 6); 0 = two kernels
+FUSE_COMBINE = os.environ.get("COPONERF_FUSE_COMBINE", "1") != "0"
 
 
 class HidGradParts:
@@ -63,6 +65,7 @@ class HidGradParts:
 
     def __init__(self):
         self.parts = []                     # (w (N,R,S) fp32, dhbar (rays,1664) fp32 scaled)
+        self.combined = False               # the key path's data-gradient GEMM already formed the masked sum (FUSE_COMBINE)
 
 
 def _mm_f32(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
@@ -103,7 +106,7 @@ class GemmFn(Function):
     """C = act(A . W^T + b) through cpn_gemm_f16.  A (M, lda) fp16 (row stride lda >= K), W (N, K) fp32, b (N)."""
 
     @staticmethod
-    def forward(ctx, A16, W, b, relu: bool, out_f32: bool, gs: GradScale, hid_parts=None, dims=None):
+    def forward(ctx, A16, W, b, relu: bool, out_f32: bool, gs: GradScale, hid_parts=None, dims=None, in_parts=None):
         M, lda = A16.shape
         N, K = W.shape
         Kp = ((K + 31) // 32) * 32
@@ -117,8 +120,29 @@ class GemmFn(Function):
              int(relu), int(out_f32), _stream())
         ctx.save_for_backward(A16, W16, C if relu else None)
         ctx.relu, ctx.K, ctx.gs = relu, K, gs
-        ctx.hid_parts, ctx.dims = hid_parts, dims
+        ctx.hid_parts, ctx.dims, ctx.in_parts = hid_parts, dims, in_parts
         return C
+
+    @staticmethod
+    def _combined_data_grad(ctx, d16, A16, W16):
+        """A16 = hid (rows, 1664): dA and the gradients parked by the two attention sums, masked, in one kernel — this layer
+        is the LAST consumer of hid that autograd runs (its gradient depends on both sums' backward passes)."""
+        hp = ctx.in_parts
+        B, V, R, S = ctx.dims
+        K = d16.shape[1]
+        if not (FUSE_COMBINE and hp is not None and hp.parts and A16.shape[1] == 1664 and S % 16 == 0 and K % 32 == 0
+                and d16.is_contiguous() and A16.is_contiguous() and ctx.needs_input_grad[0]):
+            return None
+        parts = hp.parts
+        (w1, dh1), (w2, dh2) = parts[0], (parts[1] if len(parts) > 1 else (None, None))
+        Wt = W16.t().contiguous()                                              # (1664, K)
+        out = torch.empty_like(A16)
+        call("cpn_gemm_f16_combine", d16.data_ptr(), K, Wt.data_ptr(), K, A16.data_ptr(), w1.data_ptr(), dh1.data_ptr(),
+             0 if w2 is None else w2.data_ptr(), 0 if dh2 is None else dh2.data_ptr(), B, V, R, S, 0, B * R, K, out.data_ptr(),
+             _stream())
+        hp.parts = []
+        hp.combined = True
+        return out
 
     @staticmethod
     def backward(ctx, dC):
@@ -134,22 +158,27 @@ class GemmFn(Function):
                  0 if w2 is None else w2.data_ptr(), 0 if dh2 is None else dh2.data_ptr(), B, V, R, S, 0, B * R,
                  d16.data_ptr(), _stream())
             ctx.hid_parts.parts = []
+            ctx.hid_parts.combined = False
             d = d16
             inv = 1.0 / ctx.gs.s
         else:
+            if ctx.hid_parts is not None:
+                ctx.hid_parts.combined = False
             d = ctx.gs.scaled16(dC.contiguous())                                 # s * dC (GradScale convention)
             inv = 1.0 / ctx.gs.s
             if ctx.relu:
                 d = torch.ops.aten.threshold_backward(d, C.to(d.dtype) if C.dtype != d.dtype else C, 0)   # d where C > 0
             d16 = d.to(torch.float16)
-        dA = _data_grad(d16, W16) if ctx.needs_input_grad[0] else None               # (M, lda) fp16, scaled; pad columns get 0
+        dA = GemmFn._combined_data_grad(ctx, d16, A16, W16) if ctx.in_parts is not None else None
+        if dA is None:
+            dA = _data_grad(d16, W16) if ctx.needs_input_grad[0] else None           # (M, lda) fp16, scaled; pad columns get 0
         if d16.shape[1] == 128 and A16.shape[1] == 128 and d16.is_contiguous() and ctx.needs_input_grad[1]:
             # 128 x 128 outputs over millions of rows: a streaming reduction, not a GEMM the library handles well
             dW = torch.zeros(128, 128, dtype=torch.float32, device=d16.device)
             db = torch.zeros(128, dtype=torch.float32, device=d16.device)
             call("cpn_wgrad_skinny_f16", d16.data_ptr(), A16.data_ptr(), 128, d16.shape[0], dW.data_ptr(), db.data_ptr(),
                  _stream())
-            return dA, dW[:, :ctx.K] * inv, (db * inv if ctx.needs_input_grad[2] else None), None, None, None, None, None
+            return dA, dW[:, :ctx.K] * inv, (db * inv if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
         n_out, k_in = d16.shape[1], A16.shape[1]
         both = d16.is_contiguous() and A16.is_contiguous()
         if ctx.needs_input_grad[1] and both and n_out % 208 == 0 and k_in % 128 == 0:
@@ -160,7 +189,7 @@ class GemmFn(Function):
         else:
             dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
         db = d.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[2] else None
-        return dA, dW, db, None, None, None, None, None
+        return dA, dW, db, None, None, None, None, None, None
 
 
 class LinearF32Fn(Function):
@@ -384,15 +413,21 @@ class EncodeFn(Function):
         H, Wd = ctx.HW
         s = _stream()
         d = ctx.gs.scaled16(dC.contiguous()).to(torch.float16)
-        parts = ctx.hid_parts.parts if ctx.hid_parts is not None else []
-        (w1, dh1) = parts[0] if len(parts) > 0 else (None, None)
-        (w2, dh2) = parts[1] if len(parts) > 1 else (None, None)
-        d16 = torch.empty_like(hid)                          # relu mask (.) (key-path gradient + parked rank-one parts)
-        call("cpn_hid_grad_combine", d.data_ptr(), hid.data_ptr(), 0 if w1 is None else w1.data_ptr(),
-             0 if dh1 is None else dh1.data_ptr(), 0 if w2 is None else w2.data_ptr(), 0 if dh2 is None else dh2.data_ptr(),
-             B, V, R, S, 0, B * R, d16.data_ptr(), s)
-        if ctx.hid_parts is not None:
-            ctx.hid_parts.parts = []
+        if ctx.hid_parts is not None and ctx.hid_parts.combined and not ctx.hid_parts.parts:
+            # the key path's data-gradient GEMM already added the parked parts and applied the mask (cpn_gemm_f16_combine)
+            ctx.hid_parts.combined = False
+            d16 = d.view(hid.shape)
+        else:                                                # (parts parked after a fused combine are still added here)
+            parts = ctx.hid_parts.parts if ctx.hid_parts is not None else []
+            (w1, dh1) = parts[0] if len(parts) > 0 else (None, None)
+            (w2, dh2) = parts[1] if len(parts) > 1 else (None, None)
+            d16 = torch.empty_like(hid)                      # relu mask (.) (key-path gradient + parked rank-one parts)
+            call("cpn_hid_grad_combine", d.data_ptr(), hid.data_ptr(), 0 if w1 is None else w1.data_ptr(),
+                 0 if dh1 is None else dh1.data_ptr(), 0 if w2 is None else w2.data_ptr(), 0 if dh2 is None else dh2.data_ptr(),
+                 B, V, R, S, 0, B * R, d16.data_ptr(), s)
+            if ctx.hid_parts is not None:
+                ctx.hid_parts.parts = []
+                ctx.hid_parts.combined = False
         del d
         if ctx.table_bwd:
             return EncodeFn._backward_tables(ctx, d16)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 8
+#define CPN_ABI_VERSION 9
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -328,6 +328,16 @@ int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, const uint16_t
  * the attention-weighted hidden sums (w_i: forward softmax weights, dh_i: gradient of the summed vector).            */
 int cpn_hid_grad_combine(const uint16_t* dkey, const uint16_t* hid, const float* w1, const float* dh1, const float* w2,
                          const float* dh2, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out, void* stream);
+
+/* the same result WITHOUT the stored key-path gradient (round 6): the data-gradient GEMM of the folded key map
+ * (autograd's grad_input of Conv2d 1664->128, models/CoPoNeRF.py:404 under wrapper.py:138) with cpn_hid_grad_combine as its
+ * epilogue,   out (rows,1664) = mask(hid) . (dkh (rows,K) . Wt (1664,K)^T + w1 (x) dh1 + w2 (x) dh2),   rows = nrays*V*S.
+ * dkh fp16 (row stride lda), Wt fp16 = the folded key-map weight transposed (K-contiguous rows, stride ldw), K % 32 == 0,
+ * S % 16 == 0.  Same arithmetic as cpn_gemm_f16 followed by cpn_hid_grad_combine (bit-identical), 14 GB less HBM traffic
+ * per training step at 4 x 4096 rays.                                                                                     */
+int cpn_gemm_f16_combine(const uint16_t* dkh, int lda, const uint16_t* Wt, int ldw, const uint16_t* hid, const float* w1,
+                         const float* dh1, const float* w2, const float* dh2, int B, int V, int R, int S, int ray0,
+                         int nrays, int K, uint16_t* out, void* stream);
 
 /* weight gradients of the 128-wide per-sample layers (torch.mm(dY.t(), X) in the reference's autograd, i.e. the
  * Conv2d(128->128,1x1) / Conv2d(16->128,1x1) layers of models/CoPoNeRF.py:82,85-86,95-96 under wrapper.py:138):

@@ -776,3 +776,72 @@ def test_train_step_guards_on_the_device():
     assert int(got.max()) == 1 and int(got.min()) == 0      # the parameters without a gradient keep their zero
     r = step(inp, inp["query"]["rgb"])
     assert bool(r["stepped"]) and float(r["loss"]) == float(r["loss"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,R,S,two", [(1, 5, 16, True), (2, 37, 64, True), (1, 300, 32, False), (3, 64, 128, True)])
+def test_combine_gemm_equals_gemm_then_combine(B, R, S, two):
+    """cpn_gemm_f16_combine (the key path's data-gradient GEMM with cpn_hid_grad_combine as its epilogue, round 6) gives the
+    bits of cpn_gemm_f16 followed by cpn_hid_grad_combine: same MFMA sequence, same fp16 rounding of the product, same fp32
+    sums — ragged tile tails (rows not a multiple of 256), one or two parked parts."""
+    from coponerf_amd._hip import call
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    V, K = 2, 128
+    rows = B * R * V * S
+    g = torch.Generator().manual_seed(rows + S)
+    dkh = (torch.randn(rows, K, generator=g) * 0.5).half().to(dev)
+    Wt = (torch.randn(1664, K, generator=g) * 0.1).half().to(dev)
+    hid = torch.relu(torch.randn(rows, 1664, generator=g)).half().to(dev)
+    w1 = torch.rand(B * V, R, S, generator=g).to(dev)
+    w2 = torch.rand(B * V, R, S, generator=g).to(dev)
+    dh1 = torch.randn(B * R, 1664, generator=g).to(dev)
+    dh2 = torch.randn(B * R, 1664, generator=g).to(dev)
+    zero = torch.zeros(1664, device=dev)
+    d = torch.empty(rows, 1664, dtype=torch.float16, device=dev)
+    call("cpn_gemm_f16", dkh.data_ptr(), K, Wt.data_ptr(), K, zero.data_ptr(), d.data_ptr(), 1664, rows, 1664, K, 0, 0, st)
+    want = torch.empty_like(d)
+    p2 = (w2.data_ptr(), dh2.data_ptr()) if two else (0, 0)
+    call("cpn_hid_grad_combine", d.data_ptr(), hid.data_ptr(), w1.data_ptr(), dh1.data_ptr(), p2[0], p2[1], B, V, R, S, 0, B * R,
+         want.data_ptr(), st)
+    got = torch.full_like(d, float("nan"))
+    call("cpn_gemm_f16_combine", dkh.data_ptr(), K, Wt.data_ptr(), K, hid.data_ptr(), w1.data_ptr(), dh1.data_ptr(), p2[0], p2[1],
+         B, V, R, S, 0, B * R, K, got.data_ptr(), st)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    # and against float64 on a sample of rows
+    idx = torch.arange(0, rows, max(1, rows // 64), device=dev)
+    t = idx // (V * S)
+    v = (idx // S) % V
+    s_ = idx % S
+    b, r = t // R, t % R
+    wa = w1[b * V + v, r, s_][:, None].double()
+    wb = w2[b * V + v, r, s_][:, None].double() if two else 0.0
+    ref = dkh[idx].double() @ Wt.double().t() + wa * dh1[t].double() + (wb * dh2[t].double() if two else 0.0)
+    ref = torch.where(hid[idx] > 0, ref, torch.zeros_like(ref))
+    assert float((got[idx].double() - ref).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+def test_fused_combine_training_matches_two_kernel_form(dev, monkeypatch):
+    """render_train with COPONERF_FUSE_COMBINE on / off: the same gradients (the fused epilogue is bit-identical)."""
+    from coponerf_amd import CoPoNeRF, train_fns
+    B, H, R, S = 2, 64, 40, 32
+    weights = syn.make_render_weights(seed=31)
+    inp = to_device(syn.make_inputs(B, H, H, R, seed=65), dev)
+    z, rel, flow = syn.make_latents(B, H, H, seed=66)
+    coef = syn.normal((B, 1, R, 3), seed=67).to(dev)
+    res = []
+    for fuse in (True, False):
+        monkeypatch.setattr(train_fns, "FUSE_COMBINE", fuse)
+        model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+        model.load_state_dict(weights, strict=False)
+        model = model.to(dev).train()
+        zz = [t.to(dev).requires_grad_(True) for t in z]
+        out = model(inp, z=zz, rel_pose=rel.to(dev), val=False, flow=to_device(flow, dev))
+        (out["rgb"] * coef).sum().backward()
+        grads = {"z%d" % i: t.grad for i, t in enumerate(zz)}
+        grads.update({k: p.grad for k, p in model.named_parameters() if p.grad is not None})
+        res.append(grads)
+    assert set(res[0]) == set(res[1]) and "query_encode_latent.weight" in res[0]
+    for k in res[0]:                                         # (fp32 atomics in the level-3 scatter: not bit-reproducible)
+        rel_err = float((res[0][k] - res[1][k]).norm() / (res[1][k].norm() + 1e-30))
+        assert rel_err <= 1e-5, (k, rel_err)

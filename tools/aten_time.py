@@ -5,6 +5,7 @@ Forward ops carry the innermost coponerf_amd frame; backward ops the name of the
 import argparse
 import collections
 import os
+import re
 import sys
 
 import torch
@@ -19,6 +20,7 @@ def main():
     ap.add_argument("--top", type=int, default=70)
     ap.add_argument("--getz", action="store_true")
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--kernels", default="", help="regex: only events that launched a kernel whose name matches")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = CoPoNeRF.CoPoNeRF(n_view=2)
@@ -59,6 +61,8 @@ def main():
                     and "SubTensor" not in n and "rocblas" not in n) for n in names)
         total += t
         if ours:
+            continue
+        if a.kernels and not any(re.search(a.kernels, n) for n in names):
             continue
         frame = ""
         for fs in ev.stack or []:
