@@ -48,9 +48,10 @@ SIGNATURES: Dict[str, List] = {
     "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "cpn_lightfield_decode": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "cpn_ray_outputs": [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
-    "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "cpn_hid_grad_combine": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_gemm_f16_combine": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_gemm_f16_masked": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "cpn_wgrad_skinny_f16": [_P, _P, _I, ctypes.c_longlong, _P, _P, _P],
     "cpn_wgrad_tall_f16": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
     "cpn_local_hidden_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -260,7 +260,8 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 __global__ __launch_bounds__(256) void attend_hidden_bwd_kernel(
     const __half* __restrict__ qa, const __half* __restrict__ qb, const __half* __restrict__ hid,
     const float* __restrict__ at_wt, const float* __restrict__ dhbar, const float* __restrict__ dw_ext, int V, int R,
-    int S, int ray0, __half* __restrict__ dqa, __half* __restrict__ dqb, __half* __restrict__ dhid) {
+    int S, int ray0, __half* __restrict__ dqa, __half* __restrict__ dqb, __half* __restrict__ dhid,
+    const __half* __restrict__ dqb_acc) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* dh = reinterpret_cast<float*>(smem_raw);          // HC floats: dhbar of this ray
     float* wts = dh + HC;                                    // T
@@ -333,10 +334,19 @@ __global__ __launch_bounds__(256) void attend_hidden_bwd_kernel(
         const half8 bq = *reinterpret_cast<const half8*>(qb + (row0 + row) * 128 + g * 8);
         const float d = dl[row];
         half8 oa, ob;
+        if (dqb_acc) {                      // qb is shared with another attention round: its gradient is summed here
+            const half8 pq = *reinterpret_cast<const half8*>(dqb_acc + (row0 + row) * 128 + g * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            oa[e] = (_Float16)(d * (float)bq[e]);
-            ob[e] = (_Float16)(d * (float)a[e]);
+            for (int e = 0; e < 8; ++e) {
+                oa[e] = (_Float16)(d * (float)bq[e]);
+                ob[e] = (_Float16)((float)pq[e] + d * (float)a[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                oa[e] = (_Float16)(d * (float)bq[e]);
+                ob[e] = (_Float16)(d * (float)a[e]);
+            }
         }
         *reinterpret_cast<half8*>(dqa + (row0 + row) * 128 + g * 8) = oa;
         *reinterpret_cast<half8*>(dqb + (row0 + row) * 128 + g * 8) = ob;
@@ -641,7 +651,8 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
 
 extern "C" int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, const float* at_wt,
                                      const float* dhbar, const float* dw_ext, int B, int V, int R, int S, int ray0,
-                                     int nrays, uint16_t* dqa, uint16_t* dqb, uint16_t* dhid, void* stream) {
+                                     int nrays, uint16_t* dqa, uint16_t* dqb, uint16_t* dhid, const uint16_t* dqb_acc,
+                                     void* stream) {
     CPN_REQUIRE(qa && qb && hid && at_wt && dhbar && dqa && dqb, CPN_E_ARG, "cpn_attend_hidden_bwd: null pointer");
     CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && V * S <= 2048, CPN_E_SHAPE, "cpn_attend_hidden_bwd: bad shape");
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
@@ -649,7 +660,7 @@ extern "C" int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, con
     const size_t lds = (size_t)(HC + 2 * V * S + 4) * sizeof(float);
     hipLaunchKernelGGL(attend_hidden_bwd_kernel, dim3(nrays), dim3(256), lds, (hipStream_t)stream,
                        (const __half*)qa, (const __half*)qb, (const __half*)hid, at_wt, dhbar, dw_ext, V, R, S, ray0,
-                       (__half*)dqa, (__half*)dqb, (__half*)dhid);
+                       (__half*)dqa, (__half*)dqb, (__half*)dhid, (const __half*)dqb_acc);
     CPN_LAUNCH_CHECK("cpn_attend_hidden_bwd");
     return 0;
 }

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
         f32x4 cdh[DOT == 3 ? 4 : 1];                       // DOT 3: dh1 / dh2 chunks (8 columns) of this wave's ray
         if constexpr (DOT == 3) {
             constexpr int CPR = C_::BN / 8;
-            const int T = ca.V * ca.S;
+            const int T = ca.S > 0 ? ca.V * ca.S : 1;      // S == 0: mask only (no parked parts, dh pointers are null)
             int t = (m0 + wave * 32) / T;                  // 32 | T: the wave's 32 rows belong to one ray
             const int tl = (M - 1) / T;
             t = t < tl ? t : tl;
@@ -385,26 +385,33 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
         if constexpr (DOT == 3) {
             constexpr int RS = C_::BN * 2 + 16;
             constexpr int CPR = C_::BN / 8;
+            constexpr int RPI = 64 / CPR;                              // rows per store instruction (2 at BN = 208, 4 at 128)
+            constexpr int NI = 16 / RPI;
             static_assert(8 * 16 * RS <= 2 * C_::A_BYTES, "staging must fit activation slots 1-2");
-            static_assert(2 * CPR <= 64, "two rows of chunks per instruction");
+            static_assert(RPI >= 1 && NI * RPI == 16, "whole rows per instruction");
             char* cw = smem + C_::A_BYTES + wave * (16 * RS);
-            const int c = lane % CPR, rsel = lane / CPR;               // rsel 0 / 1 live, 2 = idle lanes
-            const int T = ca.V * ca.S;
+            const int c = lane % CPR, rsel = lane / CPR;               // rsel >= RPI: idle lanes (12 of 64 at BN = 208)
+            const int rl = rsel < RPI ? rsel : 0;
+            const bool parts = ca.S > 0;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int rbase = m0 + wave * 32 + mt * 16;
-                // loads first: the hid chunks and the softmax weights of this lane's 8 rows
-                const int rb = rbase < M ? rbase : M - 16;             // M % 16 == 0 (checked by the entry point)
-                const int t = rb / T, rem = rb - t * T;
-                const int v = rem / ca.S, s0 = rem - v * ca.S;
-                const int ray = ca.ray0 + t;
-                const int b = ray / ca.R, rr = ray - b * ca.R;
-                const size_t wbase = (((size_t)(b * ca.V + v)) * ca.R + rr) * ca.S + s0;
-                half8 hv[8];
-                float wa[8], wb_[8];
+                // loads first: the mask chunks and the softmax weights of this lane's rows
+                const int rb = rbase < M ? rbase : M - 16;             // M % 16 == 0 (checked by the entry points)
+                size_t wbase = 0;
+                if (parts) {
+                    const int T = ca.V * ca.S;
+                    const int t = rb / T, rem = rb - t * T;
+                    const int v = rem / ca.S, s0 = rem - v * ca.S;
+                    const int ray = ca.ray0 + t;
+                    const int b = ray / ca.R, rr = ray - b * ca.R;
+                    wbase = (((size_t)(b * ca.V + v)) * ca.R + rr) * ca.S + s0;
+                }
+                half8 hv[NI];
+                float wa[NI], wb_[NI];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = i * 2 + (rsel & 1);
+                for (int i = 0; i < NI; ++i) {
+                    const int r = i * RPI + rl;
                     hv[i] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(Q + (size_t)(rb + r) * ldq + n0 + c * 8));
                     wa[i] = ca.w1 ? ca.w1[wbase + r] : 0.0f;
                     wb_[i] = ca.w2 ? ca.w2[wbase + r] : 0.0f;
@@ -419,8 +426,8 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __half* cbase = (__half*)Cv + (size_t)rbase * ldc + n0 + c * 8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = i * 2 + (rsel & 1);
+                for (int i = 0; i < NI; ++i) {
+                    const int r = i * RPI + rl;
                     const half8 d = *reinterpret_cast<const half8*>(cw + r * RS + c * 16);
                     half8 o;
 #pragma unroll
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
                         a += wb_[i] * cdh[2 + (e >> 2)][e & 3];
                         o[e] = (float)hv[i][e] > 0.0f ? (_Float16)a : (_Float16)0.0f;
                     }
-                    if (rsel < 2 && rbase + r < M) *reinterpret_cast<half8*>(cbase + (size_t)r * ldc) = o;
+                    if (rsel < RPI && rbase + r < M) *reinterpret_cast<half8*>(cbase + (size_t)r * ldc) = o;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
@@ -588,11 +595,12 @@ int launch_rowdot(const __half* A, int lda, const __half* W, int ldw, const floa
     return 0;
 }
 
-int launch_combine(const __half* A, int lda, const __half* W, int ldw, const __half* hid, const CombineArgs& ca, __half* out,
-                   int ld, int M, int N, int K32, hipStream_t stream) {
-    using C_ = Cfg<13>;
+template <int NT>
+int launch_combine(const __half* A, int lda, const __half* W, int ldw, const __half* hid, int ldh, const CombineArgs& ca,
+                   __half* out, int ld, int M, int N, int K32, hipStream_t stream) {
+    using C_ = Cfg<NT>;
     const size_t lds = C_::LDS_BYTES;
-    auto kern = gemm_f16_kernel<13, false, false, 3>;
+    auto kern = gemm_f16_kernel<NT, false, false, 3>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -611,7 +619,7 @@ int launch_combine(const __half* A, int lda, const __half* W, int ldw, const __h
     const int num_cu = cpn_stream_cus((void*)stream);
     dim3 grid((unsigned)std::min<long long>(total, num_cu));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, (const float*)nullptr, (void*)out, ld, M, K32, n_tiles,
-                       (int)total, hid, ld, (const __half*)nullptr, 0, (const float*)nullptr, ca);
+                       (int)total, hid, ldh, (const __half*)nullptr, 0, (const float*)nullptr, ca);
     CPN_LAUNCH_CHECK("cpn_gemm_f16_combine");
     return 0;
 }
@@ -844,8 +852,30 @@ extern "C" int cpn_gemm_f16_combine(const uint16_t* dkh, int lda, const uint16_t
                     ((uintptr_t)dh1 % 16) == 0 && ((uintptr_t)dh2 % 16) == 0, CPN_E_ARG,
                 "cpn_gemm_f16_combine: pointers must be 16-byte aligned");
     CombineArgs ca{w1, dh1, w2, dh2, V, R, S, ray0};
-    return launch_combine((const __half*)dkh, lda, (const __half*)Wt, ldw, (const __half*)hid, ca, (__half*)out, 1664, (int)M, 1664,
-                          K / 32, (hipStream_t)stream);
+    return launch_combine<13>((const __half*)dkh, lda, (const __half*)Wt, ldw, (const __half*)hid, 1664, ca, (__half*)out, 1664,
+                              (int)M, 1664, K / 32, (hipStream_t)stream);
+}
+
+extern "C" int cpn_gemm_f16_masked(const uint16_t* A, int lda, const uint16_t* Wt, int ldw, const uint16_t* mask, int ldm,
+                                   uint16_t* out, int ldc, int M, int N, int K, void* stream) {
+    CPN_REQUIRE(A && Wt && mask && out, CPN_E_ARG, "cpn_gemm_f16_masked: null pointer");
+    CPN_REQUIRE(M > 0 && (M % 16) == 0 && N > 0 && K > 0 && (K % 32) == 0, CPN_E_SHAPE,
+                "cpn_gemm_f16_masked: need M %% 16 == 0 and K %% 32 == 0 (got M=%d K=%d)", M, K);
+    CPN_REQUIRE(lda >= K && ldw >= K && (lda % 8) == 0 && (ldw % 8) == 0 && ldm >= N && (ldm % 8) == 0 && ldc >= N && (ldc % 8) == 0,
+                CPN_E_SHAPE, "cpn_gemm_f16_masked: bad leading dimension");
+    CPN_REQUIRE((long long)256 * lda * 2 < (1LL << 31) && (long long)N * ldw * 2 < (1LL << 31), CPN_E_SHAPE,
+                "cpn_gemm_f16_masked: tile exceeds the 32-bit buffer offset range");
+    CPN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)mask % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                CPN_E_ARG, "cpn_gemm_f16_masked: pointers must be 16-byte aligned");
+    CombineArgs ca{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    if (N % 208 == 0)
+        return launch_combine<13>((const __half*)A, lda, (const __half*)Wt, ldw, (const __half*)mask, ldm, ca, (__half*)out, ldc, M, N,
+                                  K / 32, (hipStream_t)stream);
+    if (N % 128 == 0)
+        return launch_combine<8>((const __half*)A, lda, (const __half*)Wt, ldw, (const __half*)mask, ldm, ca, (__half*)out, ldc, M, N,
+                                 K / 32, (hipStream_t)stream);
+    cpn_set_error("cpn_gemm_f16_masked: N=%d is neither a multiple of 208 nor of 128", N);
+    return CPN_E_SHAPE;
 }
 
 extern "C" int cpn_gemm_f16_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,

@@ -940,7 +940,8 @@ class RenderEngine:
                      z: Sequence[torch.Tensor], rel_pose, val: bool, S: int, H: int, W: int) -> Dict[str, torch.Tensor]:
         """Same forward kernels as render(), wrapped in autograd Functions (coponerf_amd/train_fns.py); all rays of
         the call form one chunk (training uses <= 4096 rays per pair, /root/reference train.py:87)."""
-        from .train_fns import GemmFn, GradScale, HidGradParts, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn, EncodeFn
+        from .train_fns import (GemmFn, GradScale, HidGradParts, KeyForward, LinearF32Fn, LocalHiddenFn, AttendHiddenFn, GatherFn,
+                                EncodeFn)
         dev = uv.device
         if dev.type != "cuda":
             raise RuntimeError("coponerf_amd renders on a HIP device only (got uv on %s)" % dev)
@@ -955,14 +956,6 @@ class RenderEngine:
         P = params
         mat = lambda n, rows: P[n + ".weight"].reshape(rows, -1)
         bias = lambda n: P[n + ".bias"]
-        if self.tables:
-            # the first layer on the node tables, as in inference: no gathered input in the forward pass
-            hid = EncodeFn.apply(z[0], z[1], z[2], z[3], mat("query_encode_latent", 832), bias("query_encode_latent"),
-                                 g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs, hp)
-        else:
-            xin = GatherFn.apply(z[0], z[1], z[2], z[3], g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs)
-            hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False, gs, hp, dims)
-        hid2 = hid.view(-1, 1664)
         W2, b2 = mat("query_encode_latent_2", 416), bias("query_encode_latent_2")
 
         def fold(name, n_out):                                   # differentiable fp32 fold
@@ -971,18 +964,28 @@ class RenderEngine:
 
         Wkf, ckf = fold("key_map", 128)
         Wvf, cvf = fold("latent_value", 416)
-        kh = GemmFn.apply(hid2, Wkf, ckf, True, False, gs, None, dims, hp)    # last consumer of hid in the backward pass
-        key2 = GemmFn.apply(kh, mat("key_map_2", 128), bias("key_map_2"), False, False, gs)
+        kf = KeyForward(Wkf, ckf)                   # the folded key layer's forward rides in the first layer's kernel
+        if self.tables:
+            # the first layer on the node tables, as in inference: no gathered input in the forward pass
+            hid = EncodeFn.apply(z[0], z[1], z[2], z[3], mat("query_encode_latent", 832), bias("query_encode_latent"),
+                                 g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs, hp, kf)
+        else:
+            xin = GatherFn.apply(z[0], z[1], z[2], z[3], g["pixel_val"], g["sec_grid"], g["pe6"], dims, (H, W), gs)
+            hid = GemmFn.apply(xin, mat("query_encode_latent", 832), bias("query_encode_latent"), True, False, gs, hp, dims)
+        hid2 = hid.view(-1, 1664)
+        # (last consumer of hid in the backward pass; its incoming gradient arrives masked by kh > 0 from key_map_2's node)
+        kh = GemmFn.apply(hid2, Wkf, ckf, True, False, gs, None, dims, hp, kf, False, True)
+        key2 = GemmFn.apply(kh, mat("key_map_2", 128), bias("key_map_2"), False, False, gs, None, None, None, None, True)
         hq = LocalHiddenFn.apply(g["loc8"], g["coords9"], mat("query_embed", 128), bias("query_embed"), None, dims, gs)
         ce = GemmFn.apply(hq, mat("query_embed_2", 128), bias("query_embed_2"), False, False, gs)
-        hbar1, w1 = AttendHiddenFn.apply(key2, ce, hid2, dims, gs, hp)
+        hbar1, w1 = AttendHiddenFn.apply(key2, ce, hid2, dims, gs, hp, True)       # coords_embed is shared by the two rounds
         z1 = GemmFn.apply(hbar1, Wvf, cvf, False, True, gs)
         ze = LinearF32Fn.apply(z1, mat("encode_latent", 128), bias("encode_latent"), None, False, False)
         Wr_z, Wr_l = mat("query_repeat_embed", 128).split((128, 16), 1)
         aq = LinearF32Fn.apply(ze, Wr_z.contiguous(), None, None, False, False)
         q2h = LocalHiddenFn.apply(g["loc8"], g["coords9"], Wr_l.contiguous(), bias("query_repeat_embed"), aq, dims, gs)
         q2 = GemmFn.apply(q2h, mat("query_repeat_embed_2", 128), bias("query_repeat_embed_2"), False, False, gs)
-        hbar2, _ = AttendHiddenFn.apply(q2, ce, hid2, dims, gs, hp)
+        hbar2, _ = AttendHiddenFn.apply(q2, ce, hid2, dims, gs, hp, False)
         zs = GemmFn.apply(hbar2, Wvf, cvf, False, True, gs)
         zl = zs + float(V) * z1                                  # CoPoNeRF.py:481-485
         nray = B * R

@@ -66,6 +66,28 @@ class HidGradParts:
     def __init__(self):
         self.parts = []                     # (w (N,R,S) fp32, dhbar (rays,1664) fp32 scaled)
         self.combined = False               # the key path's data-gradient GEMM already formed the masked sum (FUSE_COMBINE)
+        self.dqb = None                     # gradient of the shared qb (coords_embed) parked by the round that runs first
+        self.dqb_done = False
+
+
+# training forward: the folded key layer inside the first layer's kernel (cpn_encode_key, the inference default; round 6) instead
+# of its own pass over hid; 0 = cpn_encode_hidden + cpn_gemm_f16
+# coords_embed feeds both attention rounds: the second backward call adds the first one's gradient in its kernel
+SHARE_QB_GRAD = os.environ.get("COPONERF_SHARE_QB_GRAD", "1") != "0"
+# grad_input of key_map_2 with the ReLU mask of its input as the GEMM's epilogue (cpn_gemm_f16_masked)
+MASKED_DGRAD = os.environ.get("COPONERF_MASKED_DGRAD", "1") != "0"
+FUSE_KEY_FORWARD = os.environ.get("COPONERF_TRAIN_FUSE_KEY", "1") != "0"
+
+
+class KeyForward:
+    """Hand-over between EncodeFn and the GemmFn node of the folded key layer (kh = ReLU(W' . [hid_own ; hid_other] + c')): with
+    FUSE_KEY_FORWARD the first layer's kernel also forms kh (hid is not read back for it), and the GemmFn node only records what
+    its backward needs.  W (128, 1664) / b (128): the folded, differentiable fp32 weights (render_train)."""
+
+    def __init__(self, W, b):
+        self.W, self.b = W, b
+        self.W16 = None                      # (128, 1664) fp16 image of W, packed once for both nodes
+        self.kh = None                       # (rows, 128) fp16, set by EncodeFn.forward, taken by GemmFn.forward
 
 
 def _mm_f32(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
@@ -86,41 +108,56 @@ def _wgrad_tall(d16: torch.Tensor, x16: torch.Tensor, scale: torch.Tensor) -> to
     return dW
 
 
-def _data_grad(d16: torch.Tensor, W16: torch.Tensor) -> torch.Tensor:
+def _data_grad(d16: torch.Tensor, W16: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
     """dA (M, lda) = d16 (M, N) . W16 (N, lda), fp16 in / fp32 accumulate / fp16 out.  It is the forward GEMM with the
     roles of N and K swapped, so it runs on cpn_gemm_f16 with the transposed weight image (hipBLASLt reaches 355 TFLOP/s
     on the 4.2 M x 832 x 896 case, the own kernel ~800); shapes outside the kernel's tile set go to the library."""
     M, N = d16.shape
     lda = W16.shape[1]
     if N % 32 or (lda % 208 and lda % 128) or not d16.is_contiguous():
-        return torch.matmul(d16, W16)
+        dA = torch.matmul(d16, W16)
+        return dA if mask is None else torch.ops.aten.threshold_backward(dA, mask, 0)
     Wt = W16.t().contiguous()                                                      # (lda, N): K-contiguous rows
     dA = torch.empty(M, lda, dtype=torch.float16, device=d16.device)
+    if mask is not None and M % 16 == 0 and mask.is_contiguous() and mask.shape == dA.shape:
+        call("cpn_gemm_f16_masked", d16.data_ptr(), N, Wt.data_ptr(), N, mask.data_ptr(), lda, dA.data_ptr(), lda, M, lda, N,
+             _stream())
+        return dA
     zero = torch.zeros(lda, dtype=torch.float32, device=d16.device)
     call("cpn_gemm_f16", d16.data_ptr(), N, Wt.data_ptr(), N, zero.data_ptr(), dA.data_ptr(), lda, M, lda, N, 0, 0,
          _stream())
-    return dA
+    return dA if mask is None else torch.ops.aten.threshold_backward(dA, mask, 0)
 
 
 class GemmFn(Function):
     """C = act(A . W^T + b) through cpn_gemm_f16.  A (M, lda) fp16 (row stride lda >= K), W (N, K) fp32, b (N)."""
 
     @staticmethod
-    def forward(ctx, A16, W, b, relu: bool, out_f32: bool, gs: GradScale, hid_parts=None, dims=None, in_parts=None):
+    def forward(ctx, A16, W, b, relu: bool, out_f32: bool, gs: GradScale, hid_parts=None, dims=None, in_parts=None, pre=None,
+                in_relu: bool = False, premasked: bool = False):
+        """in_relu: A16 is a ReLU output whose producer was told `premasked` - this node's backward returns the data gradient
+        already masked by A16 > 0 (cpn_gemm_f16_masked), the producer skips its threshold pass."""
         M, lda = A16.shape
         N, K = W.shape
         Kp = ((K + 31) // 32) * 32
         assert Kp <= lda, (K, lda)
-        W16 = torch.zeros(N, lda, dtype=torch.float16, device=A16.device)
-        Wc = W.detach().contiguous().float()
-        call("cpn_pack_weight_f16", Wc.data_ptr(), N, K, W16.data_ptr(), lda, _stream())
-        bc = b.detach().contiguous().float()
-        C = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.float16, device=A16.device)
-        call("cpn_gemm_f16", A16.data_ptr(), lda, W16.data_ptr(), lda, bc.data_ptr(), C.data_ptr(), N, M, N, Kp,
-             int(relu), int(out_f32), _stream())
+        if pre is not None and pre.kh is not None:
+            # the product already exists (cpn_encode_key formed it with the first layer, same MFMA sequence): record only
+            assert relu and not out_f32 and pre.kh.shape == (M, N) and pre.W16.shape == (N, lda)
+            W16, C = pre.W16, pre.kh
+            pre.kh = pre.W16 = None
+        else:
+            W16 = torch.zeros(N, lda, dtype=torch.float16, device=A16.device)
+            Wc = W.detach().contiguous().float()
+            call("cpn_pack_weight_f16", Wc.data_ptr(), N, K, W16.data_ptr(), lda, _stream())
+            bc = b.detach().contiguous().float()
+            C = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.float16, device=A16.device)
+            call("cpn_gemm_f16", A16.data_ptr(), lda, W16.data_ptr(), lda, bc.data_ptr(), C.data_ptr(), N, M, N, Kp,
+                 int(relu), int(out_f32), _stream())
         ctx.save_for_backward(A16, W16, C if relu else None)
         ctx.relu, ctx.K, ctx.gs = relu, K, gs
         ctx.hid_parts, ctx.dims, ctx.in_parts = hid_parts, dims, in_parts
+        ctx.in_relu, ctx.premasked = in_relu and MASKED_DGRAD, premasked and MASKED_DGRAD
         return C
 
     @staticmethod
@@ -166,10 +203,12 @@ class GemmFn(Function):
                 ctx.hid_parts.combined = False
             d = ctx.gs.scaled16(dC.contiguous())                                 # s * dC (GradScale convention)
             inv = 1.0 / ctx.gs.s
-            if ctx.relu:
+            if ctx.relu and not (ctx.premasked and d.dtype == torch.float16):
                 d = torch.ops.aten.threshold_backward(d, C.to(d.dtype) if C.dtype != d.dtype else C, 0)   # d where C > 0
             d16 = d.to(torch.float16)
         dA = GemmFn._combined_data_grad(ctx, d16, A16, W16) if ctx.in_parts is not None else None
+        if dA is None and ctx.in_relu and ctx.needs_input_grad[0]:
+            dA = _data_grad(d16, W16, mask=A16)
         if dA is None:
             dA = _data_grad(d16, W16) if ctx.needs_input_grad[0] else None           # (M, lda) fp16, scaled; pad columns get 0
         if d16.shape[1] == 128 and A16.shape[1] == 128 and d16.is_contiguous() and ctx.needs_input_grad[1]:
@@ -178,7 +217,7 @@ class GemmFn(Function):
             db = torch.zeros(128, dtype=torch.float32, device=d16.device)
             call("cpn_wgrad_skinny_f16", d16.data_ptr(), A16.data_ptr(), 128, d16.shape[0], dW.data_ptr(), db.data_ptr(),
                  _stream())
-            return dA, dW[:, :ctx.K] * inv, (db * inv if ctx.needs_input_grad[2] else None), None, None, None, None, None, None
+            return (dA, dW[:, :ctx.K] * inv, (db * inv if ctx.needs_input_grad[2] else None)) + (None,) * 9
         n_out, k_in = d16.shape[1], A16.shape[1]
         both = d16.is_contiguous() and A16.is_contiguous()
         if ctx.needs_input_grad[1] and both and n_out % 208 == 0 and k_in % 128 == 0:
@@ -189,7 +228,7 @@ class GemmFn(Function):
         else:
             dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
         db = d.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[2] else None
-        return dA, dW, db, None, None, None, None, None, None
+        return (dA, dW, db) + (None,) * 9
 
 
 class LinearF32Fn(Function):
@@ -259,7 +298,11 @@ class AttendHiddenFn(Function):
     """(hbar fp16 (rays,1664), w fp32 (N,R,S)) = cpn_attend_hidden(qa, qb, hid)."""
 
     @staticmethod
-    def forward(ctx, qa, qb, hid2, dims, gs: GradScale, hid_parts=None):
+    def forward(ctx, qa, qb, hid2, dims, gs: GradScale, hid_parts=None, qb_last=None):
+        """qb_last: None = qb is this node's own; False / True = qb (coords_embed) is shared by two nodes and this is the one
+        whose backward runs first / last (round 2 / round 1: round 1's gradient depends on round 2's backward).  The first
+        parks its dqb in hid_parts and returns none, the last adds it inside the kernel (an autograd accumulation of two
+        0.5 GB tensors otherwise)."""
         B, V, R, S = dims
         nrays = B * R
         hbar = torch.empty(nrays, 1664, dtype=torch.float16, device=qa.device)
@@ -267,7 +310,7 @@ class AttendHiddenFn(Function):
         call("cpn_attend_hidden", qa.data_ptr(), qb.data_ptr(), 0, hid2.data_ptr(), B, V, R, S, 0, nrays, hbar.data_ptr(),
              w.data_ptr(), _stream())
         ctx.save_for_backward(qa, qb, hid2, w)
-        ctx.dims, ctx.gs, ctx.hid_parts = dims, gs, hid_parts
+        ctx.dims, ctx.gs, ctx.hid_parts, ctx.qb_last = dims, gs, hid_parts, qb_last
         return hbar, w
 
     @staticmethod
@@ -286,12 +329,21 @@ class AttendHiddenFn(Function):
         dqa, dqb = torch.empty_like(qa), torch.empty_like(qb)
         park = ctx.hid_parts is not None
         dhid = None if park else torch.empty_like(hid2)
+        hp = ctx.hid_parts
+        share = SHARE_QB_GRAD and hp is not None and ctx.qb_last is not None
+        acc = hp.dqb if (share and ctx.qb_last) else None
         call("cpn_attend_hidden_bwd", qa.data_ptr(), qb.data_ptr(), hid2.data_ptr(), w.data_ptr(), dh.data_ptr(),
              0 if dwc is None else dwc.data_ptr(), B, V, R, S, 0, nrays, dqa.data_ptr(), dqb.data_ptr(),
-             0 if park else dhid.data_ptr(), _stream())
+             0 if park else dhid.data_ptr(), 0 if acc is None else acc.data_ptr(), _stream())
         if park:                            # dhid = w (x) dhbar is formed by the producer of hid (cpn_hid_grad_combine)
-            ctx.hid_parts.parts.append((w, dh))
-        return dqa, dqb, dhid, None, None, None
+            hp.parts.append((w, dh))
+        if share:
+            if ctx.qb_last:
+                hp.dqb, hp.dqb_done = None, True
+            elif not hp.dqb_done:           # (had the other round already run, nobody would pick the parked tensor up)
+                hp.dqb = dqb
+                dqb = None
+        return dqa, dqb, dhid, None, None, None, None
 
 
 class EncodeFn(Function):
@@ -301,7 +353,7 @@ class EncodeFn(Function):
     weight gradient, forms the data gradient on cpn_gemm_f16 and scatters it into the maps (cpn_gather_rows_bwd)."""
 
     @staticmethod
-    def forward(ctx, z0, z1, z2, z3, W, b, pixel_val, sec_grid, pe6, dims, HW, gs: GradScale, hid_parts):
+    def forward(ctx, z0, z1, z2, z3, W, b, pixel_val, sec_grid, pe6, dims, HW, gs: GradScale, hid_parts, key=None):
         B, V, R, S = dims
         H, Wd = HW
         s = _stream()
@@ -328,8 +380,20 @@ class EncodeFn(Function):
              _hip.TAB_LD, 768, 0, 0, s)
         nrays = B * R
         hid = torch.empty(nrays * V * S * 2, 832, dtype=torch.float16, device=dev)
-        call("cpn_encode_hidden", tab.data_ptr(), maps[3].data_ptr(), H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
-             pe6.data_ptr(), frag.data_ptr(), bc.data_ptr(), B, V, R, S, 0, nrays, hid.data_ptr(), s)
+        if key is not None and FUSE_KEY_FORWARD:
+            from .render import pack_key_ring
+            Wk = key.W.detach().contiguous().float()
+            key.W16 = torch.empty(128, 1664, dtype=torch.float16, device=dev)
+            call("cpn_pack_weight_f16", Wk.data_ptr(), 128, 1664, key.W16.data_ptr(), 1664, s)
+            ring = pack_key_ring(key.W16)
+            kb = key.b.detach().contiguous().float()
+            key.kh = torch.empty(nrays * V * S, 128, dtype=torch.float16, device=dev)
+            call("cpn_encode_key", tab.data_ptr(), maps[3].data_ptr(), H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
+                 pe6.data_ptr(), frag.data_ptr(), bc.data_ptr(), ring.data_ptr(), kb.data_ptr(), B, V, R, S, 0, nrays,
+                 hid.data_ptr(), key.kh.data_ptr(), 0, s)
+        else:
+            call("cpn_encode_hidden", tab.data_ptr(), maps[3].data_ptr(), H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
+                 pe6.data_ptr(), frag.data_ptr(), bc.data_ptr(), B, V, R, S, 0, nrays, hid.data_ptr(), s)
         W16 = torch.zeros(832, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
         call("cpn_pack_weight_f16", Wc.data_ptr(), 832, Wc.shape[1], W16.data_ptr(), _hip.XIN_STRIDE, s)
         if TABLE_BACKWARD:
@@ -400,7 +464,7 @@ class EncodeFn(Function):
                 dW = torch.cat((dWtab, dWt[:, :ctx.K - 768]), dim=1)
             if ctx.needs_input_grad[5]:
                 db = dWt[:, ctx.K - 768].contiguous()
-        return g[0], g[1], g[2], g[3], dW, db, None, None, None, None, None, None, None
+        return g[0], g[1], g[2], g[3], dW, db, None, None, None, None, None, None, None, None
 
     @staticmethod
     def backward(ctx, dC):
@@ -455,7 +519,7 @@ class EncodeFn(Function):
                  R, S, 0, B * R, dmaps[0].data_ptr(), dmaps[1].data_ptr(), dmaps[2].data_ptr(), dmaps[3].data_ptr(),
                  boxes.data_ptr(), s)
             g = [m.mul_(inv).permute(0, 3, 1, 2).contiguous() for m in dmaps]
-        return g[0], g[1], g[2], g[3], dW, db, None, None, None, None, None, None, None
+        return g[0], g[1], g[2], g[3], dW, db, None, None, None, None, None, None, None, None
 
 
 class GatherFn(Function):

@@ -317,10 +317,12 @@ int cpn_ray_outputs(const float* at_wt, const float* pt, const float* uv, long l
 
 /* gradient of cpn_attend_hidden: dhbar (rays,1664) fp32, dw_ext (N,R,S) fp32 or NULL (external gradient on the
  * softmax weights), at_wt (N,R,S) the forward weights -> dqa, dqb (rays*V*S,128) fp16, dhid (rays*V*S,1664) fp16 or
- * NULL (the caller then forms the hidden-activation gradient of all consumers with cpn_hid_grad_combine)        */
+ * NULL (the caller then forms the hidden-activation gradient of all consumers with cpn_hid_grad_combine).
+ * dqb_acc (rays*V*S,128) fp16 or NULL: added to dqb (qb = coords_embed feeds both attention rounds, models/CoPoNeRF.py:450,475:
+ * the second call sums the two gradients instead of autograd adding two 0.5 GB tensors)                            */
 int cpn_attend_hidden_bwd(const uint16_t* qa, const uint16_t* qb, const uint16_t* hid, const float* at_wt,
                           const float* dhbar, const float* dw_ext, int B, int V, int R, int S, int ray0, int nrays,
-                          uint16_t* dqa, uint16_t* dqb, uint16_t* dhid, void* stream);
+                          uint16_t* dqa, uint16_t* dqb, uint16_t* dhid, const uint16_t* dqb_acc, void* stream);
 
 /* gradient w.r.t. the pre-activation of the first encoder layer from ALL consumers of hid, in one pass:
  *   out[row,c] = hid[row,c] > 0 ? dkey[row,c] + w1[n,r,s]*dh1[ray, j*832+c] + w2[n,r,s]*dh2[ray, j*832+c] : 0
@@ -338,6 +340,12 @@ int cpn_hid_grad_combine(const uint16_t* dkey, const uint16_t* hid, const float*
 int cpn_gemm_f16_combine(const uint16_t* dkh, int lda, const uint16_t* Wt, int ldw, const uint16_t* hid, const float* w1,
                          const float* dh1, const float* w2, const float* dh2, int B, int V, int R, int S, int ray0,
                          int nrays, int K, uint16_t* out, void* stream);
+
+/* data gradient THROUGH a ReLU in one kernel:  out (M,N) fp16 = mask (M,N) > 0 ? A (M,K) . Wt (N,K)^T : 0  — grad_input of a
+ * 1x1 Conv2d whose input `mask` is a ReLU output (key_map -> ReLU -> key_map_2, models/CoPoNeRF.py:404-408: autograd's
+ * threshold_backward pass over the (rows,128) gradient is gone).  M %% 16 == 0, K %% 32 == 0, N %% 208 == 0 or N %% 128 == 0. */
+int cpn_gemm_f16_masked(const uint16_t* A, int lda, const uint16_t* Wt, int ldw, const uint16_t* mask, int ldm, uint16_t* out,
+                        int ldc, int M, int N, int K, void* stream);
 
 /* weight gradients of the 128-wide per-sample layers (torch.mm(dY.t(), X) in the reference's autograd, i.e. the
  * Conv2d(128->128,1x1) / Conv2d(16->128,1x1) layers of models/CoPoNeRF.py:82,85-86,95-96 under wrapper.py:138):

@@ -845,3 +845,82 @@ def test_fused_combine_training_matches_two_kernel_form(dev, monkeypatch):
     for k in res[0]:                                         # (fp32 atomics in the level-3 scatter: not bit-reproducible)
         rel_err = float((res[0][k] - res[1][k]).norm() / (res[1][k].norm() + 1e-30))
         assert rel_err <= 1e-5, (k, rel_err)
+
+
+def test_key_layer_inside_the_first_layer_kernel_in_training(dev, monkeypatch):
+    """render_train with the folded key layer formed by cpn_encode_key (round 6) / by its own cpn_gemm_f16 pass over hid: the
+    kernels promise bit-identical hid and kh, so outputs and gradients agree (up to the level-3 scatter's fp32 atomics)."""
+    from coponerf_amd import CoPoNeRF, train_fns
+    B, H, R, S = 2, 64, 45, 24
+    weights = syn.make_render_weights(seed=33)
+    inp = to_device(syn.make_inputs(B, H, H, R, seed=75), dev)
+    z, rel, flow = syn.make_latents(B, H, H, seed=76)
+    coef = syn.normal((B, 1, R, 3), seed=77).to(dev)
+    res = []
+    for fuse in (True, False):
+        monkeypatch.setattr(train_fns, "FUSE_KEY_FORWARD", fuse)
+        model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+        model.load_state_dict(weights, strict=False)
+        model = model.to(dev).train()
+        zz = [t.to(dev).requires_grad_(True) for t in z]
+        out = model(inp, z=zz, rel_pose=rel.to(dev), val=False, flow=to_device(flow, dev))
+        (out["rgb"] * coef).sum().backward()
+        grads = {"z%d" % i: t.grad for i, t in enumerate(zz)}
+        grads.update({k: p.grad for k, p in model.named_parameters() if p.grad is not None})
+        res.append((out["rgb"].detach(), out["at_wt"].detach(), grads))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert set(res[0][2]) == set(res[1][2]) and "key_map.weight" in res[0][2]
+    for k in res[0][2]:
+        rel_err = float((res[0][2][k] - res[1][2][k]).norm() / (res[1][2][k].norm() + 1e-30))
+        assert rel_err <= 1e-5, (k, rel_err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(16, 128, 128), (4000, 128, 128), (272, 1664, 128), (1040, 416, 64)])
+def test_masked_data_gradient_gemm(M, N, K):
+    """cpn_gemm_f16_masked = cpn_gemm_f16 followed by the ReLU mask of the layer's input, bit for bit."""
+    from coponerf_amd._hip import call
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).half().to(dev)
+    Wt = (torch.randn(N, K, generator=g) * 0.2).half().to(dev)
+    mask = torch.relu(torch.randn(M, N, generator=g)).half().to(dev)
+    zero = torch.zeros(N, device=dev)
+    want = torch.empty(M, N, dtype=torch.float16, device=dev)
+    call("cpn_gemm_f16", A.data_ptr(), K, Wt.data_ptr(), K, zero.data_ptr(), want.data_ptr(), N, M, N, K, 0, 0, st)
+    want = torch.where(mask > 0, want, torch.zeros_like(want))
+    got = torch.full_like(want, float("nan"))
+    call("cpn_gemm_f16_masked", A.data_ptr(), K, Wt.data_ptr(), K, mask.data_ptr(), N, got.data_ptr(), N, M, N, K, st)
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError, match="M %"):
+        call("cpn_gemm_f16_masked", A.data_ptr(), K, Wt.data_ptr(), K, mask.data_ptr(), N, got.data_ptr(), N, 17, N, K, st)
+
+
+def test_backward_fusions_leave_the_gradients_alone(dev, monkeypatch):
+    """render_train with the round-6 backward fusions (shared coords_embed gradient summed inside cpn_attend_hidden_bwd, the
+    ReLU mask as the epilogue of key_map_2's data-gradient GEMM) against autograd's accumulate / threshold passes."""
+    from coponerf_amd import CoPoNeRF, train_fns
+    B, H, R, S = 2, 64, 40, 32
+    weights = syn.make_render_weights(seed=35)
+    inp = to_device(syn.make_inputs(B, H, H, R, seed=85), dev)
+    z, rel, flow = syn.make_latents(B, H, H, seed=86)
+    coef = syn.normal((B, 1, R, 3), seed=87).to(dev)
+    cw = syn.normal((B * 2, R, S), seed=88).to(dev)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(train_fns, "SHARE_QB_GRAD", on)
+        monkeypatch.setattr(train_fns, "MASKED_DGRAD", on)
+        model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
+        model.load_state_dict(weights, strict=False)
+        model = model.to(dev).train()
+        zz = [t.to(dev).requires_grad_(True) for t in z]
+        out = model(inp, z=zz, rel_pose=rel.to(dev), val=False, flow=to_device(flow, dev))
+        _loss(out, coef, cw).backward()
+        grads = {"z%d" % i: t.grad for i, t in enumerate(zz)}
+        grads.update({k: p.grad for k, p in model.named_parameters() if p.grad is not None})
+        res.append(grads)
+    assert set(res[0]) == set(res[1]) and "query_embed.weight" in res[0] and "key_map.weight" in res[0]
+    for k in res[0]:                                         # the shared gradient is summed in fp32 before ONE fp16 rounding
+        rel_err = float((res[0][k] - res[1][k]).norm() / (res[1][k].norm() + 1e-30))
+        assert rel_err <= 2e-3, (k, rel_err)

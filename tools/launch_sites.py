@@ -18,6 +18,8 @@ class Rec(TorchDispatchMode):
         super().__init__()
         self.by_frame = collections.Counter()
         self.by_op = collections.Counter()
+        self.bytes_by = collections.Counter()             # (phase, frame, op, shape) -> bytes of the op's result (a time proxy)
+        self.count_by = collections.Counter()
         self.phase = "fwd"
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -37,6 +39,9 @@ class Rec(TorchDispatchMode):
         if frame is None:
             frame = f"({self.phase}: autograd engine / library) {name}"
         self.by_frame[(self.phase, frame)] += 1
+        key = (self.phase, frame, name, tuple(t.shape), t.is_contiguous())
+        self.bytes_by[key] += t.numel() * t.element_size()
+        self.count_by[key] += 1
         self.by_op[(self.phase, name)] += 1
         return out
 
@@ -71,3 +76,11 @@ for (ph, name), n in rec.by_op.most_common(40):
 print("---- by site")
 for (ph, frame), n in rec.by_frame.most_common(top):
     print(f"{n:5d} {ph} {frame}")
+print("---- by result bytes (phase, site, op, shape, contiguous result): elementwise / copy ops only")
+ELT = {"copy_", "add", "add_", "mul", "mul_", "clone", "contiguous", "sub", "div", "fill_", "zero_", "cat", "stack", "sum", "neg",
+       "where", "clamp_min", "clamp_min_", "relu", "threshold_backward", "gelu", "gelu_backward", "elu", "elu_backward", "zeros",
+       "zeros_like", "ones_like", "repeat_interleave", "index_select", "native_layer_norm", "native_layer_norm_backward", "_to_copy"}
+rows = [(b, k) for k, b in rec.bytes_by.items() if k[2] in ELT]
+rows.sort(reverse=True)
+for b, k in rows[:int(os.environ.get("SITES_TOP", "150"))]:
+    print(f"{b / 1e6:9.1f} MB x{rec.count_by[k]:3d} {k[0]} {k[2]:14s} {str(k[3]):28s} {'c' if k[4] else 'nc'}  {k[1]}")
