@@ -132,6 +132,8 @@ def measure_train(args, dev, rank, world, steps, warmup):
         info = step(inp, gt)
     _fence(distributed)
     step.timing = {}
+    if step._exchange is not None:
+        step._exchange.timing = []
     t0 = time.perf_counter()
     for _ in range(steps):
         info = step(inp, gt)
@@ -139,12 +141,45 @@ def measure_train(args, dev, rank, world, steps, warmup):
     elapsed = _max_over_ranks(time.perf_counter() - t0, dev, distributed)
     phases = step.timing_summary()
     rays = B * R * world * steps / elapsed
+    # what the communicator itself reports (not the WORLD_SIZE this process was given): ranks, backend, the device every rank
+    # sits on, the bytes the timed steps all-reduced and when each bucket's collective completed
+    comm = {"world_size": 1, "backend": None, "devices": [f"{torch.cuda.get_device_name(dev)} #{dev.index}"]}
+    if distributed:
+        import socket
+        import torch.distributed as dist
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": dist.get_rank(), "host": socket.gethostname(), "device": dev.index, "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        comm = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": gathered,
+                "distinct_devices": len({(g["host"], g["device"]) for g in gathered})}
+    ex_t = step._exchange.timing_summary() if step._exchange is not None else {}
+    # weak-scaling efficiency of THIS run: the same ranks step again with the exchange switched off (every rank for itself -
+    # what a 1-GPU run does); ms_per_step(1 rank's work) / ms_per_step(N ranks exchanging).  The replicas diverge here, so
+    # this runs last.
+    local_ms = None
+    if distributed:
+        solo = TrainStep(model, exchange=False)
+        for _ in range(2):
+            solo(inp, gt)
+        _fence(distributed)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            solo(inp, gt)
+        _fence(distributed)
+        local_ms = 1e3 * _max_over_ranks(time.perf_counter() - t1, dev, distributed) / steps
+        del solo
     res = {"rays_per_s": rays, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
            "pairs_per_gpu": B, "rays_per_pair": R, "samples": S, "n_gpus": world,
            "collectives_per_step": info["collectives"], "allreduce_bytes_per_step": info["allreduce_bytes"],
            # ranks whose gradients were exchanged over RCCL in the timed steps (1: no exchange ran) and device -> host reads
            # the step makes (the guard flag gates the update kernel on the device, with or without an exchange)
-           "rccl_ranks": world if distributed else 1, "host_reads_per_step": info["host_reads"],
+           "rccl_ranks": comm["world_size"], "comm": comm, "exchange_timing": ex_t,
+           "gradient_mask_path": step._exchange.mask_path if step._exchange is not None else None,
+           "ms_per_step_without_exchange": local_ms,
+           "weak_scaling_efficiency": (local_ms / (1e3 * elapsed / steps)) if local_ms else None,
+           "host_reads_per_step": info["host_reads"],
            "gradient_mask_exchanges": info["mask_exchanges"],
            "broadcast_collectives": nbcast, "stepped": bool(info["stepped"]), "loss": float(info["loss"]),
            "phases_ms": phases, "peak_mem_GB": max(0.0, torch.cuda.max_memory_allocated(dev) - resident) / 2 ** 30,

@@ -191,6 +191,7 @@ class DeviceExchange:
         self._views: List = [None] * len(self.params)
         self._side = None
         self._inv_world = None
+        self.timing = None                         # set to [] to collect (event before, [event after each collective]) per exchange
         if self.active:
             if dist.get_backend(group) == "gloo":
                 self._side = group
@@ -203,6 +204,15 @@ class DeviceExchange:
                     warnings.warn(f"coponerf_amd.dist.DeviceExchange: no gloo side group ({e}); the gradient-mask agreement "
                                   "falls back to a device all-reduce with a host read per step")
                     self._side = None
+            import logging
+            logging.getLogger("coponerf_amd.dist").info(
+                "DeviceExchange: %d rank(s) over %s, gradient-mask agreement %s", self.world, dist.get_backend(group),
+                "host to host (gloo vote)" if self._side is not None else "on the device (one host read per step)")
+
+    @property
+    def mask_path(self) -> str:
+        """How the ranks agree on the set of exchanged gradients: "host-vote" (gloo, no device read) or "device-fallback"."""
+        return "host-vote" if (self._side is not None or not self.active) else "device-fallback"
 
     @property
     def world(self) -> int:
@@ -248,6 +258,16 @@ class DeviceExchange:
         dev = members[0][1].device if members else "cpu"
         self._inv_world = torch.full((), 1.0 / self.world, dtype=torch.float32, device=dev)
 
+    def timing_summary(self):
+        """Mean milliseconds from the start of the exchange to the completion of [flag, bucket 0, bucket 1, ...] (cumulative:
+        the collectives run in order on the communicator's stream) and the bytes of each bucket.  After a synchronize."""
+        if not self.timing:
+            return {}
+        n = len(self.timing)
+        k = len(self.timing[0][1])
+        ms = [sum(t[0].elapsed_time(t[1][j]) for t in self.timing) / n for j in range(k)]
+        return {"done_ms_cumulative": ms, "bucket_bytes": [f.numel() * f.element_size() for f, _ in self._flats]}
+
     def grad_views(self) -> List:
         """Per parameter: where its averaged gradient will be (a view of a persistent bucket; None outside the union)."""
         return self._views
@@ -260,7 +280,15 @@ class DeviceExchange:
         """ok: this rank's finite flag (fp32 scalar on the gradients' device), coef: its clip coefficient (device scalar) or
         None.  Returns (ok MIN-reduced over the ranks, 1 / world as a device scalar, collectives issued); afterwards every
         parameter of the union has `.grad` = its view of the SUM over the ranks of coef_r * grad_r.  Nothing here waits on
-        the host for the device (on RCCL `wait()` orders the streams)."""
+        the host for the device (on RCCL `wait()` orders the streams).
+        After a step whose flag came back 0 the buckets (= the parameters' `.grad`) hold whatever the ranks summed - NaN where
+        one of them had a non-finite gradient (inf x 0): gradients are UNDEFINED after a skipped step, the gated update does
+        not read them and the next step overwrites them."""
+        rec = None
+        if self.timing is not None and torch.cuda.is_available():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            rec = (e, [])
         works = [dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group, async_op=True)]
         for flat, entries in self._flats:
             src, dst = [], []
@@ -278,6 +306,12 @@ class DeviceExchange:
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
             w.wait()
+            if rec is not None:                      # completion of this collective as the current stream sees it
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                rec[1].append(e)
+        if rec is not None:
+            self.timing.append(rec)
         for i, v in enumerate(self._views):
             if v is not None:
                 self.params[i].grad = v

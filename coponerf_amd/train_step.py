@@ -39,8 +39,11 @@ class _LazyFlag:
 
 class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float = 5e-5 * 4, clip_grad: float = 1.0,
-                 bucket_bytes: int = 64 << 20, group=None, force_collectives: bool = False):
+                 bucket_bytes: int = 64 << 20, group=None, force_collectives: bool = False, exchange: bool = True):
+        """exchange=False: never exchange gradients, even inside an initialised process group (every rank for itself: the
+        single-GPU step measured beside the N-rank one, bench.py `ms_per_step_without_exchange`)."""
         self.model = model
+        self.exchange_enabled = bool(exchange)
         self.params = [p for p in model.parameters()]
         # train.py:102-105 (both groups share lr); where the parameters live on the GPU the update of all 636 tensors is ONE
         # launch (optim.OneLaunchAdam, csrc/adam.hip: 1.7 ms for the library's fused multi-tensor form -> 0.3; same rule)
@@ -69,11 +72,19 @@ class TrainStep:
         self._good = 0
         eng = getattr(model, "_engine", None)
         self._scale_ceiling = float(eng.grad_scale_target) if eng is not None else 0.0
-        self._exchange = None                                            # dist.DeviceExchange, built at the first exchanging step
+        # dist.DeviceExchange is built HERE, not at the first step: its gloo side group is a collective over the whole default
+        # world (dist.new_group), so every rank must reach it at the same point - constructing TrainStep is that point
+        # (ADVICE r5).  Every rank of the job constructs its TrainStep, with the same `group`.
+        self._exchange = None
+        if self._exchanging():
+            self._exchange = cdist.DeviceExchange(self.params, self.bucket_bytes, self.group, self.force_collectives)
         self._ex_reads_seen = 0
         self._pending = collections.deque()                              # `stepped` flags of steps guarded on the device
         self._flag_host = [torch.zeros(1).pin_memory() for _ in range(4)] if on_gpu else None
         self._flag_turn = 0
+
+    def _exchanging(self) -> bool:
+        return self.exchange_enabled and cdist._exchanging(self.group, self.force_collectives)
 
     def _ev(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -85,8 +96,16 @@ class TrainStep:
         timed = self.timing is not None and torch.cuda.is_available()
         # steps whose guard ran on the device: their outcome reaches the scale adaptation when its 4-byte copy has landed —
         # normally one step late, never by waiting (unless three are outstanding)
-        while self._pending and (self._pending[0]._value is not None or self._pending[0]._event.query() or len(self._pending) > 2):
-            self._adapt_grad_scale(bool(self._pending.popleft()))
+        if self._exchanging():
+            # N > 1: `query()` depends on each rank's host timing, and the ranks must change their gradient scale at the SAME
+            # step to stay reproducible step for step (the flag itself is MIN-reduced, so its value is the same everywhere):
+            # always consume the flag of step k - 2, whose copy landed long ago
+            while len(self._pending) > 2:
+                self._adapt_grad_scale(bool(self._pending.popleft()))
+        else:
+            while self._pending and (self._pending[0]._value is not None or self._pending[0]._event.query()
+                                     or len(self._pending) > 2):
+                self._adapt_grad_scale(bool(self._pending.popleft()))
         e0 = self._ev() if timed else None
         out = self.model(model_input, val=False)
         zero = lambda t: torch.where(torch.isnan(t), torch.zeros_like(t), t)      # loss_function.py:66-69
@@ -99,7 +118,7 @@ class TrainStep:
         # the flag and multiplies the coefficient in — so the host never waits for the backward pass (behind a `.item()` it
         # is no longer ahead of the GPU, and everything it does until the next step's first launch is GPU idle time: 0.4-0.9 ms
         # per step depending on the host)
-        exchanging = cdist._exchanging(self.group, self.force_collectives)
+        exchanging = self._exchanging()
         on_device = self._one_launch
         ncoll, nbytes = 0, 0
         if exchanging and self._exchange is None:

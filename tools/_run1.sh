@@ -1,6 +1,5 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
-mkdir -p gpurun_out/r06b
-python -m pytest tests/test_gpu_train.py tests/test_gpu_step.py -x -q > gpurun_out/r06b/tests.log 2>&1; tail -5 gpurun_out/r06b/tests.log
-python tools/train_time.py --steps 5 > gpurun_out/r06b/train_time.log 2>&1; tail -1 gpurun_out/r06b/train_time.log
-COPONERF_TRAIN_FUSE_KEY=0 python tools/train_time.py --steps 5 > gpurun_out/r06b/train_time_nofusekey.log 2>&1; tail -1 gpurun_out/r06b/train_time_nofusekey.log
-python tools/launch_sites.py 80 > gpurun_out/r06b/launch_sites.txt 2>&1
+mkdir -p gpurun_out/r06c
+python -m pytest tests/test_gpu_dist.py tests/test_gpu_train.py -x -q > gpurun_out/r06c/tests.log 2>&1; tail -3 gpurun_out/r06c/tests.log
+python bench.py --mode train --steps 6 --warmup 2 > gpurun_out/r06c/bench_train.json 2> gpurun_out/r06c/bench_train.err; tail -c 1500 gpurun_out/r06c/bench_train.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --mode train --gpus 2 --steps 3 --warmup 1 > gpurun_out/r06c/bench_train2.json 2> gpurun_out/r06c/bench_train2.err; tail -c 600 gpurun_out/r06c/bench_train2.err; tail -c 2500 gpurun_out/r06c/bench_train2.json
