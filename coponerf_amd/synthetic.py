@@ -199,6 +199,28 @@ def make_render_weights(seed: int = 7, gain: float = 1.0) -> Dict[str, torch.Ten
     return out
 
 
+# ---- a render case with PEAKED attention at latent statistics like get_z's --------------------------------
+# Default-init weights give logits <key, coords_embed> / 11.31 of ~1e-2: the joint softmax over the 2 x S samples of a ray is
+# flat (max weight ~ 1 / (2 S)) and rounding errors of single samples average out.  A trained model attends: scaling the two
+# factors of each logit by PEAK_GAIN makes the logits 4096 x larger (median of the largest weight of a ray 0.8, > 0.5 on most
+# rays).  The synthetic latents (unit variance, zero mean) are moved to the per-level statistics get_z produces on the
+# make_full_weights state (std 1.14 / 1.67 / 1.87 / 0.75, mean 0.24 / 0.22 / 0.28 / 0.03; tests/golden/make_golden.py).
+PEAK_GAIN = 64.0
+GETZ_LEVEL_STD = (1.144, 1.667, 1.871, 0.752)
+GETZ_LEVEL_MEAN = (0.241, 0.216, 0.282, 0.025)
+
+
+def peaked_weights(weights: Dict[str, torch.Tensor], gain: float = PEAK_GAIN) -> Dict[str, torch.Tensor]:
+    out = dict(weights)
+    for k in ("key_map_2.weight", "query_embed_2.weight", "query_repeat_embed_2.weight"):
+        out[k] = weights[k] * gain
+    return out
+
+
+def latents_at_getz_statistics(z):
+    return [t * s + m for t, s, m in zip(z, GETZ_LEVEL_STD, GETZ_LEVEL_MEAN)]
+
+
 def make_full_weights(shapes: Dict[str, Tuple], seed: int = 11) -> Dict[str, torch.Tensor]:
     """Deterministic values for EVERY state_dict entry (name -> shape), at scales that keep the 256x256 get_z stack
     numerically tame: matrices/kernels U(+-1/sqrt(fan_in)), norm scales 1 +- 0.1, biases +-0.05, BatchNorm running

@@ -13,6 +13,9 @@ Cases (names match tests/test_oracle_golden.py and tests/test_gpu_parity.py):
   train_b2    B=2 H=64  R=256 S=32 val=False narrow rig
   wide_val    B=1 H=64  R=256 S=32 val=True  wide rig     (ACID-like, config 4 geometry)
   hd_val      B=1 H=256 R=256 S=64 val=True  narrow rig   (config 2 geometry/sample count)
+  peaked_val  B=1 H=64  R=256 S=32 val=True  narrow rig, attention sharpened (key_map_2 / query_embed_2 / query_repeat_embed_2
+              x 64: the largest softmax weight of a ray > 0.5 on most rays) and latents at get_z's output statistics
+              (synthetic.peaked_weights, latents_at_getz_statistics; `--only peaked_val` writes this fixture alone)
   inter       B=1 H=64  R=6   S=32 val=True  wide rig, with intermediates of every stage
   edges       project_rays on hand-built degenerate rays
 """
@@ -40,13 +43,18 @@ CASES = {
     "train_b2": dict(B=2, H=64, R=256, S=32, val=False, rig="narrow", seed=3),
     "wide_val": dict(B=1, H=64, R=256, S=32, val=True, rig="wide", seed=5),
     "hd_val": dict(B=1, H=256, R=256, S=64, val=True, rig="narrow", seed=9),
+    "peaked_val": dict(B=1, H=64, R=256, S=32, val=True, rig="narrow", seed=21, peak=64.0, zstats=True),
 }
 
 
 def run_case(cfg, weights, capture=False):
+    if cfg.get("peak"):
+        weights = syn.peaked_weights(weights, cfg["peak"])
     model = ref_shim.build_reference_model(weights, npoints=cfg["S"], H=cfg["H"])
     inp = syn.make_inputs(cfg["B"], cfg["H"], cfg["H"], cfg["R"], seed=cfg["seed"], rig=cfg["rig"])
     z, rel, flow = syn.make_latents(cfg["B"], cfg["H"], cfg["H"], seed=cfg["seed"] + 1)
+    if cfg.get("zstats"):
+        z = syn.latents_at_getz_statistics(z)
     rec = {}
     hooks = []
     if capture:
@@ -87,12 +95,17 @@ def run_case(cfg, weights, capture=False):
 
 def main():
     weights = syn.make_render_weights()
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     for name, cfg in CASES.items():
+        if only and name != only:
+            continue
         out, _ = run_case(cfg, weights)
         blob = {k: out[k].detach().cpu().numpy() for k in OUT_KEYS}
         blob["cfg"] = np.array(repr(cfg))
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **blob)
         print(name, {k: v.shape for k, v in blob.items() if k in ("rgb", "pixel_val")})
+    if only:
+        return
 
     cfg = dict(B=1, H=64, R=6, S=32, val=True, rig="wide", seed=11)
     out, rec = run_case(cfg, weights, capture=True)

@@ -20,7 +20,14 @@ def case_inputs(cfg):
     """Regenerate exactly the inputs tests/golden/make_golden.py fed to the reference."""
     inp = syn.make_inputs(cfg["B"], cfg["H"], cfg["H"], cfg["R"], seed=cfg["seed"], rig=cfg["rig"])
     z, rel, flow = syn.make_latents(cfg["B"], cfg["H"], cfg["H"], seed=cfg["seed"] + 1)
+    if cfg.get("zstats"):
+        z = syn.latents_at_getz_statistics(z)
     return inp, z, rel, flow
+
+
+def case_weights(cfg, weights):
+    """The weights make_golden.py gave the reference for this case (cfg["peak"]: attention sharpened, synthetic.peaked_weights)."""
+    return syn.peaked_weights(weights, cfg["peak"]) if cfg.get("peak") else weights
 
 
 def to_device(obj, dev):

@@ -1,8 +1,3 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
-mkdir -p gpurun_out/r06d
-echo "== gather + GEMM form (no tables)"; python tools/grad_floor_probe.py --rays 1024 --hip --no-tables 2>&1 | grep HIP
-echo "== tables forward, gather-form backward"; COPONERF_TABLE_BACKWARD=0 python tools/grad_floor_probe.py --rays 1024 --hip 2>&1 | grep HIP
-echo "== scale target 4096"; python - <<'PY'
-import coponerf_amd.render as r
-print("default grad_scale_target", r.RenderEngine().grad_scale_target)
-PY
+mkdir -p gpurun_out/r06e
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_range.py -x -q -s -k "peaked or sharpness" > gpurun_out/r06e/peaked.log 2>&1; grep -E "peaked attention:|passed|failed|Error|^ +[0-9]+ +[0-9.]+ +|gain" gpurun_out/r06e/peaked.log | head -30
