@@ -347,9 +347,9 @@ def run(args):
         with torch.no_grad():
             step()                                              # back to the headline pair (re-primes its caches)
 
-    # ---- the same step in the reference's arithmetic: fp32 operands in every per-sample layer (RenderEngine.precision = "f32":
-    #      exact fp32 MFMA, layer by layer, nothing fused) - the same-precision number beside the headline, and how far the
-    #      fp16-operand image is from it.  One untimed + one timed step (it is ~40 x slower).
+    # ---- the same step in the reference's arithmetic (RenderEngine.precision = "f32"): fp32 node tables, fp32 blends, hid as fp16
+    #      (hi, lo) pairs with exact products, exact-fp32 small layers (csrc/encode_f32.hip) - the same-precision number beside
+    #      the headline, how far the fp16-operand image is from it, and its roofline view.  One untimed + three timed steps.
     f32 = None
     if B == 1 and not args.pair_by_pair and not args.no_f32 and world == 1:
         eng = model._engine
@@ -359,17 +359,34 @@ def run(args):
             step()
             _fence(distributed)
             t0 = time.perf_counter()
-            o32 = step()
+            for _ in range(3):
+                o32 = step()
             _fence(distributed)
-            f32 = {"seconds_per_step": time.perf_counter() - t0,
-                   "rgb_max_abs_f16_vs_f32": float((rgb16 - o32["rgb"]).abs().max())}
+            f32 = {"seconds_per_step": (time.perf_counter() - t0) / 3,
+                   "rgb_max_abs_f16_vs_f32": float((rgb16 - o32["rgb"]).abs().max()),
+                   "form": "restructured (fp32 tables, folded key / value, (hi, lo) fp16 hid)" if eng.f32_tables
+                           else "layer by layer (exact fp32 operands, the reference's order)"}
             f32["rays_per_s_f32"] = rays_per_step / f32["seconds_per_step"]
+            # what this form executes per ray: the 4 table taps in fp32 on the vector unit, the K = 68 block of the first layer and
+            # the 128-wide layers on the exact fp32 MFMA, the folded key layer as three fp16 MFMA products (exact)
+            S_ = args.samples
+            vec = 2.0 * 2 * S_ * 2 * 832 * 4
+            mfma16 = 2.0 * 2 * S_ * 128 * (3328 + 1664)
+            mfma32 = 2.0 * 2 * S_ * (2 * 832 * 68 + 3 * 128 * 128 + 2 * 16 * 128)
+            f32["executed_tflops"] = {"fp32_vector": vec * f32["rays_per_s_f32"] / 1e12,
+                                      "fp16_mfma_exact_products": mfma16 * f32["rays_per_s_f32"] / 1e12,
+                                      "fp32_mfma": mfma32 * f32["rays_per_s_f32"] / 1e12}
+            # HBM: hid written once and read by the key layer (twice: two GEMM launches) and by both attention rounds
+            f32["roofline"] = {"bound": "hbm", "achieved": 5.0 * 2 * S_ * 6656 * f32["rays_per_s_f32"] / 1e9, "peak": 8000.0,
+                               "unit": "GB/s", "frac": 5.0 * 2 * S_ * 6656 * f32["rays_per_s_f32"] / 1e9 / 8000.0,
+                               "note": "5 passes over the (hi, lo) hidden activations, 6 656 B per sample and view; the fp32 MFMA "
+                                       "(157 TFLOP/s) is the other bound: see executed_tflops"}
             del o32
         finally:
             eng.precision = "f16"
-            for k in [k for k in eng._ws if "f32." in k]:
-                del eng._ws[k]                                  # ~10 GB of fp32 chunk buffers
-            eng._m32 = None
+            for k in [k for k in eng._ws if "f32" in k]:
+                del eng._ws[k]                                  # ~20 GB of chunk buffers
+            eng._m32 = eng._t32 = None
             torch.cuda.empty_cache()
 
     value = rays_per_step * world * args.steps / elapsed
@@ -405,6 +422,7 @@ def run(args):
         # the reference's arithmetic (fp32 operands, layer by layer) on the same workload, and the image's distance from it
         "rays_per_s_f32": None if f32 is None else f32["rays_per_s_f32"],
         "rgb_max_abs_f16_vs_f32": None if f32 is None else f32["rgb_max_abs_f16_vs_f32"],
+        "f32_mode": None if f32 is None else {k: f32[k] for k in ("form", "seconds_per_step", "executed_tflops", "roofline")},
         "path_tflops": value * f_ray(S) / 1e12,          # algorithmic FLOPs of the reference formulation
         "executed_tflops": value * exec_per_ray / 1e12,  # what the kernels execute after the restructurings
     }

@@ -43,6 +43,9 @@ SIGNATURES: Dict[str, List] = {
     "cpn_attend_hidden": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_attend_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_gather_rows_f32": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "cpn_node_features_f32": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "cpn_encode_hidden_f32": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "cpn_attend_hidden_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_attend_value": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_linear_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],

@@ -21,6 +21,7 @@ UNITS = [
     ("gather.hip", []),
     ("encode.hip", []),
     ("encode_fused.hip", []),
+    ("encode_f32.hip", []),
     ("local_units.hip", []),
     ("encode_bwd.hip", []),
     ("gemm_f16.hip", []),

@@ -105,6 +105,7 @@ __device__ __forceinline__ TileWalk tile_walk(int total) {
 struct CombineArgs {
     const float* w1; const float* dh1; const float* w2; const float* dh2;      // (N, R, S) weights, (rays, 1664) fp32 dhbar
     int V, R, S, ray0;
+    int accum;                                                                   // OUT_F32: C += (the product + bias), then the ReLU
 };
 #ifndef CPN_HID_READ_NT
 #define CPN_HID_READ_NT 1
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
                     const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
                     if (m >= M) continue;
                     f32x4 v = acc[mt][nt] + bv;
+                    if (ca.accum) v += *reinterpret_cast<const f32x4*>((const float*)Cv + (size_t)m * ldc + n);
                     if (RELU) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
 
 template <int NT, bool OUT_F32, bool RELU>
 int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
-           int K32, hipStream_t stream) {
+           int K32, hipStream_t stream, int accum = 0) {
     using C_ = Cfg<NT>;
     const size_t lds = C_::LDS_BYTES;
     auto kern = gemm_f16_kernel<NT, OUT_F32, RELU>;
@@ -565,7 +567,8 @@ int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias
     const int num_cu = cpn_stream_cus((void*)stream);       // persistent grid: the CUs this stream may use
     dim3 grid((unsigned)std::min<long long>(total, num_cu));       // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, C, ldc, M, K32, n_tiles, (int)total,
-                       (const __half*)nullptr, 0, (const __half*)nullptr, 0, (const float*)nullptr, CombineArgs{});
+                       (const __half*)nullptr, 0, (const __half*)nullptr, 0, (const float*)nullptr,
+                       CombineArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, accum});
     CPN_LAUNCH_CHECK("cpn_gemm_f16");
     return 0;
 }
@@ -627,9 +630,9 @@ int launch_combine(const __half* A, int lda, const __half* W, int ldw, const __h
 template <int NT>
 int dispatch(const __half* A, int lda, const __half* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
              int K32, int relu, int out_f32, hipStream_t s) {
-    if (out_f32) {
-        return relu ? launch<NT, true, true>(A, lda, W, ldw, bias, C, ldc, M, N, K32, s)
-                    : launch<NT, true, false>(A, lda, W, ldw, bias, C, ldc, M, N, K32, s);
+    if (out_f32) {                                            // 2: accumulate onto C (fp32) before the ReLU
+        return relu ? launch<NT, true, true>(A, lda, W, ldw, bias, C, ldc, M, N, K32, s, out_f32 == 2)
+                    : launch<NT, true, false>(A, lda, W, ldw, bias, C, ldc, M, N, K32, s, out_f32 == 2);
     }
     return relu ? launch<NT, false, true>(A, lda, W, ldw, bias, C, ldc, M, N, K32, s)
                 : launch<NT, false, false>(A, lda, W, ldw, bias, C, ldc, M, N, K32, s);
@@ -851,7 +854,7 @@ extern "C" int cpn_gemm_f16_combine(const uint16_t* dkh, int lda, const uint16_t
     CPN_REQUIRE(((uintptr_t)dkh % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)hid % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                     ((uintptr_t)dh1 % 16) == 0 && ((uintptr_t)dh2 % 16) == 0, CPN_E_ARG,
                 "cpn_gemm_f16_combine: pointers must be 16-byte aligned");
-    CombineArgs ca{w1, dh1, w2, dh2, V, R, S, ray0};
+    CombineArgs ca{w1, dh1, w2, dh2, V, R, S, ray0, 0};
     return launch_combine<13>((const __half*)dkh, lda, (const __half*)Wt, ldw, (const __half*)hid, 1664, ca, (__half*)out, 1664,
                               (int)M, 1664, K / 32, (hipStream_t)stream);
 }
@@ -867,7 +870,7 @@ extern "C" int cpn_gemm_f16_masked(const uint16_t* A, int lda, const uint16_t* W
                 "cpn_gemm_f16_masked: tile exceeds the 32-bit buffer offset range");
     CPN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)mask % 16) == 0 && ((uintptr_t)out % 16) == 0,
                 CPN_E_ARG, "cpn_gemm_f16_masked: pointers must be 16-byte aligned");
-    CombineArgs ca{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    CombineArgs ca{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
     if (N % 208 == 0)
         return launch_combine<13>((const __half*)A, lda, (const __half*)Wt, ldw, (const __half*)mask, ldm, ca, (__half*)out, ldc, M, N,
                                   K / 32, (hipStream_t)stream);

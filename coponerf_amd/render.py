@@ -462,10 +462,15 @@ class RenderEngine:
         # verification / escape-hatch mode (~40 x slower: fp32 MFMA peaks at 157 TFLOP/s and nothing is fused): the test suite
         # bounds |rgb_f16 - rgb_f32| with it and bench.py reports it as `rays_per_s_f32` beside the headline.
         self.precision = os.environ.get("COPONERF_PRECISION", "f16")
-        self.f32_chunk_rays = 4096
+        self.f32_chunk_rays = 16384
+        # round 6: the f32 mode in the restructured formulation (fp32 node tables, folded key / value, hid as fp16 (hi, lo) pairs:
+        # csrc/encode_f32.hip, _per_sample_f32_tables) - 85 % fewer FLOPs than the reference's layer order; False (COPONERF_F32_TABLES=0)
+        # = round 5's layer-by-layer form with exact fp32 operands everywhere, kept as the cross-check of the restructured one
+        self.f32_tables = os.environ.get("COPONERF_F32_TABLES", "1") != "0"
         self._w32key = None
         self._w32: Dict[str, torch.Tensor] = {}
         self._m32 = None
+        self._t32 = None
         self._wkey = None
         self._w: Dict[str, torch.Tensor] = {}
         self._mkey = None
@@ -525,10 +530,108 @@ class RenderEngine:
         wr = f("query_repeat_embed", 128)                                    # (128, 144) = [encode_latent(z) 128 | local_coords 16]
         w["qr.w_z"], w["qr.w_l"], w["qr.b"] = wr[:, :128].contiguous(), wr[:, 128:].contiguous(), b("query_repeat_embed")
         w["el.w"], w["el.b"] = f("encode_latent", 128), b("encode_latent")
+        # ---- restructured form (csrc/encode_f32.hip): table projection, K = 68 block (k-major, bias as its last row), the folded
+        #      key / value matrices (products in float64, one rounding to fp32) and the key matrix as an fp16 (hi, lo) pair
+        w["tab.w"] = w1[:, :768].contiguous()                                                # (832, 768)
+        w["k80t"] = torch.cat((w1[:, 768:835].t(), w["qel.b"][None]), 0).contiguous()        # (68, 832)
+        W2d, b2d = w["qel2.w"].double(), w["qel2.b"].double()
+
+        def fold(short, n_out):
+            Wx = w[short + ".w"].double()
+            Wf = torch.cat((Wx[:, :416] @ W2d, Wx[:, 416:] @ W2d), dim=1)
+            cf = Wx[:, :416] @ b2d + Wx[:, 416:] @ b2d + w[short + ".b"].double()
+            return Wf.float().contiguous(), cf.float().contiguous()
+
+        wk, w["keyf.b"] = fold("key", 128)
+        w["valf.w"], w["valf.b"] = fold("val", 416)
+        hi = wk.half()
+        lo = (wk - hi.float()).half()
+        w["keyf.w1"] = torch.cat((hi, hi), 1).contiguous()                                   # against [hid_hi | hid_lo]
+        w["keyf.w2"] = lo.contiguous()                                                       # against hid_hi
+        w["zero128"] = torch.zeros(128, dtype=torch.float32, device=wk.device)
         self._w32, self._w32key = w, key
         return w
 
     def _per_sample_f32(self, pz, wpack, B, R, S, H, W, pixel_val, sec_grid, pe6, loc8, coords9, zl, at_wt, s) -> None:
+        if self.f32_tables:
+            return self._per_sample_f32_tables(pz, B, R, S, H, W, pixel_val, sec_grid, pe6, loc8, coords9, zl, at_wt, s)
+        return self._per_sample_f32_layers(pz, wpack, B, R, S, H, W, pixel_val, sec_grid, pe6, loc8, coords9, zl, at_wt, s)
+
+    def _lin_f32(self, s, x, ldx, wt, bias, y, ldy, m, n, k, relu, res=None):
+        for n0 in range(0, n, 128):
+            nb = min(128, n - n0)
+            call("cpn_linear_f32", x.data_ptr(), ldx, wt.data_ptr() + n0 * wt.shape[1] * 4, wt.shape[1],
+                 0 if bias is None else bias.data_ptr() + n0 * 4, 0 if res is None else res.data_ptr() + n0 * 4,
+                 0 if res is None else res.shape[1], y.data_ptr() + n0 * 4, ldy, m, nb, k, 0, int(relu), s)
+
+    def _loc16(self, loc8, coords9, B, R, S):
+        # local_coords (16 channels, CoPoNeRF.py:411-445) of every sample in row order: [ctx ray dir 3 | 0 0 0 | query dir 3 |
+        # tanh(depth x {1, .1, .01, .001}) 4 | query origin 3] from the per-sample / per-ray pieces cpn_sample_geometry wrote
+        l8 = loc8.view(B, V, R, S, 8).permute(0, 2, 1, 3, 4)                  # (B,R,V,S,8)
+        c9 = coords9.view(B, V, R, 1, 9).permute(0, 2, 1, 3, 4).expand(B, R, V, S, 9)
+        loc16 = torch.cat((l8[..., 0:3], torch.zeros_like(l8[..., 0:3]), c9[..., 0:3], l8[..., 3:7], c9[..., 6:9]), dim=-1)
+        return loc16.reshape(B * R * V * S, 16).contiguous()
+
+    def _per_sample_f32_tables(self, pz, B, R, S, H, W, pixel_val, sec_grid, pe6, loc8, coords9, zl, at_wt, s) -> None:
+        """zl, at_wt of a call in the reference's arithmetic, RESTRUCTURED like the fp16 default (csrc/encode_f32.hip, round 6):
+        fp32 node tables, the first layer as 4 fp32 table taps + an fp32 K = 68 block, hid as fp16 (hi, lo) pairs, the folded key
+        layer on cpn_gemm_f16 against (hi, lo) weights (exact products, fp32 accumulation), both attention rounds on the
+        hidden activations, the folded value projection per ray in exact fp32."""
+        params, z = pz
+        w = self._weights_f32(params)
+        dev = zl.device
+        f32, f16 = torch.float32, torch.float16
+        mk = tuple((id(t), t._version) for t in z) + (self._w32key,)
+        if self._t32 is None or self._t32[0] != mk or any(a is not b for a, b in zip(self._t32[1], z)):
+            maps = [t.detach().float().permute(0, 2, 3, 1).contiguous() for t in z]                          # NHWC fp32
+            nimg = maps[0].shape[0]
+            nodes = nimg * int(_hip.lib().cpn_encode_table_nodes(H, W))
+            feat = torch.empty(nodes, 768, dtype=f32, device=dev)
+            call("cpn_node_features_f32", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), H, W, nimg, feat.data_ptr(), s)
+            tab = torch.empty(nodes, _hip.TAB_LD, dtype=f32, device=dev)
+            self._lin_f32(s, feat, 768, w["tab.w"], None, tab, _hip.TAB_LD, nodes, _hip.TAB_LD, 768, False)
+            del feat
+            self._t32 = (mk, tuple(z), tab, maps[3])
+        tab, map3 = self._t32[2], self._t32[3]
+        T = V * S
+        nray = B * R
+        loc16 = self._loc16(loc8, coords9, B, R, S)
+        C = min(self.f32_chunk_rays, nray)
+        lin = lambda *a, **k: self._lin_f32(s, *a, **k)
+        t = lambda name, shape, dt=f32: self._buf("f32t." + name, shape, dt, dev)
+        for ray0 in range(0, nray, C):
+            n = min(C, nray - ray0)
+            rows = n * T
+            hs = t("hs", (rows, 3328), f16)
+            call("cpn_encode_hidden_f32", tab.data_ptr(), map3.data_ptr(), H, W, pixel_val.data_ptr(), sec_grid.data_ptr(),
+                 pe6.data_ptr(), w["k80t"].data_ptr(), B, V, R, S, ray0, n, hs.data_ptr(), s)
+            kh, key2 = t("kh", (rows, 128)), t("key2", (rows, 128))
+            call("cpn_gemm_f16", hs.data_ptr(), 3328, w["keyf.w1"].data_ptr(), 3328, w["keyf.b"].data_ptr(), kh.data_ptr(), 128,
+                 rows, 128, 3328, 0, 1, s)
+            call("cpn_gemm_f16", hs.data_ptr(), 3328, w["keyf.w2"].data_ptr(), 1664, w["zero128"].data_ptr(), kh.data_ptr(), 128,
+                 rows, 128, 1664, 1, 2, s)
+            lin(kh, 128, w["key2.w"], w["key2.b"], key2, 128, rows, 128, 128, False)
+            lc = loc16[ray0 * T:(ray0 + n) * T]
+            hq, ce = t("hq", (rows, 128)), t("ce", (rows, 128))
+            lin(lc, 16, w["qe.w"], w["qe.b"], hq, 128, rows, 128, 16, True)
+            lin(hq, 128, w["qe2.w"], w["qe2.b"], ce, 128, rows, 128, 128, False)
+            hbar, z1, ze, aq = t("hbar", (n, 1664)), t("z1", (n, 416)), t("ze", (n, 128)), t("aq", (n, 128))
+            call("cpn_attend_hidden_f32", key2.data_ptr(), ce.data_ptr(), hs.data_ptr(), B, V, R, S, ray0, n, hbar.data_ptr(),
+                 at_wt.data_ptr(), s)
+            lin(hbar, 1664, w["valf.w"], w["valf.b"], z1, 416, n, 416, 1664, False)
+            lin(z1, 416, w["el.w"], w["el.b"], ze, 128, n, 128, 416, False)
+            lin(ze, 128, w["qr.w_z"], None, aq, 128, n, 128, 128, False)
+            aq_rows = aq[:n].repeat_interleave(T, dim=0)                                     # the ray's vector on each of its samples
+            q2 = key2                                                                        # (the key is spent)
+            lin(lc, 16, w["qr.w_l"], w["qr.b"], hq, 128, rows, 128, 16, True, res=aq_rows)
+            lin(hq, 128, w["qr2.w"], w["qr2.b"], q2, 128, rows, 128, 128, False)
+            call("cpn_attend_hidden_f32", q2.data_ptr(), ce.data_ptr(), hs.data_ptr(), B, V, R, S, ray0, n, hbar.data_ptr(), 0, s)
+            zs = t("zs", (n, 416))
+            lin(hbar, 1664, w["valf.w"], w["valf.b"], zs, 416, n, 416, 1664, False)
+            # the round-1 vector sits in both view slots when the views are summed (CoPoNeRF.py:481-485): + V * z1
+            torch.add(zs[:n], z1[:n], alpha=float(V), out=zl[ray0:ray0 + n])
+
+    def _per_sample_f32_layers(self, pz, wpack, B, R, S, H, W, pixel_val, sec_grid, pe6, loc8, coords9, zl, at_wt, s) -> None:
         """zl, at_wt of a call with fp32 operands throughout, layer by layer in the reference's order (see __init__)."""
         params, z = pz
         w = self._weights_f32(params)
@@ -597,7 +700,7 @@ class RenderEngine:
         self._camc = None
         self._next = []
         self._early = None
-        self._w32key, self._m32 = None, None
+        self._w32key, self._m32, self._t32 = None, None, None
         self.epoch += 1
 
     def __deepcopy__(self, memo):
@@ -605,6 +708,7 @@ class RenderEngine:
         new = RenderEngine(self.chunk_rays, self.fold_value, self.lanes, self.tables, self.fuse_key, self.project)
         new.grad_scale_target, new.call_lanes, new.lazy_pixel_val = self.grad_scale_target, self.call_lanes, self.lazy_pixel_val
         new.precision, new.unit_order, new.f32_chunk_rays = self.precision, self.unit_order, self.f32_chunk_rays
+        new.f32_tables = self.f32_tables
         new.ce_recompute = self.ce_recompute
         return new
 

@@ -230,7 +230,7 @@ int cpn_local_units(int mode, const float* loc8, const float* coords9, const flo
 /* ---- K3: fused GEMM  C = act(A . W^T + bias), fp16 in, fp32 accumulate (MFMA 16x16x32 f16) -----------
  * replaces the per-sample 1x1 convolutions (CoPoNeRF.py:387-397, 404, 408, 446, 473).
  *   A (M, lda) fp16, W (N, ldw) fp16 (both K-contiguous), bias (N) fp32, K multiple of 32, N multiple of 16*tile
- *   out_f32 = 0: C fp16 (M, ldc) ; 1: C fp32 (M, ldc)                                                           */
+ *   out_f32 = 0: C fp16 (M, ldc) ; 1: C fp32 (M, ldc) ; 2: C fp32 += the product + bias, then the ReLU (round 6)        */
 int cpn_gemm_f16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
                  void* C, int ldc, int M, int N, int K, int relu, int out_f32, void* stream);
 /* Few-row form (round 4): the per-RAY value projection of a small call (M = 3 641 rays when the callers render an image as 18
@@ -312,6 +312,30 @@ int cpn_ray_outputs(const float* at_wt, const float* pt, const float* uv, long l
                     const uint8_t* mask2, const float* flow_up, int B, int V, int R, int S, long long* at_wt_max,
                     float* depth_ray, float* t_to_c1, float* t_to_c2, uint8_t* mask_c2, uint8_t* match_mask,
                     float* c2_to_c1, void* stream);
+
+/* ==== the reference-arithmetic mode in the restructured formulation (csrc/encode_f32.hip, round 6) ==================
+ * RenderEngine.precision = "f32": fp32 node tables, fp32 blends and products; the hidden activations are carried as fp16
+ * (hi, lo) pairs - hs (rows, 3328) fp16 = [hi_own 832 | hi_other 832 | lo_own 832 | lo_other 832], x = hi + lo to 22 bits -
+ * so that the folded key layer runs on cpn_gemm_f16 against (hi, lo) weights with exact products
+ * (C = [hi | lo] . [W_hi | W_hi]^T, then C += hi . W_lo^T: cpn_gemm_f16 with out_f32 = 2 accumulates onto C).              */
+
+/* the three coarse levels (NHWC fp32 maps (nimg, H/16.., 256)) sampled at every table node (grid_sample semantics of the
+ * node's table: 'border' / 'zeros', models/CoPoNeRF.py:312, 370) -> feat (nimg * cpn_encode_table_nodes, 768) fp32         */
+int cpn_node_features_f32(const float* map0, const float* map1, const float* map2, int H, int W, int nimg, float* feat,
+                          void* stream);
+
+/* first encoder layer on fp32 tables: per sample row (ray, view, sample, image j)
+ *   hid = ReLU(sum_t a_t tab[node_t] + W[:, 768:835] . [bilinear(map3) 64 | tanh(pt/5) 3] + b)     (CoPoNeRF.py:384-397)
+ * tab (nimg * nodes, 832) fp32 = node features . W[:, :768]^T, map3 (nimg, H, W, 64) fp32 NHWC, w80t (68, 832) fp32 = the
+ * layer's columns 768..834 transposed (k-major) with the bias as row 67; output hs (nrays*V*S, 3328) fp16 (hi, lo) pairs  */
+int cpn_encode_hidden_f32(const float* tab, const float* map3, int H, int W, const float* pixel_val, const float* sec_grid,
+                          const float* pe6, const float* w80t, int B, int V, int R, int S, int ray0, int nrays, uint16_t* hs,
+                          void* stream);
+
+/* joint softmax over the V*S samples of a ray of <qa, qb> / 11.31 (fp32 (rows,128) operands) and the weighted sum of the
+ * hidden activations hs (hi, lo pairs) -> hbar (nrays, 1664) fp32, at_wt (N,R,S) fp32 or NULL   (CoPoNeRF.py:450-461, 475-485) */
+int cpn_attend_hidden_f32(const float* qa, const float* qb, const uint16_t* hs, int B, int V, int R, int S, int ray0, int nrays,
+                          float* hbar, float* at_wt, void* stream);
 
 /* ==== training: backward of the two non-GEMM stages (plain GEMM gradients use hipBLASLt via torch.matmul) ==== */
 
