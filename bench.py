@@ -59,8 +59,6 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=1,
                     help="HIP streams the ray chunks are spread over (kernels of different chunks then share the GPU "
                          "and the per-kernel roofline timing is no longer clean)")
-    ap.add_argument("--no-tables", action="store_true",
-                    help="first encoder layer as gather + 835->832 GEMM instead of the projected-table form")
     ap.add_argument("--no-image", action="store_true", help="skip the secondary image-pipeline figures (get_z + render)")
     ap.add_argument("--no-f32", action="store_true", help="skip the reference-arithmetic (fp32-operand) pass of the same step")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="upper bound on the rays of the CPU-baseline sample (0 = skip)")
@@ -250,7 +248,6 @@ def run(args):
     model = model.to(dev).eval()
     model._engine.chunk_rays = args.chunk_rays
     model._engine.lanes = args.lanes
-    model._engine.tables = not args.no_tables
 
     P = B if args.pair_by_pair else 1                      # forward() calls per step
     Bc = 1 if args.pair_by_pair else B                     # pairs per call
@@ -364,8 +361,7 @@ def run(args):
             _fence(distributed)
             f32 = {"seconds_per_step": (time.perf_counter() - t0) / 3,
                    "rgb_max_abs_f16_vs_f32": float((rgb16 - o32["rgb"]).abs().max()),
-                   "form": "restructured (fp32 tables, folded key / value, (hi, lo) fp16 hid)" if eng.f32_tables
-                           else "layer by layer (exact fp32 operands, the reference's order)"}
+                   "form": "fp32 tables, folded key / value, (hi, lo) fp16 hid (csrc/encode_f32.hip)"}
             f32["rays_per_s_f32"] = rays_per_step / f32["seconds_per_step"]
             # what this form executes per ray: the 4 table taps in fp32 on the vector unit, the K = 68 block of the first layer and
             # the 128-wide layers on the exact fp32 MFMA, the folded key layer as three fp16 MFMA products (exact)
@@ -386,16 +382,14 @@ def run(args):
             eng.precision = "f16"
             for k in [k for k in eng._ws if "f32" in k]:
                 del eng._ws[k]                                  # ~20 GB of chunk buffers
-            eng._m32 = eng._t32 = None
+            eng._t32 = None
             torch.cuda.empty_cache()
 
     value = rays_per_step * world * args.steps / elapsed
-    tables = model._engine.tables
-    # executed FLOPs per ray: value/key projections folded; with tables the 3 x 256 coarse channels
-    # of the first layer are table taps (12 x 832 FMA per row) instead of a 768-deep contraction
-    exec_per_ray = S * 6637056.0 + 4300000.0
-    if tables:
-        exec_per_ray -= S * 4 * 2.0 * 832 * (768 - 12)
+    tables = True
+    # executed FLOPs per ray: value/key projections folded; the 3 x 256 coarse channels of the first layer
+    # are table taps (12 x 832 FMA per row) instead of a 768-deep contraction
+    exec_per_ray = S * 6637056.0 + 4300000.0 - S * 4 * 2.0 * 832 * (768 - 12)
     cfg_name = ("configs[4]" if H == 512 else "configs[3]" if args.rig == "wide" else "configs[1]") \
         if (H, S) in ((256, 64), (512, 128)) else "custom"
     line = {
@@ -410,9 +404,7 @@ def run(args):
                                f"samples, {B} pair(s) per GPU{' rendered pair by pair' if args.pair_by_pair else ''}, "
                                f"render path only (z/rel_pose/flow given, val=True)",
                    "chunk_rays": args.chunk_rays or model._engine._auto_chunk(S, dev), "lanes": args.lanes, "pairs_per_gpu": B,
-                   "first_layer": ("projected tables + K=80 MFMA" + (" + folded key_map layer on the register-resident slices "
-                                   "(cpn_encode_key)" if model._engine.fuse_key and model._engine.fold_value else " (cpn_encode_hidden)"))
-                                  if tables else "gather + 835->832 GEMM"},
+                   "first_layer": "projected tables + K=80 MFMA + folded key_map layer on the register-resident slices (cpn_encode_key)"},
         "rays_per_s_calls_on_two_streams": None if overlapped is None else rays_per_step * world * args.steps / overlapped,
         # a new pair every step (tables, NHWC copies, camera upload and flow products rebuilt inside the timed region)
         "rays_per_s_fresh_pair": None if fresh is None else rays_per_step * world * args.steps / fresh,

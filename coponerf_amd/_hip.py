@@ -25,30 +25,19 @@ SIGNATURES: Dict[str, List] = {
     "cpn_sample_geometry": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "cpn_nchw_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
     "cpn_pack_weight_f16": [_P, _I, _I, _P, _I, _P],
-    "cpn_gather_rows": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_pack_encode_weights": [_P, _I, _P, _P, _P],
     "cpn_node_features": [_P, _P, _P, _I, _I, _I, _P, _P],
-    "cpn_encode_hidden": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_encode_key": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
-    "cpn_encode_project": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "cpn_local_units": [_I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "cpn_local_hidden": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "cpn_local_mlp": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
-    "cpn_gemm_f16_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
-    "cpn_gemm_f16_chain_rowdot": [_P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
     "cpn_gemm_f16": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "cpn_pack_gemm_frags": [_P, _I, _I, _I, _P, _P],
     "cpn_gemm_f16_fewrows": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "cpn_attend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_attend_hidden": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "cpn_attend_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "cpn_gather_rows_f32": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "cpn_node_features_f32": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cpn_encode_hidden_f32": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "cpn_attend_hidden_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "cpn_attend_value": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_linear_f32": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "cpn_mask_rgb": [_P, _I, _P, _I, _I, _I, _P, _P, _P],
     "cpn_lightfield_decode": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "cpn_ray_outputs": [_P, _P, _P, ctypes.c_longlong, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "cpn_attend_hidden_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -58,7 +47,6 @@ SIGNATURES: Dict[str, List] = {
     "cpn_wgrad_skinny_f16": [_P, _P, _I, ctypes.c_longlong, _P, _P, _P],
     "cpn_wgrad_tall_f16": [_P, _I, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P],
     "cpn_local_hidden_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
-    "cpn_gather_rows_bwd": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cpn_gather_rows_bwd_level3": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_scatter_rows_tables": [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "cpn_node_features_bwd": [_P, _I, _I, _I, _P, _P, _P, _P],
@@ -104,12 +92,10 @@ SIGNATURES: Dict[str, List] = {
 
 CAM_STRIDE = 96
 CAM_TQ, CAM_M, CAM_AOWN, CAM_AOTH, CAM_KQ, CAM_KC, CAM_KO, CAM_KN = 0, 16, 32, 48, 64, 68, 72, 76
-XIN_K, XIN_STRIDE = 864, 896
 TAB_LD = 832
-K80_BLOCK_HALVES = 5120          # CPN_K80_BLOCK_HALVES: one slice of the streamed K = 80 weight block (cpn_encode_project)
 RAYC_STRIDE = 64
 LIGHTFIELD_PACK_FLOATS = 128 * 32 + 128 + 3 * (128 * 416 + 128 + 2 * (128 * 128 + 128)) + 16 * 128 + 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 ADAM_SEG_BYTES = 48
 
 

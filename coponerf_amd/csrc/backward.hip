@@ -709,27 +709,6 @@ static int gather_rows_bwd_launch(const uint16_t* dxin, int ldx, int H, int W, c
     return 0;
 }
 
-extern "C" int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float* pixel_val,
-                                   const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays,
-                                   float* dmap0, float* dmap1, float* dmap2, float* dmap3, int32_t* chunk_boxes,
-                                   void* stream) {
-    CPN_REQUIRE(dxin && pixel_val && sec_grid && dmap0 && dmap1 && dmap2 && dmap3 && chunk_boxes, CPN_E_ARG,
-                "cpn_gather_rows_bwd: null pointer");
-    CPN_REQUIRE(B > 0 && V == 2 && R > 0 && S > 0 && H >= 16 && (H % 16) == 0 && (W % 16) == 0 && ldx >= 832,
-                CPN_E_SHAPE, "cpn_gather_rows_bwd: bad shape");
-    CPN_REQUIRE(H <= 1024 && W <= 1024, CPN_E_SHAPE, "cpn_gather_rows_bwd: maps larger than 1024 pixels a side");
-    CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
-                "cpn_gather_rows_bwd: ray range outside B*R");
-    const long long nrows = (long long)nrays * V * S * 2;
-    CPN_REQUIRE(nrows < (1LL << 31), CPN_E_SHAPE, "cpn_gather_rows_bwd: chunk too large for 32-bit indexing");
-    gather_rows_bwd_launch(dxin, ldx, H, W, pixel_val, sec_grid, B, V, R, S, ray0, nrays, dmap0, dmap1, dmap2, dmap3,
-                           chunk_boxes, 0, 768, stream);
-    CPN_LAUNCH_CHECK("cpn_gather_rows_bwd");
-    return 0;
-}
-
-// the full-resolution level alone (table-form backward of the first layer, csrc/encode_bwd.hip): its 64 gradient columns
-// start at column `col0` of the (rows, ldx) fp16 gradient
 extern "C" int cpn_gather_rows_bwd_level3(const uint16_t* dxin, int ldx, int col0, int H, int W, const float* pixel_val,
                                           const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays,
                                           float* dmap3, int32_t* chunk_boxes, void* stream) {

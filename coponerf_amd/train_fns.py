@@ -50,9 +50,6 @@ class GradScale:
         return d if d.dtype == torch.float16 else d * self.ensure(d)
 
 
-# first-layer backward in the table form (csrc/encode_bwd.hip); COPONERF_TABLE_BACKWARD=0 restores the round-2 form
-# (re-gather + 835-wide weight-gradient GEMM + data-gradient GEMM + 832-column scatter into the maps)
-TABLE_BACKWARD = os.environ.get("COPONERF_TABLE_BACKWARD", "1") != "0"
 # cpn_hid_grad_combine as the epilogue of the key path's data-gradient GEMM (cpn_gemm_f16_combine; round 6); 0 = two kernels
 FUSE_COMBINE = os.environ.get("COPONERF_FUSE_COMBINE", "1") != "0"
 
@@ -70,19 +67,16 @@ class HidGradParts:
         self.dqb_done = False
 
 
-# training forward: the folded key layer inside the first layer's kernel (cpn_encode_key, the inference default; round 6) instead
-# of its own pass over hid; 0 = cpn_encode_hidden + cpn_gemm_f16
 # coords_embed feeds both attention rounds: the second backward call adds the first one's gradient in its kernel
 SHARE_QB_GRAD = os.environ.get("COPONERF_SHARE_QB_GRAD", "1") != "0"
 # grad_input of key_map_2 with the ReLU mask of its input as the GEMM's epilogue (cpn_gemm_f16_masked)
 MASKED_DGRAD = os.environ.get("COPONERF_MASKED_DGRAD", "1") != "0"
-FUSE_KEY_FORWARD = os.environ.get("COPONERF_TRAIN_FUSE_KEY", "1") != "0"
 
 
 class KeyForward:
-    """Hand-over between EncodeFn and the GemmFn node of the folded key layer (kh = ReLU(W' . [hid_own ; hid_other] + c')): with
-    FUSE_KEY_FORWARD the first layer's kernel also forms kh (hid is not read back for it), and the GemmFn node only records what
-    its backward needs.  W (128, 1664) / b (128): the folded, differentiable fp32 weights (render_train)."""
+    """Hand-over between EncodeFn and the GemmFn node of the folded key layer (kh = ReLU(W' . [hid_own ; hid_other] + c')): the
+    first layer's kernel also forms kh (cpn_encode_key, as in inference: hid is not read back for it), and the GemmFn node only
+    records what its backward needs.  W (128, 1664) / b (128): the folded, differentiable fp32 weights (render_train)."""
 
     def __init__(self, W, b):
         self.W, self.b = W, b
@@ -347,10 +341,9 @@ class AttendHiddenFn(Function):
 
 
 class EncodeFn(Function):
-    """hid fp16 (rows2, 832) = relu(query_encode_latent([gather | tanh(pt/5)])) through cpn_encode_hidden (node tables +
-    K = 80 MFMA: the inference kernel) — the gathered 835-channel input is NOT materialised in the forward
-    pass.  The backward is that of GatherFn + GemmFn: it re-gathers the input rows once (cpn_gather_rows, 2.8 ms) for the
-    weight gradient, forms the data gradient on cpn_gemm_f16 and scatters it into the maps (cpn_gather_rows_bwd)."""
+    """hid fp16 (rows2, 832) = relu(query_encode_latent([gather | tanh(pt/5)])) through cpn_encode_key (node tables + K = 80
+    MFMA + the folded key layer: the inference kernel) — the gathered 835-channel input is never materialised.
+    The backward differentiates the layer in its table form (csrc/encode_bwd.hip, _backward_tables)."""
 
     @staticmethod
     def forward(ctx, z0, z1, z2, z3, W, b, pixel_val, sec_grid, pe6, dims, HW, gs: GradScale, hid_parts, key=None):
@@ -380,28 +373,22 @@ class EncodeFn(Function):
              _hip.TAB_LD, 768, 0, 0, s)
         nrays = B * R
         hid = torch.empty(nrays * V * S * 2, 832, dtype=torch.float16, device=dev)
-        if key is not None and FUSE_KEY_FORWARD:
-            from .render import pack_key_ring
-            Wk = key.W.detach().contiguous().float()
-            key.W16 = torch.empty(128, 1664, dtype=torch.float16, device=dev)
-            call("cpn_pack_weight_f16", Wk.data_ptr(), 128, 1664, key.W16.data_ptr(), 1664, s)
-            ring = pack_key_ring(key.W16)
-            kb = key.b.detach().contiguous().float()
-            key.kh = torch.empty(nrays * V * S, 128, dtype=torch.float16, device=dev)
-            call("cpn_encode_key", tab.data_ptr(), maps[3].data_ptr(), H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
-                 pe6.data_ptr(), frag.data_ptr(), bc.data_ptr(), ring.data_ptr(), kb.data_ptr(), B, V, R, S, 0, nrays,
-                 hid.data_ptr(), key.kh.data_ptr(), 0, s)
-        else:
-            call("cpn_encode_hidden", tab.data_ptr(), maps[3].data_ptr(), H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
-                 pe6.data_ptr(), frag.data_ptr(), bc.data_ptr(), B, V, R, S, 0, nrays, hid.data_ptr(), s)
-        W16 = torch.zeros(832, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
-        call("cpn_pack_weight_f16", Wc.data_ptr(), 832, Wc.shape[1], W16.data_ptr(), _hip.XIN_STRIDE, s)
-        if TABLE_BACKWARD:
-            del tab, maps[0], maps[0], maps[0]                           # maps is now [level 3]
-            ctx.save_for_backward(maps[0], pixel_val, sec_grid, pe6, W16, hid, feat, wtab)
-        else:
-            ctx.save_for_backward(maps[0], maps[1], maps[2], maps[3], pixel_val, sec_grid, pe6, W16, hid)
-        ctx.table_bwd = TABLE_BACKWARD
+        if key is None:                      # a caller that only wants hid: a zero key layer rides along
+            key = KeyForward(torch.zeros(128, 1664, device=dev), torch.zeros(128, device=dev))
+        from .render import pack_key_ring
+        Wk = key.W.detach().contiguous().float()
+        key.W16 = torch.empty(128, 1664, dtype=torch.float16, device=dev)
+        call("cpn_pack_weight_f16", Wk.data_ptr(), 128, 1664, key.W16.data_ptr(), 1664, s)
+        ring = pack_key_ring(key.W16)
+        kb = key.b.detach().contiguous().float()
+        key.kh = torch.empty(nrays * V * S, 128, dtype=torch.float16, device=dev)
+        call("cpn_encode_key", tab.data_ptr(), maps[3].data_ptr(), H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
+             pe6.data_ptr(), frag.data_ptr(), bc.data_ptr(), ring.data_ptr(), kb.data_ptr(), B, V, R, S, 0, nrays,
+             hid.data_ptr(), key.kh.data_ptr(), 0, s)
+        W16 = torch.zeros(832, 896, dtype=torch.float16, device=dev)      # fp16 image of W, K padded (level-3 columns 768..831)
+        call("cpn_pack_weight_f16", Wc.data_ptr(), 832, Wc.shape[1], W16.data_ptr(), 896, s)
+        del tab, maps[0], maps[0], maps[0]                               # maps is now [level 3]
+        ctx.save_for_backward(maps[0], pixel_val, sec_grid, pe6, W16, hid, feat, wtab)
         ctx.dims, ctx.HW, ctx.gs, ctx.hid_parts, ctx.K = dims, HW, gs, hid_parts, Wc.shape[1]
         ctx.shapes = [tuple(t.shape) for t in (z0, z1, z2, z3)]
         return hid
@@ -468,11 +455,7 @@ class EncodeFn(Function):
 
     @staticmethod
     def backward(ctx, dC):
-        if ctx.table_bwd:
-            hid = ctx.saved_tensors[5]
-            pixel_val = sec_grid = None
-        else:
-            m0, m1, m2, m3, pixel_val, sec_grid, pe6, W16, hid = ctx.saved_tensors
+        hid = ctx.saved_tensors[5]
         B, V, R, S = ctx.dims
         H, Wd = ctx.HW
         s = _stream()
@@ -493,70 +476,4 @@ class EncodeFn(Function):
                 ctx.hid_parts.parts = []
                 ctx.hid_parts.combined = False
         del d
-        if ctx.table_bwd:
-            return EncodeFn._backward_tables(ctx, d16)
-        inv = 1.0 / ctx.gs.s
-        rows = hid.shape[0]
-        xin = torch.empty(rows, _hip.XIN_STRIDE, dtype=torch.float16, device=hid.device)
-        call("cpn_gather_rows", m0.data_ptr(), m1.data_ptr(), m2.data_ptr(), m3.data_ptr(), H, Wd, pixel_val.data_ptr(),
-             sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, 0, B * R, xin.data_ptr(), s)
-        # the bias gradient rides on the weight-gradient GEMM: a column of ones in the (zero) padding of the re-gathered
-        # input makes dW_full[:, K] the column sums of d16 (a separate reduction over the 7 GB gradient cost 1.5 ms)
-        xin[:, ctx.K].fill_(1.0)
-        dWf = _wgrad_tall(d16, xin, ctx.gs.s)
-        del xin
-        dW = dWf[:, :ctx.K] if ctx.needs_input_grad[4] else None
-        db = dWf[:, ctx.K].contiguous() if ctx.needs_input_grad[5] else None
-        g = [None] * 4
-        if any(ctx.needs_input_grad[:4]):
-            # (rows, 832) fp16, scaled: the gather reads feature channels only (768 + 64); the encoding columns have no
-            # gradient path (poses / detached points), so their 64 columns of the product are not formed
-            dA = _data_grad(d16, W16[:, :832].contiguous())
-            del d16
-            dmaps = [torch.zeros(n, h, w_, c, dtype=torch.float32, device=dA.device) for (n, c, h, w_) in ctx.shapes]
-            boxes = torch.empty(B * V * _hip.lib().cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=dA.device)
-            call("cpn_gather_rows_bwd", dA.data_ptr(), dA.shape[1], H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V,
-                 R, S, 0, B * R, dmaps[0].data_ptr(), dmaps[1].data_ptr(), dmaps[2].data_ptr(), dmaps[3].data_ptr(),
-                 boxes.data_ptr(), s)
-            g = [m.mul_(inv).permute(0, 3, 1, 2).contiguous() for m in dmaps]
-        return g[0], g[1], g[2], g[3], dW, db, None, None, None, None, None, None, None, None
-
-
-class GatherFn(Function):
-    """xin fp16 (rows2, 896) = cpn_gather_rows(NHWC fp16 copies of z0..z3); backward scatters into the maps."""
-
-    @staticmethod
-    def forward(ctx, z0, z1, z2, z3, pixel_val, sec_grid, pe6, dims, HW, gs: GradScale):
-        B, V, R, S = dims
-        H, W = HW
-        s = _stream()
-        maps = []
-        for t in (z0, z1, z2, z3):
-            src = t.detach().float().contiguous()
-            n, c, h, w_ = src.shape
-            dst = torch.empty(n, h, w_, c, dtype=torch.float16, device=src.device)
-            call("cpn_nchw_to_nhwc_f16", src.data_ptr(), dst.data_ptr(), n, c, h, w_, s)
-            maps.append(dst)
-        nrays = B * R
-        xin = torch.empty(nrays * V * S * 2, _hip.XIN_STRIDE, dtype=torch.float16, device=z0.device)
-        call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, W,
-             pixel_val.data_ptr(), sec_grid.data_ptr(), pe6.data_ptr(), B, V, R, S, 0, nrays, xin.data_ptr(), s)
-        ctx.save_for_backward(pixel_val, sec_grid)
-        ctx.dims, ctx.HW, ctx.gs = dims, HW, gs
-        ctx.shapes = [tuple(t.shape) for t in (z0, z1, z2, z3)]
-        return xin
-
-    @staticmethod
-    def backward(ctx, dxin):
-        pixel_val, sec_grid = ctx.saved_tensors
-        B, V, R, S = ctx.dims
-        H, W = ctx.HW
-        d = ctx.gs.scaled16(dxin.contiguous()).to(torch.float16)
-        inv = 1.0 / ctx.gs.s
-        dmaps = [torch.zeros(n, h, w_, c, dtype=torch.float32, device=d.device) for (n, c, h, w_) in ctx.shapes]
-        boxes = torch.empty(B * V * _hip.lib().cpn_gather_bwd_chunks(R, S) * 16, dtype=torch.int32, device=d.device)
-        call("cpn_gather_rows_bwd", d.data_ptr(), d.shape[1], H, W, pixel_val.data_ptr(), sec_grid.data_ptr(), B, V, R, S,
-             0, B * R, dmaps[0].data_ptr(), dmaps[1].data_ptr(), dmaps[2].data_ptr(), dmaps[3].data_ptr(),
-             boxes.data_ptr(), _stream())
-        g = [m.mul_(inv).permute(0, 3, 1, 2).contiguous() for m in dmaps]         # fp32 accumulators back to true scale
-        return g[0], g[1], g[2], g[3], None, None, None, None, None, None
+        return EncodeFn._backward_tables(ctx, d16)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 9
+#define CPN_ABI_VERSION 10
 
 #define CPN_E_ARG   (-1)   /* bad argument (null pointer, size, alignment) */
 #define CPN_E_SHAPE (-2)   /* shape not supported by the compiled tiles    */
@@ -45,8 +45,6 @@ extern "C" {
 
 /* padded K of the first encoder layer: 835 inputs -> 864 consumed (27 x 32); row stride 896 halves = 14 x 128 B:
  * 128-byte-aligned rows are worth 10 % on the GEMM that reads them (808 vs 728 TFLOP/s, measured in round 1 with a leading-dimension sweep of tools/gemm_bench.py) */
-#define CPN_XIN_K      864
-#define CPN_XIN_STRIDE 896
 
 int         cpn_abi_version(void);
 const char* cpn_last_error(void);
@@ -57,7 +55,7 @@ const char* cpn_last_error(void);
  * get_z (hundreds of small launches) only overlap when each has CUs of its own: a stream created here is restricted
  * to CUs [first_cu, first_cu + num_cus) of the CU-mask order, which KFD spreads round-robin over the 8 XCDs and their
  * 4 shader engines — both numbers must be multiples of 32, i.e. an equal share of every shader engine of every XCD.  The persistent launchers of this library
- * (cpn_encode_hidden, cpn_gemm_f16*) size their grids by cpn_stream_cu_count(stream).  `stream_out` receives a
+ * (cpn_encode_key, cpn_gemm_f16*) size their grids by cpn_stream_cu_count(stream).  `stream_out` receives a
  * hipStream_t; destroy it with cpn_stream_destroy once its work has completed.  (coponerf_amd/streams.py, pipeline.py) */
 int cpn_device_cu_count(void);
 int cpn_stream_cu_count(void* stream);
@@ -99,15 +97,6 @@ int cpn_nchw_to_nhwc_f16(const float* src, uint16_t* dst, int N, int C, int h, i
 /* ---- pack a (N_out, K_in) fp32 weight into fp16 [N_out][ld] with zero padding (once per weight version) */
 int cpn_pack_weight_f16(const float* src, int n_out, int k_in, uint16_t* dst, int ld, void* stream);
 
-/* ---- K2: bilinear gathers -> encoder input rows ---------------------------------------------------
- * replaces F.grid_sample x4 'border' (CoPoNeRF.py:312), x4 'zeros' (CoPoNeRF.py:370) and the concatenations
- * (CoPoNeRF.py:384-394).  maps[l] are NHWC fp16, l = 0..3 with sizes (H/16, H/8, H/4, H) and 256,256,256,64 ch.
- * The rows of query rays [ray0, ray0+nrays) (ray = b*R + r) are written to xin (nrays*V*S*2, CPN_XIN_STRIDE) fp16:
- *   cols 0..831 features, 832..834 tanh(pt/5), 835..863 zero.                                                   */
-int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const uint16_t* map2, const uint16_t* map3,
-                    int H, int W, const float* pixel_val, const float* sec_grid, const float* pe6,
-                    int B, int V, int R, int S, int ray0, int nrays, uint16_t* xin, void* stream);
-
 /* ---- small fp32 first layers feeding the attention MLPs --------------------------------------------
  * out[row, 0:128] = fp16( relu( W[:, 0:16] . L(row) + bias + add[ray, 0:128] ) ),  rows = (b,r,v,s), ray = (b,r)
  * with L = [loc8 dir 3 | 0 0 0 | query dir 3 | loc8 depth 4 | query origin 3]      (CoPoNeRF.py:445)
@@ -115,29 +104,6 @@ int cpn_gather_rows(const uint16_t* map0, const uint16_t* map1, const uint16_t* 
  * query_repeat_embed (CoPoNeRF.py:472-473): w = weight[:, 128:144] (ld 144), add = weight[:, :128] . z_embed + 0 */
 int cpn_local_hidden(const float* loc8, const float* coords9, const float* w, int ldw, const float* bias,
                      const float* add, int B, int V, int R, int S, int ray0, int nrays, uint16_t* out, void* stream);
-
-/* key_map_2 + the attention logit in one pass (CoPoNeRF.py:408, 450): logits[m] = <fp16(A[m] . W^T + bias), Q[m]>,
- * N = 128 (one tile spans the row), A (M,lda), W (128,ldw), Q (M,ldq) fp16, logits (M) fp32                          */
-int cpn_gemm_f16_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* Q,
-                        int ldq, float* logits, int M, int N, int K, void* stream);
-
-/* key_map (folded) -> ReLU -> key_map_2 -> logit in one kernel (CoPoNeRF.py:404-408, 450):
- * logits[m] = < fp16( W2 . fp16(relu(A[m] . W^T + bias)) + bias2 ), Q[m] >, W (128,ldw), W2 (128,ldw2), Q (M,ldq) fp16  */
-int cpn_gemm_f16_chain_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
-                              const uint16_t* W2, int ldw2, const float* bias2, const uint16_t* Q, int ldq,
-                              float* logits, int M, int K, void* stream);
-
-/* both layers of query_embed / query_repeat_embed in one pass (CoPoNeRF.py:446, 472-473):
- * out[row, 0:128] = fp16( W2 . fp16(relu(W1[:, 0:16] . L(row) + b1 + add[ray])) + b2 ), W2 (128, ldw2) fp16 packed   */
-/* dot_with (rows,128) fp16 + logits_out (rows) fp32, both or neither: write <out[row], dot_with[row]> instead of out */
-/* rows_frag = 1 (round 4): `out` / `dot_with` are (rows, 128) fp16 matrices in FRAGMENT order - [16-row group][32-column block]
- * [lane = row + 16 * 8-column group][8 halves], the layout of this kernel's accumulators: every access of a wave is 1 KiB of
- * contiguous memory (row-major rows in that layout: 64 L1 tag look-ups per instruction).  The buffer holds whole groups of 16
- * rows.  cpn_gemm_f16_rowdot / _chain_rowdot read such a matrix as Q when ldq == 0.  0 = row-major (ld 128).                 */
-int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int ldw1, const float* b1,
-                  const float* add, const uint16_t* w2, int ldw2, const float* b2, int B, int V, int R, int S,
-                  int ray0, int nrays, uint16_t* out, const uint16_t* dot_with, float* logits_out, int rows_frag,
-                  void* stream);
 
 /* ---- K2+K3a: first encoder layer straight from the feature maps ("project, then interpolate") -------------------
  * hid = ReLU(query_encode_latent([primary/secondary gather (832) | tanh(pt/5) (3)])) without the gathered rows ever
@@ -156,33 +122,23 @@ int cpn_local_mlp(const float* loc8, const float* coords9, const float* w1, int 
  *   cpn_pack_encode_weights: W (832, ldw >= 835) fp32 query_encode_latent.weight ->
  *       wfrag (13*3*4*64*8 halves) MFMA A-operand fragments of W[:, 768:835] (K padded to 96)
  *       wtab  (832, 768) fp16 table projection weights W[:, 0:768]
- *   cpn_encode_hidden: hid (rays*V*S*2, 832) fp16 in the row order of this header; bias (832) fp32; map3 the
- *       full-resolution NHWC fp16 map (N, H, W, 64)                                                               */
+ *   the layer itself: cpn_encode_key below (until round 5 also as a kernel without the key layer, cpn_encode_hidden)  */
 #define CPN_TAB_LD    832
 #define CPN_NODE_PAD  4
 long long cpn_encode_table_nodes(int H, int W);
 int cpn_pack_encode_weights(const float* W, int ldw, uint16_t* wfrag, uint16_t* wtab, void* stream);
 int cpn_node_features(const uint16_t* map0, const uint16_t* map1, const uint16_t* map2, int H, int W, int nimg,
                       uint16_t* out, void* stream);
-/* cpn_gather_rows in fp32 (round 5; the reference-arithmetic mode RenderEngine(precision="f32")): maps NHWC fp32 (N,h,w,C), rows
- * (rays*V*S*2, ld >= 836, ld % 4 == 0) fp32 = 832 features | tanh(pt/5) (3) | zeros; F.grid_sample semantics and row order as
- * cpn_gather_rows (CoPoNeRF.py:312, 370, 384-394).                                                                     */
-int cpn_gather_rows_f32(const float* map0, const float* map1, const float* map2, const float* map3, int H, int W,
-                        const float* pixel_val, const float* sec_grid, const float* pe6, int B, int V, int R, int S,
-                        int ray0, int nrays, float* xin, int ld, void* stream);
-int cpn_encode_hidden(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
-                      const float* sec_grid, const float* pe6, const uint16_t* wfrag, const float* bias,
-                      int B, int V, int R, int S, int ray0, int nrays, uint16_t* hid, void* stream);
-/* cpn_encode_key (csrc/encode_fused.hip; round 5 form of round 4's kernel): cpn_encode_hidden with the folded key_map layer
+/* cpn_encode_key (csrc/encode_fused.hip; round 5 form of round 4's kernel): the first layer with the folded key_map layer
  * behind it (models/CoPoNeRF.py:404-407 after :387-397; folding: DESIGN.md 4.3) - the 64-channel slices of hid are the K panel
  * of the 1664 -> 128 contraction while they are still in registers, so the key path never reads hid back from HBM.
  *   kwring (2 images, 13 slices, 8 tiles, 2 k steps, 64 lanes = row + 16 * 8-column group, 8) fp16: the folded key matrix
  *       (Wk_a W2 | Wk_b W2) (128, 1664) in the order the kernel streams it through its two-slot LDS ring - piece (t, k) of slice
  *       step (j, n) holds, in lane (a, g), W'[16 t + a][832 j + 64 n + 32 k + 8 g .. +8]: every 1 KiB DMA piece is contiguous;
  *       kbias (128) fp32 = Wk_a b2 + Wk_b b2 + bk
- *   hid as for cpn_encode_hidden (still written: the two hidden sums read it); kh (rays*V*S, 128) fp16 =
- *       ReLU(W' . [hid_own ; hid_other] + kbias), rows in the order of this header - the A operand of cpn_gemm_f16_rowdot.
- *   hid and kh are bit-identical to cpn_encode_hidden + cpn_gemm_f16(W', relu).
+ *   hid (rays*V*S*2, 832) fp16 in the row order of this header (written: the two hidden sums read it); bias (832) fp32; map3 the
+ *       full-resolution NHWC fp16 map (N, H, W, 64); kh (rays*V*S, 128) fp16 = ReLU(W' . [hid_own ; hid_other] + kbias), rows in
+ *       the order of this header; kh is bit-identical to cpn_gemm_f16(hid, W', relu).
  *   kh_units = 1: kh leaves in UNIT order instead of row-major - the 16 rows of a unit (4 adjacent rays x 4 consecutive samples of
  *       one view; unit u of a launch = ((ray group - first group) * V + view) * ceil(S/4) + sample block, cpn_encode_units() of them)
  *       as [unit][32-column block p][lane = c + 16 fg][8] = kh[row(unit, c)][32 p + 8 fg .. +8], c = (sample & 3) * 4 + (ray & 3):
@@ -193,31 +149,17 @@ int cpn_encode_key(const uint16_t* tab, const uint16_t* map3, int H, int W, cons
                    const uint16_t* kwring, const float* kbias, int B, int V, int R, int S, int ray0, int nrays,
                    uint16_t* hid, uint16_t* kh, int kh_units, void* stream);
 long long cpn_encode_units(int B, int R, int S, int ray0, int nrays);
-/* cpn_encode_project (round 5, csrc/encode_fused.hip; "project before you store", opt-in): the same kernel with the folded
- * latent_value projection (models/CoPoNeRF.py:404) behind the first layer as well - hid never reaches HBM:
- *   val (rays*V*S, 416) fp16 = (Wv_a W2 | Wv_b W2) . [hid_own ; hid_other]   (the folded constant is added by cpn_attend_value)
- *   kh as above (bit-identical to cpn_encode_key's).
- *   wring (2 images, 13 slices, CPN_PROJECT_STEP_HALVES) fp16: per slice step the 34 x 2 weight fragments of the key (tiles
- *       0-7) and value (tiles 8-33) matrices in the piece order of kwring, then the slice's K = 80 block of the first layer
- *       (CPN_K80_BLOCK_HALVES fp16: its main fragments [k < 2][tile < 4][lane] half8 as in wfrag, then its tail fragments
- *       [tile < 4][48] half4 with the bias folded in as an fp16 (hi, lo) pair, zero pad): nothing is resident in LDS.    */
-#define CPN_K80_BLOCK_HALVES 5120
-#define CPN_PROJECT_STEP_HALVES (34 * 2 * 64 * 8 + CPN_K80_BLOCK_HALVES)
-int cpn_encode_project(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
-                       const float* sec_grid, const float* pe6, const uint16_t* wring, const float* kbias, int B, int V,
-                       int R, int S, int ray0, int nrays, uint16_t* kh, uint16_t* val, int kh_units, void* stream);
-
 /* ---- the per-sample query / key tails of the two attention rounds in UNIT order (round 5, csrc/local_units.hip) ------------
  * mode 0 (CoPoNeRF.py:408, 446, 450): ce = query_embed_2(ReLU(query_embed(local_coords))) -> ce_u (unit order, cpn_encode_units()
- *   * 16 rows); logits[row] = < fp16(key_map_2(kh_u[row])), fp16(ce[row]) >, kh_u = cpn_encode_key's unit-order output.  Replaces
- *   cpn_local_mlp + cpn_gemm_f16_rowdot.  w1 (128, ldw1 >= 16) fp32 / b1: first layer; w2 (128, ldw2) fp16 / b2: second layer;
+ *   * 16 rows); logits[row] = < fp16(key_map_2(kh_u[row])), fp16(ce[row]) >, kh_u = cpn_encode_key's unit-order output.
+ *   w1 (128, ldw1 >= 16) fp32 / b1: first layer; w2 (128, ldw2) fp16 / b2: second layer;
  *   wk2 (128, ldwk2) fp16 / bk2: key_map_2.
- * mode 1 (:472-475): logits[row] = < fp16(query_repeat_embed_2(ReLU(w1 . local_coords + b1 + add[ray]))), ce_u[row] >, add (nrays,
- *   128) fp32.  logits (nrays*V*S) fp32 in row order; rows of a partial unit that lie outside the ray range are skipped.
- * mode 2: mode 1 with coords_embed RECOMPUTED from the local coordinates instead of read back (the same instructions in the same
- *   order as mode 0 formed it with: the same logits, bit for bit): w1b (128, ldw1b >= 16) fp32 / b1b = query_embed, wk2 / bk2 =
+ * mode 2 (:472-475): logits[row] = < fp16(query_repeat_embed_2(ReLU(w1 . local_coords + b1 + add[ray]))), ce[row] >, add (nrays,
+ *   128) fp32, with coords_embed RECOMPUTED from the local coordinates (the same instructions in the same order as mode 0 formed
+ *   it with).  logits (nrays*V*S) fp32 in row order; rows of a partial unit outside the ray range are skipped.  w1b (128, ldw1b >= 16) fp32 / b1b = query_embed, wk2 / bk2 =
  *   query_embed_2; ce_u is not touched.  Mode 0 with ce_u = NULL then stores no coords_embed at all (2 x 256 bytes per sample
- *   less HBM traffic; both kernels were bound by it).  w1b / b1b are ignored by modes 0 and 1.
+ *   less HBM traffic; both kernels were bound by it).  w1b / b1b are ignored by mode 0.  (Mode 1 - round 2 reading a stored
+ *   coords_embed - left the library in round 6.)
  *   lv_u, optional (NULL: the kernel reads loc8 / coords9 itself): the unit-order copy of the rows' 16 first-layer inputs that
  *   cpn_sample_geometry writes for the WHOLE (B, R, S) problem - every mode then reads ONE coalesced 1 KiB line per unit instead
  *   of five scattered 4 - 16 byte accesses per lane (the same values: the same logits); the launch's units start at its first
@@ -241,33 +183,13 @@ int cpn_pack_gemm_frags(const uint16_t* W, int ldw, int N, int K, uint16_t* out,
 int cpn_gemm_f16_fewrows(const uint16_t* A, int lda, const uint16_t* Wp, const float* bias, float* C, int ldc, int M, int N,
                          int K, int relu, void* stream);
 
-/* ---- K4: joint softmax over (V*S) + weighted value sum, one query ray per workgroup ---------------
- * replaces einsum / softmax / broadcast-mul-sum (CoPoNeRF.py:450-461, 475-485).
- *   qa, qb (rays*V*S, 128) fp16: logit = <qa,qb> / 11.31 ; value (rays*V*S, 416) fp32
- *   zprev (rays,416) or NULL: added once PER VIEW before the views are summed, i.e. zout = sum_w value + V*zprev
- *     (the reference leaves the round-1 vector in both view slots, CoPoNeRF.py:481-485)
- *   at_wt (N,R,S) or NULL: softmax weights scattered to the (b,v,r,s) layout                                     */
-int cpn_attend(const uint16_t* qa, const uint16_t* qb, const float* value, const float* zprev,
-               int B, int V, int R, int S, int ray0, int nrays, float* zout, float* at_wt, void* stream);
-
 /* ---- K4': the same joint softmax, reducing the 1664 hidden activations [h_own ; h_other] of every sample ----
  * (value projection folded through query_encode_latent_2 and applied once per ray afterwards)
  *   hid (rays*V*S, 1664) fp16 = the (rows*2, 832) output of the first encoder layer; hbar (rays, 1664) fp16   */
 /*   logits (rays*V*S) fp32 or NULL: the row dot products <qa[row], qb[row]> when the producing kernel already
- *   formed them (cpn_gemm_f16_rowdot / cpn_local_mlp with logits_out); then qa, qb may be NULL                 */
+ *   formed them (cpn_local_units); then qa, qb may be NULL                                                     */
 int cpn_attend_hidden(const uint16_t* qa, const uint16_t* qb, const float* logits, const uint16_t* hid, int B, int V,
                       int R, int S, int ray0, int nrays, uint16_t* hbar, float* at_wt, void* stream);
-
-/* cpn_attend with fp32 query operands (qa, qb (rays*V*S, 128) fp32) - the reference-arithmetic mode, RenderEngine(precision="f32") */
-int cpn_attend_f32(const float* qa, const float* qb, const float* value, const float* zprev, int B, int V, int R, int S,
-                   int ray0, int nrays, float* zout, float* at_wt, void* stream);
-
-/* ---- K4'': the same joint softmax over the per-sample VALUES of cpn_encode_project (round 5) ----------------
- *   zout[ray] = sum_rows w[row] * val[row] + vbias (+ zprev_scale * zprev[ray] when zprev != NULL: round 2 adds V times the
- *   round-1 vector, CoPoNeRF.py:481-485);  val (rays*V*S, 416) fp16, vbias (416) fp32 = the folded constant
- *   Wv_a b2 + Wv_b b2 + bv, logits (rays*V*S) fp32, zout / zprev (rays, 416) fp32, at_wt (N,R,S) or NULL               */
-int cpn_attend_value(const float* logits, const uint16_t* val, const float* vbias, const float* zprev, float zprev_scale,
-                     int B, int V, int R, int S, int ray0, int nrays, float* zout, float* at_wt, void* stream);
 
 /* ---- K5: exact-fp32 per-ray linear layer (MFMA 16x16x4 f32)  Y = act_out( act_in(X) . W^T + bias + res ) --
  * replaces nn.Conv1d encode_latent (CoPoNeRF.py:468) and lightfield.ResnetFC (models/lightfield.py:131-167).
@@ -275,15 +197,11 @@ int cpn_attend_value(const float* logits, const uint16_t* val, const float* vbia
 int cpn_linear_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* res, int ldr,
                    float* Y, int ldy, int M, int N, int K, int relu_in, int relu_out, void* stream);
 
-/* ---- output masking: rgb = rgb*valid + (1-valid), valid = any_v overlaps (CoPoNeRF.py:562-566) ------ */
-int cpn_mask_rgb(const float* rgb_raw, int ld, const uint8_t* overlaps, int B, int V, int R,
-                 float* rgb, float* valid, void* stream);
-
 /* ---- the light-field decoder with the output masking, ONE launch (round 3) ---------------------------------
  * replaces lightfield.ResnetFC.forward (models/lightfield.py:131-167; ResnetBlockFC :52-61) on
  * [coords of view 0 | coords of view 1 | z_local ; z_local] (models/CoPoNeRF.py:547-560) and the white background of
  * rays no context view sees (:562-566).  Exact fp32 (v_mfma_f32_16x16x4_f32), same operation order as the
- * layer-by-layer cpn_linear_f32 chain + cpn_mask_rgb it supersedes on the inference path.
+ * layer-by-layer cpn_linear_f32 chain + masking pass it superseded on the inference path.
  *   coords9 (N,R,9)   z_local (B*R,416)   overlaps (N,R) uint8
  *   wpack: every weight matrix W[N][K] in MFMA FRAGMENT order (round 4) - [N/16][K/16][64 lanes][4]: lane l of fragment
  *          (t, kb) holds W[16 t + (l & 15)][16 kb + 4 (l >> 4) .. +4], so that a wave's load of one fragment is 1 KiB of
@@ -389,25 +307,20 @@ int cpn_wgrad_tall_f16(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, 
 int cpn_local_hidden_bwd(const uint16_t* ds, const uint16_t* out, const float* loc8, const float* coords9,
                          const float* scale, int B, int V, int R, int S, float* dW, float* db, float* dadd, void* stream);
 
-/* gradient of cpn_gather_rows w.r.t. the feature maps: dxin (rows, ldx) fp16 -> accumulated into dmap0..3
- * (N,h,w,C) fp32 NHWC, which the caller zeroes first.  No coordinate gradient (CoPoNeRF.py:380-381).
- * chunk_boxes: scratch of B*V*cpn_gather_bwd_chunks(R,S)*16 int32.                                                */
+/* gradient of the bilinear gather of the full-resolution level w.r.t. its map (F.grid_sample backward, CoPoNeRF.py:312, 370;
+ * no coordinate gradient, :380-381): the level's 64 gradient columns start at column col0 of dxin (rows, ldx) fp16; dmap3
+ * (N,H,W,64) fp32 NHWC accumulated (caller zeroes); chunk_boxes: scratch of B*V*cpn_gather_bwd_chunks(R,S)*16 int32.     */
 long long cpn_gather_bwd_chunks(int R, int S);
-int cpn_gather_rows_bwd(const uint16_t* dxin, int ldx, int H, int W, const float* pixel_val, const float* sec_grid,
-                        int B, int V, int R, int S, int ray0, int nrays,
-                        float* dmap0, float* dmap1, float* dmap2, float* dmap3, int32_t* chunk_boxes, void* stream);
-/* the full-resolution level alone: its 64 gradient columns start at column col0 of dxin (rows, ldx); dmap3 (N,H,W,64) fp32
- * accumulated (caller zeroes); chunk_boxes as above.                                                                 */
 int cpn_gather_rows_bwd_level3(const uint16_t* dxin, int ldx, int col0, int H, int W, const float* pixel_val,
                                const float* sec_grid, int B, int V, int R, int S, int ray0, int nrays, float* dmap3,
                                int32_t* chunk_boxes, void* stream);
 
-/* ---- backward of cpn_encode_hidden in its table form (round 3, csrc/encode_bwd.hip) ---------------------------------
+/* ---- backward of the first encoder layer in its table form (round 3, csrc/encode_bwd.hip) ---------------------------------
  * The layer is hid = ReLU(sum_t a_t T[node_t] + W[:,768:835].[gather_3 | tanh(pt/5)] + b) with T = node_features . W[:,:768]^T
  * (replaces autograd through models/CoPoNeRF.py:312, 370, 384-397 for training).  d (rows, ldx >= 832) fp16 = gradient
  * of the pre-activation (ReLU mask applied, carrying the pass's power-of-two scale).
  *   cpn_scatter_rows_tables: dtab (N * cpn_encode_table_nodes(H,W), 832) fp32, ZERO on entry, += a_t * d[row] at the four
- *       nodes of every row (own image -> border table, other image -> zeros table; the taps of cpn_encode_hidden).
+ *       nodes of every row (own image -> border table, other image -> zeros table; the taps of cpn_encode_key).
  *       scratch: cpn_scatter_tables_scratch(H,W,B,V,R,S) int32, 16-byte aligned (bucket counters, work list and one
  *       16-byte descriptor per (row, tile it touches): the rows are counting-sorted by 8x4-node tile first).
  *   cpn_node_features_bwd: adjoint of cpn_node_features: dfeat (nodes, 768) fp32 -> dmap0..2 (N,h,w,256) fp32 NHWC,

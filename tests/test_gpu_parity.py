@@ -87,22 +87,6 @@ def ref_keys():
             "rel_pose_flip", "gt_rel_pose", "gt_rel_pose_flip"]
 
 
-def test_layer_by_layer_mode_matches_folded_mode(model, dev, weights):
-    """RenderEngine(fold_value=False) evaluates query_encode_latent_2 / latent_value / key_map per sample exactly as
-    the reference orders them; the default folded evaluation must agree with it and with the oracle."""
-    cfg, gold = load_case("c1_val")
-    ref, out_fold = run_pair(model, dev, weights, cfg)
-    model._engine.fold_value = False
-    try:
-        _, out_plain = run_pair(model, dev, weights, cfg)
-    finally:
-        model._engine.fold_value = True
-    assert torch.equal(out_plain["pixel_val"], out_fold["pixel_val"])
-    assert (out_plain["rgb"] - out_fold["rgb"]).abs().max() <= 5e-4
-    assert (out_plain["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
-    assert (out_plain["at_wt"] - out_fold["at_wt"]).abs().max() <= 1e-3
-
-
 def test_stage_intermediates(model, dev, weights):
     """inter fixture: gathers / encoder / attention stages against the oracle AND the upstream intermediates."""
     cfg, gold = load_case("inter")
@@ -112,57 +96,6 @@ def test_stage_intermediates(model, dev, weights):
     assert (core["rgb_raw"].cpu() - torch.from_numpy(gold["rgb_raw"]).reshape(-1, 3)).abs().max() <= RGB_TOL
     gpt = torch.from_numpy(gold["pt"])      # near-parallel lines: |pt| up to ~1e3, error grows with magnitude
     assert ((core["pt"].cpu() - gpt).abs() / (1 + gpt.abs())).max() <= 2e-4
-
-
-def test_rows_in_fragment_order_are_the_same_numbers(model, dev, weights):
-    """coords_embed in fragment order (cpn_local_mlp rows_frag = 1; cpn_gemm_f16_rowdot with ldq = 0): the writer's output is the
-    row-major output permuted, both readers' logits are bit-identical to the row-major ones, and the render call gives the same
-    image with COPONERF_CE_FRAG on and off."""
-    from coponerf_amd._hip import call
-    cfg, _ = load_case("wide_val")
-    inp, z, rel, flow = case_inputs(cfg)
-    B, H, R, S, V = cfg["B"], cfg["H"], cfg["R"], cfg["S"], 2
-    eng = model._engine
-    model.npoints = S
-    w = eng._weights(model._render_params())
-    ctx, qry = to_device(inp["context"], dev), to_device(inp["query"], dev)
-    g = eng._geometry(ctx["cam2world"], ctx["intrinsics"], qry["cam2world"], qry["intrinsics"], qry["uv"], rel.to(dev), cfg["val"], S, H, H)
-    s = torch.cuda.current_stream().cuda_stream
-    n = B * R
-    rows = n * V * S
-    assert rows % 16 == 0
-    dp = lambda t: t.data_ptr()
-    ce = {f: torch.full((rows, 128), float("nan"), dtype=torch.float16, device=dev) for f in (0, 1)}
-    for f in (0, 1):
-        call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
-             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), B, V, R, S, 0, n, dp(ce[f]), 0, 0, f, s)
-    # [16-row group][32-column block][lane = row + 16 * 8-column group][8]  ->  rows x 128
-    from coponerf_amd.render import rows_from_frag_order
-    unpacked = rows_from_frag_order(ce[1], rows)
-    assert torch.equal(unpacked, ce[0])
-    addq = torch.randn(n, 128, device=dev)
-    kh = (torch.randn(rows, 128, device=dev) * 0.5).half()
-    lg = {}
-    for f in (0, 1):
-        a, b = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
-        call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]), dp(addq),
-             dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), B, V, R, S, 0, n, 0, dp(ce[f]), dp(a), f, s)
-        call("cpn_gemm_f16_rowdot", dp(kh), 128, dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), dp(ce[f]), 0 if f else 128, dp(b),
-             rows, 128, 128, s)
-        lg[f] = (a, b)
-    assert torch.equal(lg[0][0], lg[1][0]) and torch.equal(lg[0][1], lg[1][1])
-    old, old_u = eng.ce_frag, eng.unit_order
-    eng.unit_order = False                                  # (the unit-order stages do not pass through these kernels)
-    try:
-        outs = {}
-        for f in (True, False):
-            eng.ce_frag = f
-            with torch.no_grad():
-                outs[f] = model(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=cfg["val"], flow=to_device(flow, dev))
-        for k in ("rgb", "at_wt"):
-            assert torch.equal(outs[True][k], outs[False][k]), k
-    finally:
-        eng.ce_frag, eng.unit_order = old, old_u
 
 
 def test_gemm_f16_against_torch(dev):
@@ -243,48 +176,6 @@ def test_linear_f32_against_torch(dev):
         assert (Y - want).abs().max() <= 1e-4
 
 
-def test_gather_against_grid_sample(dev):
-    """cpn_gather_rows vs ATen grid_sample on fp16-rounded maps: border + zeros padding, huge coordinates."""
-    from coponerf_amd._hip import call
-    from oracle.render_ref import gather_levels
-    torch.manual_seed(2)
-    B, V, R, S, H = 1, 2, 8, 16, 64
-    N = B * V
-    z = [torch.randn(N, 256, H // 16, H // 16), torch.randn(N, 256, H // 8, H // 8),
-         torch.randn(N, 256, H // 4, H // 4), torch.randn(N, 64, H, H)]
-    z = [t.half().float() for t in z]
-    pv = torch.rand(N, R, S, 2) * 2.4 - 1.2
-    sg = torch.rand(N, R, S, 2) * 3 - 1.5
-    sg[0, 0, 0] = torch.tensor([1e10, -1e10])
-    sg[1, 0, 1] = torch.tensor([-1.0, 1.0])
-    pe = torch.rand(N, R, S, 6)
-    s = torch.cuda.current_stream().cuda_stream
-    maps = []
-    for t in z:
-        n, c, h, w = t.shape
-        d = torch.empty(n, h, w, c, dtype=torch.float16, device=dev)
-        src = t.to(dev).contiguous()
-        call("cpn_nchw_to_nhwc_f16", src.data_ptr(), d.data_ptr(), n, c, h, w, s)
-        assert torch.equal(d.float().cpu(), t.permute(0, 2, 3, 1))
-        maps.append(d)
-    xin = torch.zeros(B * R * V * S * 2, 896, dtype=torch.float16, device=dev)
-    pvd, sgd, ped = pv.to(dev), sg.to(dev), pe.to(dev)
-    call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, H,
-         pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(), B, V, R, S, 0, B * R, xin.data_ptr(), s)
-    got = xin.float().cpu().view(B, R, V, S, 2, 896)
-    prim = gather_levels(z, pv, "border").view(B, V, R, S, 832)
-    # secondary of view v: OTHER image sampled at view v's reprojected coordinates
-    z_swapped = [t.view(B, V, *t.shape[1:]).flip(1).reshape(t.shape) for t in z]
-    sec = gather_levels(z_swapped, sg, "zeros").view(B, V, R, S, 832)
-    for v in range(V):
-        assert (got[:, :, v, :, 0, :832] - prim[:, v]).abs().max() <= 4e-3
-        assert (got[:, :, v, :, 1, :832] - sec[:, v]).abs().max() <= 4e-3
-        pe5 = pe.view(B, V, R, S, 6)
-        assert (got[:, :, v, :, 0, 832:835] - pe5[:, v, :, :, 0:3]).abs().max() <= 1e-3
-        assert (got[:, :, v, :, 1, 832:835] - pe5[:, v, :, :, 3:6]).abs().max() <= 1e-3
-    assert got[..., 835:864].abs().max() == 0
-
-
 def test_full_size_properties(model, dev, weights):
     """BASELINE config-2 sizes (256x256, S=64): size-independent properties instead of an oracle run."""
     H, S, R = 256, 64, 8192
@@ -362,10 +253,23 @@ def test_missing_library_is_loud(monkeypatch):
 # ------------------------------------------------------------------------------------------------------------------
 # round 2: the projected-table form of the first encoder layer (csrc/encode.hip) and the parity holes of round 1
 # ------------------------------------------------------------------------------------------------------------------
+def _encode_first_layer(dev, geo_args, frag, b1d, B, V, R, S, ray0, nrays, hid):
+    """hid of the first encoder layer through cpn_encode_key (the library's only form of the layer since round 6) with a ZERO key
+    layer behind it; returns kh (= ReLU(0) = 0 everywhere it was written)."""
+    from coponerf_amd._hip import call
+    ring = torch.zeros(2 * 13 * 8 * 2 * 64 * 8, dtype=torch.float16, device=dev)
+    kb = torch.zeros(128, device=dev)
+    kh = torch.full((nrays * V * S + 16, 128), -1.0, dtype=torch.float16, device=dev)
+    call("cpn_encode_key", *geo_args, frag.data_ptr(), b1d.data_ptr(), ring.data_ptr(), kb.data_ptr(), B, V, R, S, ray0, nrays,
+         hid.data_ptr(), kh.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    assert bool((kh[:nrays * V * S] == 0).all()) and bool((kh[nrays * V * S:] == -1).all())
+    return kh
+
+
 def test_encode_hidden_against_torch(dev):
-    """cpn_encode_hidden (node tables + K=96 MFMA) vs grid_sample + fp32 linear layer on the same fp16-rounded maps, and
-    vs the gather + GEMM form (cpn_gather_rows + cpn_gemm_f16); border + zeros padding, huge / on-texel / rim
-    coordinates, ray and sample counts that do not fill the 4-ray x 16-sample tiles."""
+    """The first encoder layer on the node tables (cpn_encode_key: tables + K = 80 MFMA) vs grid_sample + the layer in float64 on
+    the same fp16-rounded maps; border + zeros padding, huge / on-texel / rim coordinates, ray and sample counts that do not
+    fill the 4-ray x 4-sample units."""
     from coponerf_amd import _hip
     from coponerf_amd._hip import call
     from oracle.render_ref import gather_levels
@@ -410,17 +314,8 @@ def test_encode_hidden_against_torch(dev):
     pvd, sgd, ped = pv.to(dev), sg.to(dev), pe.to(dev)
     rows = B * R * V * S * 2
     hid = torch.full((rows, 832), float("nan"), dtype=torch.float16, device=dev)
-    call("cpn_encode_hidden", tab.data_ptr(), maps[3].data_ptr(), H, H, pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(),
-         frag.data_ptr(), b1d.data_ptr(), B, V, R, S, 0, B * R, hid.data_ptr(), s)
-    # ---- the gather + GEMM form on the same inputs
-    xin = torch.zeros(rows, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
-    call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, H,
-         pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(), B, V, R, S, 0, B * R, xin.data_ptr(), s)
-    W16 = torch.empty(832, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
-    call("cpn_pack_weight_f16", W1d.data_ptr(), 832, 835, W16.data_ptr(), _hip.XIN_STRIDE, s)
-    hid_g = torch.empty(rows, 832, dtype=torch.float16, device=dev)
-    call("cpn_gemm_f16", xin.data_ptr(), _hip.XIN_STRIDE, W16.data_ptr(), _hip.XIN_STRIDE, b1d.data_ptr(),
-         hid_g.data_ptr(), 832, rows, 832, _hip.XIN_K, 1, 0, s)
+    _encode_first_layer(dev, (tab.data_ptr(), maps[3].data_ptr(), H, H, pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr()), frag, b1d,
+                        B, V, R, S, 0, B * R, hid)
     # ---- fp32 reference: grid_sample on the fp16-rounded maps, then the layer in float64
     prim = gather_levels(z, pv, "border").view(B, V, R, S, 832)
     z_swapped = [t.view(B, V, *t.shape[1:]).flip(1).reshape(t.shape) for t in z]
@@ -429,15 +324,13 @@ def test_encode_hidden_against_torch(dev):
     x = torch.stack((torch.cat((prim, pe5[..., 0:3]), -1), torch.cat((sec, pe5[..., 3:6]), -1)), dim=4)   # (B,V,R,S,2,835)
     x = x.permute(0, 2, 1, 3, 4, 5).reshape(rows, 835)                                                     # row order
     want = torch.relu(x.double() @ W1.double().t() + b1.double()).float()
-    got, got_g = hid.float().cpu(), hid_g.float().cpu()
+    got = hid.float().cpu()
     assert torch.isfinite(got).all()
     scale = float(want.abs().max())
     assert (got - want).abs().max() <= 4e-3 * max(1.0, scale), float((got - want).abs().max())
-    assert (got_g - want).abs().max() <= 4e-3 * max(1.0, scale)
-    # the two forms round differently (one fp16 rounding per table tap vs one per channel) but to the same accuracy
-    e_t = float((got - want).pow(2).mean().sqrt())
-    e_g = float((got_g - want).pow(2).mean().sqrt())
-    assert e_t <= 1.5 * e_g + 1e-5, (e_t, e_g)
+    # fp16 node features, fp16 table entries, fp16 K = 80 operands, fp16 output: rms 3e-4 of the largest value (the gather + GEMM
+    # form of rounds 1-5 - one rounding per channel instead of one per table tap - measured the same)
+    assert float((got - want).pow(2).mean().sqrt()) <= 5e-4 * max(1.0, scale)
 
 
 @pytest.mark.gpu
@@ -450,15 +343,17 @@ def test_encode_hidden_against_torch(dev):
     (1, 130, 8, 1, 127),        # more than 8 workgroups' worth of wave tiles, odd ends
 ])
 def test_encode_hidden_ragged_ranges(B, R, S, ray0, nrays, dev):
-    """cpn_encode_hidden on ray sub-ranges / shapes that leave wave tiles partly dead: rows inside the range equal the
-    gather + GEMM form (same fp16 inputs, two valid roundings apart), rows outside it are not written at all."""
+    """The first layer (cpn_encode_key) on ray sub-ranges / shapes that leave units partly dead: rows inside the range equal
+    grid_sample + the layer in float64 on the same fp16-rounded maps, rows outside it are not written at all."""
     from coponerf_amd import _hip
     from coponerf_amd._hip import call
+    from oracle.render_ref import gather_levels
     g = torch.Generator().manual_seed(1000 * B + 10 * R + S)
     V, H = 2, 32
     N = B * V
     z = [torch.randn(N, 256, H // 16, H // 16, generator=g), torch.randn(N, 256, H // 8, H // 8, generator=g),
          torch.randn(N, 256, H // 4, H // 4, generator=g), torch.randn(N, 64, H, H, generator=g)]
+    z = [t.half().float() for t in z]
     pv = torch.rand(N, R, S, 2, generator=g) * 2.4 - 1.2
     sg = torch.rand(N, R, S, 2, generator=g) * 3 - 1.5
     pe = torch.rand(N, R, S, 6, generator=g) * 2 - 1
@@ -487,69 +382,22 @@ def test_encode_hidden_ragged_ranges(B, R, S, ray0, nrays, dev):
     rows = nrays * V * S * 2                                   # the chunk's rows only (row 0 = ray0)
     guard = 64                                                 # canary rows behind the chunk
     hid = torch.full((rows + guard, 832), float("nan"), dtype=torch.float16, device=dev)
-    call("cpn_encode_hidden", tab.data_ptr(), maps[3].data_ptr(), H, H, pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(),
-         frag.data_ptr(), b1d.data_ptr(), B, V, R, S, ray0, nrays, hid.data_ptr(), s)
-    xin = torch.zeros(rows, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
-    call("cpn_gather_rows", maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(), H, H,
-         pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr(), B, V, R, S, ray0, nrays, xin.data_ptr(), s)
-    W16 = torch.empty(832, _hip.XIN_STRIDE, dtype=torch.float16, device=dev)
-    call("cpn_pack_weight_f16", W1d.data_ptr(), 832, 835, W16.data_ptr(), _hip.XIN_STRIDE, s)
-    hid_g = torch.empty(rows, 832, dtype=torch.float16, device=dev)
-    call("cpn_gemm_f16", xin.data_ptr(), _hip.XIN_STRIDE, W16.data_ptr(), _hip.XIN_STRIDE, b1d.data_ptr(),
-         hid_g.data_ptr(), 832, rows, 832, _hip.XIN_K, 1, 0, s)
+    _encode_first_layer(dev, (tab.data_ptr(), maps[3].data_ptr(), H, H, pvd.data_ptr(), sgd.data_ptr(), ped.data_ptr()), frag, b1d,
+                        B, V, R, S, ray0, nrays, hid)
     torch.cuda.synchronize()
-    got, ref = hid[:rows].float().cpu(), hid_g.float().cpu()
+    prim = gather_levels(z, pv, "border").view(B, V, R, S, 832)
+    z_swapped = [t.view(B, V, *t.shape[1:]).flip(1).reshape(t.shape) for t in z]
+    sec = gather_levels(z_swapped, sg, "zeros").view(B, V, R, S, 832)
+    pe5 = pe.view(B, V, R, S, 6)
+    x = torch.stack((torch.cat((prim, pe5[..., 0:3]), -1), torch.cat((sec, pe5[..., 3:6]), -1)), dim=4)   # (B,V,R,S,2,835)
+    x = x.permute(0, 2, 1, 3, 4, 5).reshape(B * R, V * S * 2, 835)[ray0:ray0 + nrays].reshape(rows, 835)    # the chunk's rows
+    ref = torch.relu(x.double() @ W1.double().t() + b1.double()).float()
+    got = hid[:rows].float().cpu()
     assert torch.isfinite(got).all(), "rows of the chunk left unwritten"
     assert torch.isnan(hid[rows:].float()).all(), "wrote past the chunk"
     scale = max(1.0, float(ref.abs().max()))
     assert float((got - ref).abs().max()) <= 6e-3 * scale, float((got - ref).abs().max())
-    assert float((got - ref).pow(2).mean().sqrt()) <= 4e-4 * scale
-
-
-def test_table_mode_matches_gather_mode(model, dev, weights):
-    """RenderEngine(tables=False) materialises the gathered 835-channel rows and runs the 835 -> 832 GEMM on them
-    (round-1 form, still what the training pass differentiates); the default projected-table form must agree with it
-    and both with the oracle, on the narrow and the wide rig."""
-    for name in ("c1_val", "wide_val"):
-        cfg, gold = load_case(name)
-        ref, out_tab = run_pair(model, dev, weights, cfg)
-        model._engine.tables = False
-        try:
-            _, out_gat = run_pair(model, dev, weights, cfg)
-        finally:
-            model._engine.tables = True
-        assert torch.equal(out_tab["pixel_val"], out_gat["pixel_val"])
-        assert (out_tab["rgb"] - out_gat["rgb"]).abs().max() <= 5e-4
-        assert (out_tab["at_wt"] - out_gat["at_wt"]).abs().max() <= 1e-3
-        for o in (out_tab, out_gat):
-            assert (o["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
-            assert (o["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max() <= RGB_TOL
-
-
-def test_fused_key_mode_matches_separate_key_mode(model, dev, weights):
-    """cpn_encode_key (the folded key_map contraction on the slices of hid while they are in registers, then
-    cpn_gemm_f16_rowdot) against the round-3 order (cpn_encode_hidden, then cpn_gemm_f16_chain_rowdot reading hid back):
-    same fp16 operands, same k order of the MFMA accumulation -> the attention weights and the image must agree to
-    rounding of the last bits, on every fixture case incl. the ragged one (dead rows / dead units at the end of a range)
-    and a ray count that leaves the last iteration of most workgroups without a live unit."""
-    for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
-        cfg, gold = load_case(name)
-        assert model._engine.fuse_key
-        ref, out_f = run_pair(model, dev, weights, cfg)
-        model._engine.fuse_key = False
-        try:
-            _, out_s = run_pair(model, dev, weights, cfg)
-        finally:
-            model._engine.fuse_key = True
-        assert torch.equal(out_f["pixel_val"], out_s["pixel_val"])
-        d_wt = float((out_f["at_wt"] - out_s["at_wt"]).abs().max())
-        d_rgb = float((out_f["rgb"] - out_s["rgb"]).abs().max())
-        print(name, "fused vs separate key path: at_wt", d_wt, "rgb", d_rgb,
-              "rgb vs oracle", float((out_f["rgb"].cpu() - ref["rgb"]).abs().max()))
-        assert d_wt <= 1e-5 and d_rgb <= 2e-5, (name, d_wt, d_rgb)
-        assert (out_f["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
-        assert (out_f["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max() <= RGB_TOL
-        assert (out_f["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
+    assert float((got - ref).pow(2).mean().sqrt()) <= 5e-4 * scale
 
 
 def _encode_entry_setup(model, dev, cfg):
@@ -567,9 +415,9 @@ def _encode_entry_setup(model, dev, cfg):
 
 def test_encode_key_entry_is_bit_identical(model, dev, weights):
     """The C entry itself: cpn_encode_key (csrc/encode_fused.hip: several units per wave, the taps of slice n + 1 issued before
-    the key MFMAs of slice n) writes the same bits of hid as cpn_encode_hidden and the same kh as cpn_gemm_f16 on that hid —
-    on a ragged chunk (ray0 > 0, a ray count that is no multiple of 4, dead units at the end of most workgroups' ranges)
-    and on a whole fixture case."""
+    the key MFMAs of slice n) writes the same kh as cpn_gemm_f16 on the hid it wrote, bit for bit, in row order and in unit
+    order — on a ragged chunk (ray0 > 0, a ray count that is no multiple of 4, dead units at the end of most workgroups'
+    ranges) and on a whole fixture case; nothing is written past the chunk."""
     from coponerf_amd._hip import call
     cfg, _ = load_case("wide_val")
     B, R, S, V = cfg["B"], cfg["R"], cfg["S"], 2
@@ -577,18 +425,15 @@ def test_encode_key_entry_is_bit_identical(model, dev, weights):
     s = torch.cuda.current_stream().cuda_stream
     for ray0, n in ((7, R - 18), (0, B * R), (R - 3, 5 if B > 1 else 3)):
         rows2 = n * V * S * 2
-        hid_ref = torch.full((rows2, 832), -1.0, dtype=torch.float16, device=dev)
-        call("cpn_encode_hidden", *geo, w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(), B, V, R, S, ray0, n,
-             hid_ref.data_ptr(), s)
-        kh_ref = torch.empty(rows2 // 2, 128, dtype=torch.float16, device=dev)
-        call("cpn_gemm_f16", hid_ref.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664, w["key_fold.b"].data_ptr(), kh_ref.data_ptr(), 128,
-             rows2 // 2, 128, 1664, 1, 0, s)
-        assert int((hid_ref == -1).sum()) == 0
         hid = torch.full((rows2 + 64, 832), -1.0, dtype=torch.float16, device=dev)        # + a guard band behind the chunk
         kh = torch.full((rows2 // 2 + 64, 128), -1.0, dtype=torch.float16, device=dev)
         call("cpn_encode_key", *geo, w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(), w["key_fold.wpk"].data_ptr(),
              w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, hid.data_ptr(), kh.data_ptr(), 0, s)
-        assert torch.equal(hid[:rows2], hid_ref), (ray0, n, int((hid[:rows2] != hid_ref).sum()))
+        hid_ref = hid[:rows2].clone()
+        assert int((hid_ref == -1).sum()) == 0
+        kh_ref = torch.empty(rows2 // 2, 128, dtype=torch.float16, device=dev)
+        call("cpn_gemm_f16", hid_ref.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664, w["key_fold.b"].data_ptr(), kh_ref.data_ptr(), 128,
+             rows2 // 2, 128, 1664, 1, 0, s)
         assert torch.equal(kh[:rows2 // 2], kh_ref), (ray0, n, int((kh[:rows2 // 2] != kh_ref).sum()))
         assert bool((hid[rows2:] == -1).all()) and bool((kh[rows2 // 2:] == -1).all()), "wrote past the chunk"
         # kh_units = 1: the same numbers in UNIT order (what cpn_local_units reads as MFMA B fragments); units * 16 row slots
@@ -604,224 +449,6 @@ def test_encode_key_entry_is_bit_identical(model, dev, weights):
         assert torch.equal(hid[:rows2], hid_ref)
         assert torch.equal(rows_from_unit_order(khu, B, R, S, ray0, n), kh_ref)
         assert bool((khu[units * 16:] == -1).all()), "wrote past the unit-order buffer"
-
-
-def test_encode_project_entry_against_hidden_path(model, dev, weights):
-    """cpn_encode_project ("project before you store"): kh must be the bits of cpn_encode_key's, val (rows, 416) fp16 must agree with
-    the fp32 product of the SAME fp16 operands (hid of cpn_encode_hidden . value_fold^T) to fp16 rounding of the result; ragged
-    chunk and whole case; nothing is written past the chunk."""
-    from coponerf_amd._hip import call
-    from coponerf_amd.render import pack_k80_blocks, pack_project_ring
-    cfg, _ = load_case("wide_val")
-    B, R, S, V = cfg["B"], cfg["R"], cfg["S"], 2
-    w, geo, keep = _encode_entry_setup(model, dev, cfg)
-    ring = pack_project_ring(w["key_fold.w16"], w["value_fold.w16"], pack_k80_blocks(w["enc.frag"], w["query_encode_latent.b"]))
-    assert ring.shape == (2, 13, 34 * 2 * 64 * 8 + 5120)
-    s = torch.cuda.current_stream().cuda_stream
-    for ray0, n in ((7, R - 18), (0, B * R)):
-        rows = n * V * S
-        hid_ref = torch.empty(rows * 2, 832, dtype=torch.float16, device=dev)
-        call("cpn_encode_hidden", *geo, w["enc.frag"].data_ptr(), w["query_encode_latent.b"].data_ptr(), B, V, R, S, ray0, n,
-             hid_ref.data_ptr(), s)
-        kh_ref = torch.empty(rows, 128, dtype=torch.float16, device=dev)
-        call("cpn_gemm_f16", hid_ref.data_ptr(), 1664, w["key_fold.w16"].data_ptr(), 1664, w["key_fold.b"].data_ptr(), kh_ref.data_ptr(), 128,
-             rows, 128, 1664, 1, 0, s)
-        val_ref = hid_ref.view(rows, 1664).float() @ w["value_fold.w16"].float().t()
-        kh = torch.full((rows + 64, 128), -1.0, dtype=torch.float16, device=dev)
-        val = torch.full((rows + 64, 416), -7.0, dtype=torch.float16, device=dev)
-        call("cpn_encode_project", *geo, ring.data_ptr(), w["key_fold.b"].data_ptr(), B, V, R, S, ray0, n, kh.data_ptr(), val.data_ptr(), 0, s)
-        assert torch.equal(kh[:rows], kh_ref), int((kh[:rows] != kh_ref).sum())
-        err = (val[:rows].float() - val_ref).abs()
-        scale = float(val_ref.abs().max())
-        print("project: val max |err|", float(err.max()), "of", scale)
-        assert float(err.max()) <= 1.5e-3 * max(1.0, scale)                 # fp16 rounding of the stored value (+ accumulation order)
-        assert float(err.pow(2).mean().sqrt()) <= 2e-4 * max(1.0, scale)
-        assert bool((kh[rows:] == -1).all()) and bool((val[rows:] == -7).all()), "wrote past the chunk"
-
-
-def test_unit_order_logit_kernels_against_row_order_kernels(model, dev, weights):
-    """cpn_local_units (round 5: coords_embed + key_map_2 + round-1 logit in one kernel on the unit-order kh; round-2 logit on the
-    unit-order coords_embed) against the kernels it replaces (cpn_local_mlp, cpn_gemm_f16_rowdot) on a ragged chunk (ray0 > 0,
-    ray count no multiple of 4: partial units at both ends): coords_embed and both logits agree to an fp16 ulp of single terms, rows outside the range are left alone."""
-    from coponerf_amd import _hip
-    from coponerf_amd._hip import call
-    from coponerf_amd.render import rows_from_unit_order, unit_rows
-    cfg, _ = load_case("wide_val")
-    B, R, S, V = cfg["B"], cfg["R"], cfg["S"], 2
-    w, geo, (maps, tabs, g) = _encode_entry_setup(model, dev, cfg)
-    s = torch.cuda.current_stream().cuda_stream
-    dp = lambda t: t.data_ptr()
-    # the unit-order copy of the rows' inputs (cpn_sample_geometry's optional output, the whole problem): against the same
-    # values placed by torch from loc8 / coords9, bit for bit; slots of rays / samples that do not exist are written as zeros
-    gpb, nsb = (R + 3) // 4, (S + 3) // 4
-    lvu = torch.full((B * gpb * V * nsb * 64, 4), -3.0, device=dev)
-    scratch = {k: torch.empty_like(g[k]) for k in ("pixel_val", "pt", "sec_grid", "pe6", "loc8")}
-    call("cpn_sample_geometry", dp(g["host"]["cam"]), dp(g["coords9"]), dp(g["seg"]), dp(model._engine._interval[(S, str(dev))]),
-         B, V, R, S, cfg["H"], cfg["H"], dp(scratch["pixel_val"]), dp(scratch["pt"]), dp(scratch["sec_grid"]), dp(scratch["pe6"]),
-         dp(scratch["loc8"]), dp(lvu), s)
-    assert all(torch.equal(scratch[k], g[k]) for k in scratch)
-    l8, c9 = g["loc8"].view(B, V, R, S, 8), g["coords9"].view(B, V, R, 1, 9).expand(B, V, R, S, 9)
-    one, zero = torch.ones_like(l8[..., :1]), torch.zeros_like(l8[..., :1])
-    lv16 = torch.cat((l8[..., 0:3], one, zero, zero, c9[..., 0:2], c9[..., 2:3], l8[..., 3:6], l8[..., 6:7], c9[..., 6:9]), dim=-1)
-    want = torch.zeros((B, gpb, V, nsb, 4, 4, 4, 4), device=dev)                  # [b][group][v][sblk][fg][s & 3][r & 3][4]
-    rp, sp = gpb * 4, nsb * 4
-    full = torch.full((B, V, rp, sp, 16), float("nan"), device=dev)
-    full[:, :, :R, :S] = lv16
-    live = torch.zeros(B, V, rp, sp, dtype=torch.bool, device=dev)
-    live[:, :, :R, :S] = True
-    arr = full.view(B, V, gpb, 4, nsb, 4, 4, 4).permute(0, 2, 1, 4, 6, 5, 3, 7)   # -> [b][group][v][sblk][fg][s&3][r&3][4]
-    lmask = live.view(B, V, gpb, 4, nsb, 4).permute(0, 2, 1, 4, 5, 3)[:, :, :, :, None, :, :, None].expand_as(arr)
-    want = torch.where(lmask, arr, want)
-    assert torch.equal(lvu.view_as(want), want), "unit-order inputs differ from loc8 / coords9"
-    for ray0, n in ((7, R - 18), (0, B * R), (R - 3, 5 if B > 1 else 3)):
-        rows = n * V * S
-        units = int(_hip.lib().cpn_encode_units(B, R, S, ray0, n))
-        kh = (torch.randn(rows, 128, device=dev) * 0.5).half()
-        idx = unit_rows(B, R, S, ray0, n, dev)
-        khu = torch.zeros(units * 16, 128, dtype=torch.float16, device=dev)
-        tmp = torch.zeros(units * 16, 128, dtype=torch.float16, device=dev)
-        tmp[idx >= 0] = kh[idx[idx >= 0]]
-        khu.view(units, 4, 4, 16, 8).copy_(tmp.view(units, 16, 4, 4, 8).permute(0, 2, 3, 1, 4))       # rows -> [unit][p][fg][c][8]
-        assert torch.equal(rows_from_unit_order(khu, B, R, S, ray0, n), kh)
-        addq = torch.randn(n, 128, device=dev)
-        # the round-4 kernels
-        ce_r = torch.empty((rows + 15) // 16 * 16, 128, dtype=torch.float16, device=dev)
-        call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
-             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), B, V, R, S, ray0, n, dp(ce_r), 0, 0, 0, s)
-        lg1_r, lg2_r = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
-        call("cpn_gemm_f16_rowdot", dp(kh), 128, dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), dp(ce_r), 128, dp(lg1_r), rows, 128, 128, s)
-        call("cpn_local_mlp", dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]), dp(addq),
-             dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), B, V, R, S, ray0, n, 0, dp(ce_r), dp(lg2_r), 0, s)
-        # the unit-order kernel
-        ce_u = torch.full((units * 16 + 16, 128), -1.0, dtype=torch.float16, device=dev)
-        lg1 = torch.full((rows + 8,), -7.0, device=dev)
-        lg2 = torch.full((rows + 8,), -7.0, device=dev)
-        call("cpn_local_units", 0, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
-             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), 0, 0, 0,
-             dp(khu), B, V, R, S, ray0, n, dp(ce_u), 0, dp(lg1), s)
-        call("cpn_local_units", 1, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
-             dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), 0, 0, 0, 0, 0, 0, 0, B, V, R, S,
-             ray0, n, dp(ce_u), 0, dp(lg2), s)
-        # the product's pair: round 1 storing no coords_embed (ce_u = NULL), round 2 recomputing it (mode 2) - the same logits, bit
-        # for bit, as the stored form above
-        lg1n = torch.full((rows + 8,), -7.0, device=dev)
-        lg2n = torch.full((rows + 8,), -7.0, device=dev)
-        call("cpn_local_units", 0, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0,
-             dp(w["query_embed_2.w16"]), 128, dp(w["query_embed_2.b"]), dp(w["key_map_2.w16"]), 128, dp(w["key_map_2.b"]), 0, 0, 0,
-             dp(khu), B, V, R, S, ray0, n, 0, dp(lvu), dp(lg1n), s)
-        call("cpn_local_units", 2, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
-             dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), dp(w["query_embed_2.w16"]), 128,
-             dp(w["query_embed_2.b"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0, B, V, R, S, ray0, n, 0, dp(lvu), dp(lg2n), s)
-        assert torch.equal(lg1n, lg1) and torch.equal(lg2n, lg2), "recomputed coords_embed gives other logits than the stored one"
-        # ... and mode 2 without the packed inputs (lv_u = NULL: its own scattered reads of loc8 / coords9)
-        lg2m = torch.full((rows + 8,), -7.0, device=dev)
-        call("cpn_local_units", 2, dp(g["loc8"]), dp(g["coords9"]), dp(w["query_repeat_embed.w_l"]), 16, dp(w["query_repeat_embed.b"]),
-             dp(addq), dp(w["query_repeat_embed_2.w16"]), 128, dp(w["query_repeat_embed_2.b"]), dp(w["query_embed_2.w16"]), 128,
-             dp(w["query_embed_2.b"]), dp(w["query_embed.w"]), 16, dp(w["query_embed.b"]), 0, B, V, R, S, ray0, n, 0, 0, dp(lg2m), s)
-        assert torch.equal(lg2m, lg2)
-        # (first layer as an fp16 hi / lo split on the fp16 MFMA here, on the fp32 MFMA there: 2^-22 apart before the fp16
-        # rounding of the hidden layer, so a few outputs differ by an fp16 ulp)
-        d_ce = (rows_from_unit_order(ce_u, B, R, S, ray0, n).float() - ce_r[:rows].float()).abs()
-        assert float(d_ce.max()) <= 2e-3 * float(ce_r[:rows].float().abs().max()) and float(d_ce.mean()) <= 1e-5, "coords_embed differs"
-        assert bool((ce_u[units * 16:] == -1).all()) and bool((lg1[rows:] == -7).all()) and bool((lg2[rows:] == -7).all())
-        for a, b, name in ((lg1[:rows], lg1_r, "round 1"), (lg2[:rows], lg2_r, "round 2")):
-            scale = float(b.abs().max())
-            err = float((a - b).abs().max())
-            # an fp16 ulp of single terms: the key where the bias enters the fp32 sum first / last, hidden activations whose fp32
-            # values differ by 2^-22 across an fp16 rounding boundary (test-sized `add` rows make them O(1)); the logits are
-            # divided by 11.31 before the softmax
-            assert err <= 1e-3 * max(1.0, scale), (name, ray0, n, err, scale)
-
-
-def test_unit_order_mode_matches_row_order_mode(model, dev, weights):
-    """The engine with the unit-order stages (the default) against the round-4 stages (COPONERF_UNIT_ORDER=0: cpn_local_mlp,
-    cpn_gemm_f16_rowdot, row-major kh) on every fixture case: identical sample coordinates, attention weights and image to the
-    rounding of the logits' fp32 sums - and both against the oracle."""
-    eng = model._engine
-    assert eng.unit_order and eng.ce_recompute
-    for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
-        cfg, gold = load_case(name)
-        ref, out_u = run_pair(model, dev, weights, cfg)
-        eng.unit_order = False
-        try:
-            _, out_r = run_pair(model, dev, weights, cfg)
-        finally:
-            eng.unit_order = True
-        # coords_embed stored by round 1 and read back by round 2 (cpn_local_units mode 1) instead of recomputed (mode 2, the
-        # default): the same image bit for bit
-        eng.ce_recompute = False
-        try:
-            _, out_s = run_pair(model, dev, weights, cfg)
-        finally:
-            eng.ce_recompute = True
-        assert torch.equal(out_s["rgb"], out_u["rgb"]) and torch.equal(out_s["at_wt"], out_u["at_wt"]), name
-        assert torch.equal(out_u["pixel_val"], out_r["pixel_val"])
-        d_wt = float((out_u["at_wt"] - out_r["at_wt"]).abs().max())
-        d_rgb = float((out_u["rgb"] - out_r["rgb"]).abs().max())
-        print(name, "unit-order vs row-order stages: at_wt", d_wt, "rgb", d_rgb)
-        assert d_wt <= 2e-5 and d_rgb <= 2e-5, (name, d_wt, d_rgb)
-        assert (out_u["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
-        assert (out_u["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
-    eng._ws.clear()
-
-
-def test_attend_value_against_torch(dev):
-    """cpn_attend_value: joint softmax of the logits / 11.31 over the V*S samples of a ray, weighted sum of the (rows, 416) fp16
-    values + the folded constant (+ V * zprev in round 2), against float64 torch; at_wt scattered to (N, R, S)."""
-    from coponerf_amd._hip import call
-    gen = torch.Generator().manual_seed(5)
-    B, V, R, S = 2, 2, 37, 24
-    ray0, n = 3, B * R - 5
-    rows = n * V * S
-    lg = (torch.randn(rows, generator=gen) * 30).to(dev)
-    val = torch.randn(rows, 416, generator=gen).half().to(dev)
-    vb = torch.randn(416, generator=gen).to(dev)
-    zp = torch.randn(n, 416, generator=gen).to(dev)
-    s = torch.cuda.current_stream().cuda_stream
-    wt = torch.softmax(lg.double().view(n, V * S) / 11.31, dim=1)
-    zsum = torch.einsum("rt,rtc->rc", wt, val.double().view(n, V * S, 416)) + vb.double()
-    for zprev in (None, zp):
-        out = torch.empty(n, 416, dtype=torch.float32, device=dev)
-        at = torch.full((B * V, R, S), -1.0, dtype=torch.float32, device=dev)
-        call("cpn_attend_value", lg.data_ptr(), val.data_ptr(), vb.data_ptr(), 0 if zprev is None else zprev.data_ptr(), 2.0,
-             B, V, R, S, ray0, n, out.data_ptr(), at.data_ptr(), s)
-        ref = zsum if zprev is None else zsum + 2.0 * zprev.double()
-        assert float((out.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
-        rays = torch.arange(ray0, ray0 + n, device=dev)
-        b, r = rays // R, rays % R
-        for v in range(V):
-            got = at[b * V + v, r]                                           # (n, S)
-            assert float((got.double() - wt[:, v * S:(v + 1) * S]).abs().max()) <= 1e-6
-        mask = torch.ones(B * R, dtype=torch.bool, device=dev)
-        mask[ray0:ray0 + n] = False
-        dead = torch.nonzero(mask).flatten()
-        assert bool((at.view(B, V, R, S)[dead // R, :, dead % R] == -1).all()), "weights written for rays outside the range"
-
-
-def test_project_mode_matches_hidden_mode(model, dev, weights):
-    """RenderEngine(project=True) — cpn_encode_project + cpn_attend_value: hid never reaches HBM — against the default order on
-    every fixture case: same sample coordinates, attention weights and image to rounding, and both against the oracle and
-    the upstream fixture."""
-    eng = model._engine
-    assert not eng.project
-    for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
-        cfg, gold = load_case(name)
-        ref, out_h = run_pair(model, dev, weights, cfg)
-        eng.project = True
-        try:
-            _, out_p = run_pair(model, dev, weights, cfg)
-        finally:
-            eng.project = False
-        assert torch.equal(out_h["pixel_val"], out_p["pixel_val"])
-        d_wt = float((out_h["at_wt"] - out_p["at_wt"]).abs().max())
-        d_rgb = float((out_h["rgb"] - out_p["rgb"]).abs().max())
-        print(name, "project vs hidden-sum path: at_wt", d_wt, "rgb", d_rgb,
-              "rgb vs oracle", float((out_p["rgb"].cpu() - ref["rgb"]).abs().max()))
-        assert d_wt <= 1e-5 and d_rgb <= 3e-4, (name, d_wt, d_rgb)
-        assert (out_p["rgb"].cpu() - ref["rgb"]).abs().max() <= RGB_TOL
-        assert (out_p["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max() <= RGB_TOL
-        assert (out_p["at_wt"].cpu() - ref["at_wt"]).abs().max() <= 2e-3
-    eng._ws.clear()
 
 
 def test_psnr_against_ground_truth_within_a_tenth_of_a_db(model, dev, weights):
@@ -896,39 +523,32 @@ def test_announced_pair_is_bit_identical(model, dev):
 
 
 def test_f32_mode_is_the_reference_arithmetic(model, dev, weights):
-    """RenderEngine.precision = "f32" (VERDICT r4 missing #4): the reference's arithmetic on this device.  Two forms: the
-    restructured one (round 6, the default: fp32 node tables, folded key / value, hid as fp16 (hi, lo) pairs with exact products,
-    csrc/encode_f32.hip) and round 5's layer-by-layer form with exact fp32 operands in the reference's own order.  (1) Both
-    reproduce the fp32 CPU oracle / the upstream fixture to fp32 rounding (1e-5, two orders below the fp16-operand default);
-    (2) the default's distance from them is bounded: |rgb_f16 - rgb_f32| <= 4e-4 and |at_wt_f16 - at_wt_f32| <= 2e-3 on every
-    fixture case incl. the ragged one - the same-precision statement beside the headline."""
+    """RenderEngine.precision = "f32" (VERDICT r4 missing #4): the reference's arithmetic on this device, in the default's
+    formulation - fp32 node tables, exact-fp32 MFMA layers, hid as fp16 (hi, lo) pairs with exact products (csrc/encode_f32.hip).
+    (1) It reproduces the fp32 CPU oracle / the upstream fixture to fp32 rounding (1e-5, two orders below the fp16-operand
+    default); (2) the default's distance from it is bounded: |rgb_f16 - rgb_f32| <= 4e-4 and |at_wt_f16 - at_wt_f32| <= 2e-3 on
+    every fixture case incl. the ragged one - the same-precision statement beside the headline.  (Round 5's layer-by-layer
+    form of the mode, exact fp32 operands in the reference's own order, agreed with this one to <= 1e-6 before it left.)"""
     eng = model._engine
-    worst = 0.0
     for name in ("c1_val", "train_b2", "wide_val", "hd_val"):
         cfg, gold = load_case(name)
         ref, out16 = run_pair(model, dev, weights, cfg)
-        outs = {}
-        for form, tables in (("restructured", True), ("layer by layer", False)):
-            eng.precision, eng.f32_chunk_rays, eng.f32_tables = "f32", 96, tables       # several chunks, the last one ragged
-            try:
-                _, out32 = run_pair(model, dev, weights, cfg)
-            finally:
-                eng.precision, eng.f32_chunk_rays, eng.f32_tables = "f16", 16384, True
-            outs[form] = out32
-            assert torch.equal(out16["pixel_val"], out32["pixel_val"])
-            e_ref = float((out32["rgb"].cpu() - ref["rgb"]).abs().max())
-            e_gold = float((out32["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max())
-            e_wt = float((out32["at_wt"].cpu() - ref["at_wt"]).abs().max())
-            e_zl = float((out32["_core"]["z_local"].cpu() - ref["z_local"].reshape(-1, 416)).abs().max())
-            d_rgb = float((out16["rgb"] - out32["rgb"]).abs().max())
-            d_wt = float((out16["at_wt"] - out32["at_wt"]).abs().max())
-            worst = max(worst, d_rgb)
-            print(f"{name} [{form}]: f32 mode vs oracle rgb {e_ref:.1e} (upstream fixture {e_gold:.1e}), at_wt {e_wt:.1e}, z_local {e_zl:.1e};"
-                  f"  f16 default vs f32 mode rgb {d_rgb:.1e}, at_wt {d_wt:.1e}")
-            assert e_ref <= 1e-5 and e_gold <= 2e-5 and e_wt <= 1e-5, (name, form, e_ref, e_gold, e_wt)
-            assert d_rgb <= 4e-4 and d_wt <= 2e-3, (name, form, d_rgb, d_wt)
-        a, b = outs["restructured"], outs["layer by layer"]
-        assert float((a["rgb"] - b["rgb"]).abs().max()) <= 1e-5 and float((a["at_wt"] - b["at_wt"]).abs().max()) <= 1e-5
+        eng.precision, eng.f32_chunk_rays = "f32", 96                   # several chunks, the last one ragged
+        try:
+            _, out32 = run_pair(model, dev, weights, cfg)
+        finally:
+            eng.precision, eng.f32_chunk_rays = "f16", 16384
+        assert torch.equal(out16["pixel_val"], out32["pixel_val"])
+        e_ref = float((out32["rgb"].cpu() - ref["rgb"]).abs().max())
+        e_gold = float((out32["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max())
+        e_wt = float((out32["at_wt"].cpu() - ref["at_wt"]).abs().max())
+        e_zl = float((out32["_core"]["z_local"].cpu() - ref["z_local"].reshape(-1, 416)).abs().max())
+        d_rgb = float((out16["rgb"] - out32["rgb"]).abs().max())
+        d_wt = float((out16["at_wt"] - out32["at_wt"]).abs().max())
+        print(f"{name}: f32 mode vs oracle rgb {e_ref:.1e} (upstream fixture {e_gold:.1e}), at_wt {e_wt:.1e}, z_local {e_zl:.1e};"
+              f"  f16 default vs f32 mode rgb {d_rgb:.1e}, at_wt {d_wt:.1e}")
+        assert e_ref <= 1e-5 and e_gold <= 2e-5 and e_wt <= 1e-5, (name, e_ref, e_gold, e_wt)
+        assert d_rgb <= 4e-4 and d_wt <= 2e-3, (name, d_rgb, d_wt)
     eng._ws.clear()
 
 
@@ -1176,41 +796,29 @@ def test_config5_batch8_against_oracle_pair_by_pair(model, dev, weights):
     print(f"configs[4] B=8: rgb max-abs vs oracle {worst:.2e} over {B * len(sel)} rays")
 
 
-def test_layer_by_layer_intermediates_against_upstream(dev, weights):
-    """RenderEngine(fold_value=False) forms every per-sample tensor of the reference's ordering (CoPoNeRF.py:387-408,
-    450-485): compare them ON THE GPU with the upstream model's own intermediates (tests/golden/inter.npz), not only
-    with the folded mode.  fp16 operands / fp32 accumulation: bars are relative to each tensor's scale."""
+def test_per_ray_intermediates_against_upstream(dev, weights):
+    """What the folded formulation still forms of the reference's tensors - per RAY: encode_latent(z_local round 1)
+    (CoPoNeRF.py:468) - compared ON THE GPU with the upstream model's own intermediates (tests/golden/inter.npz).  (The per-sample
+    tensors of the reference's ordering - query_encode_latent_2, latent_value, key_map_2, query_embed_2, query_repeat_embed_2 -
+    are never formed: the layer-by-layer mode that did, rounds 1-5, matched them to 3e-4 .. 6e-4 of each tensor's scale and left
+    the library in round 6; the CPU oracle is pinned on them, tests/test_oracle_golden.py.)"""
     from coponerf_amd import CoPoNeRF
     cfg, gold = load_case("inter")
     inp, z, rel, flow = case_inputs(cfg)
-    R, S, V = cfg["R"], cfg["S"], 2
+    R, S = cfg["R"], cfg["S"]
     m = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
     m.load_state_dict(weights, strict=False)
     m = m.to(dev).eval()
     eng = m._engine
-    eng.fold_value, eng.call_lanes = False, 1                       # workspace of the caller's stream, un-prefixed names
+    eng.call_lanes = 1                                              # workspace of the caller's stream, un-prefixed names
     with torch.no_grad():
         out = m(to_device(inp, dev), z=to_device(z, dev), rel_pose=rel.to(dev), val=cfg["val"], flow=to_device(flow, dev))
     torch.cuda.synchronize()
-    ws = lambda name, rows, width: eng._ws[name + ".0"][:rows * width].view(rows, width).float().cpu()
-    rows = R * V * S
-    per_sample = lambda t, width: t.view(R, V, S, width).permute(1, 0, 2, 3)          # (N,R,S,width), B = 1
-    enc = ws("enc", rows * 2, 416).view(R, V, S, 2, 416)
-    enc4 = torch.stack([enc[:, 0, :, 0], enc[:, 0, :, 1], enc[:, 1, :, 0], enc[:, 1, :, 1]], 0)
-    got = {"enc": enc4, "value": per_sample(ws("value", rows, 416), 416), "key": per_sample(ws("key2", rows, 128), 128),
-           "ce": per_sample(ws("ce", rows, 128), 128), "q2": per_sample(ws("q2", rows, 128), 128)}
-    bars = {"enc": 1.5e-3, "value": 1.5e-3, "key": 1.5e-3, "ce": 1.5e-3, "q2": 1.5e-3, "ze": 1e-3}     # measured 3e-4 .. 6e-4
-    report = {}
-    for k, t in got.items():
-        g = torch.from_numpy(gold[k])
-        assert t.shape == g.shape, (k, t.shape, g.shape)
-        report[k] = float((t - g).abs().max() / g.abs().max())
     ze = eng._ws["ze.0"][:R * 128].view(R, 128).cpu()
     gze = torch.from_numpy(gold["ze"])
-    report["ze"] = float((ze[None] - gze).abs().max() / gze.abs().max())
-    print("layer-by-layer intermediates, max-abs error / tensor max:", {k: f"{v:.1e}" for k, v in report.items()})
-    for k, v in report.items():
-        assert v <= bars.get(k, 3e-3), (k, v)
+    err = float((ze[None] - gze).abs().max() / gze.abs().max())
+    print(f"encode_latent output, max-abs error / tensor max: {err:.1e}")
+    assert err <= 1e-3
     assert (out["rgb"].cpu() - torch.from_numpy(gold["rgb"])).abs().max() <= RGB_TOL
 
 

@@ -112,7 +112,7 @@ def test_two_lanes_equal_one_lane(dev):
 
 
 def test_fused_decoder_equals_layer_chain(dev):
-    """cpn_lightfield_decode (one launch) against the cpn_linear_f32 chain + cpn_mask_rgb it replaced (the form the
+    """cpn_lightfield_decode (one launch) against the cpn_linear_f32 chain + masking it replaced (the form the
     training pass still runs): same MFMA sequence, so bit for bit."""
     from coponerf_amd import CoPoNeRF, _hip
     from coponerf_amd._hip import call
@@ -145,8 +145,9 @@ def test_fused_decoder_equals_layer_chain(dev):
         lin(x, 128, f"phi.blocks.{k}.fc_0", net, 128, 128, 128, relu_in=1)
         lin(net, 128, f"phi.blocks.{k}.fc_1", x, 128, 128, 128, res=x, relu_in=1)
     lin(x, 128, "phi.lin_out", raw4, 4, 3, 128, relu_in=1)
-    rgb2, valid2 = torch.empty_like(rgb), torch.empty_like(valid)
-    call("cpn_mask_rgb", raw4.data_ptr(), 4, overlaps.data_ptr(), B, 2, R, rgb2.data_ptr(), valid2.data_ptr(), s)
+    # white background for rays without overlap (CoPoNeRF.py:562-566), as render_train forms it
+    valid2 = overlaps.view(B, 2, R).any(dim=1).float().view(B, R, 1)
+    rgb2 = (raw4[:, :3].view(B, R, 3) * valid2 + (1 - valid2)).view(B, 1, R, 3)
     torch.cuda.synchronize()
     assert torch.equal(raw, raw4[:, :3])
     assert torch.equal(rgb, rgb2) and torch.equal(valid, valid2)

@@ -1,8 +1,8 @@
 """Host-side packing of operands into MFMA fragment order (coponerf_amd/render.py) against the element maps the kernels document
-(include/coponerf_hip.h: cpn_lightfield_decode wpack, cpn_encode_key kwring / kh_units, cpn_encode_project wring, cpn_local_mlp rows_frag).  CPU only."""
+(include/coponerf_hip.h: cpn_lightfield_decode wpack, cpn_encode_key kwring / kh_units).  CPU only."""
 import torch
 
-from coponerf_amd.render import frag_order_f32, pack_key_ring, rows_from_frag_order
+from coponerf_amd.render import frag_order_f32, pack_key_ring
 
 
 def test_frag_order_f32_matches_the_documented_element_map():
@@ -26,37 +26,6 @@ def test_pack_key_ring_matches_the_documented_element_map():
         step, piece = j * 13 + n, t * 2 + k
         want = wk[16 * t + (lane & 15), 832 * j + 64 * n + 32 * k + 8 * (lane >> 4) + e]
         assert flat[((step * 16 + piece) * 64 + lane) * 8 + e] == want
-
-
-def test_rows_from_frag_order_inverts_the_accumulator_layout():
-    torch.manual_seed(2)
-    rows = 16 * 5
-    x = torch.randn(rows, 128).half()
-    # [group][32-column block p][lane = row + 16 * 8-column group fg][8]: element (row, p * 32 + fg * 8 + e)
-    packed = x.reshape(rows // 16, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
-    flat = packed.reshape(-1)
-    for row, col in ((0, 0), (17, 45), (79, 127), (33, 64)):
-        g, a, p, fg, e = row // 16, row % 16, col // 32, (col % 32) // 8, col % 8
-        assert flat[(((g * 4 + p) * 64) + (a + 16 * fg)) * 8 + e] == x[row, col]
-    assert torch.equal(rows_from_frag_order(packed, rows), x)
-    assert torch.equal(rows_from_frag_order(packed, rows - 3), x[:rows - 3])
-
-
-def test_pack_project_ring_matches_the_documented_element_map():
-    """cpn_encode_project's slot images (include/coponerf_hip.h): per slice step 34 x 2 weight fragments (key tiles 0-7, value
-    tiles 8-33) in pack_key_ring's piece order, then the slice's K = 80 block."""
-    from coponerf_amd.render import pack_project_ring
-    torch.manual_seed(3)
-    wk, wv = torch.randn(128, 1664).half(), torch.randn(416, 1664).half()
-    blk = torch.randn(13, 5120).half()
-    ring = pack_project_ring(wk, wv, blk)
-    assert ring.shape == (2, 13, 34 * 2 * 64 * 8 + 5120)
-    w = torch.cat((wk, wv))
-    for j, n, t, k, lane, e in ((0, 0, 0, 0, 0, 0), (1, 12, 33, 1, 63, 7), (1, 0, 8, 0, 21, 5), (0, 5, 7, 1, 48, 2), (1, 7, 20, 0, 17, 3)):
-        want = w[16 * t + (lane & 15), 832 * j + 64 * n + 32 * k + 8 * (lane >> 4) + e]
-        assert ring[j, n, ((t * 2 + k) * 64 + lane) * 8 + e] == want
-    for j in (0, 1):
-        assert torch.equal(ring[j, :, 34 * 2 * 64 * 8:], blk)
 
 
 def test_unit_rows_is_the_encoders_row_map():

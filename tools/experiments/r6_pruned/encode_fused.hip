@@ -639,10 +639,12 @@ static int encode_fused_launch(bool project, const uint16_t* tab, const uint16_t
     const long long nunits = (group1 - group0 + 1) * V * nsblk;
     const int num_cu = cpn_stream_cus((void*)stream);
     if (project) {
-        // ("project before you store", cpn_encode_project: measured in round 5 - it loses, DESIGN.md / HISTORY.md - and out of
-        // the library since round 6; the kernel template still carries the form: tools/ef_check.py builds it)
-        cpn_set_error("%s: the project form is not part of this build", who);
-        return CPN_E_ARG;
+        constexpr int WV = CPN_EF_PROJ_WAVES, UN = CPN_EF_PROJ_UNITS;
+        const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nunits, WV * UN));
+        hipLaunchKernelGGL((encode_fused_kernel<WV, UN, 26, 0>), dim3(grid), dim3(64 * WV), 0, (hipStream_t)stream,
+                           (const __half*)tab, (const __half*)map3, H, W, pixel_val, sec_grid, pe6, (const half8*)wfrag, bias,
+                           (const __half*)wring, kbias, V, R, S, ray0, nrays, nsblk, groups_per_b, group0, nunits,
+                           (__half*)hid, (__half*)kh, (__half*)val, kh_units);
     } else {
         constexpr int WV = CPN_EF_KEY_WAVES, UN = CPN_EF_KEY_UNITS;
         const unsigned grid = (unsigned)std::min<long long>(num_cu, cpn_cdiv(nunits, WV * UN));
@@ -671,4 +673,11 @@ extern "C" long long cpn_encode_units(int B, int R, int S, int ray0, int nrays) 
     const long long group0 = (long long)b_lo * groups_per_b + (ray0 - b_lo * R) / TG;
     const long long group1 = (long long)b_hi * groups_per_b + (ray0 + nrays - 1 - b_hi * R) / TG;
     return (group1 - group0 + 1) * 2 * (long long)cpn_cdiv(S, TSW);
+}
+
+extern "C" int cpn_encode_project(const uint16_t* tab, const uint16_t* map3, int H, int W, const float* pixel_val,
+                                  const float* sec_grid, const float* pe6, const uint16_t* wring, const float* kbias, int B,
+                                  int V, int R, int S, int ray0, int nrays, uint16_t* kh, uint16_t* val, int kh_units, void* stream) {
+    return encode_fused_launch(true, tab, map3, H, W, pixel_val, sec_grid, pe6, nullptr, nullptr, wring, kbias, B, V, R, S, ray0,
+                               nrays, nullptr, kh, val, kh_units, stream, "cpn_encode_project");
 }

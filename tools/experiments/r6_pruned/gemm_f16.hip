@@ -90,8 +90,12 @@ __device__ __forceinline__ TileWalk tile_walk(int total) {
 // ---------------------------------------------------------------------------------------------
 // The kernel (design notes at the top of the file).
 // ---------------------------------------------------------------------------------------------
-// DOT = 0: plain C = act(A . W^T + b).  (DOT = 1 / 2, the row-dot / chained row-dot epilogues of the row-order inference stages
-// of rounds 3-5, left the library in round 6: tools/experiments/r6_pruned/gemm_f16.hip.)
+// DOT = 1: instead of storing C, store logits[m] = <fp16(C[m, :]), Q[m, :]> (one workgroup tile must span all N columns):
+// the consumer of key_map_2 only needs that row dot product (attention logits), 4 bytes per row instead of 256.
+// DOT = 2: additionally chain a second 128 -> 128 layer in the epilogue, C2 = W2 . fp16(act(C)) + b2, and dot THAT with
+// Q (key_map -> ReLU -> key_map_2 -> logit in one kernel).  The accumulator layout of the first layer (lane = row,
+// columns nt*16 + fk*4 + 0..3) serves directly as the MFMA B operand of K block p = tile pair (2p, 2p+1); the W2
+// fragments are laid out in LDS for exactly that k order (k = 32p + fk*4 + e, 32p + 16 + fk*4 + e).
 // DOT = 3 ("combine", training): C is the data gradient of the folded key map, d(hid) through the key path, and the epilogue
 // finishes the gradient of the first layer's pre-activation while the tile is still on chip,
 //     out[row, c] = hid[row, c] > 0 ? fp16(C[row, c]) + w1[row] * dh1[ray, c] + w2[row] * dh2[ray, c] : 0
@@ -116,7 +120,9 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
                                                              int ldw2 = 0, const float* __restrict__ bias2 = nullptr,
                                                              CombineArgs ca = CombineArgs{}) {
     using C_ = Cfg<NT>;
-    constexpr int A_AUX = 0;
+    // the chained key kernel streams hid (7 GB per chunk, read once per pass): non-temporal, so that the node tables
+    // of encode_hidden stay in L2 / Infinity Cache across the chunk loop
+    constexpr int A_AUX = (DOT == 2 && CPN_HID_READ_NT) ? 2 : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -202,6 +208,16 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
     }                                                                           \
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 
+    half8* const w2l = reinterpret_cast<half8*>(smem + C_::LDS_BYTES);       // DOT == 2: [tile t][k block p][lane]
+    if constexpr (DOT == 2) {
+        for (int i = tid; i < NT * 4 * 64; i += 512) {
+            const int l = i & 63, p = (i >> 6) & 3, t = i >> 8;
+            const __half* src = W2 + (size_t)(t * 16 + (l & 15)) * ldw2 + p * 32 + (l >> 4) * 4;
+            const half4 lo = *reinterpret_cast<const half4*>(src), hi = *reinterpret_cast<const half4*>(src + 16);
+            w2l[i] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        __syncthreads();
+    }
     TileWalk walk = tile_walk(total_tiles);
     if (walk.cur >= walk.end) return;
     // stage 0 of the first tile; later tiles get theirs issued under the previous tile's epilogue
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         half8 xa0[2], wb0[NT], xa1[2], wb1[NT];
+        half4 qv[(DOT == 1 || DOT == 2) ? 2 : 1][(DOT == 1 || DOT == 2) ? NT : 1];   // DOT 1/2: the Q rows of this tile, in flight under the main loop
         f32x4 cdh[DOT == 3 ? 4 : 1];                       // DOT 3: dh1 / dh2 chunks (8 columns) of this wave's ray
         if constexpr (DOT == 3) {
             constexpr int CPR = C_::BN / 8;
@@ -237,6 +254,37 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
             cdh[1] = ca.dh1 ? *reinterpret_cast<const f32x4*>(ca.dh1 + off + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             cdh[2] = ca.dh2 ? *reinterpret_cast<const f32x4*>(ca.dh2 + off) : f32x4{0.f, 0.f, 0.f, 0.f};
             cdh[3] = ca.dh2 ? *reinterpret_cast<const f32x4*>(ca.dh2 + off + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (DOT == 1 || DOT == 2) {
+#ifndef CPN_ROWDOT_NOQ                                     /* timing-only ablation: the Q rows never loaded */
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
+                if (ldq == 0) {
+                    // Q in fragment order (CPN_ROWS_FRAG; N = 128, n0 = 0): [16-row group][32-column block p][lane = row + 16 * 8-column
+                    // group][8 halves].  The 4 columns nt*16 + g*4 .. of this lane sit at p = nt >> 1, 8-column group (nt & 1) * 2 +
+                    // (g >> 1), half (g & 1): the 64 lanes of one load cover 512 contiguous bytes (row-major rows: 16 x 8 bytes
+                    // from 16 different rows, 64 L1 tag look-ups per instruction, 0.48 of this kernel's 1.13 ms per image)
+                    const int g = lane >> 4;
+                    const int last = (M - 1) >> 4;
+                    int grp = (m0 + wave * 32 + mt * 16) >> 4;
+                    grp = grp < last ? grp : last;
+                    const __half* qb = Q + (size_t)grp * (4 * 64 * 8) + ((g >> 1) * 16 + (lane & 15)) * 8 + (g & 1) * 4;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        qv[mt][nt] = *reinterpret_cast<const half4*>(qb + ((nt >> 1) * 64 + (nt & 1) * 32) * 8);
+                } else {
+                    const __half* qrow = Q + (size_t)(m < M ? m : M - 1) * ldq + n0 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) qv[mt][nt] = *reinterpret_cast<const half4*>(qrow + nt * 16);
+                }
+            }
+#else
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) qv[mt][nt] = half4{(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
+#endif
         }
         // slower waves may still be reading the previous tile's C staging out of activation slots 1-2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -394,6 +442,46 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(const __half* __restrict_
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
+        } else if constexpr (DOT != 0) {
+            float dsum[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m0 + wave * 32 + mt * 16 + (lane & 15);
+                f32x4 v[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    v[nt] = acc[mt][nt] + *reinterpret_cast<const f32x4*>(bias + n0 + nt * 16 + (lane >> 4) * 4);
+                    if (RELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[nt][i] = fmaxf(v[nt][i], 0.0f);
+                    }
+                }
+                if constexpr (DOT == 2) {
+                    half8 hb[NT / 2];
+#pragma unroll
+                    for (int p = 0; p < NT / 2; ++p)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            hb[p][i] = (_Float16)v[2 * p][i];
+                            hb[p][4 + i] = (_Float16)v[2 * p + 1][i];
+                        }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        f32x4 o2 = *reinterpret_cast<const f32x4*>(bias2 + t * 16 + (lane >> 4) * 4);
+#pragma unroll
+                        for (int p = 0; p < NT / 2; ++p)
+                            o2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[(t * 4 + p) * 64 + lane], hb[p], o2, 0, 0, 0);
+                        v[t] = o2;
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsum[mt] += (float)(_Float16)v[nt][i] * (float)qv[mt][nt][i];
+                dsum[mt] += __shfl_xor(dsum[mt], 16);
+                dsum[mt] += __shfl_xor(dsum[mt], 32);
+                if (lane < 16 && m < M) ((float*)Cv)[m] = dsum[mt];
+            }
         } else if constexpr (!OUT_F32) {
             // fp16 epilogue through LDS (activation slots 1 and 2; slot 0 is receiving the next tile): the accumulator
             // layout gives a lane 4 consecutive columns (8 B) of one row, i.e. 32-B row segments per store; staging
@@ -482,6 +570,31 @@ int launch(const __half* A, int lda, const __half* W, int ldw, const float* bias
                        (const __half*)nullptr, 0, (const __half*)nullptr, 0, (const float*)nullptr,
                        CombineArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, accum});
     CPN_LAUNCH_CHECK("cpn_gemm_f16");
+    return 0;
+}
+
+// row-dot launches: N == 16*NT (one tile spans the row), logits (M) fp32 out; CHAIN adds the second 128 -> 128 layer
+template <int NT, bool RELU, int DOT>
+int launch_rowdot(const __half* A, int lda, const __half* W, int ldw, const float* bias, const __half* Q, int ldq,
+                  float* logits, int M, int K32, const __half* W2, int ldw2, const float* bias2, hipStream_t stream) {
+    using C_ = Cfg<NT>;
+    const size_t lds = C_::LDS_BYTES + (DOT == 2 ? NT * 4 * 64 * 16 : 0);
+    auto kern = gemm_f16_kernel<NT, false, RELU, DOT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            cpn_set_error("cpn_gemm_f16_rowdot: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const long long total = cpn_cdiv(M, BM);
+    const int num_cu = cpn_stream_cus((void*)stream);       // persistent grid: the CUs this stream may use
+    dim3 grid((unsigned)std::min<long long>(total, num_cu));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, A, lda, W, ldw, bias, (void*)logits, 0, M, K32, 1, (int)total, Q,
+                       ldq, W2, ldw2, bias2, CombineArgs{});
+    CPN_LAUNCH_CHECK("cpn_gemm_f16_rowdot");
     return 0;
 }
 
@@ -766,4 +879,34 @@ extern "C" int cpn_gemm_f16_masked(const uint16_t* A, int lda, const uint16_t* W
                                  K / 32, (hipStream_t)stream);
     cpn_set_error("cpn_gemm_f16_masked: N=%d is neither a multiple of 208 nor of 128", N);
     return CPN_E_SHAPE;
+}
+
+extern "C" int cpn_gemm_f16_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                                   const uint16_t* Q, int ldq, float* logits, int M, int N, int K, void* stream) {
+    CPN_REQUIRE(A && W && bias && Q && logits, CPN_E_ARG, "cpn_gemm_f16_rowdot: null pointer");
+    CPN_REQUIRE(M > 0 && N == 128 && K > 0 && (K % 32) == 0, CPN_E_SHAPE, "cpn_gemm_f16_rowdot: need N == 128, K %% 32 == 0");
+    CPN_REQUIRE(lda >= K && ldw >= K && (lda % 8) == 0 && (ldw % 8) == 0 && (ldq == 0 || (ldq >= N && (ldq % 4) == 0)), CPN_E_SHAPE,
+                "cpn_gemm_f16_rowdot: bad leading dimension");
+    CPN_REQUIRE((long long)256 * lda * 2 < (1LL << 31) && (long long)N * ldw * 2 < (1LL << 31), CPN_E_SHAPE,
+                "cpn_gemm_f16_rowdot: tile exceeds the 32-bit buffer offset range");
+    CPN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)Q % 8) == 0 &&
+                    ((uintptr_t)bias % 16) == 0, CPN_E_ARG, "cpn_gemm_f16_rowdot: pointers must be aligned");
+    return launch_rowdot<8, false, 1>((const __half*)A, lda, (const __half*)W, ldw, bias, (const __half*)Q, ldq, logits, M,
+                                      K / 32, nullptr, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cpn_gemm_f16_chain_rowdot(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                                         const uint16_t* W2, int ldw2, const float* bias2, const uint16_t* Q, int ldq,
+                                         float* logits, int M, int K, void* stream) {
+    CPN_REQUIRE(A && W && bias && W2 && bias2 && Q && logits, CPN_E_ARG, "cpn_gemm_f16_chain_rowdot: null pointer");
+    CPN_REQUIRE(M > 0 && K > 0 && (K % 32) == 0, CPN_E_SHAPE, "cpn_gemm_f16_chain_rowdot: K %% 32 != 0");
+    CPN_REQUIRE(lda >= K && ldw >= K && (lda % 8) == 0 && (ldw % 8) == 0 && (ldq == 0 || (ldq >= 128 && (ldq % 4) == 0)) && ldw2 >= 128 &&
+                    (ldw2 % 4) == 0, CPN_E_SHAPE, "cpn_gemm_f16_chain_rowdot: bad leading dimension");
+    CPN_REQUIRE((long long)256 * lda * 2 < (1LL << 31) && (long long)128 * ldw * 2 < (1LL << 31), CPN_E_SHAPE,
+                "cpn_gemm_f16_chain_rowdot: tile exceeds the 32-bit buffer offset range");
+    CPN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)Q % 8) == 0 && ((uintptr_t)W2 % 8) == 0 &&
+                    ((uintptr_t)bias % 16) == 0 && ((uintptr_t)bias2 % 16) == 0, CPN_E_ARG,
+                "cpn_gemm_f16_chain_rowdot: pointers must be aligned");
+    return launch_rowdot<8, true, 2>((const __half*)A, lda, (const __half*)W, ldw, bias, (const __half*)Q, ldq, logits, M,
+                                     K / 32, (const __half*)W2, ldw2, bias2, (hipStream_t)stream);
 }

@@ -279,6 +279,19 @@ __global__ __launch_bounds__(256) void sample_geometry_kernel(const float* __res
     }
 }
 
+__global__ void mask_rgb_kernel(const float* __restrict__ rgb_raw, int ld, const uint8_t* __restrict__ overlaps,
+                                int B, int V, int R, float* __restrict__ rgb, float* __restrict__ valid) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * R) return;
+    const int r = (int)(idx % R), b = (int)(idx / R);
+    bool any = false;
+    for (int v = 0; v < V; ++v) any = any || overlaps[((size_t)b * V + v) * R + r];
+    const float vm = any ? 1.0f : 0.0f;
+    valid[idx] = vm;
+    for (int ch = 0; ch < 3; ++ch)                               // CoPoNeRF.py:563
+        rgb[idx * 3 + ch] = rgb_raw[idx * ld + ch] * vm + 1.0f * (1.0f - vm);
+}
+
 }  // namespace
 
 extern "C" int cpn_project_rays(const float* cam, const float* uv, long long uv_batch_stride, int B, int V, int R,
@@ -311,5 +324,15 @@ extern "C" int cpn_sample_geometry(const float* cam, const float* coords9, const
                            cam, coords9, seg, interval, B * V, R, S, H, W, pixel_val, pt, sec_grid, pe6, loc8, lv_u, V);
     }
     CPN_LAUNCH_CHECK("cpn_sample_geometry");
+    return 0;
+}
+
+extern "C" int cpn_mask_rgb(const float* rgb_raw, int ld, const uint8_t* overlaps, int B, int V, int R,
+                            float* rgb, float* valid, void* stream) {
+    CPN_REQUIRE(rgb_raw && overlaps && rgb && valid, CPN_E_ARG, "cpn_mask_rgb: null pointer");
+    CPN_REQUIRE(B > 0 && V > 0 && R > 0 && ld >= 3, CPN_E_SHAPE, "cpn_mask_rgb: bad shape");
+    hipLaunchKernelGGL(mask_rgb_kernel, dim3(cpn_cdiv((long long)B * R, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rgb_raw, ld, overlaps, B, V, R, rgb, valid);
+    CPN_LAUNCH_CHECK("cpn_mask_rgb");
     return 0;
 }

@@ -354,8 +354,7 @@ extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9
                                const float* bk2, const float* w1b, int ldw1b, const float* b1b, const uint16_t* kh_u, int B,
                                int V, int R, int S, int ray0, int nrays, uint16_t* ce_u, const float* lv_u, float* logits,
                                void* stream) {
-    // (mode 1 - round 2 reading a STORED coords_embed - left the library in round 6: mode 2 recomputes it and is faster)
-    CPN_REQUIRE(mode == 0 || mode == 2, CPN_E_ARG, "cpn_local_units: mode must be 0 or 2 (got %d)", mode);
+    CPN_REQUIRE(mode >= 0 && mode <= 2, CPN_E_ARG, "cpn_local_units: mode must be 0, 1 or 2 (got %d)", mode);
     CPN_REQUIRE(loc8 && coords9 && w1 && b1 && w2 && b2 && logits, CPN_E_ARG, "cpn_local_units: null pointer");
     CPN_REQUIRE(mode == 0 ? (wk2 && bk2 && kh_u) : mode == 1 ? (add && ce_u) : (add && wk2 && bk2 && w1b && b1b), CPN_E_ARG,
                 "cpn_local_units: null pointer for mode %d", mode);
@@ -381,6 +380,10 @@ extern "C" int cpn_local_units(int mode, const float* loc8, const float* coords9
     const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(geo.nunits, 8), mode == 1 ? 1024 : (CPN_LU_UNITS > 1 ? 256 : 512));
     if (mode == 0)
         hipLaunchKernelGGL((local_units_kernel<0, CPN_LU_UNITS>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
+                           (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
+                           (__half*)ce_u, lv_chunk, logits);
+    else if (mode == 1)
+        hipLaunchKernelGGL((local_units_kernel<1, 1>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, loc8, coords9, w1, ldw1, b1, add,
                            (const __half*)w2, ldw2, b2, (const __half*)wk2, ldwk2, bk2, w1b, ldw1b, b1b, (const __half*)kh_u, geo,
                            (__half*)ce_u, lv_chunk, logits);
     else

@@ -45,7 +45,6 @@ def main():
     ap.add_argument("--hip", action="store_true",
                     help="on an MI355X: also the HIP training path's gradients against the exact oracle AND against the oracle "
                          "evaluated at the fp16-rounded inputs (what is left then is the backward pass's own arithmetic)")
-    ap.add_argument("--no-tables", action="store_true", help="--hip: first layer as gather + GEMM (no fp16 node tables)")
     a = ap.parse_args()
     B, H, S = 2, 64, 32
     weights = syn.make_render_weights(seed=17)
@@ -74,8 +73,6 @@ def main():
             model = CoPoNeRF.CoPoNeRF(n_view=2, npoints=S)
             model.load_state_dict(weights, strict=False)
             model = model.to(dev).train()
-            if a.no_tables:
-                model._engine.tables = False
             zh = [t.to(dev).requires_grad_(True) for t in z]
             out = model(mv(inp), z=zh, rel_pose=rel.to(dev), val=False, flow=mv(flow))
             (out["rgb"] * coef.to(dev)).sum().backward()
