@@ -42,6 +42,9 @@
 #ifndef CPN_EF_STAGE_PROJECT
 #define CPN_EF_STAGE_PROJECT 2
 #endif
+#ifndef CPN_EF_ACC_F16
+#define CPN_EF_ACC_F16 1       // 1: the K = 80 accumulators change layout as fp16 pairs (8 ds_bpermute instead of 16); 0: as fp32 (rounds 4-5)
+#endif
 #ifndef CPN_EF_FRAG_DEPTH
 #define CPN_EF_FRAG_DEPTH 4
 #endif
@@ -417,6 +420,23 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
                     if (CPN_EF_ABLATE & 2048) {
                         // (timing only: the accumulators stay where they are)
                     } else {
+#if CPN_EF_ACC_F16
+                    // the K = 80 partial sums cross to the load layout as fp16 PAIRS (round 6): 8 ds_bpermute per unit and slice
+                    // instead of 16 on the kernel's busiest pipe.  One more rounding (2^-11 of the partial sum, which is one of
+                    // five summands of a value that is rounded to fp16 two instructions later); hid is no longer the bits of the
+                    // round-2 kernel, the bound that counts is the one against the oracle (tests/test_gpu_parity.py)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const f32x2v two = {acc[u][nt][2 * i], acc[u][nt][2 * i + 1]};
+                            const half2v hv = __builtin_convertvector(two, half2v);
+                            const unsigned got = (unsigned)__builtin_amdgcn_ds_bpermute(to_ll, (int)__builtin_bit_cast(unsigned, hv));
+                            const half2v back = __builtin_bit_cast(half2v, got);
+                            acc[u][nt][2 * i] = (float)back[0];
+                            acc[u][nt][2 * i + 1] = (float)back[1];
+                        }
+#else
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -424,6 +444,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void encode_fused_kernel(
                             const float t = acc[u][nt][i];
                             acc[u][nt][i] = __int_as_float(__builtin_amdgcn_ds_bpermute(to_ll, __float_as_int(t)));
                         }
+#endif
                     }
                     // ---- 4 table taps per row in fp32 on top of it, ReLU, fp16
                     if (!(CPN_EF_ABLATE & 1)) {
