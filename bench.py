@@ -352,7 +352,8 @@ def run(args):
         eng = model._engine
         rgb16 = out["rgb"].clone()
         eng.precision = "f32"
-        try:
+        lanes_held, eng.call_lanes = eng.call_lanes, 1          # one stream, like the headline loop (two co-running calls of the
+        try:                                                    # mode's LDS-resident persistent kernels take turns, badly)
             step()
             _fence(distributed)
             t0 = time.perf_counter()
@@ -380,6 +381,7 @@ def run(args):
             del o32
         finally:
             eng.precision = "f16"
+            eng.call_lanes = lanes_held
             for k in [k for k in eng._ws if "f32" in k]:
                 del eng._ws[k]                                  # ~20 GB of chunk buffers
             eng._t32 = None

@@ -17,11 +17,9 @@ python bench.py $C5 --cpu-rays 1024 > "$OUT/c5_bench.json" 2> "$OUT/c5_bench.err
 python tools/summarize_pmc.py "$(find "$OUT/c4_prof" -name '*kernel_stats.csv' | head -1)" "$OUT/c4_kernel_stats.summary.csv" 30
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5_prof" -o r -- python "$ROOT/bench.py" $C5 --cpu-rays 0 ) > "$OUT/c5_bench_under_rocprof.json" 2> "$OUT/c5_prof.log"
 python tools/summarize_pmc.py "$(find "$OUT/c5_prof" -name '*kernel_stats.csv' | head -1)" "$OUT/c5_kernel_stats.summary.csv" 30
-tools/pmc_passes.sh "$OUT/c4_pmc_encode" encode_fused -- python "$ROOT/tools/encode_bench.py" --only fused --iters 3 --rig wide > "$OUT/c4_pmc_encode.log" 2>&1
-tools/pmc_passes.sh "$OUT/c5_pmc_encode" encode_fused -- python "$ROOT/tools/encode_bench.py" --only fused --iters 3 --height 512 --samples 128 > "$OUT/c5_pmc_encode.log" 2>&1
-python tools/encode_bench.py --only both --height 512 --samples 128 > "$OUT/c5_encode_bench.json" 2>&1
-python tools/encode_bench.py --only both --rig wide > "$OUT/c4_encode_bench.json" 2>&1
-python tools/encode_bench.py --only tables > "$OUT/c2_encode_bench.json" 2>&1
+# FETCH / WRITE / TCC counters of the dominant kernel on the configs' own bench commands (one counter group per run)
+tools/pmc_passes.sh "$OUT/c4_pmc_encode" encode_fused -- python "$ROOT/bench.py" $C4 --cpu-rays 0 --no-two-stream-pass --no-fresh-pair --steps 3 --warmup 1 > "$OUT/c4_pmc_encode.log" 2>&1
+tools/pmc_passes.sh "$OUT/c5_pmc_encode" encode_fused -- python "$ROOT/bench.py" $C5 --cpu-rays 0 --no-two-stream-pass --no-fresh-pair --no-f32 > "$OUT/c5_pmc_encode.log" 2>&1
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*.csv" -size +2M -delete
 rm -rf "$OUT"/c4_prof "$OUT"/c5_prof
