@@ -31,7 +31,15 @@ class OneLaunchAdam(torch.optim.Optimizer):
     reference's MultiLR wrapper drive it - /root/reference train.py:106-108, wrapper.py:134-136), and `state_dict()` /
     `load_state_dict()` in torch.optim.Adam's layout (per parameter `step`, `exp_avg`, `exp_avg_sq`: the reference's
     checkpoints hold `optimizer.state_dict()`, wrapper.py:98).  All groups must share one learning rate (the reference's two
-    do): it is a scalar argument of the single launch."""
+    do): it is a scalar argument of the single launch.
+
+    Two differences from torch.optim.Adam a caller's tooling may see: (1) `optimizer.state` is EMPTY between calls - the
+    moments live in two flat buffers (`exp_avg`, `exp_avg_sq`) and the update counts on the device; `state_dict()` builds
+    the per-parameter layout from them (and synchronises the device to read the counts), so read state through
+    `state_dict()`, not `opt.state[p]`.  (2) every parameter with a gradient gets its version counter bumped at every
+    step(), also when the device-side gate skipped the update (non-finite gradients): the version-keyed caches (the
+    render engine's weight packs, the trunk / UFC packs, captured get_z graphs) are rebuilt after a skipped step too -
+    harmless, one repack."""
 
     def __init__(self, params: Iterable, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
         # the keys of torch.optim.Adam's groups, at the values this kernel implements: a checkpoint written here loads into

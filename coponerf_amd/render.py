@@ -768,11 +768,15 @@ class RenderEngine:
                    all(a is b for a, b in zip(e["z"], z))), None)
         if nx is not None:
             # built by prepare_next() on its own stream while the previous pair rendered
-            # (no record_stream on the adopted tensors: when this entry is dropped their blocks return to the preparation
-            # stream's pool, and that stream begins every preparation by waiting for what the caller's stream holds at
-            # that moment - which includes every reader queued before the drop, the lanes' completion events too)
-            torch.cuda.current_stream(z[0].device).wait_event(nx["built"])
+            # Their blocks belong to the preparation stream's pool: record the adopting stream on them so that a block is
+            # not handed out again before this stream's readers are done, whatever stream the NEXT preparation is issued
+            # from (the preparation stream also begins every preparation by waiting for the caller's then-current stream,
+            # which covers the chunk lanes: their completion is joined into the caller's stream before render() returns).
+            cur = torch.cuda.current_stream(z[0].device)
+            cur.wait_event(nx["built"])
             maps, tabs = nx["maps"], nx["tabs"]
+            for t in list(maps) + list(tabs):
+                t.record_stream(cur)
             nx["mkey"], nx["maps"], nx["tabs"] = None, None, None
         else:
             maps, tabs = self._build_maps(z, w)
@@ -819,8 +823,12 @@ class RenderEngine:
         previous pair's kernels, and its table build ran beside them (0.35 ms of kernels at 256x256).
         Call it before render() of the current pair is queued so that the copy is not ordered behind that render:
             prepare_next(pair[i+1]); render(pair[i]); prepare_next(pair[i+2]); render(pair[i+1]); ...
-        Two prepared pairs are held (the one about to be rendered and the one after it); a third replaces the older.  Results are those of an unprepared call, bit for bit
-        (the same kernels on the same inputs)."""
+        Two prepared pairs are held (the one about to be rendered and the one after it); a third replaces the older.
+        Results are those of an unprepared call, bit for bit (the same kernels on the same inputs).
+        Stream contract: issue prepare_next() and the render() that consumes it from the SAME torch stream (the loop above
+        on one stream is the supported use).  The adopted maps and tables are record_stream-ed for the adopting stream,
+        so rendering from another stream is memory-safe, but the staged host copy of the 4x4 inputs is ordered only
+        against the stream prepare_next() was called on."""
         dev = z[0].device
         if dev.type != "cuda":
             raise RuntimeError("coponerf_amd renders on a HIP device only (got z on %s)" % dev)
