@@ -63,6 +63,73 @@ class _TrunkBatchNorm(nn.BatchNorm2d):
                 torch._foreach_add_(pend, 1)
 
 
+# Training: data and weight gradient of the trunk's 3x3 / 1x1 convolutions with fp16 operands (fp32 accumulation in the
+# library's implicit-GEMM kernels), every layer's incoming gradient scaled by a power of two found on the device
+# (cpn_scale_to_f16).  The forward stays fp32.  tools/conv_bwd_precision_bench.py, 8 images of 256 x 256: 6.8 -> 4.6 ms for
+# the 36 layers including the casts; each layer's dx / dw within 8e-4 / 1.4e-3 (relative L2) of the fp32 kernels' — a
+# tenth of what the forward's fp16 operands already leave upstream of z (tests/test_gpu_step.py).  0 = the library's fp32 backward.
+F16_TRUNK_BACKWARD = os.environ.get("CPN_TRUNK_BWD_F16", "1") != "0"
+
+
+class _ScaleSlots:
+    """[amax bits, scale, 1 / scale] triples for cpn_scale_to_f16, zero when handed out: one fill per 128 layers."""
+    _pools = {}
+
+    @classmethod
+    def take(cls, dev):
+        pool = cls._pools.get(dev)
+        if pool is None or pool[1] == 128:
+            pool = cls._pools[dev] = [torch.zeros(128, 4, dtype=torch.float32, device=dev), 0]
+        pool[1] += 1
+        return pool[0][pool[1] - 1]
+
+
+class _ConvF16BwdFn(torch.autograd.Function):
+    """F.conv2d(x, w, None, stride, padding) whose backward runs on fp16 operands (see F16_TRUNK_BACKWARD)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        ctx.save_for_backward(x, w)
+        ctx.geo = (int(stride), int(padding))
+        return F.conv2d(x, w, None, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ._hip import call
+        x, w = ctx.saved_tensors
+        st, pd = ctx.geo
+        # (in training the trunk runs channels-last: the stem's input is an NHWC-strided view of the images.  The scale + cast
+        # pass is elementwise over dense memory, whichever of the two layouts it is)
+        if not (dy.is_contiguous() or dy.is_contiguous(memory_format=torch.channels_last)):
+            dy = dy.contiguous()
+        if dy.numel() % 4:                                     # cpn_scale_to_f16 works on 16-byte pieces
+            return tuple(torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pd, pd], [1, 1], False, [0, 0], 1,
+                                                             [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])[:2]) + (None, None)
+        slot = _ScaleSlots.take(dy.device)
+        dy16 = torch.empty_like(dy, dtype=torch.float16)       # keeps dy's layout
+        # target 64: three decades of headroom above the largest entry for the sums inside the kernels' fp16 epilogue
+        call("cpn_scale_to_f16", dy.data_ptr(), dy.numel(), 64.0, slot.data_ptr(), dy16.data_ptr(), slot[1:].data_ptr(),
+             _stream_handle())
+        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False]
+        dx16, dw16, _ = torch.ops.aten.convolution_backward(dy16, x.half(), w.half(), None, [st, st], [pd, pd], [1, 1], False,
+                                                            [0, 0], 1, need)
+        inv = slot[2:3]                                        # 1-d fp32: the product is fp32
+        dw = None
+        if need[1]:
+            # the library returns dw in the activations' layout (channels-last in training): the parameter's gradient is
+            # written contiguous, or the norm / clip / Adam passes over the gradients fall off their multi-tensor paths
+            dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+            torch.mul(dw16, inv, out=dw)
+        return (dx16 * inv if need[0] else None), dw, None, None
+
+
+def _conv(conv: nn.Conv2d, x):
+    if (F16_TRUNK_BACKWARD and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and conv.bias is None
+            and x.numel() % 4 == 0 and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))):
+        return _ConvF16BwdFn.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+    return conv(x)
+
+
 class _BasicBlock(nn.Module):
     def __init__(self, cin: int, cout: int, stride: int):
         super().__init__()
@@ -76,8 +143,8 @@ class _BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), _TrunkBatchNorm(cout))
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        idt = x if self.downsample is None else self.downsample[1](_conv(self.downsample[0], x))
+        out = self.bn2(_conv(self.conv2, self.relu(self.bn1(_conv(self.conv1, x)))))
         return self.relu(out + idt)
 
 

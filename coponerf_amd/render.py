@@ -652,6 +652,12 @@ class RenderEngine:
         version of the five input tensors — a full-image render is 18 forward() calls with the same cameras
         (/root/reference test.py:176-190).  The entries are views of one flat buffer that is also handed to the caller
         (gt_rel_pose ...): an in-place write to any of them bumps the buffer's version and drops the entry."""
+        if not val and torch.is_grad_enabled():
+            # a training step: the geometry uses the given poses (CoPoNeRF.py:239-244, 325-332), rel_pose is this step's
+            # network output and only its inverse would be taken here - which the caller forms on the device when it
+            # differentiates (CoPoNeRF._render).  Left in, it made every step a cache miss whose device -> host read
+            # waited for get_z (3.7 ms of host stall per step, tools/host_step_profile.py)
+            rel_pose = None
         mats = (ctx_c2w, ctx_K, qry_c2w, qry_K, rel_pose)
         hit = self._camera_entry(mats, val, H, dev)
         if hit is not None:

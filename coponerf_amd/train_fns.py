@@ -415,7 +415,7 @@ class EncodeFn(Function):
              R, S, 0, B * R, dT.data_ptr(), boxes.data_ptr(), s)
         # a node sums up to thousands of rows: its own power-of-two scale for the fp16 GEMM operands (device side, no sync)
         dT16 = torch.empty(nodes, _hip.TAB_LD, dtype=torch.float16, device=dev)
-        sc = torch.zeros(2, dtype=torch.float32, device=dev)                  # [amax bits scratch, chosen scale]
+        sc = torch.zeros(3, dtype=torch.float32, device=dev)                  # [amax bits scratch, chosen scale, 1 / scale]
         call("cpn_scale_to_f16", dT.data_ptr(), dT.numel(), 4096.0, sc.data_ptr(), dT16.data_ptr(), sc[1:].data_ptr(), s)
         s2 = sc[1]
         del dT

@@ -569,11 +569,20 @@ def cost_volume_attention_reference_order(ops, q, k, v_corr, fs, residual=None, 
     return msg if residual is None else residual + msg
 
 
+_NORM_CONSTS = {}
+
+
 def _conv_map_lib(rgb, w, b):
     """Library-op statement of cpn_conv_map7x7 (only its VJP is used): CoPoNeRF.py:182-187."""
     x = (rgb.permute(0, 3, 1, 2) + 1) / 2.
-    mean = torch.tensor((0.485, 0.456, 0.406), device=x.device).view(1, 3, 1, 1)
-    std = torch.tensor((0.229, 0.224, 0.225), device=x.device).view(1, 3, 1, 1)
+    # cached per device: torch.tensor(..., device=) is a pageable host -> device copy, ordered behind everything queued on
+    # the stream — inside the backward pass it held the host until the render backward had drained (34 ms per step,
+    # tools/host_step_profile.py --ops), and the rest of the backward was enqueued against an empty queue
+    c = _NORM_CONSTS.get(x.device)
+    if c is None:
+        c = _NORM_CONSTS[x.device] = (torch.tensor((0.485, 0.456, 0.406), device=x.device).view(1, 3, 1, 1),
+                                      torch.tensor((0.229, 0.224, 0.225), device=x.device).view(1, 3, 1, 1))
+    mean, std = c
     return F.conv2d((x - mean) / std, w, b, stride=1, padding=3)
 
 

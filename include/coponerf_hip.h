@@ -328,8 +328,9 @@ int cpn_gather_rows_bwd_level3(const uint16_t* dxin, int ldx, int col0, int H, i
  *   cpn_gather_tail: xt (rows, 128) fp16 = [bilinear gather of the full-resolution map (64) | tanh(pt/5) (3) | 1 | 0 x 60],
  *       the K = 80 operand of the forward kernel with a ones column for the bias gradient.
  *   cpn_scale_to_f16: y = fp16(x * s) with s = 2^floor(log2(target / max|x|)) clamped to [2^-40, 2^40] found on the device and
- *       written to scale_out[0] (the table gradient sums up to thousands of rows per node: its own scale before the two
- *       fp16 GEMMs); amax_scratch: one uint32, ZERO on entry; n % 4 == 0.                                            */
+ *       written to scale_out[0], 1 / s to scale_out[1] (TWO floats; the table gradient sums up to thousands of rows per node:
+ *       its own scale before the two fp16 GEMMs; the trunk's convolution backward scales every layer's incoming gradient
+ *       this way); amax_scratch: one uint32, ZERO on entry; n % 4 == 0.                                             */
 long long cpn_scatter_tables_scratch(int H, int W, int B, int V, int R, int S);
 int cpn_scale_to_f16(const float* x, long long n, float target, uint32_t* amax_scratch, uint16_t* y, float* scale_out,
                      void* stream);

@@ -52,6 +52,16 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
         ph = step.timing_summary()
+        # what the HOST needs to enqueue one step (device idle at the start, the call returns before the device is done):
+        # the step is launch-bound as soon as the device needs less than this
+        host = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            res = step(inp, gt)
+            host.append((time.perf_counter() - h0) * 1e3)
+        torch.cuda.synchronize()
+        ph["host_enqueue_ms"] = min(host)
         print(json.dumps({"train_ms_per_step": dt * 1e3, "rays_per_s": a.batch * a.rays / dt, **{k: round(v, 3) for k, v in ph.items()},
                           "peak_mem_GB": torch.cuda.max_memory_allocated() / 2**30, "batch": a.batch, "rays_per_pair": a.rays,
                           "stepped": bool(res["stepped"]), "loss": float(res["loss"])}))
