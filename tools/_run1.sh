@@ -1,5 +1,4 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
-mkdir -p gpurun_out/r06j
-python tools/train_time.py > gpurun_out/r06j/train_time.log 2>&1; tail -1 gpurun_out/r06j/train_time.log
-CPN_TRUNK_BWD_F16=0 python tools/train_time.py > gpurun_out/r06j/train_time_f32bwd.log 2>&1; tail -1 gpurun_out/r06j/train_time_f32bwd.log
-python tools/host_step_profile.py --ops > gpurun_out/r06j/host_ops_f16.txt 2>&1; grep "^host:" gpurun_out/r06j/host_ops_f16.txt; sed -n 6,14p gpurun_out/r06j/host_ops_f16.txt | cut -c1-150
+mkdir -p gpurun_out/r06l
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > gpurun_out/r06l/gpu_tests.log 2>&1; tail -6 gpurun_out/r06l/gpu_tests.log
+python bench.py > gpurun_out/r06l/bench.json 2> gpurun_out/r06l/bench.err; python tools/show_rates.py gpurun_out/r06l/bench.json | head -40
