@@ -71,6 +71,20 @@ class _TrunkBatchNorm(nn.BatchNorm2d):
 F16_TRUNK_BACKWARD = os.environ.get("CPN_TRUNK_BWD_F16", "1") != "0"
 
 
+_TRUNK_BWD_TARGET = [4.0]
+
+
+def trunk_bwd_target_backoff(stepped: bool) -> None:
+    """Called with the outcome of every optimizer step (coponerf_amd.train_step): non-finite gradients quarter the target
+    of the trunk's fp16 backward (an overflowing dw / dx would otherwise repeat for ever), a finite step doubles it back
+    towards 4."""
+    t = _TRUNK_BWD_TARGET
+    t[0] = min(4.0, t[0] * 2.0) if stepped else max(2.0 ** -12, t[0] * 0.25)
+
+
+F16_BWD_TRACE = None          # set to a list to collect (x shape, max |dx16|, max |dw16|) per layer (device scalars, no sync)
+
+
 class _ScaleSlots:
     """[amax bits, scale, 1 / scale] triples for cpn_scale_to_f16, zero when handed out: one fill per 128 layers."""
     _pools = {}
@@ -107,12 +121,17 @@ class _ConvF16BwdFn(torch.autograd.Function):
                                                              [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])[:2]) + (None, None)
         slot = _ScaleSlots.take(dy.device)
         dy16 = torch.empty_like(dy, dtype=torch.float16)       # keeps dy's layout
-        # target 64: three decades of headroom above the largest entry for the sums inside the kernels' fp16 epilogue
-        call("cpn_scale_to_f16", dy.data_ptr(), dy.numel(), 64.0, slot.data_ptr(), dy16.data_ptr(), slot[1:].data_ptr(),
-             _stream_handle())
+        # the largest |dy| lands in [target / 2, target]: dx and dw come back as fp16 tensors, and dw sums dy . x over up to
+        # 131 072 positions per image batch — at target 64 its largest entry reached 7 160 of fp16's 65 504 on the synthetic
+        # step (tools/trunk_bwd_headroom.py); at 4 there are two decades of room, and entries down to 1.5e-5 of the largest
+        # keep all their bits.  A skipped step backs the target off further (trunk_bwd_target_backoff, called by TrainStep).
+        call("cpn_scale_to_f16", dy.data_ptr(), dy.numel(), float(_TRUNK_BWD_TARGET[0]), slot.data_ptr(), dy16.data_ptr(),
+             slot[1:].data_ptr(), _stream_handle())
         need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False]
         dx16, dw16, _ = torch.ops.aten.convolution_backward(dy16, x.half(), w.half(), None, [st, st], [pd, pd], [1, 1], False,
                                                             [0, 0], 1, need)
+        if F16_BWD_TRACE is not None:                          # tests / tools: the largest fp16 entries, still on the device
+            F16_BWD_TRACE.append((tuple(x.shape), dx16.abs().max() if need[0] else None, dw16.abs().max() if need[1] else None))
         inv = slot[2:3]                                        # 1-d fp32: the product is fp32
         dw = None
         if need[1]:

@@ -177,6 +177,8 @@ class TrainStep:
 
     def _adapt_grad_scale(self, stepped: bool) -> None:
         eng = getattr(self.model, "_engine", None)
+        from . import getz as _getz
+        _getz.trunk_bwd_target_backoff(stepped)
         if stepped:
             self.skipped_in_a_row = 0
             self._good += 1

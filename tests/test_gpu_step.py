@@ -92,3 +92,44 @@ def test_step_gradients_match_reference_at_4096_rays(tag, model, dev):
     print(f"[{tag}, 4096 rays] worst per-ray decoder / render-layer tensors:\n" +
           sc.report([r for r in rows if r[5].startswith("phi.")][:3] + [r for r in rows if r[5].split(".")[0] in RENDER_LAYERS][:3], 6))
     assert not bad, sc.report(bad, 40)
+
+
+def test_trunk_fp16_backward_against_fp32_backward(model, dev):
+    """The trunk's convolution backward on fp16 operands (getz._ConvF16BwdFn) against the library's fp32 backward of the same
+    step, with the run-to-run spread of the fp32 backward itself beside it (the render backward accumulates with atomics, so
+    two fp32 passes already differ upstream of z), and the fp16 results dx / dw two decades below fp16's largest number."""
+    from coponerf_amd import getz
+    inp, gt = sc.inputs(4096)
+    inp, gt = to_device(inp, dev), gt.to(dev)
+
+    def trunk_grads(f16: bool):
+        old = getz.F16_TRUNK_BACKWARD
+        getz.F16_TRUNK_BACKWARD = f16
+        try:
+            model.zero_grad(set_to_none=True)
+            out = model(inp, val=False)
+            sum(sc.loss_terms("img", out, gt).values()).backward()
+            return {n: p.grad.detach().clone() for n, p in model.named_parameters()
+                    if n.startswith("encoder.") and p.grad is not None}
+        finally:
+            getz.F16_TRUNK_BACKWARD = old
+
+    def apart(a, b):
+        rows = sorted((((a[n] - g).norm() / g.norm().clamp_min(1e-30)).item(), n) for n, g in b.items())
+        return rows[-1]
+
+    ref = trunk_grads(False)
+    again = trunk_grads(False)
+    getz.F16_BWD_TRACE = []
+    try:
+        half = trunk_grads(True)
+        trace = getz.F16_BWD_TRACE
+    finally:
+        getz.F16_BWD_TRACE = None
+    assert len(trace) >= 30                                   # the 3x3 / 1x1 layers of the trunk took the fp16 path
+    top = max(float(t) for _, dx, dw in trace for t in (dx, dw) if t is not None)
+    spread, worst = apart(again, ref), apart(half, ref)
+    print(f"largest fp16 entry of the trunk backward: {top:.1f}")
+    print(f"trunk gradients: fp32 backward run to run {spread[0]:.2e} ({spread[1]}), fp16-operand backward vs fp32 {worst[0]:.2e} ({worst[1]})")
+    assert top < 65504 / 64
+    assert worst[0] < max(5e-3, 3 * spread[0])

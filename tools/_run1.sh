@@ -1,4 +1,3 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
-mkdir -p gpurun_out/r06l
-( time timeout 1500 python -m pytest tests -m gpu -x -q ) > gpurun_out/r06l/gpu_tests.log 2>&1; tail -6 gpurun_out/r06l/gpu_tests.log
-python bench.py > gpurun_out/r06l/bench.json 2> gpurun_out/r06l/bench.err; python tools/show_rates.py gpurun_out/r06l/bench.json | head -40
+mkdir -p gpurun_out/r06n
+( time timeout 900 python -m pytest tests/test_gpu_step.py -x -q -s -k trunk_fp16 ) > gpurun_out/r06n/tests.log 2>&1; tail -5 gpurun_out/r06n/tests.log; grep -n "largest fp16\|trunk gradients" gpurun_out/r06n/tests.log
