@@ -1,3 +1,5 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
-mkdir -p gpurun_out/r06n
-( time timeout 900 python -m pytest tests/test_gpu_step.py -x -q -s -k trunk_fp16 ) > gpurun_out/r06n/tests.log 2>&1; tail -5 gpurun_out/r06n/tests.log; grep -n "largest fp16\|trunk gradients" gpurun_out/r06n/tests.log
+mkdir -p gpurun_out/r06z
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > gpurun_out/r06z/gpu_tests.log 2>&1; tail -6 gpurun_out/r06z/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r06z/smoke.log 2>&1; tail -2 gpurun_out/r06z/smoke.log
+python bench.py --mode train > gpurun_out/r06z/bench_train.json 2> gpurun_out/r06z/bench_train.err; python tools/show_rates.py gpurun_out/r06z/bench_train.json | head -5
