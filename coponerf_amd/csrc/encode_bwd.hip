@@ -498,7 +498,13 @@ __global__ __launch_bounds__(64 * BSW, 1) void bucket_accumulate_kernel(const __
     auto load_desc = [&](int base) {
         const int idx = min(base + (lane < NBK ? lane : NBK - 1), last);
         Desc dsc;
+#ifdef CPN_BUCKET_ABLATE_SEQ                                   // timing only: rows read in memory order.  Round 6: 4.37 vs 4.47 ms inside
+        // the training step - the random 1.6 KB rows are NOT what bounds this kernel any more (per-row issue work is: six
+        // v_readlane, the address, the convert and four packed FMAs per row and wave at < 2 waves per SIMD)
+        dsc.row = (unsigned)(idx % (2 * geo.nrays * geo.V * geo.S));
+#else
         dsc.row = rows[idx];
+#endif
         dsc.cells = cellsv[idx];
         dsc.w = wts[idx];
         return dsc;

@@ -1,5 +1,12 @@
-export PYTHONPATH=$PWD TMPDIR=/tmp
-mkdir -p gpurun_out/r06z
-( time timeout 1500 python -m pytest tests -m gpu -x -q ) > gpurun_out/r06z/gpu_tests.log 2>&1; tail -6 gpurun_out/r06z/gpu_tests.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r06z/smoke.log 2>&1; tail -2 gpurun_out/r06z/smoke.log
-python bench.py --mode train > gpurun_out/r06z/bench_train.json 2> gpurun_out/r06z/bench_train.err; python tools/show_rates.py gpurun_out/r06z/bench_train.json | head -5
+export TMPDIR=/tmp PYTHONPATH=$PWD
+ROOT=$PWD
+for mode in seq prod; do
+OUT=$ROOT/gpurun_out/r06y_$mode
+mkdir -p $OUT
+LIB=""; [ $mode = seq ] && LIB=$ROOT/tools/_build/libcpn_bucket_seq.so
+( cd /tmp && COPONERF_HIP_LIB=$LIB rocprofv3 --kernel-trace --output-format csv -d "$OUT/train_prof" -o t -- python "$ROOT/tools/train_time.py" --steps 3 ) > "$OUT/train_prof.log" 2>&1
+T=$(find "$OUT/train_prof" -name '*kernel_trace.csv' | head -1)
+python tools/trace_step.py "$T" project_rays 1000 > "$OUT/train_step_kernels.txt" 2>&1
+rm -rf "$OUT/train_prof"
+grep "bucket_accumulate" $OUT/train_step_kernels.txt | cut -c1-80
+done
