@@ -507,6 +507,11 @@ __global__ __launch_bounds__(64 * BSW, 1) void bucket_accumulate_kernel(const __
 #endif
         dsc.cells = cellsv[idx];
         dsc.w = wts[idx];
+        // slots past the end of the item repeat its last row with ZERO weights: the row loop below then needs no early
+        // exit and unrolls (with the `break` it stayed a loop: the rows of a batch were picked out of their registers
+        // through s_set_gpr_idx, 28 instructions per row and wave where the unrolled form has 14 — the kernel is bound by
+        // its issue slots, not by the rows' addresses: reading them in memory order changed nothing, HISTORY.md round 6)
+        if (base + (lane < NBK ? lane : NBK - 1) > last) dsc.w = f32x4{0.f, 0.f, 0.f, 0.f};
         return dsc;
     };
     auto lane_u = [](unsigned v, int u) { return (unsigned)__builtin_amdgcn_readlane((int)v, u); };
@@ -524,7 +529,6 @@ __global__ __launch_bounds__(64 * BSW, 1) void bucket_accumulate_kernel(const __
         for (int u = 0; u < NBK; ++u) nxt[u] = dcol[(size_t)lane_u(dnxt.row, u) * ldw];     // rows past `last` repeat the last one
 #pragma unroll
         for (int u = 0; u < NBK; ++u) {
-            if (base + u > last) break;
             const hv_t hv = __builtin_bit_cast(hv_t, cur[u]);
             const fv du = __builtin_convertvector(hv, fv);
             const unsigned cells = lane_u(dcur.cells, u);
