@@ -745,14 +745,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
     const int pair = wave % npairs, kpart = wave / npairs, kparts = 4 / npairs;
     const int mt = pair % MT, ct = pair / MT;
     const int ln = lane & 15, lk = lane >> 4;
-    f32x4 acc[9];
+    // Cin <= 8 (CI == 8): the 16 columns of the MFMA's B operand hold 8 input channels x TWO taps (column n = channel n & 7
+    // of tap 2 t + (n >> 3)), so the nine taps take five MFMAs per k step instead of nine with half of every tile empty
+    // (these launches ran at twice their MFMA bound, which the padding had doubled: round 6)
+    constexpr bool PACK = CI == 8;
+    constexpr int NACC = PACK ? 5 : 9;
+    const int tapsel = PACK ? (ln >> 3) : 0;
+    f32x4 acc[NACC];
+    int boff[NACC];                                   // PACK: offset of tap 2 t + tapsel in the haloed plane (the tenth slot re-reads tap 8: discarded)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NACC; ++t) {
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tap = min(2 * t + tapsel, 8);
+        boff[t] = (tap / 3) * (W + 2) + tap % 3;
+    }
     float bsum = 0.0f;
     const int ksteps = (P + 3) >> 2;
     const int k_lo = kpart * ksteps / kparts, k_hi = (kpart + 1) * ksteps / kparts;
     const float* arow = ds + (mt * 16 + ln) * DS;
-    const float* brow = xs + (ct * 16 + ln) * XS;
+    const float* brow = xs + (PACK ? (ln & 7) : ct * 16 + ln) * XS;
     // staging: P <= 256, so thread tid owns position tid of every plane
     const bool stg = tid < P;
     const int sy = stg ? tid / W : 0, sx = stg ? tid - sy * W : 0;
@@ -792,30 +803,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
         // next step's 10 LDS reads are issued before the current step's 9 MFMAs (predicated reads + a wait before every
         // MFMA ran this loop at a quarter of the MFMA rate)
         int yy = y0, xx = x0;
-        auto read_step = [&](int ks, float& av, float (&bv)[9]) {
+        auto read_step = [&](int ks, float& av, float (&bv)[NACC]) {
             const int pos = ks * 4 + lk;
             av = arow[pos];
             const float* bp = brow + (pos < P ? yy * (W + 2) + xx : 0);
+            if constexpr (PACK) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int t = 0; t < 5; ++t) bv[t] = bp[boff[t]];
+            } else {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) bv[i * 3 + j] = bp[i * (W + 2) + j];
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) bv[i * 3 + j] = bp[i * (W + 2) + j];
+            }
             xx += 4;
             const bool wrap = xx >= W;                 // W >= 4: at most one row per step
             xx -= wrap ? W : 0;
             yy += wrap ? 1 : 0;
         };
-        float av, bv[9];
+        float av, bv[NACC];
         if (k_lo < k_hi) read_step(k_lo, av, bv);
         for (int ks = k_lo; ks < k_hi; ++ks) {
-            float an = 0.0f, bn[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float an = 0.0f, bn[NACC];
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) bn[t] = 0.0f;
             if (ks + 1 < k_hi) read_step(ks + 1, an, bn);
             bsum += av;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
             av = an;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) bv[t] = bn[t];
+            for (int t = 0; t < NACC; ++t) bv[t] = bn[t];
         }
     }
     // partial sums of this workgroup: [Cout*Cin*9 weights | Cout biases]; D[m = lk*4 + e][n = ln]: m -> output
@@ -826,15 +844,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
     float* red = wgl;                                 // reuse LDS: nw + Cout floats <= 32*32*9 + 32
     for (int i = tid; i < nw + Cout; i += 256) red[i] = 0.0f;
     __syncthreads();
-    const int c = ct * 16 + ln;
+    const int c = PACK ? (ln & 7) : ct * 16 + ln;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int o = mt * 16 + lk * 4 + e;
-            if (o < Cout && c < Cin) {
-                if (kparts > 1) atomicAdd(red + ((size_t)o * Cin + c) * 9 + t, acc[t][e]);
-                else red[((size_t)o * Cin + c) * 9 + t] = acc[t][e];
+            const int tap = PACK ? 2 * t + tapsel : t;
+            if (o < Cout && c < Cin && tap < 9) {
+                if (kparts > 1) atomicAdd(red + ((size_t)o * Cin + c) * 9 + tap, acc[t][e]);
+                else red[((size_t)o * Cin + c) * 9 + tap] = acc[t][e];
             }
         }
     if (ct == 0) {                                    // bias: lanes (ln = o, lk) hold disjoint position subsets

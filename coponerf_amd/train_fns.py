@@ -440,7 +440,11 @@ class EncodeFn(Function):
             call("cpn_gather_rows_bwd_level3", dA.data_ptr(), dA.shape[1], 0, H, Wd, pixel_val.data_ptr(), sec_grid.data_ptr(),
                  B, V, R, S, 0, B * R, dm3.data_ptr(), boxes3.data_ptr(), s)
             del dA
-            g[3] = dm3.mul_(1.0 / gs).permute(0, 3, 1, 2).contiguous()
+            # handed on as the NHWC buffer it is (an NCHW view with channels-last strides): its only consumer is conv_map's
+            # backward, a library convolution that takes that layout; the .contiguous() here was a 134 MB transpose
+            g[3] = dm3.mul_(1.0 / gs).permute(0, 3, 1, 2)
+            if os.environ.get("COPONERF_NCHW_LEVEL3_GRAD") == "1":
+                g[3] = g[3].contiguous()
         dW = db = None
         if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
             xt = torch.empty(d16.shape[0], 128, dtype=torch.float16, device=dev)

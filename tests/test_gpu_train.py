@@ -237,7 +237,8 @@ def test_conv_weight_gradient_kernels(dev):
     from coponerf_amd import _hip
     from coponerf_amd._hip import call
     st = torch.cuda.current_stream().cuda_stream
-    for (B, Cin, Cout, G, H, W) in ((2, 32, 32, 9, 16, 16), (1, 4, 8, 5, 8, 8), (2, 8, 32, 3, 6, 10), (1, 1, 8, 4, 16, 16)):
+    for (B, Cin, Cout, G, H, W) in ((2, 32, 32, 9, 16, 16), (1, 4, 8, 5, 8, 8), (2, 8, 32, 3, 6, 10), (1, 1, 8, 4, 16, 16),
+                                  (2, 8, 8, 4, 16, 16), (1, 32, 8, 3, 16, 16), (2, 7, 20, 3, 16, 16)):
         x = syn.normal((B, Cin, G, H, W), seed=70).to(dev)
         dy = syn.normal((B, Cout, G, H, W), seed=71).to(dev)
         w = torch.zeros(Cout, Cin, 3, 3, device=dev, requires_grad=True)

@@ -1,12 +1,11 @@
 export TMPDIR=/tmp PYTHONPATH=$PWD
 ROOT=$PWD
-for mode in cpl4 prod; do
-OUT=$ROOT/gpurun_out/r06y_$mode
+OUT=$ROOT/gpurun_out/r06q
 mkdir -p $OUT
-LIB=""; [ $mode = cpl4 ] && LIB=$ROOT/tools/_build/libcpn_bucket_cpl4.so
-( cd /tmp && COPONERF_HIP_LIB=$LIB rocprofv3 --kernel-trace --output-format csv -d "$OUT/train_prof" -o t -- python "$ROOT/tools/train_time.py" --steps 3 ) > "$OUT/train_prof.log" 2>&1
+( timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_getz.py tests/test_gpu_step.py -x -q ) > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/train_prof" -o t -- python "$ROOT/tools/train_time.py" --steps 3 ) > "$OUT/train_prof.log" 2>&1
 T=$(find "$OUT/train_prof" -name '*kernel_trace.csv' | head -1)
 python tools/trace_step.py "$T" project_rays 1000 > "$OUT/train_step_kernels.txt" 2>&1
 rm -rf "$OUT/train_prof"
-grep "bucket_accumulate" $OUT/train_step_kernels.txt | cut -c1-80
-done
+grep "conv_wgrad_planes" $OUT/train_step_kernels.txt | cut -c1-90
+python tools/train_time.py 2>/dev/null | tail -1 | cut -c1-130
