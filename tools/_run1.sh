@@ -7,5 +7,5 @@ mkdir -p $OUT
 T=$(find "$OUT/train_prof" -name '*kernel_trace.csv' | head -1)
 python tools/trace_step.py "$T" project_rays 1000 > "$OUT/train_step_kernels.txt" 2>&1
 rm -rf "$OUT/train_prof"
-grep "conv_wgrad_planes" $OUT/train_step_kernels.txt | cut -c1-90
+grep "reduce_kernel" $OUT/train_step_kernels.txt | cut -c1-100
 python tools/train_time.py 2>/dev/null | tail -1 | cut -c1-130
