@@ -101,6 +101,7 @@ def test_trunk_fp16_backward_against_fp32_backward(model, dev):
     from coponerf_amd import getz
     inp, gt = sc.inputs(4096)
     inp, gt = to_device(inp, dev), gt.to(dev)
+    getz._TRUNK_BWD_TARGET[0] = 4.0            # (process-wide; tests that force skipped steps back it off)
 
     def trunk_grads(f16: bool):
         old = getz.F16_TRUNK_BACKWARD
