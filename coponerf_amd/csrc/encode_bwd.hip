@@ -735,7 +735,9 @@ extern "C" int cpn_scale_to_f16(const float* x, long long n, float target, uint3
     CPN_REQUIRE(n > 0 && (n % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0 && target > 0.0f, CPN_E_SHAPE,
                 "cpn_scale_to_f16: need n %% 4 == 0 and aligned pointers");
     const unsigned blocks = (unsigned)std::min<long long>(cpn_cdiv(n / 4, 256), 8192);
-    const unsigned ablocks = (unsigned)std::min<long long>(cpn_cdiv(n / 4, 1024), 2048);   // four loads in flight per thread
+    // four loads in flight per thread; at most two workgroups per CU: their atomics on the one word serialise (2 048 of them
+    // were 10 of the kernel's 18 us on a 33 MB tensor)
+    const unsigned ablocks = (unsigned)std::min<long long>(cpn_cdiv(n / 4, 1024), 512);
     hipLaunchKernelGGL(absmax_kernel, dim3(ablocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, amax_scratch);
     hipLaunchKernelGGL(scale_to_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n / 4, amax_scratch, target,
                        (__half*)y, scale_out);
