@@ -480,9 +480,13 @@ __device__ __forceinline__ void level_xy(float2 g, int j, float fW, float fH, fl
     }
 }
 
+// Conservative pixel boxes of the rows' footprints at ONE level, per 16-row QUARTER of a 64-row chunk (round 6).  A chunk
+// is one ray's samples along its epipolar line: the box of the whole line covers some 300 tiles of which 40 hold samples,
+// and the tiles' scan evaluated every row of every chunk whose box they touched (that scan, not the accumulation, was the
+// kernel's time: 1.58 ms for a gigabyte of rows); a quarter line's box is a sixteenth of the area.
 __global__ __launch_bounds__(256) void gather_bbox_kernel(
     int H, int W, const float* __restrict__ pixel_val, const float* __restrict__ sec_grid, int V, int R, int S,
-    int ray0, int nrays, int maxchunks, int nimg, int4* __restrict__ bbox) {
+    int ray0, int nrays, int maxchunks, int nimg, int lvl, int4* __restrict__ bbox) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int img = wid / maxchunks, c = wid - img * maxchunks;
@@ -492,25 +496,21 @@ __global__ __launch_bounds__(256) void gather_bbox_kernel(
     const int per = max(rhi - rlo, 0) * S, total = 2 * per;
     const int idx = c * 64 + lane;
     const bool live = idx < total;
-    RowRef rf;
-    if (live) rf = row_of(idx, per, S, (S & (S - 1)) == 0, 31 - __builtin_clz(S), rlo, b, vi, V, R, ray0, pixel_val, sec_grid);
-#pragma unroll
-    for (int lvl = 0; lvl < 4; ++lvl) {
-        const int shift = 4 - lvl - (lvl == 3);
-        int x0 = 1 << 30, y0 = 1 << 30, x1 = -(1 << 30), y1 = -(1 << 30);
-        if (live) {
-            float x, y;
-            level_xy(rf.g, rf.j, (float)(W >> shift), (float)(H >> shift), x, y);
-            x0 = (int)floorf(x); y0 = (int)floorf(y);
-            x1 = x0 + 1; y1 = y0 + 1;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            x0 = min(x0, __shfl_xor(x0, o)); y0 = min(y0, __shfl_xor(y0, o));
-            x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
-        }
-        if (lane == 0) bbox[((size_t)img * maxchunks + c) * 4 + lvl] = make_int4(x0, y0, x1, y1);
+    const int shift = 4 - lvl - (lvl == 3);
+    int x0 = 1 << 30, y0 = 1 << 30, x1 = -(1 << 30), y1 = -(1 << 30);
+    if (live) {
+        const RowRef rf = row_of(idx, per, S, (S & (S - 1)) == 0, 31 - __builtin_clz(S), rlo, b, vi, V, R, ray0, pixel_val, sec_grid);
+        float x, y;
+        level_xy(rf.g, rf.j, (float)(W >> shift), (float)(H >> shift), x, y);
+        x0 = (int)floorf(x); y0 = (int)floorf(y);
+        x1 = x0 + 1; y1 = y0 + 1;
     }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {                          // within the 16 lanes of a quarter
+        x0 = min(x0, __shfl_xor(x0, o)); y0 = min(y0, __shfl_xor(y0, o));
+        x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
+    }
+    if ((lane & 15) == 0) bbox[((size_t)img * maxchunks + c) * 4 + (lane >> 4)] = make_int4(x0, y0, x1, y1);
 }
 
 __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
     const bool s_pow2 = (S & (S - 1)) == 0;
     const int s_shift = 31 - __builtin_clz(S);
     const float fW = (float)Wl, fH = (float)Hl;
-    const int4* boxes = bbox + (size_t)img * plan.maxchunks * 4 + lvl;
+    const int4* boxes = bbox + (size_t)img * plan.maxchunks * 4;          // [chunk][16-row quarter], this level
 
     auto drain = [&](int n) {
 #ifdef CPN_GBWD_NO_DRAIN                                       // timing-only ablation (tools/gbwd_bench.py): scan phase alone
@@ -587,19 +587,41 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
     };
 
     int qn = 0;
+    // A1: lane = chunk; its four quarter boxes are one 64-byte read, and the next 64 chunks' boxes are in flight while
+    // this batch is worked on (a tile scans every chunk of its image: the scan is a latency chain unless it is fed ahead)
+    auto load_boxes = [&](int cb, int4 (&bx)[4]) {
+        const int c = min(cb + lane, c_end - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bx[k] = boxes[(size_t)c * 4 + k];
+    };
+    int4 nxt[4];
+    if (g * cpg < c_end) load_boxes(g * cpg, nxt);
     for (int cb = g * cpg; cb < c_end; cb += 64) {
-        // A1: lane = chunk, conservative box test
-        bool maybe = false;
-        if (cb + lane < c_end) {
-            const int4 bx = boxes[(size_t)(cb + lane) * 4];
-            maybe = (bx.z >= tx0) && (bx.x < tx0 + TP) && (bx.w >= ty0) && (bx.y < ty0 + TPY);
+        int4 cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+        if (cb + 64 < c_end) load_boxes(cb + 64, nxt);
+        unsigned long long qmask[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int4 bx = cur[k];
+            const bool maybe = (cb + lane < c_end) && (bx.z >= tx0) && (bx.x < tx0 + TP) && (bx.w >= ty0) && (bx.y < ty0 + TPY);
+            qmask[k] = __ballot(maybe);
         }
-        unsigned long long cmask = __ballot(maybe);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+        unsigned long long cmask = qmask[k];
         while (cmask) {
-            const int c = cb + (int)__builtin_ctzll(cmask);
-            cmask &= cmask - 1;
-            // A2: lane = row of chunk c
-            const int idx = c * 64 + lane;
+            // A2: up to four hit quarters (quarter k of four chunks) at once: lane = (hit slot, row of its quarter)
+            int hq = -1;
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                if (cmask) {                                   // wave-uniform
+                    const int bit = (int)__builtin_ctzll(cmask);
+                    cmask &= cmask - 1;
+                    if ((lane >> 4) == h) hq = bit;
+                }
+            const int idx = hq < 0 ? total : (cb + hq) * 64 + k * 16 + (lane & 15);
             uint4 desc = make_uint4(0, 0, 0, 0);
             int flags = 0;
             if (idx < total) {
@@ -634,6 +656,7 @@ __global__ __launch_bounds__(64 * WAVES) void gather_rows_bwd_kernel(
                 qn += __builtin_popcountll(mask);
                 if (qn > QCAP - 64) { drain(qn); qn = 0; }
             }
+        }
         }
     }
     if (qn) drain(qn);
@@ -686,8 +709,6 @@ static int gather_rows_bwd_launch(const uint16_t* dxin, int ldx, int H, int W, c
     const int maxchunks = (int)cpn_gather_bwd_chunks(R, S);
     const int nimg = B * V;
     const long long nwaves = (long long)nimg * maxchunks;
-    hipLaunchKernelGGL(gather_bbox_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, H, W,
-                       pixel_val, sec_grid, V, R, S, ray0, nrays, maxchunks, nimg, (int4*)chunk_boxes);
     const long long cand = 2LL * (long long)((nrays + B - 1) / B) * S;       // rows that read one image
     for (int l = first_level; l < 4; ++l) {
         GatherBwdPlan plan;
@@ -702,6 +723,8 @@ static int gather_rows_bwd_launch(const uint16_t* dxin, int ldx, int H, int W, c
         const long long hits = cand / plan.tiles;                            // expected rows landing on one tile
         plan.G = (int)std::min<long long>(64, std::max<long long>(1, (hits + 1023) / 2048));
         const int nroles = nimg * plan.G * plan.tiles * plan.slices;
+        hipLaunchKernelGGL(gather_bbox_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, H, W,
+                           pixel_val, sec_grid, V, R, S, ray0, nrays, maxchunks, nimg, l, (int4*)chunk_boxes);
         hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((nroles + WAVES - 1) / WAVES), dim3(64 * WAVES), 0,
                            (hipStream_t)stream, (const __half*)dxin, ldx, H, W, pixel_val, sec_grid, V, R, S, ray0,
                            nrays, dmap0, dmap1, dmap2, dmap3, plan, nroles, (const int4*)chunk_boxes);
