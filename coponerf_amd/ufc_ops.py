@@ -53,8 +53,10 @@ def wgrad_f32(dY2, X2, want_bias: bool):
     launch + a fixed-order reduction) where its layout rules hold, the stock products otherwise."""
     R, O = dY2.shape
     I = X2.shape[1]
-    ok = (dY2.is_cuda and dY2.dtype == torch.float32 and X2.dtype == torch.float32 and R >= WGRAD_MIN_ROWS
-          and O % 4 == 0 and I % 4 == 0)
+    # (a handful of rows against a huge layer - the pose regressor's 512 x 134 144 first Linear at batch 4 - is an outer
+    # product that is all output: the library's TN GEMM took 310 us for a 275 MB result)
+    ok = (dY2.is_cuda and dY2.dtype == torch.float32 and X2.dtype == torch.float32
+          and (R >= WGRAD_MIN_ROWS or O * I >= (1 << 24)) and O % 4 == 0 and I % 4 == 0)
     if ok:
         # cpn_wgrad_f32 wants unit column stride, 16-byte aligned rows and a leading dimension that covers a row (a row-expanded
         # gradient has stride(0) == 0, a column slice of a narrower parent stride(0) < O)
@@ -78,6 +80,15 @@ class LinearFn(Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if (x.dim() == 2 and x.shape[0] <= 4 and x.shape[1] >= (1 << 15) and x.shape[1] % 4 == 0 and x.is_contiguous()
+                and weight.is_contiguous() and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0):
+            # a few rows against 275 MB of weights: the inference path's chunked GEMV (cpn_pose_gemv), 60 us where the
+            # library's GEMM took 160
+            nsplit, O = 8, weight.shape[0]
+            h = torch.empty(x.shape[0], O, nsplit, dtype=torch.float32, device=x.device)
+            call("cpn_pose_gemv", x.data_ptr(), weight.data_ptr(), x.shape[0], x.shape[1], O, nsplit, h.data_ptr(), _stream())
+            y = h.sum(-1)
+            return y if bias is None else y + bias
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -93,7 +104,8 @@ class LinearFn(Function):
 
 def linear(x, weight, bias=None):
     """torch.nn.functional.linear; under autograd on the GPU with the weight gradient on `cpn_wgrad_f32`."""
-    if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.numel() // x.shape[-1] >= WGRAD_MIN_ROWS
+    if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+            and (x.numel() // x.shape[-1] >= WGRAD_MIN_ROWS or weight.numel() >= (1 << 24))
             and (weight.requires_grad or (bias is not None and bias.requires_grad))):
         return LinearFn.apply(x, weight, bias)
     return F.linear(x, weight, bias)

@@ -1,11 +1,12 @@
 export TMPDIR=/tmp PYTHONPATH=$PWD
 ROOT=$PWD
-OUT=$ROOT/gpurun_out/r06s
+OUT=$ROOT/gpurun_out/r06t
 mkdir -p $OUT
-( timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_step.py tests/test_gpu_converge.py -x -q ) > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
+( timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_step.py tests/test_gpu_getz.py -x -q ) > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/train_prof" -o t -- python "$ROOT/tools/train_time.py" --steps 3 ) > "$OUT/train_prof.log" 2>&1
 T=$(find "$OUT/train_prof" -name '*kernel_trace.csv' | head -1)
 python tools/trace_step.py "$T" project_rays 1000 > "$OUT/train_step_kernels.txt" 2>&1
 rm -rf "$OUT/train_prof"
-grep "gather_rows_bwd\|gather_bbox" $OUT/train_step_kernels.txt | cut -c1-100
+head -1 $OUT/train_step_kernels.txt
+grep "MT64x32x128\|pose_gemv\|wgrad_f32" $OUT/train_step_kernels.txt | cut -c1-110
 python tools/train_time.py 2>/dev/null | tail -1 | cut -c1-130
