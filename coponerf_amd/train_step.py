@@ -10,6 +10,7 @@ all-reduces.  One process per GPU; ranks draw independent batches (train.py:84-9
 from __future__ import annotations
 
 import collections
+import os
 from typing import Dict, Optional
 
 import torch
@@ -61,6 +62,8 @@ class TrainStep:
         # single device; the update is unchanged (the mean over one rank is the rank's own gradient)
         self.force_collectives = bool(force_collectives)
         self.timing: Optional[Dict[str, list]] = None                    # set to {} to collect HIP-event timings
+        # reorder every step's query rays by image tile (_rays_by_tile); COPONERF_SORT_RAYS=0: as given
+        self.sort_rays = os.environ.get("COPONERF_SORT_RAYS", "1") != "0"
         # fp16 activation gradients carry a static per-pass scale (train_fns.GradScale).  If they overflow the guard
         # skips the step and the next pass would pick the same scale: back the target off (x 1/4 per skipped step, down
         # to 1) and restore it (x 2 every `growth_interval` good steps) like an AMP GradScaler does.  Where the guard runs on
@@ -91,9 +94,33 @@ class TrainStep:
         e.record()
         return e
 
+    @staticmethod
+    def _rays_by_tile(model_input: Dict, gt_rgb: torch.Tensor):
+        """The step's query rays of every pair reordered by 8 x 8-pixel tile of the query image (the dataset draws them at
+        random, dataio.py:385-390): rays that are neighbours in the image project to neighbouring epipolar lines, so the
+        table taps of consecutive rays share cache lines and the backward's scatter tiles fill in bursts - 1.0-1.5 ms of the
+        step.  Every ray is rendered exactly as before (rays do not interact) and the loss is a mean over them; the per-ray
+        outputs come back in the new order, `order` (B, R) says which input ray each one is."""
+        q = model_input["query"]
+        uv = q["uv"]                                                   # (B, 1, R, 2) pixel coordinates
+        R = uv.shape[2]
+        x, y = uv[..., 0].floor().long(), uv[..., 1].floor().long()
+        key = ((y >> 3) << 20) + ((x >> 3) << 6) + ((y & 7) << 3) + (x & 7)
+        order = key.argsort(dim=-1)                                    # (B, 1, R)
+        take = lambda t: torch.gather(t, 2, order[..., None].expand(-1, -1, -1, t.shape[-1]))
+        q2 = {k: (take(v) if torch.is_tensor(v) and v.dim() == 4 and v.shape[1] == 1 and v.shape[2] == R else v)
+              for k, v in q.items()}
+        out = dict(model_input)
+        out["query"] = q2
+        gt = take(gt_rgb) if gt_rgb.dim() == 4 and gt_rgb.shape[2] == R else gt_rgb
+        return out, gt, order[:, 0]
+
     def __call__(self, model_input: Dict, gt_rgb: torch.Tensor) -> Dict[str, object]:
         """model_input: the reference's input dict on the device; gt_rgb (B,1,R,3).  Returns loss / bookkeeping."""
         timed = self.timing is not None and torch.cuda.is_available()
+        ray_order = None
+        if self.sort_rays and gt_rgb.is_cuda:
+            model_input, gt_rgb, ray_order = self._rays_by_tile(model_input, gt_rgb)
         # steps whose guard ran on the device: their outcome reaches the scale adaptation when its 4-byte copy has landed —
         # normally one step late, never by waiting (unless three are outstanding)
         if self._exchanging():
@@ -173,7 +200,7 @@ class TrainStep:
         return {"loss": loss.detach(), "stepped": stepped, "collectives": ncoll, "allreduce_bytes": nbytes,
                 "host_reads": (0 if on_device else 1) + (0 if ex is None else ex.host_reads - reads_before),
                 "mask_exchanges": 0 if ex is None else ex.mask_exchanges,
-                "at_wt": out["at_wt"].detach(), "skipped_in_a_row": self.skipped_in_a_row}
+                "at_wt": out["at_wt"].detach(), "ray_order": ray_order, "skipped_in_a_row": self.skipped_in_a_row}
 
     def _adapt_grad_scale(self, stepped: bool) -> None:
         eng = getattr(self.model, "_engine", None)
