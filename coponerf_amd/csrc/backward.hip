@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void local_hidden_bwd_kernel(
     for (int ray = ray_lo; ray < ray_hi; ++ray) {
         const int b = ray / R, r = ray - b * R;
         f32x4 racc = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int U = 4;
+#ifndef CPN_LHB_U
+#define CPN_LHB_U 4
+#endif
+        constexpr int U = CPN_LHB_U;                              // rows in flight per thread
         for (int m = rl * U; m < rpr; m += 8 * U) {
             half4 dv[U], ov[U];
 #pragma unroll
