@@ -758,14 +758,14 @@ def test_config4_full_image_wide_rig_against_oracle(model, dev, weights):
 
 def test_config5_batch8_against_oracle_pair_by_pair(model, dev, weights):
     """BASELINE configs[4] at its real batch: 8 pairs of 512x512, 128 samples, all 8 x 262 144 rays in ONE
-    call (128 chunks of 16 384 rays; 16 node tables = 2 GB).  The oracle renders every 2 039th ray (prime) of every pair,
+    call (128 chunks of 16 384 rays; 16 node tables = 2 GB).  The oracle renders every 4 093rd ray (prime) of every pair,
     pair by pair (its own memory stays that of one pair)."""
     from oracle import render_ref as orc
     H, S, B = 512, 128, 8
     inp = syn.make_inputs(B, H, H, 0, seed=57, full_image=True)
     z, rel, flow = syn.make_latents(B, H, H, seed=58)
     R = inp["query"]["uv"].shape[2]
-    sel = torch.arange(0, R, 2039)
+    sel = torch.arange(0, R, 4093)
     old_n, old_c = model.npoints, model._engine.chunk_rays
     model.npoints, model._engine.chunk_rays = S, 16384
     try:
