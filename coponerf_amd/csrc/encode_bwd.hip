@@ -627,13 +627,15 @@ __global__ __launch_bounds__(256) void gather_tail_kernel(const __half* __restri
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrows * 16) return;
     const int piece = (int)(idx & 15);
-    const long long row = idx >> 4;
-    const int j = (int)(row & 1);
-    long long t = row >> 1;
-    const int s = (int)(t % S); t /= S;
-    const int v = (int)(t % V); t /= V;
-    const long long ray = t + ray0;
-    const int b = (int)(ray / R), r = (int)(ray - (long long)b * R);
+    // 32-bit index arithmetic (rows < 2^31, checked by the entry): as 64-bit quotients and remainders these five were most of
+    // the kernel's 265 VALU instructions per thread
+    const unsigned row = (unsigned)(idx >> 4);
+    const int j = (int)(row & 1u);
+    unsigned t = row >> 1;
+    const int s = (int)(t % (unsigned)S); t /= (unsigned)S;
+    const int v = (int)(t % (unsigned)V); t /= (unsigned)V;
+    const unsigned ray = t + (unsigned)ray0;
+    const int b = (int)(ray / (unsigned)R), r = (int)(ray - (unsigned)b * (unsigned)R);
     const size_t sidx = (((size_t)(b * V + v)) * R + r) * S + s;
     half8 o;
 #pragma unroll
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256) void gather_tail_kernel(const __half* __restri
         o[0] = (_Float16)pe[0]; o[1] = (_Float16)pe[1]; o[2] = (_Float16)pe[2];
         o[3] = (_Float16)1.0f;                                 // the bias column
     }
-    *reinterpret_cast<half8*>(xt + row * 128 + piece * 8) = o;
+    *reinterpret_cast<half8*>(xt + (size_t)row * 128 + piece * 8) = o;
 }
 
 // ---- fp32 -> fp16 with a power-of-two scale chosen on the device: two passes over the data instead of the five of
@@ -868,6 +870,7 @@ extern "C" int cpn_gather_tail(const uint16_t* map3, int H, int W, const float* 
     CPN_REQUIRE(ray0 >= 0 && nrays > 0 && (long long)ray0 + nrays <= (long long)B * R, CPN_E_ARG,
                 "cpn_gather_tail: ray range outside B*R");
     CPN_REQUIRE(((uintptr_t)map3 % 16) == 0 && ((uintptr_t)xt % 16) == 0, CPN_E_ARG, "cpn_gather_tail: pointers must be 16-byte aligned");
+    CPN_REQUIRE((long long)nrays * V * S * 2 < (1LL << 31), CPN_E_SHAPE, "cpn_gather_tail: more than 2^31 rows");
     const long long nrows = (long long)nrays * V * S * 2;
     hipLaunchKernelGGL(gather_tail_kernel, dim3((unsigned)cpn_cdiv(nrows * 16, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const __half*)map3, H, W, pixel_val, sec_grid, pe6, V, R, S, ray0, nrows, (__half*)xt);
