@@ -94,6 +94,8 @@ class LinearFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        if not dy.is_contiguous():
+            dy = dy.contiguous()          # ONE copy: the product below and wgrad_f32 each made their own (2 x 67 MB at the q/k split)
         dx = dy.matmul(w) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
