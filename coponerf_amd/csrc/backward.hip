@@ -131,84 +131,99 @@ __global__ __launch_bounds__(256) void local_hidden_bwd_kernel(
     const __half* __restrict__ ds, const __half* __restrict__ out, const float* __restrict__ loc8,
     const float* __restrict__ coords9, const float* __restrict__ scale, int V, int R, int S, int nrays, int rays_per_block,
     float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dadd) {
-    __shared__ float red[128 * 16];
-    __shared__ float rsum[8][128];
-    const int n4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    for (int i = threadIdx.x; i < 128 * 16; i += 256) red[i] = 0.0f;
+    // Round 6: on the fp32 matrix cores.  C[n][k] += sum_rows d[row][n] * L[row][k] is a GEMM with the rows as its contraction
+    // index: 64 rows of masked d (fp16, still scaled) and of L are staged in LDS, a wave owns two of the eight 16-channel
+    // tiles and issues 2 v_mfma_f32_16x16x4_f32 per 4 rows.  Columns 3..5 of L are zeros by construction (CoPoNeRF.py:445):
+    // column 3 carries ONES here, so C[n][3] is the sum of d over the rows - per ray that is dadd, over everything db - and
+    // dW[:, 3] is left at zero.  (The VALU form, 32 packed FMAs per row and thread, ran at 0.5 ms per launch, a third of it
+    // issue and the rest waiting.)
+    constexpr int CH = 64;                                       // rows per staged chunk
+    constexpr int DLD = 128 + 8;                                 // halves per staged row of d
+    __shared__ __half dsh[CH * DLD];
+    __shared__ float lsh[CH * 17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
     const float inv = 1.0f / scale[0];
     const int rpr = V * S;
-    f32x4 acc[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int srow = tid >> 2, sq = tid & 3;                     // staging: thread = (row of the chunk, quarter of its 128 channels)
+    f32x4 blk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const int ray_lo = blockIdx.x * rays_per_block;
     const int ray_hi = min(ray_lo + rays_per_block, nrays);
+    half8 dv[4], ov[4];
+    auto load_chunk = [&](int ray, int m0) {
+        const size_t row = (size_t)ray * rpr + min(m0 + srow, rpr - 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            dv[u] = *reinterpret_cast<const half8*>(ds + row * 128 + sq * 32 + u * 8);
+            ov[u] = *reinterpret_cast<const half8*>(out + row * 128 + sq * 32 + u * 8);
+        }
+    };
+    const int nchunk = (rpr + CH - 1) / CH;
+    if (ray_lo < ray_hi) load_chunk(ray_lo, 0);
     for (int ray = ray_lo; ray < ray_hi; ++ray) {
         const int b = ray / R, r = ray - b * R;
-        f32x4 racc = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifndef CPN_LHB_U
-#define CPN_LHB_U 4
-#endif
-        constexpr int U = CPN_LHB_U;                              // rows in flight per thread
-        for (int m = rl * U; m < rpr; m += 8 * U) {
-            half4 dv[U], ov[U];
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int c = 0; c < nchunk; ++c) {
+            const int m0 = c * CH;
+            const bool live = m0 + srow < rpr;
+            __syncthreads();                                     // the previous chunk has been consumed
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const size_t row = (size_t)ray * rpr + min(m + u, rpr - 1);
-                dv[u] = *reinterpret_cast<const half4*>(ds + row * 128 + n4 * 4);
-                ov[u] = *reinterpret_cast<const half4*>(out + row * 128 + n4 * 4);
+            for (int u = 0; u < 4; ++u) {
+                half8 d8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    d8[e] = (live && (float)ov[u][e] > 0.0f) ? dv[u][e] : (_Float16)0.0f;
+                *reinterpret_cast<half8*>(dsh + srow * DLD + sq * 32 + u * 8) = d8;
             }
+            {   // L(row), four of its sixteen entries per thread (the forward kernel's construction; k = 3 carries the ones)
+                f32x4 lv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (live) {
+                    const int m = m0 + srow;
+                    const int v = m / S, sm = m - v * S;
+                    const size_t nr = ((size_t)(b * V + v)) * R + r;
+                    const float* lp = loc8 + (nr * S + sm) * 8;
+                    const float* c9 = coords9 + nr * 9;
+                    if (sq == 0) lv = f32x4{lp[0], lp[1], lp[2], 1.0f};
+                    else if (sq == 1) lv = f32x4{0.f, 0.f, c9[0], c9[1]};
+                    else if (sq == 2) lv = f32x4{c9[2], lp[3], lp[4], lp[5]};
+                    else lv = f32x4{lp[6], c9[6], c9[7], c9[8]};
+                }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (m + u >= rpr) break;
-                const half4 dh = dv[u], oh = ov[u];
-                f32x4 d;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = (float)oh[e] > 0.0f ? (float)dh[e] : 0.0f;
-                racc += d;
-                const int v = (m + u) / S, sm = (m + u) - v * S;
-                const size_t nr = ((size_t)(b * V + v)) * R + r;
-                const float* lp = loc8 + (nr * S + sm) * 8;
-                const float* c9 = coords9 + nr * 9;
-                const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp), l1 = *reinterpret_cast<const f32x4*>(lp + 4);
-                const float Lrow[16] = {l0[0], l0[1], l0[2], 0.f, 0.f, 0.f, c9[0], c9[1], c9[2], l0[3], l1[0], l1[1], l1[2],
-                                        c9[6], c9[7], c9[8]};
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc[k] += d * Lrow[k];
+                for (int e = 0; e < 4; ++e) lsh[srow * 17 + sq * 4 + e] = lv[e];
             }
-        }
-        bacc += racc;
-        if (dadd) {
-            __syncthreads();                                  // previous ray's sums are consumed
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rsum[rl][n4 * 4 + e] = racc[e];
             __syncthreads();
-            if (threadIdx.x < 128) {
-                float t = 0.0f;
+            // the next chunk's rows are in flight under this chunk's MFMAs
+            if (c + 1 < nchunk) load_chunk(ray, m0 + CH);
+            else if (ray + 1 < ray_hi) load_chunk(ray + 1, 0);
+#pragma unroll 4
+            for (int k4 = 0; k4 < CH / 4; ++k4) {
+                const int row = k4 * 4 + lk;
+                const float bval = lsh[row * 17 + li];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) t += rsum[q][threadIdx.x];
-                dadd[(size_t)ray * 128 + threadIdx.x] = t * inv;
+                for (int t = 0; t < 2; ++t) {
+                    const float aval = (float)dsh[row * DLD + (wave * 2 + t) * 16 + li];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aval, bval, acc[t], 0, 0, 0);
+                }
             }
         }
+        // D[m = 4 lk + i][n = li]: m -> channel of the tile, n -> column of L
+        if (dadd && li == 3) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dadd[(size_t)ray * 128 + (wave * 2 + t) * 16 + lk * 4 + i] = acc[t][i] * inv;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) blk[t] += acc[t];
     }
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(&red[(n4 * 4 + e) * 16 + k], acc[k][e]);
-    __syncthreads();
-    for (int i = threadIdx.x; i < 128 * 16; i += 256) atomicAdd(dW + i, red[i] * inv);
-    __syncthreads();
-    // bias gradient: reuse rsum
-#pragma unroll
-    for (int e = 0; e < 4; ++e) rsum[rl][n4 * 4 + e] = bacc[e];
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        float t = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t += rsum[q][threadIdx.x];
-        atomicAdd(db + threadIdx.x, t * inv);
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int n = (wave * 2 + t) * 16 + lk * 4 + i;
+            if (li == 3) atomicAdd(db + n, blk[t][i] * inv);
+            else atomicAdd(dW + n * 16 + li, blk[t][i] * inv);
+        }
 }
 
 }  // namespace

@@ -866,3 +866,41 @@ def test_backward_fusions_leave_the_gradients_alone(dev, monkeypatch):
     for k in res[0]:                                         # the shared gradient is summed in fp32 before ONE fp16 rounding
         rel_err = float((res[0][k] - res[1][k]).norm() / (res[1][k].norm() + 1e-30))
         assert rel_err <= 2e-3, (k, rel_err)
+
+
+def test_local_hidden_backward_kernel(dev):
+    """cpn_local_hidden_bwd (ReLU mask, un-scaling, the 128 x 16 weight gradient, the bias gradient and the per-ray sums in
+    one pass, on the fp32 MFMA) against the same sums formed by float64 tensor ops; shapes with rays of 48 and 128 rows (a
+    partial and two full 64-row chunks)."""
+    from coponerf_amd._hip import call
+    st = torch.cuda.current_stream().cuda_stream
+    for (B, V, R, S, scale) in ((2, 2, 5, 24, 8.0), (1, 2, 3, 64, 0.5), (3, 2, 9, 64, 1.0)):
+        nrays, rpr = B * R, V * S
+        rows = nrays * rpr
+        ds = (syn.normal((rows, 128), seed=81) * 0.5).to(dev).half()
+        out = syn.normal((rows, 128), seed=82).to(dev).half()
+        loc8 = syn.normal((B * V * R * S, 8), seed=83).to(dev)
+        coords9 = syn.normal((B * V * R, 9), seed=84).to(dev)
+        sc_t = torch.tensor([scale], device=dev)
+        dW = torch.zeros(128, 16, device=dev)
+        db = torch.zeros(128, device=dev)
+        dadd = torch.empty(nrays, 128, device=dev)
+        call("cpn_local_hidden_bwd", ds.data_ptr(), out.data_ptr(), loc8.data_ptr(), coords9.data_ptr(), sc_t.data_ptr(), B, V, R, S,
+             dW.data_ptr(), db.data_ptr(), dadd.data_ptr(), st)
+        # row (ray, v, s) of the launch -> L from loc8[((b V + v) R + r) S + s] and coords9[(b V + v) R + r]
+        ray = torch.arange(nrays, device=dev).repeat_interleave(rpr)
+        m = torch.arange(rpr, device=dev).repeat(nrays)
+        v, s = m // S, m % S
+        b, r = ray // R, ray % R
+        nr = (b * V + v) * R + r
+        l8, c9 = loc8[nr * S + s].double(), coords9[nr].double()
+        z = torch.zeros(rows, dtype=torch.float64, device=dev)
+        L = torch.stack([l8[:, 0], l8[:, 1], l8[:, 2], z, z, z, c9[:, 0], c9[:, 1], c9[:, 2], l8[:, 3], l8[:, 4], l8[:, 5], l8[:, 6],
+                         c9[:, 6], c9[:, 7], c9[:, 8]], dim=1)
+        d = torch.where(out.double() > 0, ds.double(), torch.zeros((), dtype=torch.float64, device=dev)) / scale
+        want_dW, want_db = d.t() @ L, d.sum(0)
+        want_dadd = d.view(nrays, rpr, 128).sum(1)
+        tol = lambda w: 2e-5 * (1 + w.abs().max())
+        assert (dW.double() - want_dW).abs().max() <= tol(want_dW), (B, V, R, S)
+        assert (db.double() - want_db).abs().max() <= tol(want_db), (B, V, R, S)
+        assert (dadd.double() - want_dadd).abs().max() <= tol(want_dadd), (B, V, R, S)
