@@ -90,6 +90,15 @@ def _mm_f32(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
     return torch.mm(a16, b16, out_dtype=torch.float32)
 
 
+def _colsum_f32(d: torch.Tensor) -> torch.Tensor:
+    """d.sum(0) in fp32.  Over millions of 128-wide rows the library's column reduction runs at 1.8 TB/s (292 us for the key
+    layer's 537 MB); the same rows viewed 64 at a time are 8 192 columns wide and it streams them at 5 TB/s (103 us)."""
+    n, c = d.shape
+    if d.is_contiguous() and n % 64 == 0 and n >= (1 << 16):
+        return d.view(n // 64, 64 * c).sum(0, dtype=torch.float32).view(64, c).sum(0)
+    return d.sum(0, dtype=torch.float32)
+
+
 def _wgrad_tall(d16: torch.Tensor, x16: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     """dW (N, K) fp32 = d16^T (N, M) . x16 (M, K) / scale on cpn_wgrad_tall_f16 (N % 208 == 0, K % 128 == 0; the library's
     split-K GEMM runs the 832 x 896 x 4.2 M case at 500 TFLOP/s, 12.5 ms of the training step)."""
@@ -221,7 +230,7 @@ class GemmFn(Function):
             dW = _wgrad_tall(A16, d16, ctx.gs.s).t()[:, :ctx.K]
         else:
             dW = _mm_f32(d16.t(), A16)[:, :ctx.K] * inv if ctx.needs_input_grad[1] else None
-        db = d.sum(0, dtype=torch.float32) * inv if ctx.needs_input_grad[2] else None
+        db = _colsum_f32(d) * inv if ctx.needs_input_grad[2] else None
         return (dA, dW, db) + (None,) * 9
 
 
