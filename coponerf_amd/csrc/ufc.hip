@@ -727,7 +727,11 @@ constexpr int WG_MAXP = 256;          // H * W <= 256
 #define CPN_WG_BLOCKS 512
 #endif
 constexpr int WG_BLOCKS = CPN_WG_BLOCKS;   // workgroups (= partial sums) per call
-template <int CI, int CO>                 // channel counts rounded up to 8 or 32: the staging registers of one plane
+// SWAP (Cout <= 8 < Cin): the kernel is handed (dy, x, Cout, Cin) in place of (x, dy, Cin, Cout) - the gradient planes take
+// the halo and the two-taps-per-column packing, since dW[o][c][tap] = sum_p dy[o][p - tap] x[c][p] is the same sum with the
+// roles exchanged and the tap mirrored (8 - tap) - and writes its partial sums in the caller's (o, c, tap) order; the bias
+// sum is then taken from the centre tap of the haloed operand.
+template <int CI, int CO, bool SWAP = false>   // channel counts rounded up to 8 or 32: the staging registers of one plane
 __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, int Cin, int Cout, int G, int H, int W, int nplanes,
     float* __restrict__ partial) {
@@ -803,9 +807,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
         // next step's 10 LDS reads are issued before the current step's 9 MFMAs (predicated reads + a wait before every
         // MFMA ran this loop at a quarter of the MFMA rate)
         int yy = y0, xx = x0;
+        bool bvalid = false;                           // SWAP: the position of the step just read lies inside the plane
         auto read_step = [&](int ks, float& av, float (&bv)[NACC]) {
             const int pos = ks * 4 + lk;
             av = arow[pos];
+            if constexpr (SWAP) bvalid = pos < P;
             const float* bp = brow + (pos < P ? yy * (W + 2) + xx : 0);
             if constexpr (PACK) {
 #pragma unroll
@@ -824,11 +830,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
         float av, bv[NACC];
         if (k_lo < k_hi) read_step(k_lo, av, bv);
         for (int ks = k_lo; ks < k_hi; ++ks) {
+            if constexpr (SWAP) bsum += (bvalid && tapsel == 0) ? bv[2] : 0.0f;     // centre tap (4 = 2 * 2 + 0) of the gradient plane
+            else bsum += av;
             float an = 0.0f, bn[NACC];
 #pragma unroll
             for (int t = 0; t < NACC; ++t) bn[t] = 0.0f;
             if (ks + 1 < k_hi) read_step(ks + 1, an, bn);
-            bsum += av;
 #pragma unroll
             for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
             av = an;
@@ -839,10 +846,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
     // partial sums of this workgroup: [Cout*Cin*9 weights | Cout biases]; D[m = lk*4 + e][n = ln]: m -> output
     // channel, n -> input channel.  Waves that split the positions of one tile (kparts > 1) combine with LDS atomics.
     const int nw = Cout * Cin * 9;
-    float* mine = partial + (size_t)blockIdx.x * (nw + Cout);
+    const int nbias = SWAP ? Cin : Cout;              // the caller's output channels
+    float* mine = partial + (size_t)blockIdx.x * (nw + nbias);
     __syncthreads();
-    float* red = wgl;                                 // reuse LDS: nw + Cout floats <= 32*32*9 + 32
-    for (int i = tid; i < nw + Cout; i += 256) red[i] = 0.0f;
+    float* red = wgl;                                 // reuse LDS: nw + nbias floats <= 32*32*9 + 32
+    for (int i = tid; i < nw + nbias; i += 256) red[i] = 0.0f;
     __syncthreads();
     const int c = PACK ? (ln & 7) : ct * 16 + ln;
 #pragma unroll
@@ -852,18 +860,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_planes_kernel(
             const int o = mt * 16 + lk * 4 + e;
             const int tap = PACK ? 2 * t + tapsel : t;
             if (o < Cout && c < Cin && tap < 9) {
-                if (kparts > 1) atomicAdd(red + ((size_t)o * Cin + c) * 9 + tap, acc[t][e]);
-                else red[((size_t)o * Cin + c) * 9 + tap] = acc[t][e];
+                // SWAP: (o, c) are (input channel, output channel) of the caller's problem, the tap is mirrored
+                const size_t at = SWAP ? ((size_t)c * Cout + o) * 9 + (8 - tap) : ((size_t)o * Cin + c) * 9 + tap;
+                if (kparts > 1) atomicAdd(red + at, acc[t][e]);
+                else red[at] = acc[t][e];
             }
         }
-    if (ct == 0) {                                    // bias: lanes (ln = o, lk) hold disjoint position subsets
+    if constexpr (SWAP) {                             // bias of the caller's output channel c' = ln (tapsel 0 lanes), once per k part
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (mt == 0 && lk == 0 && ln < Cin) atomicAdd(red + nw + ln, bsum);
+    } else if (ct == 0) {                             // bias: lanes (ln = o, lk) hold disjoint position subsets
         bsum += __shfl_xor(bsum, 16);
         bsum += __shfl_xor(bsum, 32);
         const int o = mt * 16 + ln;
         if (lk == 0 && o < Cout) atomicAdd(red + nw + o, bsum);
     }
     __syncthreads();
-    for (int i = tid; i < nw + Cout; i += 256) mine[i] = red[i];
+    for (int i = tid; i < nw + nbias; i += 256) mine[i] = red[i];
 }
 
 __global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int nw,
@@ -1982,12 +1996,13 @@ extern "C" int cpn_conv_wgrad_planes(const float* x, const float* dy, int B, int
     const int P = H * W, HP = (H + 2) * (W + 2);
     const int XS = HP + ((HP & 31) == 5 ? 0 : ((37 - (HP & 31)) & 31));
     const int DS = P + ((P & 31) == 4 ? 0 : ((36 - (P & 31)) & 31));
-    const int CT = (Cin + 15) / 16, MT = (Cout + 15) / 16;
+    const bool swap = Cout <= 8 && Cin > 8;                  // conv_wgrad_planes_kernel<8, 32, true>: the operands change places
+    const int CT = ((swap ? Cout : Cin) + 15) / 16, MT = ((swap ? Cin : Cout) + 15) / 16;
     const size_t lds = std::max((size_t)CT * 16 * XS + (size_t)MT * 16 * DS, (size_t)Cout * Cin * 9 + Cout) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         for (const void* k : {(const void*)conv_wgrad_planes_kernel<8, 8>, (const void*)conv_wgrad_planes_kernel<8, 32>,
-                              (const void*)conv_wgrad_planes_kernel<32, 8>, (const void*)conv_wgrad_planes_kernel<32, 32>}) {
+                              (const void*)conv_wgrad_planes_kernel<8, 32, true>, (const void*)conv_wgrad_planes_kernel<32, 32>}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) {
                 cpn_set_error("cpn_conv_wgrad_planes: cannot reserve LDS: %s", hipGetErrorString(e));
@@ -2004,8 +2019,8 @@ extern "C" int cpn_conv_wgrad_planes(const float* x, const float* dy, int B, int
         hipLaunchKernelGGL((conv_wgrad_planes_kernel<8, 8>), grid, block, lds, st, x, dy, Cin, Cout, G, H, W, nplanes, partial);
     else if (Cin <= 8)
         hipLaunchKernelGGL((conv_wgrad_planes_kernel<8, 32>), grid, block, lds, st, x, dy, Cin, Cout, G, H, W, nplanes, partial);
-    else if (Cout <= 8)
-        hipLaunchKernelGGL((conv_wgrad_planes_kernel<32, 8>), grid, block, lds, st, x, dy, Cin, Cout, G, H, W, nplanes, partial);
+    else if (Cout <= 8)                               // roles exchanged: the 8 gradient planes take the two-taps-per-column form
+        hipLaunchKernelGGL((conv_wgrad_planes_kernel<8, 32, true>), grid, block, lds, st, dy, x, Cout, Cin, G, H, W, nplanes, partial);
     else
         hipLaunchKernelGGL((conv_wgrad_planes_kernel<32, 32>), grid, block, lds, st, x, dy, Cin, Cout, G, H, W, nplanes, partial);
     CPN_LAUNCH_CHECK("cpn_conv_wgrad_planes");
